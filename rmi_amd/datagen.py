@@ -1,0 +1,128 @@
+"""Deterministic, integer-only synthetic key sets.
+
+Every generator emits an already-sorted array so CPU and GPU see bit-identical input without
+a sort, and writes/reads the reference's on-disk format: ``u64 LE count`` followed by
+``count`` little-endian items, dtype selected by a substring of the file name
+(reference: src/load.rs:132-157, src/main.rs:122-132).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_U64 = np.uint64
+_MASK = (1 << 64) - 1
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser on uint64 arrays (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = (x + _U64(0x9E3779B97F4A7C15)).astype(np.uint64)
+        z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
+        return z ^ (z >> _U64(31))
+
+
+def _h(i: np.ndarray, seed: int) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        return splitmix64(i.astype(np.uint64) + _U64(seed))
+
+
+def uniform_u64(n: int, seed: int = 42, start: int = 0, count: int | None = None) -> np.ndarray:
+    """key[i] = 1 + i*stride + (h(i) mod stride): strictly increasing, unique, in [1, 2^64-2].
+
+    ``start``/``count`` select a contiguous index window of the *global* n-key array (used to
+    shard generation across ranks)."""
+    count = n - start if count is None else count
+    stride = (_MASK - 1) // n
+    i = np.arange(start, start + count, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return _U64(1) + i * _U64(stride) + (_h(i, seed) % _U64(stride))
+
+
+def uniform_u32(n: int, seed: int = 46, start: int = 0, count: int | None = None) -> np.ndarray:
+    count = n - start if count is None else count
+    stride = ((1 << 32) - 3) // n
+    if stride < 1:
+        raise ValueError("n too large for unique u32 keys")
+    i = np.arange(start, start + count, dtype=np.uint64)
+    k = _U64(1) + i * _U64(stride) + (_h(i, seed) % _U64(stride))
+    return k.astype(np.uint32)
+
+
+def _apply_dups(keys: np.ndarray, seed: int) -> np.ndarray:
+    """key[i] := key[i - (i mod r_i)], r_i in {1,1,1,2,8} chosen per group of 8 indices."""
+    n = len(keys)
+    i = np.arange(n, dtype=np.uint64)
+    choice = (_h(i >> _U64(3), seed) % _U64(5)).astype(np.int64)
+    r = np.array([1, 1, 1, 2, 8], dtype=np.uint64)[choice]
+    src = (i - (i % r)).astype(np.int64)
+    return keys[src]
+
+
+def dups_u64(n: int, seed: int = 45) -> np.ndarray:
+    return _apply_dups(uniform_u64(n, 42), seed)
+
+
+def dups_u32(n: int, seed: int = 47) -> np.ndarray:
+    return _apply_dups(uniform_u32(n, 46), seed)
+
+
+def books_u64(n: int, seed: int = 43, segments: int = 4096) -> np.ndarray:
+    """Heavy-tailed local density ("books_200M-shaped"): equal-count segments whose mean gap
+    is 2^(20 + h(g) mod 14); unique, strictly increasing, total < 2^63."""
+    segments = max(1, min(segments, n))
+    i = np.arange(n, dtype=np.uint64)
+    per = -(-n // segments)
+    g = i // _U64(per)
+    expo = _U64(20) + (_h(np.arange(segments, dtype=np.uint64), seed) % _U64(14))
+    G = (_U64(1) << expo)
+    cap = _U64(max(1, (1 << 62) // max(n, 1)))
+    G = np.minimum(G, cap)
+    Gi = G[g.astype(np.int64)]
+    with np.errstate(over="ignore"):
+        gap = _U64(1) + (_h(i, seed + 1) % (_U64(2) * Gi))
+        return _U64(1) + np.cumsum(gap, dtype=np.uint64)
+
+
+def clustered_u64(n: int, seed: int = 48, base: int = 1 << 62) -> np.ndarray:
+    """Ill-conditioned set: tiny gaps on a huge offset (keys near 2^62 with gaps < 2^12), so
+    f64(key) collapses many distinct keys; exercises the as-float rounding rules."""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        gap = _U64(1) + (_h(i, seed) % _U64(4096))
+        return _U64(base) + np.cumsum(gap, dtype=np.uint64)
+
+
+GENERATORS = {
+    "uniform_u64": uniform_u64,
+    "books_u64": books_u64,
+    "dups_u64": dups_u64,
+    "uniform_u32": uniform_u32,
+    "dups_u32": dups_u32,
+    "clustered_u64": clustered_u64,
+}
+
+
+def write_keys(path: str, keys: np.ndarray) -> None:
+    """Reference data-file format (README.md:26-31; src/load.rs:140)."""
+    with open(path, "wb") as f:
+        f.write(np.array([len(keys)], dtype="<u8").tobytes())
+        f.write(np.ascontiguousarray(keys).astype(keys.dtype.newbyteorder("<"), copy=False).tobytes())
+
+
+def dtype_from_path(path: str):
+    """src/main.rs:122-132: dtype by substring of the path, in this order."""
+    if "uint64" in path:
+        return np.dtype("<u8")
+    if "uint32" in path:
+        return np.dtype("<u4")
+    if "f64" in path:
+        return np.dtype("<f8")
+    raise ValueError("Data file must contain uint64, uint32, or f64.")
+
+
+def read_keys(path: str) -> np.ndarray:
+    dt = dtype_from_path(path)
+    with open(path, "rb") as f:
+        n = int(np.frombuffer(f.read(8), dtype="<u8")[0])
+    return np.memmap(path, dtype=dt, mode="r", offset=8, shape=(n,))

@@ -1,0 +1,138 @@
+"""Pins the CPU oracle against every known-answer test the reference holds for this path.
+
+The reference's in-file unit tests are stale (written against a removed ModelData API and never
+run by its CI -- SURVEY.md section 4) but their inputs/expected values are still meaningful for
+the current arithmetic; they are the only numeric pins that exist ("parity unpinned").
+Citations: /root/reference/rmi_lib/src/models/*.rs.
+"""
+import numpy as np
+import pytest
+
+
+def u64(*v):
+    return np.array(v, dtype=np.uint64)
+
+
+def test_linear1(oracle):
+    # linear.rs:127-134
+    m = oracle.fit_pairs("linear", u64(1, 2, 3), [2, 3, 4])
+    assert m.predict_to_int(1) == 2
+    assert m.predict_to_int(6) == 7
+
+
+def test_linear_single(oracle):
+    # linear.rs:137-143
+    m = oracle.fit_pairs("linear", u64(1), [2])
+    assert m.predict_to_int(1) == 2
+
+
+def test_linear_spline1(oracle):
+    # linear_spline.rs:90-97
+    m = oracle.fit_pairs("linear_spline", u64(1, 2, 3), [2, 3, 8])
+    assert m.predict_to_int(1) == 2
+    assert m.predict_to_int(3) == 8
+
+
+def test_linear_spline_single(oracle):
+    # linear_spline.rs:100-106
+    m = oracle.fit_pairs("linear_spline", u64(1), [2])
+    assert m.predict_to_int(1) == 2
+
+
+@pytest.mark.parametrize("keys,ys,lo,hi", [
+    ((1, 2, 3, 4), (2, 3, 8, 20), (1, 2.0), (4, 20.0)),            # cubic_spline.rs:200-207
+    ((1, 2, 3, 4, 5), (2, 3, 8, 20, 80), (1, 2.0), (5, 80.0)),      # :210-217
+    ((1, 1, 3, 4, 5), (2, 2, 8, 20, 80), (1, 2.0), (5, 80.0)),      # :220-227 (dup)
+])
+def test_cubic_endpoints(oracle, keys, ys, lo, hi):
+    m = oracle.fit_pairs("cubic", u64(*keys), list(ys))
+    assert abs(m.predict_to_float(lo[0]) - lo[1]) <= 0.5
+    assert abs(m.predict_to_float(hi[0]) - hi[1]) <= 0.5
+
+
+def test_cubic_all_dup_and_single(oracle):
+    # cubic_spline.rs:230-245
+    m = oracle.fit_pairs("cubic", u64(1, 1, 1), [2, 2, 2])
+    assert abs(m.predict_to_float(1) - 2.0) <= 0.5
+    m = oracle.fit_pairs("cubic", u64(1), [2])
+    assert m.predict_to_int(1) == 2
+
+
+@pytest.mark.parametrize("kind,expect", [
+    ("linear", (0.0, 0.0, 0.0, 0.0)),           # linear.rs:37-39
+    ("linear_spline", (0.0, 0.0, 0.0, 0.0)),    # linear_spline.rs:14-16
+    ("cubic", (0.0, 0.0, 1.0, 0.0)),            # cubic_spline.rs:19-21
+    ("robust_linear", (0.0, 0.0, 0.0, 0.0)),    # linear.rs:241-245
+])
+def test_empty(oracle, kind, expect):
+    # test_empty in every model file: models must accept empty data
+    m = oracle.fit_pairs(kind, u64(), [])
+    assert m.p == expect
+
+
+def test_radix_empty(oracle):
+    m = oracle.fit_pairs("radix", u64(), [])
+    assert m.ip == (0, 0)
+
+
+def test_common_prefix_size(oracle):
+    # utils.rs:110-126
+    assert oracle.common_prefix_size(u64(1, 4, 8)) == 60
+    assert oracle.common_prefix_size(u64(1, 8, 9, 12)) == 60
+
+
+def test_num_bits(oracle):
+    # utils.rs:13-21: floor(log2(t+1)); asserts >= 1
+    assert oracle.num_bits(0) == -1
+    assert oracle.num_bits(1) == 1
+    assert oracle.num_bits(2) == 1
+    assert oracle.num_bits(3) == 2
+    assert oracle.num_bits(1023) == 10
+    assert oracle.num_bits(1024) == 10
+    assert oracle.num_bits((1 << 20) - 1) == 20
+
+
+def test_fixdups_tail_duplicate_q1(oracle):
+    """Q1 (models/mod.rs:170-181): iter() yields len+1 items, last one twice.  slr over
+    {(0,0),(1,1),(2,5)} therefore sees (2,5) twice; check against a direct Welford run."""
+    pts = [(0.0, 0.0), (1.0, 1.0), (2.0, 5.0), (2.0, 5.0)]
+    mx = my = c = m2 = 0.0
+    n = 0
+    for x, y in pts:
+        n += 1
+        dx = x - mx
+        mx += dx / n
+        my += (y - my) / n
+        c += dx * (y - my)
+        m2 += dx * (x - mx)
+    beta = (c / (n - 1)) / (m2 / (n - 1))
+    alpha = my - beta * mx
+    m = oracle.fit_pairs("linear", u64(0, 1, 2), [0, 1, 5])
+    assert m.p[0] == alpha and m.p[1] == beta
+
+
+def test_rmi_size_readme_sample():
+    # README.md:51 : RMI_SIZE 50331680 = 32 (cubic root) + 24 * 2^21 (codegen.rs:375-394)
+    assert 4 * 8 + (2 * 8 + 8) * (1 << 21) == 50331680
+
+
+def test_worked_example_survey(oracle):
+    """SURVEY.md section 8a worked example (Q1-Q3) with a toy monotone linear root."""
+    keys = u64(10, 11, 12, 20, 21, 30, 30, 31, 40, 41, 42, 50)
+    # root t(k) = floor((k-10)/11): as linear model alpha=-10/11, beta=1/11 is inexact, so use a
+    # radix-free exact form: beta = 1/16, alpha = -0.625 -> targets floor((k-10)/16)
+    root = oracle.Model(oracle.MODEL_LINEAR, (-0.625, 0.0625, 0.0, 0.0), (0, 0))
+    ids = oracle.bucket_ids(root, keys, 4)
+    assert ids.tolist() == [0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2]
+    r = oracle.train_two_layer("linear", "linear_spline", keys, 4, root=root)
+    assert r.leaf_start.tolist() == [0, 5, 10, 12, 12]
+    # leaf 0 (first half, ends before split_idx=10): container = own [0..4] + next-first (30, 5)
+    # linear_spline uses get(0)/get(len-1): (10,0) and (30,5) -> slope 5/20
+    assert r.leaf_params[0, 1] == (0.0 - 5.0) / (10.0 - 30.0)
+    # leaf 1: prev-last (21,4) + own (30,5),(30,5),(31,7),(40,8),(41,9); no next (half boundary, Q3)
+    assert r.leaf_params[1, 1] == (4.0 - 9.0) / (21.0 - 41.0)
+    # leaf 2 = st: key at split_idx (42,10) dropped (Q2); own = (50,11) only, no prev (Q3) -> single point
+    assert r.leaf_params[2].tolist() == [11.0, 0.0]
+    # leaf 3: empty and last (Q6) -> stays (0,0)
+    assert r.leaf_params[3].tolist() == [0.0, 0.0]
+    assert oracle.check_lookup_property(r, keys)[0] == 0
