@@ -1,0 +1,169 @@
+/*
+ * rmi_hip.h -- C ABI of the MI355X-native replacement for the leaf-fitting hot path of
+ * learnedsystems/RMI's `rmi_lib::train` (two-layer RMIs).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  A Rust caller
+ * binds it with `extern "C"` (see INTEGRATION.md for the stub that replaces the body of
+ * rmi_lib::train::two_layer::train_two_layer).  All citations are file:line in the reference
+ * repository (/root/reference at build time).
+ *
+ * What each entry point replaces:
+ *   rmi_hip_upload_keys / rmi_hip_attach_device_keys
+ *       RMITrainingData<T> over the mmap'd key file (src/load.rs:21-95, 132-157;
+ *       rmi_lib/src/models/mod.rs:233-317).  Keys stay resident in HBM across many train calls
+ *       (the optimizer / param-grid callers, optimizer.rs:220-231, src/main.rs:241-248).
+ *   rmi_hip_fit_root
+ *       `train_model(layer1_model, data)` with scale = L/N (two_layer.rs:109-110; factory
+ *       train/mod.rs:35-57).
+ *   rmi_hip_train_two_layer
+ *       two_layer.rs:126-287: bucketing of every key with the root model, split for the 2-way
+ *       join (:130-175), build_models_from (:20-99) incl. the per-leaf fits (linear.rs:12-59,
+ *       linear_spline.rs:13-35, cubic_spline.rs:18-137), LowerBoundCorrection::new
+ *       (lower_bound_correction.rs:92-137), empty-leaf fix (:185-197), last-level error pass
+ *       (:207-217), lower-bound widening (:226-259) and the aggregate statistics (:267-287).
+ *   rmi_hip_download_* / rmi_hip_result
+ *       the fields of TrainedRMI (train/mod.rs:18-33) that codegen::output_rmi consumes
+ *       (codegen.rs:450-788).  `rows` is byte-for-byte the reference's L1_PARAMETERS file
+ *       (codegen.rs:288-315, 164-182; models/mod.rs:613-651).
+ *
+ * Error behaviour: the reference panics (process abort); this ABI never aborts -- every
+ * reference panic on this path is mapped to a negative return code (enum below).
+ *
+ * Threading: a context is not thread-safe; use one context per caller thread (the reference
+ * calls train() concurrently from Rayon workers on shared read-only data -- here each worker
+ * would own a context that attaches the same device key buffer).
+ */
+#ifndef RMI_HIP_H
+#define RMI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMI_HIP_ABI_VERSION 1
+
+/* src/load.rs:15-19 */
+enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
+
+/* model registry, train/mod.rs:37-54.  Ids 0-4 are implemented on the device path; the rest
+ * of the registry is recognised by name and rejected with RMI_ERR_UNSUPPORTED_MODEL. */
+enum rmi_hip_model_kind {
+  RMI_MODEL_LINEAR = 0,
+  RMI_MODEL_LINEAR_SPLINE = 1,
+  RMI_MODEL_CUBIC = 2,
+  RMI_MODEL_RADIX = 3,
+  RMI_MODEL_ROBUST_LINEAR = 4,
+  RMI_MODEL_LOGLINEAR = 5,
+  RMI_MODEL_NORMAL = 6,
+  RMI_MODEL_LOGNORMAL = 7,
+  RMI_MODEL_RADIX8 = 8,
+  RMI_MODEL_RADIX18 = 9,
+  RMI_MODEL_RADIX22 = 10,
+  RMI_MODEL_RADIX26 = 11,
+  RMI_MODEL_RADIX28 = 12,
+  RMI_MODEL_BRADIX = 13,
+  RMI_MODEL_HISTOGRAM = 14
+};
+
+enum rmi_hip_error {
+  RMI_OK = 0,
+  RMI_ERR_UNKNOWN_MODEL = -1,      /* panic!("Unknown model type") train/mod.rs:53 */
+  RMI_ERR_RESTRICTION = -2,        /* MustBeTop / MustBeBottom, train/mod.rs:69-82 */
+  RMI_ERR_NON_MONOTONE = -3,       /* assert!(target >= last_target) two_layer.rs:50; :144 */
+  RMI_ERR_DEGENERATE_SPLIT = -4,   /* assert!(end_idx > start_idx) two_layer.rs:27 */
+  RMI_ERR_ROOT_OUT_OF_BOUNDS = -5, /* two_layer.rs:45-48 (roots without bounds check) */
+  RMI_ERR_BAD_ARG = -6,
+  RMI_ERR_NEGATIVE_VARIANCE = -7,  /* linear.rs:48 */
+  RMI_ERR_ROBUST_TOO_SMALL = -8,   /* linear.rs:248 */
+  RMI_ERR_NUM_BITS = -9,           /* utils.rs:18 */
+  RMI_ERR_CUBIC_DEGENERATE = -10,  /* cubic_spline.rs:50 / :61 unwrap() on None */
+  RMI_ERR_UNSUPPORTED_MODEL = -11, /* registry name known, not on the device path */
+  RMI_ERR_LAYERS = -12,            /* != 2 layers: panic!() train/mod.rs:125 */
+  RMI_ERR_NO_KEYS = -13,
+  RMI_ERR_HIP = -14,               /* HIP runtime failure; see rmi_hip_last_error */
+  RMI_ERR_NO_DEVICE = -15
+};
+
+typedef struct rmi_hip_ctx rmi_hip_ctx;
+
+/* Model parameters in `params()` order of each plugin: linear / linear_spline / robust_linear:
+ * p = (alpha, beta) (linear.rs:99-101); cubic: p = (a, b, c, d) (cubic_spline.rs:160-167);
+ * radix: ip = (prefix_len, bits) (radix.rs:60-62). */
+typedef struct {
+  int32_t kind;
+  int32_t _pad;
+  double p[4];
+  uint64_t ip[2];
+} rmi_hip_model_params;
+
+/* Aggregates of two_layer.rs:267-287 + timings.  Per-leaf arrays stay in HBM until downloaded. */
+typedef struct {
+  uint64_t num_rows;              /* TrainedRMI::num_rmi_rows / num_data_rows */
+  uint64_t num_leaves;            /* branching_factor */
+  int32_t leaf_kind;
+  int32_t params_per_leaf;        /* 2 or 4 */
+  uint64_t row_bytes;             /* params_per_leaf*8 + 8 */
+  double model_avg_error;
+  double model_avg_l2_error;
+  double model_avg_log2_error;
+  double model_max_log2_error;
+  uint64_t model_max_error;
+  uint64_t model_max_error_idx;
+  uint64_t split_idx;             /* two_layer.rs:132 (== num_rows when there is no split) */
+  uint64_t split_target;          /* two_layer.rs:152-156 */
+  uint64_t device_ns;             /* hipEvent time of all device work of this call */
+  uint64_t kernel_ns[8];          /* per-kernel hipEvent times, see RMI_K_* */
+} rmi_hip_result;
+
+enum { RMI_K_BOUNDARIES = 0, RMI_K_FILL = 1, RMI_K_FIT = 2, RMI_K_ERR = 3, RMI_K_FINALIZE = 4 };
+
+/* ---- lifetime ---- */
+int rmi_hip_abi_version(void);
+int rmi_hip_device_count(void);
+int rmi_hip_create(int device_id, rmi_hip_ctx** out);
+void rmi_hip_destroy(rmi_hip_ctx* ctx);
+const char* rmi_hip_last_error(const rmi_hip_ctx* ctx);
+const char* rmi_hip_strerror(int code);
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = context's own. */
+int rmi_hip_set_stream(rmi_hip_ctx* ctx, void* hip_stream);
+
+/* ---- registry ---- */
+int rmi_hip_model_from_name(const char* name);       /* id, or RMI_ERR_UNKNOWN_MODEL */
+const char* rmi_hip_model_name(int kind);
+/* validate() + layer-count check of train() (train/mod.rs:59-85, 100-126) for a spec string
+ * such as "linear,linear"; on success writes the two kinds. */
+int rmi_hip_parse_spec(const char* spec, int* root_kind, int* leaf_kind);
+
+/* ---- data ---- */
+/* Copy n keys from host memory into HBM (buffer borrowed for the duration of the call). */
+int rmi_hip_upload_keys(rmi_hip_ctx* ctx, const void* host_keys, uint64_t n, int dtype);
+/* Borrow a device buffer that already holds the sorted keys (stays owned by the caller). */
+int rmi_hip_attach_device_keys(rmi_hip_ctx* ctx, const void* device_keys, uint64_t n, int dtype);
+uint64_t rmi_hip_num_keys(const rmi_hip_ctx* ctx);
+
+/* ---- root model ---- */
+/* Fit the root exactly as the reference does.  `host_keys` may be NULL, in which case the keys
+ * are read back from HBM for the order-dependent fits (linear / robust_linear / cubic). */
+int rmi_hip_fit_root(rmi_hip_ctx* ctx, int root_kind, uint64_t num_leaves, const void* host_keys,
+                     rmi_hip_model_params* out);
+
+/* ---- the hot path ---- */
+int rmi_hip_train_two_layer(rmi_hip_ctx* ctx, const rmi_hip_model_params* root, int leaf_kind,
+                            uint64_t num_leaves, rmi_hip_result* out);
+
+/* ---- results (valid until the next train call on this context) ---- */
+int rmi_hip_download_leaf_params(rmi_hip_ctx* ctx, double* host_out /* L*ppl */);
+int rmi_hip_download_leaf_errors(rmi_hip_ctx* ctx, uint64_t* host_out /* L */);
+int rmi_hip_download_leaf_counts(rmi_hip_ctx* ctx, uint64_t* host_out /* L */);
+int rmi_hip_download_leaf_starts(rmi_hip_ctx* ctx, uint64_t* host_out /* L+1 */);
+int rmi_hip_download_rows(rmi_hip_ctx* ctx, void* host_out /* L*row_bytes */);
+/* Device pointer of the packed rows (for an all-gather over RCCL without a host bounce). */
+void* rmi_hip_device_rows(rmi_hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

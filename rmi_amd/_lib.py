@@ -1,0 +1,70 @@
+"""ctypes loader for librmi_hip.so (the C ABI of include/rmi_hip.h).  Fails loudly when the
+library is missing -- there is no CPU fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "librmi_hip.so")
+
+
+class ModelParams(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("p", C.c_double * 4), ("ip", C.c_uint64 * 2)]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("num_rows", C.c_uint64), ("num_leaves", C.c_uint64),
+        ("leaf_kind", C.c_int32), ("params_per_leaf", C.c_int32), ("row_bytes", C.c_uint64),
+        ("model_avg_error", C.c_double), ("model_avg_l2_error", C.c_double),
+        ("model_avg_log2_error", C.c_double), ("model_max_log2_error", C.c_double),
+        ("model_max_error", C.c_uint64), ("model_max_error_idx", C.c_uint64),
+        ("split_idx", C.c_uint64), ("split_target", C.c_uint64),
+        ("device_ns", C.c_uint64), ("kernel_ns", C.c_uint64 * 8),
+    ]
+
+
+# every symbol include/rmi_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("rmi_hip_abi_version", C.c_int, []),
+    ("rmi_hip_device_count", C.c_int, []),
+    ("rmi_hip_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("rmi_hip_destroy", None, [C.c_void_p]),
+    ("rmi_hip_last_error", C.c_char_p, [C.c_void_p]),
+    ("rmi_hip_strerror", C.c_char_p, [C.c_int]),
+    ("rmi_hip_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rmi_hip_model_from_name", C.c_int, [C.c_char_p]),
+    ("rmi_hip_model_name", C.c_char_p, [C.c_int]),
+    ("rmi_hip_parse_spec", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("rmi_hip_upload_keys", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    ("rmi_hip_attach_device_keys", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    ("rmi_hip_num_keys", C.c_uint64, [C.c_void_p]),
+    ("rmi_hip_fit_root", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(ModelParams)]),
+    ("rmi_hip_train_two_layer", C.c_int, [C.c_void_p, C.POINTER(ModelParams), C.c_int, C.c_uint64, C.POINTER(Result)]),
+    ("rmi_hip_download_leaf_params", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rmi_hip_download_leaf_errors", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rmi_hip_download_leaf_counts", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rmi_hip_download_leaf_starts", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rmi_hip_download_rows", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rmi_hip_device_rows", C.c_void_p, [C.c_void_p]),
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise ImportError(
+            f"{SO} is missing: build it with `python -m rmi_amd.build` (hipcc --offload-arch=gfx950). "
+            "rmi_amd has no CPU fallback for the training hot path.")
+    L = C.CDLL(SO)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

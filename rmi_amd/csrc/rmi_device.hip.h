@@ -1,0 +1,142 @@
+// rmi_device.hip.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Arithmetic rules: IEEE f64, no contraction (built with
+// -ffp-contract=off) except the explicit fma() that mirrors f64::mul_add in the reference
+// (linear.rs:89, linear_spline.rs:52, cubic_spline.rs:146-148); `f64 as u64` saturates
+// (models/mod.rs:736); `u64 as f64` is round-to-nearest-even.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rmi {
+
+enum : int { K_LINEAR = 0, K_LINEAR_SPLINE = 1, K_CUBIC = 2, K_RADIX = 3, K_ROBUST_LINEAR = 4 };
+
+// error bits raised by kernels (host maps them to rmi_hip_error codes)
+enum : uint32_t {
+  EF_NON_MONOTONE = 1u << 0,
+  EF_DEGENERATE_SPLIT = 1u << 1,
+  EF_ROOT_OOB = 1u << 2,
+  EF_NEG_VARIANCE = 1u << 3,
+};
+
+// Root model parameters + branching factor, passed by value to kernels.
+struct RootP {
+  double p0, p1, p2, p3;   // linear-like: (alpha, beta); cubic: (a, b, c, d)
+  uint32_t prefix, bits;   // radix
+  uint64_t L;              // number of leaves
+};
+
+// Small device-resident state shared between the kernels of one train call.
+struct DevState {
+  unsigned long long split_idx;     // two_layer.rs:132-136 ; == n when no key reaches L/2
+  unsigned long long split_target;  // two_layer.rs:152-156
+  unsigned long long last_target;   // leaf of key[n-1] (owner of the Q7 extra count)
+  unsigned int err_flags;
+  unsigned int _pad;
+  // aggregate statistics (two_layer.rs:267-287), filled by the stats kernel
+  unsigned long long max_err;
+  unsigned long long max_err_idx;
+  unsigned long long sum_n_err;     // sum(n*err) wrapping u64
+  double sum_l2;                    // sum((n*err)^2 / N)
+  double sum_log2;                  // sum(n * log2(2 err + 2))
+};
+
+template <typename K> struct KeyTraits;
+template <> struct KeyTraits<uint64_t> {
+  static __device__ __forceinline__ double as_float(uint64_t k) { return (double)k; }   // mod.rs:83
+  static __device__ __forceinline__ uint64_t as_uint(uint64_t k) { return k; }
+  static __device__ __forceinline__ uint64_t minus_eps(uint64_t k) { return k - 1ull; }  // mod.rs:78
+  static __device__ __forceinline__ uint64_t plus_eps(uint64_t k) { return k + 1ull; }   // mod.rs:80
+  static __device__ __forceinline__ uint64_t max_value() { return ~0ull; }
+  static __device__ __forceinline__ uint64_t zero_value() { return 0ull; }
+};
+template <> struct KeyTraits<uint32_t> {
+  static __device__ __forceinline__ double as_float(uint32_t k) { return (double)k; }   // mod.rs:95
+  static __device__ __forceinline__ uint64_t as_uint(uint32_t k) { return (uint64_t)k; } // mod.rs:474-478
+  static __device__ __forceinline__ uint32_t minus_eps(uint32_t k) { return k - 1u; }
+  static __device__ __forceinline__ uint32_t plus_eps(uint32_t k) { return k + 1u; }
+  static __device__ __forceinline__ uint32_t max_value() { return 0xFFFFFFFFu; }
+  static __device__ __forceinline__ uint32_t zero_value() { return 0u; }
+};
+
+// Rust `f64 as u64` (saturating, NaN -> 0)
+__device__ __forceinline__ uint64_t sat_f64_to_u64(double v) {
+  if (!(v > 0.0)) return 0ull;
+  if (v >= 18446744073709551616.0) return ~0ull;
+  return (uint64_t)v;
+}
+template <> struct KeyTraits<double> {
+  static __device__ __forceinline__ double as_float(double k) { return k; }              // mod.rs:107
+  static __device__ __forceinline__ uint64_t as_uint(double k) { return sat_f64_to_u64(k); } // mod.rs:108
+  static __device__ __forceinline__ double minus_eps(double k) { return k - 2.220446049250313e-16; }
+  static __device__ __forceinline__ double plus_eps(double k) { return k + 2.220446049250313e-16; }
+  static __device__ __forceinline__ double max_value() { return 1.7976931348623157e308; }
+  static __device__ __forceinline__ double zero_value() { return 0.0; }
+};
+
+// Model::predict_to_int default (models/mod.rs:735-737) applied to a float prediction
+__device__ __forceinline__ uint64_t float_pred_to_int(double f) {
+  return sat_f64_to_u64(fmax(0.0, floor(f)));
+}
+
+// Root prediction, NOT yet clamped to L-1.
+template <int ROOT, typename K>
+__device__ __forceinline__ uint64_t root_predict(const RootP& r, K k) {
+  if constexpr (ROOT == K_RADIX) {
+    // radix.rs:43-50 (release-mode masked shifts)
+    uint64_t v = KeyTraits<K>::as_uint(k);
+    return (v << (r.prefix & 63u)) >> ((64u - r.bits) & 63u);
+  } else if constexpr (ROOT == K_CUBIC) {
+    double x = KeyTraits<K>::as_float(k);
+    double v1 = __builtin_fma(r.p0, x, r.p1);     // cubic_spline.rs:146-148
+    double v2 = __builtin_fma(v1, x, r.p2);
+    double v3 = __builtin_fma(v2, x, r.p3);
+    return float_pred_to_int(v3);
+  } else {
+    double x = KeyTraits<K>::as_float(k);
+    return float_pred_to_int(__builtin_fma(r.p1, x, r.p0));   // linear.rs:87-90
+  }
+}
+
+template <int ROOT>
+__device__ __forceinline__ constexpr bool root_needs_bounds_check() {
+  return !(ROOT == K_CUBIC || ROOT == K_RADIX);   // cubic_spline.rs:184-186, radix.rs:72-74
+}
+
+// Leaf prediction (predict_to_int) from a row of parameters.
+template <int LEAF, typename K>
+__device__ __forceinline__ uint64_t leaf_predict(const double* __restrict__ p, K k) {
+  double x = KeyTraits<K>::as_float(k);
+  if constexpr (LEAF == K_CUBIC) {
+    double v1 = __builtin_fma(p[0], x, p[1]);
+    double v2 = __builtin_fma(v1, x, p[2]);
+    double v3 = __builtin_fma(v2, x, p[3]);
+    return float_pred_to_int(v3);
+  } else {
+    return float_pred_to_int(__builtin_fma(p[1], x, p[0]));
+  }
+}
+
+// error_between: two_layer.rs:14-18
+__device__ __forceinline__ uint64_t error_between(uint64_t v1, uint64_t v2, uint64_t max_pred) {
+  uint64_t p1 = v1 < max_pred ? v1 : max_pred;
+  uint64_t p2 = v2 < max_pred ? v2 : max_pred;
+  return p1 > p2 ? p1 - p2 : p2 - p1;
+}
+
+// Offset of the first occurrence of keys[i] (FixDupsIter semantics, models/mod.rs:154-185):
+// lower_bound of keys[i] in [0, i].  O(1) when keys[i-1] != keys[i].
+template <typename K>
+__device__ __forceinline__ uint64_t first_occurrence(const K* __restrict__ keys, uint64_t i) {
+  K v = keys[i];
+  if (i == 0 || keys[i - 1] != v) return i;
+  uint64_t lo = 0, hi = i - 1;   // keys[hi] == v
+  while (lo < hi) {
+    uint64_t mid = lo + ((hi - lo) >> 1);
+    if (keys[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+}  // namespace rmi

@@ -1,0 +1,417 @@
+// rmi_hip.hip -- C ABI (include/rmi_hip.h) over the gfx950 kernels.  Host orchestration only:
+// every per-key / per-leaf computation of the hot path runs in the HIP kernels of
+// rmi_kernels.hip.h.  There is no CPU fallback: without a HIP device every compute entry point
+// returns RMI_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rmi_hip.h"
+#include "rmi_kernels.hip.h"
+#include "rmi_root_host.h"
+
+using namespace rmi;
+
+struct rmi_hip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // keys
+  const void* d_keys = nullptr;
+  void* d_keys_owned = nullptr;
+  uint64_t n = 0;
+  int dtype = RMI_KEY_U64;
+  // outputs (capacity in leaves)
+  uint64_t cap_leaves = 0;
+  int cap_ppl = 0;
+  unsigned long long* d_leaf_start = nullptr;   // L+1
+  double* d_params = nullptr;                   // L*ppl
+  unsigned long long* d_maxerr = nullptr;       // L
+  unsigned long long* d_run = nullptr;          // L
+  unsigned long long* d_err = nullptr;          // L
+  unsigned long long* d_count = nullptr;        // L
+  unsigned char* d_rows = nullptr;              // L*(ppl*8+8)
+  unsigned long long* d_tilemin = nullptr;
+  DevState* d_state = nullptr;
+  DevState* h_state = nullptr;                  // pinned
+  hipEvent_t ev[10] = {};
+  bool profile_kernels = false;
+  // last result
+  uint64_t last_L = 0;
+  int last_ppl = 2;
+  std::string err;
+};
+
+static void set_err(rmi_hip_ctx* c, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (c) c->err = buf;
+}
+
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (call);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      set_err(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return RMI_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+extern "C" {
+
+int rmi_hip_abi_version(void) { return RMI_HIP_ABI_VERSION; }
+
+int rmi_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* rmi_hip_strerror(int code) {
+  switch (code) {
+    case RMI_OK: return "ok";
+    case RMI_ERR_UNKNOWN_MODEL: return "unknown model type (train/mod.rs:53)";
+    case RMI_ERR_RESTRICTION: return "model layer restriction violated (train/mod.rs:69-82)";
+    case RMI_ERR_NON_MONOTONE: return "root model is not monotone on the data (two_layer.rs:50)";
+    case RMI_ERR_DEGENERATE_SPLIT: return "degenerate split: a half of the 2-way join is empty (two_layer.rs:27)";
+    case RMI_ERR_ROOT_OUT_OF_BOUNDS: return "root prediction out of bounds for a root without bounds check (two_layer.rs:45)";
+    case RMI_ERR_BAD_ARG: return "bad argument";
+    case RMI_ERR_NEGATIVE_VARIANCE: return "negative variance in SLR (linear.rs:48)";
+    case RMI_ERR_ROBUST_TOO_SMALL: return "robust_linear needs more data (linear.rs:248)";
+    case RMI_ERR_NUM_BITS: return "radix: num_bits assertion (utils.rs:18)";
+    case RMI_ERR_CUBIC_DEGENERATE: return "cubic: no interior point (cubic_spline.rs:50/61)";
+    case RMI_ERR_UNSUPPORTED_MODEL: return "model type is in the registry but not on the device path";
+    case RMI_ERR_LAYERS: return "only two-layer RMIs are supported (train/mod.rs:125)";
+    case RMI_ERR_NO_KEYS: return "no keys resident";
+    case RMI_ERR_HIP: return "HIP runtime error";
+    case RMI_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown error";
+  }
+}
+
+static const char* const kModelNames[] = {
+    "linear", "linear_spline", "cubic", "radix", "robust_linear", "loglinear", "normal", "lognormal",
+    "radix8", "radix18", "radix22", "radix26", "radix28", "bradix", "histogram"};
+constexpr int kNumModels = sizeof(kModelNames) / sizeof(kModelNames[0]);
+
+int rmi_hip_model_from_name(const char* name) {
+  if (!name) return RMI_ERR_UNKNOWN_MODEL;
+  for (int i = 0; i < kNumModels; i++)
+    if (std::strcmp(name, kModelNames[i]) == 0) return i;
+  return RMI_ERR_UNKNOWN_MODEL;
+}
+
+const char* rmi_hip_model_name(int kind) {
+  if (kind < 0 || kind >= kNumModels) return nullptr;
+  return kModelNames[kind];
+}
+
+static bool must_be_top(int kind) {
+  // radix.rs:75-80, radix.rs:166-168 (RadixTable), balanced_radix.rs, histogram.rs (MustBeTop)
+  switch (kind) {
+    case RMI_MODEL_RADIX: case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22:
+    case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28: case RMI_MODEL_BRADIX: case RMI_MODEL_HISTOGRAM:
+      return true;
+    default: return false;
+  }
+}
+
+int rmi_hip_parse_spec(const char* spec, int* root_kind, int* leaf_kind) {
+  if (!spec) return RMI_ERR_BAD_ARG;
+  std::vector<std::string> parts;
+  std::string cur;
+  for (const char* p = spec;; p++) {
+    if (*p == ',' || *p == 0) { parts.push_back(cur); cur.clear(); if (!*p) break; }
+    else cur.push_back(*p);
+  }
+  std::vector<int> kinds;
+  for (size_t i = 0; i < parts.size(); i++) {      // validate(): train/mod.rs:59-85
+    int k = rmi_hip_model_from_name(parts[i].c_str());
+    if (k < 0) return RMI_ERR_UNKNOWN_MODEL;
+    if (must_be_top(k) && i != 0) return RMI_ERR_RESTRICTION;
+    kinds.push_back(k);
+  }
+  if (kinds.size() != 2) return RMI_ERR_LAYERS;    // train/mod.rs:111-125
+  if (root_kind) *root_kind = kinds[0];
+  if (leaf_kind) *leaf_kind = kinds[1];
+  return RMI_OK;
+}
+
+int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
+  if (!out) return RMI_ERR_BAD_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return RMI_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= ndev) return RMI_ERR_BAD_ARG;
+  rmi_hip_ctx* c = new rmi_hip_ctx();
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  c->stream = c->own_stream;
+  if (hipMalloc(&c->d_state, sizeof(DevState)) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  if (hipHostMalloc((void**)&c->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  const char* pk = std::getenv("RMI_HIP_PROFILE_KERNELS");
+  c->profile_kernels = pk && *pk && *pk != '0';
+  *out = c;
+  return RMI_OK;
+}
+
+static void free_outputs(rmi_hip_ctx* c) {
+  (void)hipFree(c->d_leaf_start); (void)hipFree(c->d_params); (void)hipFree(c->d_maxerr); (void)hipFree(c->d_run);
+  (void)hipFree(c->d_err); (void)hipFree(c->d_count); (void)hipFree(c->d_rows); (void)hipFree(c->d_tilemin);
+  c->d_leaf_start = nullptr; c->d_params = nullptr; c->d_maxerr = nullptr; c->d_run = nullptr;
+  c->d_err = nullptr; c->d_count = nullptr; c->d_rows = nullptr; c->d_tilemin = nullptr;
+  c->cap_leaves = 0; c->cap_ppl = 0;
+}
+
+void rmi_hip_destroy(rmi_hip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_outputs(c);
+  if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
+  if (c->d_state) (void)hipFree(c->d_state);
+  if (c->h_state) (void)hipHostFree(c->h_state);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* rmi_hip_last_error(const rmi_hip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rmi_hip_set_stream(rmi_hip_ctx* c, void* s) {
+  if (!c) return RMI_ERR_BAD_ARG;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return RMI_OK;
+}
+
+static size_t key_size(int dtype) { return dtype == RMI_KEY_U32 ? 4 : 8; }
+
+int rmi_hip_upload_keys(rmi_hip_ctx* c, const void* host_keys, uint64_t n, int dtype) {
+  if (!c || !host_keys || n == 0 || dtype < 0 || dtype > 2) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->d_keys_owned) { HIPCHK(c, hipFree(c->d_keys_owned)); c->d_keys_owned = nullptr; }
+  HIPCHK(c, hipMalloc(&c->d_keys_owned, n * key_size(dtype)));
+  HIPCHK(c, hipMemcpyAsync(c->d_keys_owned, host_keys, n * key_size(dtype), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->d_keys = c->d_keys_owned; c->n = n; c->dtype = dtype;
+  return RMI_OK;
+}
+
+int rmi_hip_attach_device_keys(rmi_hip_ctx* c, const void* device_keys, uint64_t n, int dtype) {
+  if (!c || !device_keys || n == 0 || dtype < 0 || dtype > 2) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->d_keys_owned) { HIPCHK(c, hipFree(c->d_keys_owned)); c->d_keys_owned = nullptr; }
+  c->d_keys = device_keys; c->n = n; c->dtype = dtype;
+  return RMI_OK;
+}
+
+uint64_t rmi_hip_num_keys(const rmi_hip_ctx* c) { return c ? c->n : 0; }
+
+int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const void* host_keys,
+                     rmi_hip_model_params* out) {
+  if (!c || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  if (root_kind < 0 || root_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
+  if (root_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
+  if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  std::vector<unsigned char> tmp;
+  const void* hk = host_keys;
+  if (!hk) {
+    // TODO(next): radix / linear_spline need O(1) keys only; linear needs the full pass.
+    HIPCHK(c, hipSetDevice(c->device));
+    tmp.resize(c->n * key_size(c->dtype));
+    HIPCHK(c, hipMemcpy(tmp.data(), c->d_keys, tmp.size(), hipMemcpyDeviceToHost));
+    hk = tmp.data();
+  }
+  switch (c->dtype) {
+    case RMI_KEY_U64: return rmi_host::fit_root<uint64_t>(root_kind, (const uint64_t*)hk, c->n, num_leaves, out);
+    case RMI_KEY_U32: return rmi_host::fit_root<uint32_t>(root_kind, (const uint32_t*)hk, c->n, num_leaves, out);
+    case RMI_KEY_F64: return rmi_host::fit_root<double>(root_kind, (const double*)hk, c->n, num_leaves, out);
+  }
+  return RMI_ERR_BAD_ARG;
+}
+
+}  // extern "C"
+
+static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
+  if (L <= c->cap_leaves && ppl <= c->cap_ppl) return RMI_OK;
+  free_outputs(c);
+  HIPCHK(c, hipMalloc(&c->d_leaf_start, (L + 1) * 8));
+  HIPCHK(c, hipMalloc(&c->d_params, L * ppl * 8));
+  HIPCHK(c, hipMalloc(&c->d_maxerr, L * 8));
+  HIPCHK(c, hipMalloc(&c->d_run, L * 8));
+  HIPCHK(c, hipMalloc(&c->d_err, L * 8));
+  HIPCHK(c, hipMalloc(&c->d_count, L * 8));
+  HIPCHK(c, hipMalloc(&c->d_rows, L * (ppl * 8 + 8)));
+  HIPCHK(c, hipMalloc(&c->d_tilemin, ((L + 1 + FILL_TILE - 1) / FILL_TILE + 1) * 8));
+  c->cap_leaves = L; c->cap_ppl = ppl;
+  return RMI_OK;
+}
+
+template <int ROOT, int LEAF, typename K>
+static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
+  const K* keys = (const K*)c->d_keys;
+  const uint64_t n = c->n;
+  hipStream_t s = c->stream;
+  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
+  const bool pk = c->profile_kernels;
+  int evi = 0;
+  auto mark = [&]() { if (pk) (void)hipEventRecord(c->ev[1 + evi], s); evi++; };
+
+  // --- init ---
+  DevState init; std::memset(&init, 0, sizeof init);
+  init.split_idx = n; init.split_target = 0;
+  *c->h_state = init;
+  HIPCHK(c, hipMemcpyAsync(c->d_state, c->h_state, sizeof(DevState), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->d_leaf_start, 0xFF, (L + 1) * 8, s));
+  HIPCHK(c, hipMemcpyAsync(c->d_leaf_start + L, &c->n, 8, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->d_maxerr, 0, L * 8, s));
+  HIPCHK(c, hipMemsetAsync(c->d_run, 0, L * 8, s));
+
+  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  // --- bucketing scan ---
+  {
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_leaf_start, c->d_state);
+  }
+  mark();
+  // --- fill empty leaves ---
+  {
+    const uint64_t count = L + 1;
+    const uint64_t ntiles = (count + FILL_TILE - 1) / FILL_TILE;
+    hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count, c->d_tilemin);
+    hipLaunchKernelGGL(k_fill_scan_tiles, dim3(1), dim3(1024), 0, s, c->d_tilemin, ntiles);
+    hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count, c->d_tilemin);
+  }
+  mark();
+  // --- per-leaf fit ---
+  {
+    const uint64_t blocks = (L + 255) / 256;
+    hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, L, c->d_leaf_start, c->d_state, c->d_params);
+  }
+  mark();
+  // --- error pass ---
+  {
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run);
+  }
+  mark();
+  // --- finalize + stats ---
+  {
+    const uint64_t blocks = (L + 255) / 256;
+    hipLaunchKernelGGL((k_finalize<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, L, c->d_leaf_start, c->d_state,
+                       c->d_params, c->d_maxerr, c->d_run, c->d_err, c->d_count, c->d_rows);
+    const unsigned sb = (unsigned)(blocks < 256 ? blocks : 256);
+    hipLaunchKernelGGL(k_stats, dim3(sb), dim3(256), 0, s, L, n, c->d_err, c->d_count, c->d_state);
+    hipLaunchKernelGGL(k_stats_argmax, dim3(sb), dim3(256), 0, s, L, c->d_err, c->d_state);
+  }
+  mark();
+  HIPCHK(c, hipEventRecord(c->ev[9], s));
+  HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipGetLastError());
+  (void)PPL;
+  return RMI_OK;
+}
+
+template <int ROOT, typename K>
+static int dispatch_leaf(rmi_hip_ctx* c, const RootP& rp, int leaf_kind, uint64_t L) {
+  switch (leaf_kind) {
+    case RMI_MODEL_LINEAR: return launch_pipeline<ROOT, K_LINEAR, K>(c, rp, L);
+    case RMI_MODEL_LINEAR_SPLINE: return launch_pipeline<ROOT, K_LINEAR_SPLINE, K>(c, rp, L);
+    default: return RMI_ERR_UNSUPPORTED_MODEL;
+  }
+}
+
+template <typename K>
+static int dispatch_root(rmi_hip_ctx* c, int root_kind, const RootP& rp, int leaf_kind, uint64_t L) {
+  switch (root_kind) {
+    case RMI_MODEL_LINEAR: case RMI_MODEL_ROBUST_LINEAR: case RMI_MODEL_LINEAR_SPLINE:
+      return dispatch_leaf<K_LINEAR, K>(c, rp, leaf_kind, L);     // all three predict with fma(beta, x, alpha)
+    case RMI_MODEL_CUBIC: return dispatch_leaf<K_CUBIC, K>(c, rp, leaf_kind, L);
+    case RMI_MODEL_RADIX: return dispatch_leaf<K_RADIX, K>(c, rp, leaf_kind, L);
+    default: return RMI_ERR_UNSUPPORTED_MODEL;
+  }
+}
+
+extern "C" {
+
+int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, int leaf_kind,
+                            uint64_t num_leaves, rmi_hip_result* out) {
+  if (!c || !root || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  if (root->kind < 0 || root->kind >= kNumModels || leaf_kind < 0 || leaf_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
+  if (must_be_top(leaf_kind)) return RMI_ERR_RESTRICTION;
+  if (root->kind > RMI_MODEL_ROBUST_LINEAR || leaf_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
+  // robust_linear as a leaf trims 0.01% tails of each container (linear.rs:247-252); not on the device path yet
+  if (leaf_kind == RMI_MODEL_ROBUST_LINEAR || leaf_kind == RMI_MODEL_CUBIC) return RMI_ERR_UNSUPPORTED_MODEL;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int ppl = leaf_kind == RMI_MODEL_CUBIC ? 4 : 2;
+  int rc = ensure_outputs(c, num_leaves, ppl);
+  if (rc) return rc;
+  RootP rp;
+  rp.p0 = root->p[0]; rp.p1 = root->p[1]; rp.p2 = root->p[2]; rp.p3 = root->p[3];
+  rp.prefix = (uint32_t)root->ip[0]; rp.bits = (uint32_t)root->ip[1];
+  rp.L = num_leaves;
+  switch (c->dtype) {
+    case RMI_KEY_U64: rc = dispatch_root<uint64_t>(c, root->kind, rp, leaf_kind, num_leaves); break;
+    case RMI_KEY_U32: rc = dispatch_root<uint32_t>(c, root->kind, rp, leaf_kind, num_leaves); break;
+    case RMI_KEY_F64: rc = dispatch_root<double>(c, root->kind, rp, leaf_kind, num_leaves); break;
+    default: rc = RMI_ERR_BAD_ARG;
+  }
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->last_L = num_leaves; c->last_ppl = ppl;
+
+  const DevState& st = *c->h_state;
+  if (st.err_flags) {
+    if (st.err_flags & EF_NON_MONOTONE) rc = RMI_ERR_NON_MONOTONE;
+    else if (st.err_flags & EF_ROOT_OOB) rc = RMI_ERR_ROOT_OUT_OF_BOUNDS;
+    else if (st.err_flags & EF_DEGENERATE_SPLIT) rc = RMI_ERR_DEGENERATE_SPLIT;
+    else if (st.err_flags & EF_NEG_VARIANCE) rc = RMI_ERR_NEGATIVE_VARIANCE;
+    set_err(c, "%s", rmi_hip_strerror(rc));
+    return rc;
+  }
+  std::memset(out, 0, sizeof *out);
+  out->num_rows = c->n; out->num_leaves = num_leaves; out->leaf_kind = leaf_kind;
+  out->params_per_leaf = ppl; out->row_bytes = (uint64_t)ppl * 8 + 8;
+  out->model_max_error = st.max_err; out->model_max_error_idx = st.max_err_idx;
+  out->model_avg_error = (double)st.sum_n_err / (double)c->n;
+  out->model_avg_l2_error = st.sum_l2;
+  out->model_avg_log2_error = st.sum_log2 / (double)c->n;
+  out->model_max_log2_error = std::log2((double)st.max_err);
+  out->split_idx = st.split_idx; out->split_target = st.split_target;
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[9]));
+  out->device_ns = (uint64_t)((double)ms * 1e6);
+  if (c->profile_kernels) {
+    for (int k = 0; k < 5; k++) {
+      float m2 = 0.f;
+      hipEvent_t a = k == 0 ? c->ev[0] : c->ev[k];
+      if (hipEventElapsedTime(&m2, a, c->ev[k + 1]) == hipSuccess) out->kernel_ns[k] = (uint64_t)((double)m2 * 1e6);
+    }
+  }
+  return RMI_OK;
+}
+
+static int dl(rmi_hip_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || !dst) return RMI_ERR_BAD_ARG;
+  if (!c->last_L) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RMI_OK;
+}
+int rmi_hip_download_leaf_params(rmi_hip_ctx* c, double* o) { return dl(c, o, c ? c->d_params : nullptr, c ? c->last_L * c->last_ppl * 8 : 0); }
+int rmi_hip_download_leaf_errors(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_err : nullptr, c ? c->last_L * 8 : 0); }
+int rmi_hip_download_leaf_counts(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_count : nullptr, c ? c->last_L * 8 : 0); }
+int rmi_hip_download_leaf_starts(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_leaf_start : nullptr, c ? (c->last_L + 1) * 8 : 0); }
+int rmi_hip_download_rows(rmi_hip_ctx* c, void* o) { return dl(c, o, c ? c->d_rows : nullptr, c ? c->last_L * (c->last_ppl * 8 + 8) : 0); }
+void* rmi_hip_device_rows(rmi_hip_ctx* c) { return c ? c->d_rows : nullptr; }
+
+}  // extern "C"

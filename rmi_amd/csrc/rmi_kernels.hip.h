@@ -1,0 +1,399 @@
+// rmi_kernels.hip.h -- gfx950 kernels of the two-layer leaf path (pipeline "v1": one kernel per
+// reference pass; see DESIGN.md for the roofline of each and for the fused successors).
+//
+//   k_boundaries   bucketing scan: target(key) for every key, leaf boundary table, split point,
+//                  monotonicity / bounds checks            (two_layer.rs:43-50, 130-156)
+//   k_fill_*       suffix-min fill of leaf_start for empty leaves
+//   k_fit_leaf     per-leaf fit on the reference's container C_j (two_layer.rs:52-90) in
+//                  reference order: Welford SLR (linear.rs:12-59) / endpoints
+//                  (linear_spline.rs:13-35)
+//   k_err          last-level error pass + run lengths    (two_layer.rs:207-217,
+//                  lower_bound_correction.rs:104-125)
+//   k_finalize     empty-leaf fix, lower-bound widening, row packing
+//                  (two_layer.rs:185-197, 226-259; codegen.rs:288-315)
+//   k_stats        aggregates                              (two_layer.rs:267-287)
+#pragma once
+#include "rmi_device.hip.h"
+
+namespace rmi {
+
+constexpr int WAVE = 64;
+constexpr unsigned long long NO_START = ~0ull;
+
+// ---------------------------------------------------------------------------------------------
+// k_boundaries: one thread per key.  Targets are monotone non-decreasing (else the reference
+// panics), so leaf_start[j] = first i with target(key[i]) >= j is a boundary detect.
+// ---------------------------------------------------------------------------------------------
+template <int ROOT, typename K>
+__global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, uint64_t n, RootP r,
+                                                    unsigned long long* __restrict__ leaf_start,
+                                                    DevState* __restrict__ st) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t Lm1 = r.L - 1;
+  const uint64_t mid = r.L / 2;                                   // two_layer.rs:131
+  const uint64_t p = root_predict<ROOT, K>(r, keys[i]);
+  if constexpr (!root_needs_bounds_check<ROOT>()) {
+    if (p > Lm1) atomicOr(&st->err_flags, EF_ROOT_OOB);           // two_layer.rs:45-48
+  }
+  const uint64_t t = p < Lm1 ? p : Lm1;                           // two_layer.rs:49
+  if (i == 0) {
+    leaf_start[t] = 0;
+    if (t >= mid) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);  // split_idx == 0 -> :27
+  } else {
+    const uint64_t pp = root_predict<ROOT, K>(r, keys[i - 1]);
+    const uint64_t tp = pp < Lm1 ? pp : Lm1;
+    if (t < tp) atomicOr(&st->err_flags, EF_NON_MONOTONE);        // two_layer.rs:50 / :144
+    else if (t > tp) {
+      leaf_start[t] = i;
+      if (tp < mid && t >= mid) {                                 // two_layer.rs:132-136,152-156
+        st->split_idx = i;
+        st->split_target = t;
+        if (i + 1 >= n) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);  // second half empty -> :27
+      }
+    }
+  }
+  if (i == n - 1) st->last_target = t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Suffix-min fill: leaf_start[j] = min_{j' >= j} leaf_start[j'] with leaf_start[L] = n.
+// Three small kernels over L+1 entries (tile = 2048 entries per block).
+// ---------------------------------------------------------------------------------------------
+constexpr int FILL_TILE = 2048;
+
+__global__ void __launch_bounds__(256) k_fill_tilemin(const unsigned long long* __restrict__ ls, uint64_t count,
+                                                      unsigned long long* __restrict__ tile_min) {
+  __shared__ unsigned long long sm[256];
+  const uint64_t base = (uint64_t)blockIdx.x * FILL_TILE;
+  unsigned long long m = NO_START;
+  for (int k = threadIdx.x; k < FILL_TILE; k += 256) {
+    uint64_t idx = base + k;
+    if (idx < count) { unsigned long long v = ls[idx]; m = v < m ? v : m; }
+  }
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { unsigned long long o = sm[threadIdx.x + s]; if (o < sm[threadIdx.x]) sm[threadIdx.x] = o; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tile_min[blockIdx.x] = sm[0];
+}
+
+// single block: exclusive suffix-min over the tile minima (carry-in for each tile)
+__global__ void __launch_bounds__(1024) k_fill_scan_tiles(unsigned long long* __restrict__ tile_min, uint64_t ntiles) {
+  __shared__ unsigned long long sm[1024];
+  // each thread owns a contiguous span of tiles, processed right-to-left
+  const uint64_t per = (ntiles + 1023) / 1024;
+  const uint64_t lo = (uint64_t)threadIdx.x * per;
+  const uint64_t hi = lo + per < ntiles ? lo + per : ntiles;
+  unsigned long long m = NO_START;
+  for (uint64_t k = hi; k-- > lo;) { unsigned long long v = tile_min[k]; m = v < m ? v : m; }
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  // carry for thread t = min over threads > t (serial over 1024 entries by one thread: tiny)
+  if (threadIdx.x == 0) {
+    unsigned long long run = NO_START;
+    for (int k = 1023; k >= 0; k--) { unsigned long long v = sm[k]; sm[k] = run; run = v < run ? v : run; }
+  }
+  __syncthreads();
+  unsigned long long carry = sm[threadIdx.x];
+  for (uint64_t k = hi; k-- > lo;) {
+    unsigned long long v = tile_min[k];
+    tile_min[k] = carry;              // exclusive: min of all tiles to the right
+    carry = v < carry ? v : carry;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fill_apply(unsigned long long* __restrict__ ls, uint64_t count,
+                                                    const unsigned long long* __restrict__ tile_carry) {
+  // one wave-serial pass per tile is enough: tile is 2048 entries; thread t owns 8 consecutive
+  // entries, block-level exclusive suffix-min across threads via LDS.
+  __shared__ unsigned long long sm[256];
+  const uint64_t base = (uint64_t)blockIdx.x * FILL_TILE + (uint64_t)threadIdx.x * 8;
+  unsigned long long v[8];
+  unsigned long long m = NO_START;
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    uint64_t idx = base + k;
+    v[k] = idx < count ? ls[idx] : NO_START;
+    m = v[k] < m ? v[k] : m;
+  }
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = tile_carry[blockIdx.x];
+    for (int k = 255; k >= 0; k--) { unsigned long long x = sm[k]; sm[k] = run; run = x < run ? x : run; }
+  }
+  __syncthreads();
+  unsigned long long carry = sm[threadIdx.x];
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    uint64_t idx = base + k;
+    carry = v[k] < carry ? v[k] : carry;
+    if (idx < count) ls[idx] = carry;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Container bounds of leaf j (closed form of build_models_from, two_layer.rs:20-99, including
+// the quirks Q2-Q4 of SURVEY.md section 8a).  Returns kind of container:
+//   0 = empty model, 1 = single borrowed point at index `lo` (Q4), 2 = range [lo, hi] inclusive.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int leaf_container(uint64_t j, uint64_t s, uint64_t e, uint64_t n,
+                                              uint64_t split_idx, uint64_t split_target,
+                                              uint64_t& lo, uint64_t& hi) {
+  uint64_t a, b, f;
+  if (split_idx < n) {
+    if (j < split_target) { a = 0; b = split_idx; f = 0; }          // first half  (:162-165)
+    else { a = split_idx + 1; b = n; f = split_target; }            // second half (:166-169), Q2
+  } else { a = 0; b = n; f = 0; }                                   // :147-150
+  uint64_t own_lo = s > a ? s : a;
+  uint64_t own_hi = e < b ? e : b;
+  if (own_lo >= own_hi) {
+    if (j == f) { lo = hi = a; return 1; }                          // Q4 (:52-63 on empty data)
+    return 0;                                                       // :67-69 / :94-96
+  }
+  lo = own_lo > a ? own_lo - 1 : own_lo;                            // prev-last  (:74-78), Q3
+  hi = own_hi < b ? own_hi : own_hi - 1;                            // next-first (:58-59), Q3
+  return 2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fit_leaf: one lane per leaf, reference order.  (Exact mode: the SLR recurrence is order
+// dependent, so each leaf is a sequential chain; parallelism is across leaves.)
+// ---------------------------------------------------------------------------------------------
+template <int LEAF, typename K>
+__global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, uint64_t n, uint64_t L,
+                                                  const unsigned long long* __restrict__ leaf_start,
+                                                  DevState* __restrict__ st,
+                                                  double* __restrict__ params) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= L) return;
+  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
+  const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+  uint64_t lo, hi;
+  const int ck = leaf_container(j, s, e, n, st->split_idx, st->split_target, lo, hi);
+  double* out = params + j * PPL;
+  if (ck == 0) {
+    if constexpr (LEAF == K_CUBIC) { out[0] = 0.0; out[1] = 0.0; out[2] = 1.0; out[3] = 0.0; }  // cubic_spline.rs:19-21
+    else { out[0] = 0.0; out[1] = 0.0; }                                                         // linear.rs:37-39
+    return;
+  }
+  if (ck == 1) {
+    // single point (key[lo], y = lo): its key differs from key[lo-1] (different leaf) so y == lo
+    const double y = (double)lo;
+    if constexpr (LEAF == K_CUBIC) { out[0] = 0.0; out[1] = 0.0; out[2] = 0.0; out[3] = y; }    // cubic_spline.rs:23-25
+    else { out[0] = y; out[1] = 0.0; }   // linear.rs:50-53 (two identical items) / linear_spline.rs:18-20
+    return;
+  }
+  if constexpr (LEAF == K_LINEAR) {
+    // slr: linear.rs:12-59 over C_j.iter(): FixDups offsets + the tail duplicate (Q1)
+    double mean_x = 0.0, mean_y = 0.0, c = 0.0, m2 = 0.0;
+    uint64_t cnt = 0;
+    uint64_t y = first_occurrence(keys, lo);
+    K prev = keys[lo];
+    double x = 0.0, yf = 0.0;
+    for (uint64_t i = lo; i <= hi; i++) {
+      const K k = keys[i];
+      if (i > lo && !(k == prev)) y = i;
+      prev = k;
+      x = KeyTraits<K>::as_float(k);
+      yf = (double)y;
+      cnt += 1;
+      const double nf = (double)cnt;
+      const double dx = x - mean_x;
+      mean_x += dx / nf;
+      mean_y += (yf - mean_y) / nf;
+      c += dx * (yf - mean_y);
+      const double dx2 = x - mean_x;
+      m2 += dx * dx2;
+    }
+    {  // Q1: last item once more (models/mod.rs:180)
+      cnt += 1;
+      const double nf = (double)cnt;
+      const double dx = x - mean_x;
+      mean_x += dx / nf;
+      mean_y += (yf - mean_y) / nf;
+      c += dx * (yf - mean_y);
+      const double dx2 = x - mean_x;
+      m2 += dx * dx2;
+    }
+    const double cov = c / (double)(cnt - 1);
+    const double var = m2 / (double)(cnt - 1);
+    if (!(var >= 0.0)) atomicOr(&st->err_flags, EF_NEG_VARIANCE);   // linear.rs:48
+    if (var == 0.0) { out[0] = mean_y; out[1] = 0.0; return; }       // linear.rs:50-53
+    const double beta = cov / var;
+    const double alpha = mean_y - beta * mean_x;                     // no fma: linear.rs:56
+    out[0] = alpha; out[1] = beta;
+  } else if constexpr (LEAF == K_LINEAR_SPLINE) {
+    // linear_splines: linear_spline.rs:13-35 on get(0), get(len-1) of the container
+    const K k0 = keys[lo], k1 = keys[hi];
+    const double y0 = (double)first_occurrence(keys, lo);
+    if (lo == hi || k0 == k1) { out[0] = y0; out[1] = 0.0; return; }
+    const double y1 = (double)first_occurrence(keys, hi);
+    const double x0 = KeyTraits<K>::as_float(k0), x1 = KeyTraits<K>::as_float(k1);
+    const double slope = (y0 - y1) / (x0 - x1);
+    const double intercept = y0 - slope * x0;                        // plain mul+sub
+    out[0] = intercept; out[1] = slope;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_err: one thread per key: err = |min(pred,N) - min(y,N)| with the leaf's model
+// (two_layer.rs:207-217) and run lengths of equal keys (lower_bound_correction.rs:104-119,
+// incl. Q5: the globally last run is never recorded).  Keys of one leaf are contiguous, so a
+// wave first reduces per leaf segment with shuffles and issues one atomic per segment.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int d) {
+  unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+  lo = __shfl_up(lo, d, WAVE); hi = __shfl_up(hi, d, WAVE);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int d) {
+  unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+  lo = __shfl_down(lo, d, WAVE); hi = __shfl_down(hi, d, WAVE);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int ROOT, int LEAF, typename K>
+__global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, uint64_t n, RootP r,
+                                             const double* __restrict__ params,
+                                             unsigned long long* __restrict__ leaf_maxerr,
+                                             unsigned long long* __restrict__ leaf_run) {
+  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const bool active = i < n;
+  const uint64_t Lm1 = r.L - 1;
+  unsigned long long t = ~0ull, err = 0, run = 0;
+  if (active) {
+    const K k = keys[i];
+    const uint64_t p = root_predict<ROOT, K>(r, k);
+    t = p < Lm1 ? p : Lm1;
+    const uint64_t y = first_occurrence(keys, i);
+    const uint64_t pred = leaf_predict<LEAF, K>(params + t * PPL, k);
+    err = error_between(pred, y, n);
+    if (i + 1 < n && !(keys[i + 1] == k)) run = i - y + 1;   // a run is recorded when the next different item arrives
+  }
+  // segmented inclusive max-scan over lanes with equal t (segments are contiguous)
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    unsigned long long ot = shfl_up_u64(t, d);
+    unsigned long long oe = shfl_up_u64(err, d);
+    unsigned long long orn = shfl_up_u64(run, d);
+    if (lane >= d && ot == t) { err = oe > err ? oe : err; run = orn > run ? orn : run; }
+  }
+  unsigned long long nt = shfl_down_u64(t, 1);
+  const bool tail = active && (lane == WAVE - 1 || nt != t);
+  if (tail) {
+    if (err) atomicMax(&leaf_maxerr[t], err);
+    if (run) atomicMax(&leaf_run[t], run);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_finalize: one thread per leaf (O(L)).
+// ---------------------------------------------------------------------------------------------
+template <int LEAF, typename K>
+__global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, uint64_t n, uint64_t L,
+                                                  const unsigned long long* __restrict__ leaf_start,
+                                                  const DevState* __restrict__ st,
+                                                  double* __restrict__ params,
+                                                  const unsigned long long* __restrict__ leaf_maxerr,
+                                                  const unsigned long long* __restrict__ leaf_run,
+                                                  unsigned long long* __restrict__ leaf_err,
+                                                  unsigned long long* __restrict__ leaf_count,
+                                                  unsigned char* __restrict__ rows) {
+  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
+  constexpr int ROWB = PPL * 8 + 8;
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= L) return;
+  const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+  double p[PPL];
+#pragma unroll
+  for (int q = 0; q < PPL; q++) p[q] = params[j * PPL + q];
+  // empty-leaf fix: two_layer.rs:185-197 (last leaf excluded); next_index(j) == e
+  if (s == e && j + 1 < L) {
+    if constexpr (LEAF == K_CUBIC) { p[0] = 0.0; p[1] = 0.0; p[2] = 0.0; p[3] = (double)e; }   // cubic_spline.rs:188-191
+    else { p[0] = (double)e; p[1] = 0.0; }                                                      // linear.rs:116-119
+#pragma unroll
+    for (int q = 0; q < PPL; q++) params[j * PPL + q] = p[q];
+  }
+  const uint64_t curr = leaf_maxerr[j];
+  // upper error: two_layer.rs:229-235 ; next(j) = first (idx,key) of the next non-empty leaf
+  const K key_next = e < n ? keys[e] : KeyTraits<K>::max_value();          // lower_bound_correction.rs:47-49
+  const uint64_t up_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::minus_eps(key_next));
+  const uint64_t upper = error_between(up_pred, e + 1, n);
+  // lower error: two_layer.rs:237-247 ; prev_key(j) = last key of the nearest non-empty leaf below
+  const K key_prev = s > 0 ? keys[s - 1] : KeyTraits<K>::zero_value();     // lower_bound_correction.rs:62-63
+  const uint64_t first_idx = (j == 0) ? e : s;                             // next_index(max(j-1,0))
+  const uint64_t lo_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::plus_eps(key_prev));
+  const uint64_t lower = error_between(lo_pred, first_idx, n);
+  uint64_t m = curr;
+  m = upper > m ? upper : m;
+  m = lower > m ? lower : m;
+  const uint64_t final_err = m + leaf_run[j];                              // two_layer.rs:250-251
+  leaf_err[j] = final_err;
+  leaf_count[j] = (e - s) + (st->last_target == j ? 1ull : 0ull);          // Q7: tail duplicate
+  // packed row = the reference's L1_PARAMETERS record (codegen.rs:288-315)
+  double* rp = reinterpret_cast<double*>(rows + j * ROWB);
+#pragma unroll
+  for (int q = 0; q < PPL; q++) rp[q] = p[q];
+  *reinterpret_cast<unsigned long long*>(rows + j * ROWB + PPL * 8) = final_err;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_stats: aggregates of two_layer.rs:267-287 (parallel reduction; the f64 sums are not
+// bit-identical to the reference's sequential sums -- rmi_hip_stats_exact recomputes on host).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_stats(uint64_t L, uint64_t n,
+                                               const unsigned long long* __restrict__ leaf_err,
+                                               const unsigned long long* __restrict__ leaf_count,
+                                               DevState* __restrict__ st) {
+  __shared__ unsigned long long s_max[256], s_idx[256], s_sum[256];
+  __shared__ double s_l2[256], s_lg[256];
+  unsigned long long mx = 0, mi = 0, sm = 0;
+  double l2 = 0.0, lg = 0.0;
+  const double nf = (double)n;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long e = leaf_err[j], c = leaf_count[j];
+    if (e >= mx) { mx = e; mi = j; }                 // max_by_key keeps the last maximum
+    const unsigned long long ne = c * e;
+    sm += ne;
+    const double v = (double)ne;
+    l2 += (v * v) / nf;
+    lg += (double)c * log2((double)(2 * e + 2));
+  }
+  s_max[threadIdx.x] = mx; s_idx[threadIdx.x] = mi; s_sum[threadIdx.x] = sm; s_l2[threadIdx.x] = l2; s_lg[threadIdx.x] = lg;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const int o = threadIdx.x + s;
+      if (s_max[o] > s_max[threadIdx.x] || (s_max[o] == s_max[threadIdx.x] && s_idx[o] > s_idx[threadIdx.x])) {
+        s_max[threadIdx.x] = s_max[o]; s_idx[threadIdx.x] = s_idx[o];
+      }
+      s_sum[threadIdx.x] += s_sum[o]; s_l2[threadIdx.x] += s_l2[o]; s_lg[threadIdx.x] += s_lg[o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // combine across blocks with atomics: max/idx packed compare via CAS loop on max_err then idx
+    atomicAdd(&st->sum_n_err, s_sum[0]);
+    atomicAdd(&st->sum_l2, s_l2[0]);
+    atomicAdd(&st->sum_log2, s_lg[0]);
+    // (max_err, max_err_idx): lexicographic max; single-word CAS on max_err, idx fixed up after
+    unsigned long long old = atomicMax(&st->max_err, s_max[0]);
+    (void)old;
+  }
+}
+// second tiny pass: the last index attaining max_err
+__global__ void __launch_bounds__(256) k_stats_argmax(uint64_t L, const unsigned long long* __restrict__ leaf_err,
+                                                      DevState* __restrict__ st) {
+  const unsigned long long mx = st->max_err;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
+    if (leaf_err[j] == mx) atomicMax(&st->max_err_idx, (unsigned long long)j);
+  }
+}
+
+}  // namespace rmi

@@ -1,0 +1,229 @@
+// rmi_root_host.h -- host-side root-model fits in reference order.
+//
+// The root of a two-layer RMI is `train_model(layer1, data)` with scale = L/N
+// (two_layer.rs:109-110).  For `linear` / `robust_linear` this is a *sequential* streaming SLR
+// recurrence over N+1 points (linear.rs:12-59): floating-point non-associativity means a
+// parallel formulation changes low bits of (alpha, beta) and therefore a handful of bucket
+// assignments.  Bit-identical buckets need the identical recurrence, so
+// the exact root fit runs here on the host, once per (data, root, L); its result is an *input*
+// of the device hot path.  `radix`, `linear_spline` and the `cubic` coefficients are O(1).
+//
+// This is product code, independent of oracle/ (which restates the same reference lines for
+// the tests).  Build with -ffp-contract=off.
+#pragma once
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/rmi_hip.h"
+
+namespace rmi_host {
+
+inline uint64_t sat_u64(double v) {           // Rust `f64 as u64`
+  if (!(v > 0.0)) return 0;
+  if (v >= 18446744073709551616.0) return UINT64_MAX;
+  return (uint64_t)v;
+}
+
+template <typename K> inline double as_float(K k) { return (double)k; }
+template <typename K> inline uint64_t as_uint(K k) { return (uint64_t)k; }
+template <> inline uint64_t as_uint<double>(double k) { return sat_u64(k); }
+
+// View of RMITrainingData<T> over a raw slice with `scale` (models/mod.rs:233-317).
+template <typename K>
+struct Data {
+  const K* keys;
+  uint64_t n;
+  double scale;
+  inline uint64_t scale_y(uint64_t y) const {        // map_scale!: mod.rs:238-250
+    if (std::fabs(scale - 1.0) > DBL_EPSILON) return sat_u64((double)y * scale);
+    return y;
+  }
+};
+
+// Calls f(key, scaled_y) for every item of data.iter() -- FixDupsIter (mod.rs:154-185): y is the
+// offset of the first occurrence of the key, and the last item is yielded twice (Q1).
+// Items [skip, skip+take) of that sequence are visited.
+template <typename K, typename F>
+inline void for_each_fixdups(const Data<K>& d, uint64_t skip, uint64_t take, F&& f) {
+  if (d.n == 0) return;
+  uint64_t first = 0;
+  uint64_t emitted = 0, visited = 0;
+  const uint64_t total = d.n + 1;
+  for (uint64_t i = 0; i < total && visited < take; i++) {
+    const uint64_t src = i < d.n ? i : d.n - 1;      // tail duplicate
+    if (i < d.n && (i == 0 || !(d.keys[i] == d.keys[i - 1]))) first = i;
+    if (emitted++ < skip) continue;
+    f(d.keys[src], d.scale_y(first));
+    visited++;
+  }
+}
+
+struct Slr {                                          // linear.rs:12-59
+  double mean_x = 0.0, mean_y = 0.0, c = 0.0, m2 = 0.0;
+  uint64_t n = 0;
+  inline void push(double x, double y) {
+    n += 1;
+    const double dx = x - mean_x;
+    mean_x += dx / (double)n;
+    mean_y += (y - mean_y) / (double)n;
+    c += dx * (y - mean_y);
+    const double dx2 = x - mean_x;
+    m2 += dx * dx2;
+  }
+  inline int finish(double* alpha, double* beta) const {
+    if (n == 0) { *alpha = 0.0; *beta = 0.0; return RMI_OK; }
+    if (n == 1) { *alpha = mean_y; *beta = 0.0; return RMI_OK; }
+    const double cov = c / (double)(n - 1);
+    const double var = m2 / (double)(n - 1);
+    if (!(var >= 0.0)) return RMI_ERR_NEGATIVE_VARIANCE;
+    if (var == 0.0) { *alpha = mean_y; *beta = 0.0; return RMI_OK; }
+    const double b = cov / var;
+    *alpha = mean_y - b * mean_x;
+    *beta = b;
+    return RMI_OK;
+  }
+};
+
+template <typename K>
+inline int fit_linear(const Data<K>& d, rmi_hip_model_params* m) {        // linear.rs:79-83
+  Slr s;
+  for_each_fixdups(d, 0, UINT64_MAX, [&](K k, uint64_t y) { s.push(as_float(k), (double)y); });
+  return s.finish(&m->p[0], &m->p[1]);
+}
+
+template <typename K>
+inline int fit_robust_linear(const Data<K>& d, rmi_hip_model_params* m) { // linear.rs:239-260
+  if (d.n == 0) { m->p[0] = 0.0; m->p[1] = 0.0; return RMI_OK; }
+  uint64_t bnd = sat_u64((double)d.n * 0.0001);
+  if (bnd < 1) bnd = 1;
+  if (!(bnd * 2 + 1 < d.n)) return RMI_ERR_ROBUST_TOO_SMALL;
+  Slr s;
+  for_each_fixdups(d, bnd, d.n - 2 * bnd, [&](K k, uint64_t y) { s.push(as_float(k), (double)y); });
+  return s.finish(&m->p[0], &m->p[1]);
+}
+
+template <typename K>
+inline void linear_splines(const Data<K>& d, double* alpha, double* beta) { // linear_spline.rs:13-35
+  if (d.n == 0) { *alpha = 0.0; *beta = 0.0; return; }
+  const double y0 = (double)d.scale_y(0);
+  if (d.n == 1) { *alpha = y0; *beta = 0.0; return; }
+  const K k0 = d.keys[0], k1 = d.keys[d.n - 1];
+  if (k0 == k1) { *alpha = y0; *beta = 0.0; return; }
+  const double y1 = (double)d.scale_y(d.n - 1);       // get(): raw index, no FixDups
+  const double slope = (y0 - y1) / (as_float(k0) - as_float(k1));
+  *alpha = y0 - slope * as_float(k0);
+  *beta = slope;
+}
+
+inline double cubic_eval(const double p[4], double x) {                     // cubic_spline.rs:140-151
+  return std::fma(std::fma(std::fma(p[0], x, p[1]), x, p[2]), x, p[3]);
+}
+
+template <typename K>
+inline int cubic_coeffs(const Data<K>& d, double out[4]) {                  // cubic_spline.rs:18-101
+  if (d.n == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = 1.0; out[3] = 0.0; return RMI_OK; }
+  const double y_first = (double)d.scale_y(0);
+  if (d.n == 1) { out[0] = out[1] = out[2] = 0.0; out[3] = y_first; return RMI_OK; }
+  const K k0 = d.keys[0], kl = d.keys[d.n - 1];
+  if (k0 == kl) { out[0] = out[1] = out[2] = 0.0; out[3] = y_first; return RMI_OK; }  // sorted: all equal
+  const double xmin = as_float(k0), ymin = y_first;
+  const double xmax = as_float(kl), ymax = (double)d.scale_y(d.n - 1);
+  auto sc = [](double v, double mn, double mx) { return (v - mn) / (mx - mn); };
+  // m1: first item of iter() whose scaled x > 0 (FixDups offsets)
+  double m1;
+  {
+    bool found = false; K xn = k0; uint64_t yn = 0; uint64_t first = 0;
+    for (uint64_t i = 0; i < d.n; i++) {
+      if (i == 0 || !(d.keys[i] == d.keys[i - 1])) first = i;
+      if (sc(as_float(d.keys[i]), xmin, xmax) > 0.0) { xn = d.keys[i]; yn = d.scale_y(first); found = true; break; }
+    }
+    if (!found) return RMI_ERR_CUBIC_DEGENERATE;
+    const double sxn = sc(as_float(xn), xmin, xmax), syn = sc((double)yn, ymin, ymax);
+    m1 = (syn - 0.0) / (sxn - 0.0);
+  }
+  double m2;
+  {
+    bool found = false; K xp = k0; uint64_t yp = 0;
+    for (uint64_t i = d.n; i-- > 0;) {
+      if (sc(as_float(d.keys[i]), xmin, xmax) < 1.0) { xp = d.keys[i]; yp = d.scale_y(i); found = true; break; }
+    }
+    if (!found) return RMI_ERR_CUBIC_DEGENERATE;
+    const double sxp = sc(as_float(xp), xmin, xmax), syp = sc((double)yp, ymin, ymax);
+    m2 = (1.0 - syp) / (1.0 - sxp);
+  }
+  if (m1 * m1 + m2 * m2 > 9.0) {
+    const double tau = 3.0 / std::sqrt(m1 * m1 + m2 * m2);
+    m1 *= tau; m2 *= tau;
+  }
+  const double den = std::pow(xmax - xmin, 3.0);
+  double a = (m1 + m2 - 2.0) / den;
+  double b = -(xmax * (2.0 * m1 + m2 - 3.0) + xmin * (m1 + 2.0 * m2 - 3.0)) / den;
+  double c = (m1 * (xmax * xmax) + m2 * (xmin * xmin) + xmax * xmin * (2.0 * m1 + 2.0 * m2 - 6.0)) / den;
+  double dd = -xmin * (m1 * (xmax * xmax) + xmax * xmin * (m2 - 3.0) + (xmin * xmin)) / den;
+  a *= ymax - ymin; b *= ymax - ymin; c *= ymax - ymin; dd *= ymax - ymin; dd += ymin;
+  out[0] = a; out[1] = b; out[2] = c; out[3] = dd;
+  return RMI_OK;
+}
+
+template <typename K>
+inline int fit_cubic(const Data<K>& d, rmi_hip_model_params* m) {          // cubic_spline.rs:108-136
+  double cp[4];
+  int rc = cubic_coeffs(d, cp);
+  if (rc) return rc;
+  double la, lb; linear_splines(d, &la, &lb);
+  double our_error = 0.0, lin_error = 0.0;
+  for_each_fixdups(d, 0, UINT64_MAX, [&](K k, uint64_t y) {
+    const double x = as_float(k);
+    our_error += std::fabs(cubic_eval(cp, x) - (double)y);
+    lin_error += std::fabs(std::fma(lb, x, la) - (double)y);
+  });
+  if (lin_error < our_error) { m->p[0] = 0.0; m->p[1] = 0.0; m->p[2] = lb; m->p[3] = la; }
+  else std::memcpy(m->p, cp, sizeof cp);
+  return RMI_OK;
+}
+
+inline int num_bits(uint64_t largest) {                                    // utils.rs:13-21
+  int nbits = 0;
+  while (nbits + 1 < 64 && ((1ull << (nbits + 1)) - 1) <= largest) nbits++;
+  return nbits >= 1 ? nbits : -1;
+}
+
+template <typename K>
+inline int fit_radix(const Data<K>& d, rmi_hip_model_params* m) {          // radix.rs:18-39
+  m->ip[0] = 0; m->ip[1] = 0;
+  if (d.n == 0) return RMI_OK;
+  // max scaled y over iter(): y is monotone, so it is the first-occurrence offset of the last key
+  uint64_t first = d.n - 1;
+  while (first > 0 && d.keys[first - 1] == d.keys[d.n - 1]) first--;
+  const int bits = num_bits(d.scale_y(first));
+  if (bits < 0) return RMI_ERR_NUM_BITS;
+  // common_prefix_size (utils.rs:23-36): OR/AND fold over sorted keys.  For unsigned integer
+  // keys the fold over a sorted array equals the fold over {first, last} only in its leading
+  // bits; do the full fold to stay literal.
+  uint64_t any_ones = 0, no_ones = ~0ull;
+  for (uint64_t i = 0; i < d.n; i++) { const uint64_t v = as_uint(d.keys[i]); any_ones |= v; no_ones &= v; }
+  const uint64_t inv = ~((~no_ones) ^ any_ones);
+  const int prefix = inv == 0 ? 64 : __builtin_clzll(inv);
+  m->ip[0] = (uint64_t)(uint8_t)prefix;
+  m->ip[1] = (uint64_t)(uint8_t)bits;
+  return RMI_OK;
+}
+
+template <typename K>
+inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rmi_hip_model_params* m) {
+  std::memset(m, 0, sizeof *m);
+  m->kind = kind;
+  Data<K> d{keys, n, (double)num_leaves / (double)n};                       // two_layer.rs:109
+  switch (kind) {
+    case RMI_MODEL_LINEAR: return fit_linear(d, m);
+    case RMI_MODEL_ROBUST_LINEAR: return fit_robust_linear(d, m);
+    case RMI_MODEL_LINEAR_SPLINE: linear_splines(d, &m->p[0], &m->p[1]); return RMI_OK;
+    case RMI_MODEL_CUBIC: return fit_cubic(d, m);
+    case RMI_MODEL_RADIX: return fit_radix(d, m);
+    default: return RMI_ERR_UNSUPPORTED_MODEL;
+  }
+}
+
+}  // namespace rmi_host

@@ -1,0 +1,251 @@
+"""Host-side mirror of the reference's training surface for two-layer RMIs.
+
+Reference (all under /root/reference/rmi_lib/src): ``train()`` train/mod.rs:100-126,
+``TrainedRMI`` train/mod.rs:18-33, model registry train/mod.rs:35-57, ``RMITrainingData``
+models/mod.rs:233-317.  The arithmetic runs in the HIP kernels behind include/rmi_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+KEY_U64, KEY_U32, KEY_F64 = 0, 1, 2
+_DTYPES = {np.dtype(np.uint64): KEY_U64, np.dtype(np.uint32): KEY_U32, np.dtype(np.float64): KEY_F64}
+
+# train/mod.rs:37-54
+MODEL_NAMES = ["linear", "linear_spline", "cubic", "radix", "robust_linear", "loglinear", "normal",
+               "lognormal", "radix8", "radix18", "radix22", "radix26", "radix28", "bradix", "histogram"]
+
+
+class RMIError(RuntimeError):
+    """A condition on which the reference panics, reported as a code (include/rmi_hip.h)."""
+
+    def __init__(self, code: int, detail: str = ""):
+        lib = _lib.load()
+        msg = lib.rmi_hip_strerror(code).decode()
+        super().__init__(f"rmi_hip error {code}: {msg}" + (f" [{detail}]" if detail else ""))
+        self.code = code
+
+
+def _check(rc: int, ctx=None):
+    if rc != 0:
+        detail = ""
+        if ctx is not None and rc == -14:
+            detail = _lib.load().rmi_hip_last_error(ctx).decode()
+        raise RMIError(rc, detail)
+
+
+def parse_spec(spec: str):
+    """validate() + the two-layer check of train() (train/mod.rs:59-85, 104-125)."""
+    lib = _lib.load()
+    r, l = C.c_int(), C.c_int()
+    _check(lib.rmi_hip_parse_spec(spec.encode(), C.byref(r), C.byref(l)))
+    return r.value, l.value
+
+
+@dataclass
+class Model:
+    """Parameters of one model in `params()` order (models/mod.rs:742)."""
+    kind: int
+    p: tuple = (0.0, 0.0, 0.0, 0.0)
+    ip: tuple = (0, 0)
+
+    @property
+    def name(self) -> str:
+        return MODEL_NAMES[self.kind]
+
+    def _c(self) -> _lib.ModelParams:
+        m = _lib.ModelParams()
+        m.kind = self.kind
+        for i in range(4):
+            m.p[i] = self.p[i]
+        for i in range(2):
+            m.ip[i] = self.ip[i]
+        return m
+
+    @staticmethod
+    def _from_c(m) -> "Model":
+        return Model(int(m.kind), tuple(float(x) for x in m.p), tuple(int(x) for x in m.ip))
+
+
+@dataclass
+class TrainedRMI:
+    """train/mod.rs:18-33.  Per-leaf arrays are downloaded lazily from HBM."""
+    num_rmi_rows: int
+    num_data_rows: int
+    model_avg_error: float
+    model_avg_l2_error: float
+    model_avg_log2_error: float
+    model_max_error: int
+    model_max_error_idx: int
+    model_max_log2_error: float
+    models: str
+    branching_factor: int
+    root: Model
+    leaf_kind: int
+    params_per_leaf: int
+    build_time: int = 0            # ns, train/mod.rs:103-118
+    device_ns: int = 0
+    kernel_ns: tuple = ()
+    split_idx: int = 0
+    split_target: int = 0
+    cache_fix: object = None
+    _trainer: object = field(default=None, repr=False)
+    _cache: dict = field(default_factory=dict, repr=False)
+
+    def _get(self, what: str):
+        if what not in self._cache:
+            self._cache[what] = self._trainer._download(what, self)
+        return self._cache[what]
+
+    @property
+    def leaf_params(self) -> np.ndarray:        # rmi[1][j].params()
+        return self._get("params")
+
+    @property
+    def last_layer_max_l1s(self) -> np.ndarray:
+        return self._get("errors")
+
+    @property
+    def leaf_counts(self) -> np.ndarray:
+        return self._get("counts")
+
+    @property
+    def leaf_starts(self) -> np.ndarray:
+        return self._get("starts")
+
+    @property
+    def rows(self) -> np.ndarray:
+        """Byte image of the reference's L1_PARAMETERS file (codegen.rs:288-315)."""
+        return self._get("rows")
+
+
+class Trainer:
+    """Owns one device context with the key array resident in HBM (the role of
+    RMITrainingData + soft_copy in the reference: many train() calls over one data set)."""
+
+    def __init__(self, keys=None, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _check(self._lib.rmi_hip_create(device, C.byref(h)))
+        self._h = h
+        self._host_keys = None
+        self._keepalive = None
+        self.n = 0
+        if keys is not None:
+            self.set_keys(keys)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rmi_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_keys(self, keys):
+        """numpy array (copied to HBM) or a torch CUDA tensor (borrowed in place)."""
+        if isinstance(keys, np.ndarray) or isinstance(keys, np.memmap):
+            arr = np.ascontiguousarray(keys)
+            if arr.dtype not in _DTYPES:
+                raise TypeError(f"unsupported key dtype {arr.dtype}")
+            _check(self._lib.rmi_hip_upload_keys(self._h, arr.ctypes.data, arr.size, _DTYPES[arr.dtype]), self._h)
+            self._host_keys = arr
+            self._keepalive = None
+            self.n = arr.size
+            return
+        # torch tensor on the GPU: uint64 is carried as int64 bit patterns
+        import torch
+        if isinstance(keys, torch.Tensor) and keys.is_cuda:
+            t = keys.contiguous()
+            if t.dtype in (torch.int64, torch.uint64):
+                dt = KEY_U64
+            elif t.dtype in (torch.int32, torch.uint32):
+                dt = KEY_U32
+            elif t.dtype == torch.float64:
+                dt = KEY_F64
+            else:
+                raise TypeError(f"unsupported tensor dtype {t.dtype}")
+            _check(self._lib.rmi_hip_attach_device_keys(self._h, C.c_void_p(t.data_ptr()), t.numel(), dt), self._h)
+            self._keepalive = t
+            self._host_keys = None
+            self.n = t.numel()
+            return
+        raise TypeError("keys must be a numpy array or a CUDA torch tensor")
+
+    def set_stream(self, stream_ptr: int | None):
+        _check(self._lib.rmi_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def fit_root(self, root: str | int, num_leaves: int) -> Model:
+        kind = root if isinstance(root, int) else self._lib.rmi_hip_model_from_name(root.encode())
+        if kind < 0:
+            raise RMIError(kind)
+        m = _lib.ModelParams()
+        hk = C.c_void_p(self._host_keys.ctypes.data) if self._host_keys is not None else None
+        _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
+        return Model._from_c(m)
+
+    def train_leaves(self, root: Model, leaf: str | int, num_leaves: int) -> TrainedRMI:
+        leaf_kind = leaf if isinstance(leaf, int) else self._lib.rmi_hip_model_from_name(leaf.encode())
+        if leaf_kind < 0:
+            raise RMIError(leaf_kind)
+        res = _lib.Result()
+        rc = self._lib.rmi_hip_train_two_layer(self._h, C.byref(root._c()), leaf_kind, num_leaves, C.byref(res))
+        _check(rc, self._h)
+        return TrainedRMI(
+            num_rmi_rows=int(res.num_rows), num_data_rows=int(res.num_rows),
+            model_avg_error=res.model_avg_error, model_avg_l2_error=res.model_avg_l2_error,
+            model_avg_log2_error=res.model_avg_log2_error, model_max_error=int(res.model_max_error),
+            model_max_error_idx=int(res.model_max_error_idx), model_max_log2_error=res.model_max_log2_error,
+            models=f"{root.name},{MODEL_NAMES[leaf_kind]}", branching_factor=int(num_leaves), root=root,
+            leaf_kind=leaf_kind, params_per_leaf=int(res.params_per_leaf),
+            device_ns=int(res.device_ns), kernel_ns=tuple(int(x) for x in res.kernel_ns),
+            split_idx=int(res.split_idx), split_target=int(res.split_target), _trainer=self)
+
+    def train(self, model_spec: str, branch_factor: int) -> TrainedRMI:
+        """rmi_lib::train (train/mod.rs:100-126)."""
+        t0 = time.perf_counter_ns()
+        root_kind, leaf_kind = parse_spec(model_spec)
+        root = self.fit_root(root_kind, branch_factor)
+        out = self.train_leaves(root, leaf_kind, branch_factor)
+        out.build_time = time.perf_counter_ns() - t0
+        return out
+
+    def _download(self, what: str, rmi: TrainedRMI):
+        L, ppl = rmi.branching_factor, rmi.params_per_leaf
+        if what == "params":
+            a = np.empty((L, ppl), dtype=np.float64)
+            _check(self._lib.rmi_hip_download_leaf_params(self._h, a.ctypes.data), self._h)
+        elif what == "errors":
+            a = np.empty(L, dtype=np.uint64)
+            _check(self._lib.rmi_hip_download_leaf_errors(self._h, a.ctypes.data), self._h)
+        elif what == "counts":
+            a = np.empty(L, dtype=np.uint64)
+            _check(self._lib.rmi_hip_download_leaf_counts(self._h, a.ctypes.data), self._h)
+        elif what == "starts":
+            a = np.empty(L + 1, dtype=np.uint64)
+            _check(self._lib.rmi_hip_download_leaf_starts(self._h, a.ctypes.data), self._h)
+        elif what == "rows":
+            a = np.empty(L * (ppl * 8 + 8), dtype=np.uint8)
+            _check(self._lib.rmi_hip_download_rows(self._h, a.ctypes.data), self._h)
+        else:
+            raise KeyError(what)
+        return a
+
+
+def train(keys, model_spec: str, branch_factor: int, device: int = 0) -> TrainedRMI:
+    """One-shot convenience mirror of ``rmi_lib::train(data, model_spec, branch_factor)``."""
+    tr = Trainer(keys, device=device)
+    out = tr.train(model_spec, branch_factor)
+    # materialise before the context goes away
+    _ = out.leaf_params, out.last_layer_max_l1s, out.leaf_counts, out.leaf_starts, out.rows
+    tr.close()
+    return out

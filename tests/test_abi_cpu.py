@@ -1,0 +1,78 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+include/rmi_hip.h declares, and the registry / spec validation (host logic) behaves like the
+reference's train_model()/validate() (train/mod.rs:35-85)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rmi_amd import build, _lib
+    build.build_hip()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "rmi_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rmi_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    from rmi_amd import _lib
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, f"header/binding mismatch: {declared ^ bound}"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+
+
+def test_abi_version(lib):
+    assert lib.rmi_hip_abi_version() == 1
+
+
+def test_registry_names(lib):
+    # train/mod.rs:37-54
+    names = ["linear", "robust_linear", "linear_spline", "cubic", "loglinear", "normal", "lognormal",
+             "radix", "radix8", "radix18", "radix22", "radix26", "radix28", "bradix", "histogram"]
+    ids = set()
+    for n in names:
+        k = lib.rmi_hip_model_from_name(n.encode())
+        assert k >= 0
+        assert lib.rmi_hip_model_name(k).decode() == n
+        ids.add(k)
+    assert len(ids) == len(names)
+    assert lib.rmi_hip_model_from_name(b"nope") == -1
+
+
+def test_parse_spec(lib):
+    from rmi_amd import train
+    assert train.parse_spec("linear,linear") == (0, 0)
+    assert train.parse_spec("cubic,linear") == (2, 0)
+    assert train.parse_spec("radix,linear_spline") == (3, 1)
+    for spec, code in [("linear,radix", -2), ("linear,bradix", -2), ("foo,linear", -1),
+                       ("linear", -12), ("linear,linear,linear", -12)]:
+        with pytest.raises(train.RMIError) as e:
+            train.parse_spec(spec)
+        assert e.value.code == code, spec
+
+
+def test_no_device_fails_loudly(lib):
+    """Without a GPU the compute entry points refuse to run (no CPU fallback)."""
+    if lib.rmi_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert lib.rmi_hip_create(0, C.byref(h)) == -15
+    from rmi_amd import train
+    with pytest.raises(train.RMIError):
+        train.Trainer()
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rmi_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in src and "import oracle" not in src and "rmi_oracle" not in src, f

@@ -1,0 +1,112 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): bucket assignments and per-leaf max-error integers bit-identical,
+leaf coefficients within 1e-9 relative.  The device path is the exact (reference-order) mode, so
+coefficients are additionally expected to be bit-identical and are checked as such.
+"""
+import numpy as np
+import pytest
+
+from rmi_amd import datagen as dg
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-9   # tolerance stated by north_star for leaf coefficients
+
+
+@pytest.fixture(scope="module")
+def trainer_mod():
+    from rmi_amd import train
+    lib = __import__("rmi_amd._lib", fromlist=["load"]).load()
+    assert lib.rmi_hip_device_count() >= 1, "no HIP device visible"
+    return train
+
+
+def _compare(trainer_mod, oracle, keys, root, leaf, L, exact_root=True):
+    tr = trainer_mod.Trainer(keys)
+    o_root = oracle.fit_root(root, keys, L)
+    g_root = tr.fit_root(root, L)
+    assert g_root.p == o_root.p and g_root.ip == o_root.ip, f"root params differ: {g_root} vs {o_root}"
+    g = tr.train_leaves(g_root, leaf, L)
+    o = oracle.train_two_layer(root, leaf, keys, L)
+    assert np.array_equal(g.leaf_starts, o.leaf_start), "bucket assignment differs"
+    gp, op = g.leaf_params, o.leaf_params
+    denom = np.maximum(np.abs(op), 1e-300)
+    rel = np.abs(gp - op) / denom
+    rel[op == gp] = 0.0
+    assert float(rel.max()) <= REL_TOL, f"leaf coefficient rel err {rel.max()}"
+    assert np.array_equal(gp, op), f"exact mode: {np.count_nonzero(gp != op)} coefficient words differ"
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err), \
+        f"{np.count_nonzero(g.last_layer_max_l1s != o.leaf_err)} max-error ints differ"
+    assert np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error
+    assert g.model_max_error_idx == o.model_max_error_idx
+    assert g.model_avg_error == o.model_avg_error
+    assert abs(g.model_avg_l2_error - o.model_avg_l2_error) <= 1e-9 * max(1.0, abs(o.model_avg_l2_error))
+    assert abs(g.model_avg_log2_error - o.model_avg_log2_error) <= 1e-9 * max(1.0, abs(o.model_avg_log2_error))
+    # rows == the reference's L1_PARAMETERS image: (alpha, beta, err) per leaf, little endian
+    rows = g.rows.view(np.uint64).reshape(L, g.params_per_leaf + 1)
+    assert np.array_equal(rows[:, :-1], gp.view(np.uint64))
+    assert np.array_equal(rows[:, -1], g.last_layer_max_l1s)
+    tr.close()
+    return g, o
+
+
+GENS = ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "uniform_u32", "dups_u32"]
+
+
+@pytest.mark.parametrize("gen", GENS)
+@pytest.mark.parametrize("root,leaf,L", [
+    ("linear", "linear", 1024),
+    ("linear", "linear", 16384),
+    ("cubic", "linear", 4096),
+    ("radix", "linear_spline", 8192),
+    ("radix", "linear", 1024),
+    ("linear_spline", "linear", 4096),
+    ("robust_linear", "linear", 4096),
+    ("linear", "linear_spline", 4096),
+])
+def test_parity_small(trainer_mod, oracle, gen, root, leaf, L):
+    keys = dg.GENERATORS[gen](300_000)
+    _compare(trainer_mod, oracle, keys, root, leaf, L)
+
+
+def test_parity_config1(trainer_mod, oracle):
+    """BASELINE config 1: linear,linear 1024 on 1M synthetic sorted uint64."""
+    keys = dg.uniform_u64(1_000_000)
+    g, o = _compare(trainer_mod, oracle, keys, "linear", "linear", 1024)
+    bad, _ = oracle.check_lookup_property(o, keys)
+    assert bad == 0
+
+
+def test_parity_many_empty_leaves(trainer_mod, oracle):
+    """More leaves than keys: long runs of empty leaves (suffix fill + constant models)."""
+    keys = dg.books_u64(20_000)
+    _compare(trainer_mod, oracle, keys, "linear", "linear", 65536)
+    _compare(trainer_mod, oracle, keys, "radix", "linear_spline", 1 << 18)
+
+
+def test_parity_tiny(trainer_mod, oracle):
+    keys = np.array([10, 11, 12, 20, 21, 30, 30, 31, 40, 41, 42, 50], dtype=np.uint64)
+    for L in (2, 3, 4, 7):
+        _compare(trainer_mod, oracle, keys, "linear", "linear", L)
+        _compare(trainer_mod, oracle, keys, "linear", "linear_spline", L)
+
+
+def test_error_codes(trainer_mod, oracle):
+    keys = dg.uniform_u64(10_000)
+    tr = trainer_mod.Trainer(keys)
+    bad_root = trainer_mod.Model(0, (15.0, -1e-18, 0.0, 0.0), (0, 0))     # decreasing -> non monotone
+    with pytest.raises(trainer_mod.RMIError) as e:
+        tr.train_leaves(bad_root, "linear", 16)
+    assert e.value.code in (-3, -4)
+    with pytest.raises(trainer_mod.RMIError) as e:
+        tr.train("linear,linear", 1)          # L=1: split_idx == 0 (two_layer.rs:27)
+    assert e.value.code == -4
+    with pytest.raises(trainer_mod.RMIError) as e:
+        tr.train("linear,radix", 16)
+    assert e.value.code == -2
+    with pytest.raises(trainer_mod.RMIError) as e:
+        tr.train("linear,linear,linear", 16)
+    assert e.value.code == -12
+    tr.close()
