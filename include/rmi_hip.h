@@ -143,6 +143,14 @@ int rmi_hip_upload_keys(rmi_hip_ctx* ctx, const void* host_keys, uint64_t n, int
 /* Borrow a device buffer that already holds the sorted keys (stays owned by the caller). */
 int rmi_hip_attach_device_keys(rmi_hip_ctx* ctx, const void* device_keys, uint64_t n, int dtype);
 uint64_t rmi_hip_num_keys(const rmi_hip_ctx* ctx);
+/* Synthetic sorted keys generated in HBM (bit-identical to rmi_amd/datagen.py):
+ * generator 0 = uniform, 1 = uniform with duplicate runs.  Produces indices
+ * [start, start+count) of the n_global-key array (so ranks can generate their own shard).
+ * seed 0 = the documented default seed.  dtype: RMI_KEY_U64 or RMI_KEY_U32. */
+int rmi_hip_generate_keys(rmi_hip_ctx* ctx, int generator, int dtype, uint64_t n_global,
+                          uint64_t start, uint64_t count, uint64_t seed);
+int rmi_hip_download_keys(rmi_hip_ctx* ctx, void* host_out);
+const void* rmi_hip_device_keys(const rmi_hip_ctx* ctx);
 
 /* ---- root model ---- */
 /* Fit the root exactly as the reference does.  `host_keys` may be NULL, in which case the keys

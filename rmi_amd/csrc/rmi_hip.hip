@@ -214,6 +214,39 @@ int rmi_hip_attach_device_keys(rmi_hip_ctx* c, const void* device_keys, uint64_t
 
 uint64_t rmi_hip_num_keys(const rmi_hip_ctx* c) { return c ? c->n : 0; }
 
+int rmi_hip_generate_keys(rmi_hip_ctx* c, int generator, int dtype, uint64_t n_global, uint64_t start,
+                          uint64_t count, uint64_t seed) {
+  if (!c || n_global == 0 || count == 0 || start + count > n_global) return RMI_ERR_BAD_ARG;
+  if (generator < 0 || generator > 1 || (dtype != RMI_KEY_U64 && dtype != RMI_KEY_U32)) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->d_keys_owned) { HIPCHK(c, hipFree(c->d_keys_owned)); c->d_keys_owned = nullptr; }
+  HIPCHK(c, hipMalloc(&c->d_keys_owned, count * key_size(dtype)));
+  const unsigned long long span = dtype == RMI_KEY_U64 ? 0xFFFFFFFFFFFFFFFEull : 0xFFFFFFFDull;  // 2^64-2 / 2^32-3
+  const unsigned long long stride = span / n_global;
+  if (stride == 0) return RMI_ERR_BAD_ARG;
+  const unsigned long long base_seed = seed ? seed : (dtype == RMI_KEY_U64 ? 42ull : 46ull);
+  const unsigned long long dup_seed = dtype == RMI_KEY_U64 ? 45ull : 47ull;
+  const unsigned blocks = (unsigned)((count + 255) / 256);
+  if (dtype == RMI_KEY_U64)
+    hipLaunchKernelGGL((k_generate<uint64_t>), dim3(blocks), dim3(256), 0, c->stream, (uint64_t*)c->d_keys_owned, start, count, stride, base_seed, generator, dup_seed);
+  else
+    hipLaunchKernelGGL((k_generate<uint32_t>), dim3(blocks), dim3(256), 0, c->stream, (uint32_t*)c->d_keys_owned, start, count, stride, base_seed, generator, dup_seed);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->d_keys = c->d_keys_owned; c->n = count; c->dtype = dtype;
+  return RMI_OK;
+}
+
+int rmi_hip_download_keys(rmi_hip_ctx* c, void* host_out) {
+  if (!c || !host_out) return RMI_ERR_BAD_ARG;
+  if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy(host_out, c->d_keys, c->n * key_size(c->dtype), hipMemcpyDeviceToHost));
+  return RMI_OK;
+}
+
+const void* rmi_hip_device_keys(const rmi_hip_ctx* c) { return c ? c->d_keys : nullptr; }
+
 int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const void* host_keys,
                      rmi_hip_model_params* out) {
   if (!c || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;

@@ -396,4 +396,33 @@ __global__ void __launch_bounds__(256) k_stats_argmax(uint64_t L, const unsigned
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Synthetic key generators (bit-identical to rmi_amd/datagen.py).  Integer only,
+// sorted by construction, so a shard of the global array can be produced in place on any rank.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// gen 0: uniform  key[i] = 1 + i*stride + (h(i + seed) mod stride)
+// gen 1: dups     key[i] = uniform[i - (i mod r_i)], r_i in {1,1,1,2,8} by h(i/8 + dup_seed) mod 5
+template <typename K>
+__global__ void __launch_bounds__(256) k_generate(K* __restrict__ out, uint64_t start, uint64_t count,
+                                                  unsigned long long stride, unsigned long long seed,
+                                                  int gen, unsigned long long dup_seed) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  unsigned long long i = start + t;
+  if (gen == 1) {
+    const unsigned long long c = splitmix64((i >> 3) + dup_seed) % 5ull;
+    const unsigned long long r = c < 3 ? 1ull : (c == 3 ? 2ull : 8ull);
+    i = i - (i % r);
+  }
+  const unsigned long long k = 1ull + i * stride + (splitmix64(i + seed) % stride);
+  out[t] = (K)k;
+}
+
 }  // namespace rmi

@@ -181,6 +181,25 @@ class Trainer:
             return
         raise TypeError("keys must be a numpy array or a CUDA torch tensor")
 
+    def generate_keys(self, generator: str, dtype, n_global: int, start: int = 0, count: int | None = None, seed: int = 0):
+        """Synthetic sorted keys produced directly in HBM (datagen.uniform_* / dups_* shards)."""
+        gen = {"uniform": 0, "dups": 1}[generator]
+        dt = _DTYPES[np.dtype(dtype)]
+        count = n_global - start if count is None else count
+        _check(self._lib.rmi_hip_generate_keys(self._h, gen, dt, n_global, start, count, seed), self._h)
+        self._host_keys = None
+        self._keepalive = None
+        self._np_dtype = np.dtype(dtype)
+        self.n = count
+
+    def download_keys(self) -> np.ndarray:
+        if self._host_keys is not None:
+            return self._host_keys
+        a = np.empty(self.n, dtype=getattr(self, "_np_dtype", np.dtype(np.uint64)))
+        _check(self._lib.rmi_hip_download_keys(self._h, a.ctypes.data), self._h)
+        self._host_keys = a
+        return a
+
     def set_stream(self, stream_ptr: int | None):
         _check(self._lib.rmi_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 

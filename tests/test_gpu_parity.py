@@ -27,8 +27,16 @@ def _compare(trainer_mod, oracle, keys, root, leaf, L, exact_root=True):
     o_root = oracle.fit_root(root, keys, L)
     g_root = tr.fit_root(root, L)
     assert g_root.p == o_root.p and g_root.ip == o_root.ip, f"root params differ: {g_root} vs {o_root}"
+    try:
+        o = oracle.train_two_layer(root, leaf, keys, L)
+    except oracle.OracleError as oe:
+        # where the reference panics, the ABI must report the matching code
+        with pytest.raises(trainer_mod.RMIError) as ge:
+            tr.train_leaves(g_root, leaf, L)
+        assert ge.value.code == oe.code
+        tr.close()
+        return None, None
     g = tr.train_leaves(g_root, leaf, L)
-    o = oracle.train_two_layer(root, leaf, keys, L)
     assert np.array_equal(g.leaf_starts, o.leaf_start), "bucket assignment differs"
     gp, op = g.leaf_params, o.leaf_params
     denom = np.maximum(np.abs(op), 1e-300)
@@ -91,6 +99,19 @@ def test_parity_tiny(trainer_mod, oracle):
     for L in (2, 3, 4, 7):
         _compare(trainer_mod, oracle, keys, "linear", "linear", L)
         _compare(trainer_mod, oracle, keys, "linear", "linear_spline", L)
+
+
+def test_device_generators_match_numpy(trainer_mod):
+    for gen, dt, ref in [("uniform", np.uint64, dg.uniform_u64), ("dups", np.uint64, dg.dups_u64),
+                         ("uniform", np.uint32, dg.uniform_u32), ("dups", np.uint32, dg.dups_u32)]:
+        tr = trainer_mod.Trainer()
+        tr.generate_keys(gen, dt, 1_000_003)
+        assert np.array_equal(tr.download_keys(), ref(1_000_003))
+        tr.close()
+    tr = trainer_mod.Trainer()
+    tr.generate_keys("uniform", np.uint64, 10_000_000, start=777_777, count=1234)
+    assert np.array_equal(tr.download_keys(), dg.uniform_u64(10_000_000, start=777_777, count=1234))
+    tr.close()
 
 
 def test_error_codes(trainer_mod, oracle):
