@@ -41,6 +41,9 @@ struct rmi_hip_ctx {
   DevState* h_state = nullptr;                  // pinned
   hipEvent_t ev[10] = {};
   bool profile_kernels = false;
+  int pipeline = 2;                             // 1 = one kernel per reference pass; 2 = tiled/streaming kernels
+  uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
+  int fit_min_chunk = 64;
   // last result
   uint64_t last_L = 0;
   int last_ppl = 2;
@@ -158,6 +161,12 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   const char* pk = std::getenv("RMI_HIP_PROFILE_KERNELS");
   c->profile_kernels = pk && *pk && *pk != '0';
+  const char* pl = std::getenv("RMI_HIP_PIPELINE");
+  if (pl && *pl) c->pipeline = std::atoi(pl);
+  const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
+  if (ft && *ft) c->fit_threads = std::strtoull(ft, nullptr, 10);
+  const char* fc = std::getenv("RMI_HIP_FIT_MIN_CHUNK");
+  if (fc && *fc) c->fit_min_chunk = std::atoi(fc);
   *out = c;
   return RMI_OK;
 }
@@ -308,12 +317,24 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   HIPCHK(c, hipMemsetAsync(c->d_run, 0, L * 8, s));
 
   HIPCHK(c, hipEventRecord(c->ev[0], s));
-  // --- bucketing scan ---
-  {
-    const uint64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_leaf_start, c->d_state);
+  const bool stream_fit = (c->pipeline != 1) && (LEAF == K_LINEAR);
+  if (!stream_fit) {
+    // --- bucketing scan ---
+    {
+      const uint64_t blocks = (n + 255) / 256;
+      hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_leaf_start, c->d_state);
+    }
+    mark();
+  } else {
+    // --- pass A: bucketing scan + exact per-leaf fit in one streaming pass ---
+    uint64_t C = (n + c->fit_threads - 1) / c->fit_threads;
+    C = ((C + FS_ROW - 1) / FS_ROW) * FS_ROW;
+    if (C < (uint64_t)c->fit_min_chunk) C = c->fit_min_chunk;
+    const uint64_t chunks = (n + C - 1) / C;
+    const uint64_t waves = (chunks + 63) / 64;
+    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, n, rp, C, c->d_leaf_start, c->d_params, c->d_state);
+    mark();
   }
-  mark();
   // --- fill empty leaves ---
   {
     const uint64_t count = L + 1;
@@ -323,16 +344,19 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count, c->d_tilemin);
   }
   mark();
-  // --- per-leaf fit ---
-  {
+  if (!stream_fit) {
+    // --- per-leaf fit ---
     const uint64_t blocks = (L + 255) / 256;
     hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, L, c->d_leaf_start, c->d_state, c->d_params);
   }
   mark();
   // --- error pass ---
-  {
+  if (c->pipeline == 1) {
     const uint64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run);
+  } else {
+    const uint64_t blocks = (n + ERR_TILE - 1) / ERR_TILE;
+    hipLaunchKernelGGL((k_err_tile<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run, c->d_state);
   }
   mark();
   // --- finalize + stats ---
@@ -376,7 +400,7 @@ extern "C" {
 
 int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, int leaf_kind,
                             uint64_t num_leaves, rmi_hip_result* out) {
-  if (!c || !root || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  if (!c || !root || !out || num_leaves == 0 || num_leaves > (1ull << 31)) return RMI_ERR_BAD_ARG;
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
   if (root->kind < 0 || root->kind >= kNumModels || leaf_kind < 0 || leaf_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
   if (must_be_top(leaf_kind)) return RMI_ERR_RESTRICTION;

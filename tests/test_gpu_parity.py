@@ -22,6 +22,14 @@ def trainer_mod():
     return train
 
 
+@pytest.fixture(autouse=True, params=["2", "1"], ids=["pipeline2", "pipeline1"])
+def pipeline(request, monkeypatch):
+    """Both device pipelines (streaming/tiled kernels and the one-kernel-per-pass version) are
+    held to the same parity bar; small chunks force leaves to straddle lane/wave boundaries."""
+    monkeypatch.setenv("RMI_HIP_PIPELINE", request.param)
+    return request.param
+
+
 def _compare(trainer_mod, oracle, keys, root, leaf, L, exact_root=True):
     tr = trainer_mod.Trainer(keys)
     o_root = oracle.fit_root(root, keys, L)
@@ -92,6 +100,17 @@ def test_parity_many_empty_leaves(trainer_mod, oracle):
     keys = dg.books_u64(20_000)
     _compare(trainer_mod, oracle, keys, "linear", "linear", 65536)
     _compare(trainer_mod, oracle, keys, "radix", "linear_spline", 1 << 18)
+
+
+@pytest.mark.parametrize("threads,min_chunk", [(1 << 20, 16), (4096, 64), (64, 64)])
+def test_parity_chunk_geometry(trainer_mod, oracle, monkeypatch, threads, min_chunk):
+    """Pass A must give identical results for any chunking (leaves far smaller / larger than a chunk)."""
+    monkeypatch.setenv("RMI_HIP_FIT_THREADS", str(threads))
+    monkeypatch.setenv("RMI_HIP_FIT_MIN_CHUNK", str(min_chunk))
+    for gen in ("books_u64", "dups_u64"):
+        keys = dg.GENERATORS[gen](150_000)
+        _compare(trainer_mod, oracle, keys, "linear", "linear", 512)
+        _compare(trainer_mod, oracle, keys, "linear", "linear", 50_000)
 
 
 def test_parity_tiny(trainer_mod, oracle):
