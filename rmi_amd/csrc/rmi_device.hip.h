@@ -139,4 +139,32 @@ __device__ __forceinline__ uint64_t first_occurrence(const K* __restrict__ keys,
   return lo;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Root target in the f64 domain: min(L-1, predict_to_int(key)) as a double.  Exact because every
+// intermediate is an integer < 2^53 (L <= 2^31 is enforced by the host): identical buckets to
+// the integer formulation, without the 64-bit float->int conversions.
+// ---------------------------------------------------------------------------------------------
+template <int ROOT, typename K>
+__device__ __forceinline__ double root_target_f(const RootP& r, double Lm1f, K k, bool& oob) {
+  if constexpr (ROOT == K_RADIX) {
+    uint64_t v = KeyTraits<K>::as_uint(k);
+    uint64_t p = (v << (r.prefix & 63u)) >> ((64u - r.bits) & 63u);
+    oob = p > (uint64_t)Lm1f;
+    p = p < r.L - 1 ? p : r.L - 1;
+    return (double)p;
+  } else {
+    double x = KeyTraits<K>::as_float(k);
+    double f;
+    if constexpr (ROOT == K_CUBIC) {
+      f = __builtin_fma(__builtin_fma(__builtin_fma(r.p0, x, r.p1), x, r.p2), x, r.p3);
+    } else {
+      f = __builtin_fma(r.p1, x, r.p0);
+    }
+    f = fmax(0.0, floor(f));          // f64::max(0.0, NaN) == 0.0, as in models/mod.rs:736
+    oob = f > Lm1f;
+    return fmin(f, Lm1f);
+  }
+}
+
+
 }  // namespace rmi

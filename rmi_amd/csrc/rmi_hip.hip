@@ -13,6 +13,7 @@
 
 #include "../../include/rmi_hip.h"
 #include "rmi_kernels.hip.h"
+#include "rmi_stream.hip.h"
 #include "rmi_root_host.h"
 
 using namespace rmi;
@@ -43,7 +44,9 @@ struct rmi_hip_ctx {
   bool profile_kernels = false;
   int pipeline = 2;                             // 1 = one kernel per reference pass; 2 = tiled/streaming kernels
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
+  uint64_t err_threads = 262144;                // lanes of pass B
   int fit_min_chunk = 64;
+  int dbg = 0;                                  // ablation switches for profiling (0 = product behaviour)
   // last result
   uint64_t last_L = 0;
   int last_ppl = 2;
@@ -165,6 +168,10 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (pl && *pl) c->pipeline = std::atoi(pl);
   const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
   if (ft && *ft) c->fit_threads = std::strtoull(ft, nullptr, 10);
+  const char* et = std::getenv("RMI_HIP_ERR_THREADS");
+  if (et && *et) c->err_threads = std::strtoull(et, nullptr, 10);
+  const char* dbg = std::getenv("RMI_HIP_DBG");
+  if (dbg && *dbg) c->dbg = std::atoi(dbg);
   const char* fc = std::getenv("RMI_HIP_FIT_MIN_CHUNK");
   if (fc && *fc) c->fit_min_chunk = std::atoi(fc);
   *out = c;
@@ -332,7 +339,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     if (C < (uint64_t)c->fit_min_chunk) C = c->fit_min_chunk;
     const uint64_t chunks = (n + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
-    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, n, rp, C, c->d_leaf_start, c->d_params, c->d_state);
+    const uint64_t fblocks = (waves + FA_WAVES - 1) / FA_WAVES;
+    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, n, rp, C, c->d_leaf_start, c->d_params, c->d_state, c->dbg);
     mark();
   }
   // --- fill empty leaves ---
@@ -355,8 +363,12 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     const uint64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run);
   } else {
-    const uint64_t blocks = (n + ERR_TILE - 1) / ERR_TILE;
-    hipLaunchKernelGGL((k_err_tile<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run, c->d_state);
+    uint64_t C = (n + c->err_threads - 1) / c->err_threads;
+    C = ((C + FS_ROW - 1) / FS_ROW) * FS_ROW;
+    if (C < (uint64_t)c->fit_min_chunk) C = c->fit_min_chunk;
+    const uint64_t chunks = (n + C - 1) / C;
+    const uint64_t waves = (chunks + 63) / 64;
+    hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, n, rp, C, c->d_params, c->d_maxerr, c->d_run, c->dbg);
   }
   mark();
   // --- finalize + stats ---

@@ -293,321 +293,6 @@ __global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, uint64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Root target in the f64 domain: min(L-1, predict_to_int(key)) as a double.  Exact because every
-// intermediate is an integer < 2^53 (L <= 2^31 is enforced by the host): identical buckets to
-// the integer formulation, without the 64-bit float->int conversions.
-// ---------------------------------------------------------------------------------------------
-template <int ROOT, typename K>
-__device__ __forceinline__ double root_target_f(const RootP& r, double Lm1f, K k, bool& oob) {
-  if constexpr (ROOT == K_RADIX) {
-    uint64_t v = KeyTraits<K>::as_uint(k);
-    uint64_t p = (v << (r.prefix & 63u)) >> ((64u - r.bits) & 63u);
-    oob = p > (uint64_t)Lm1f;
-    p = p < r.L - 1 ? p : r.L - 1;
-    return (double)p;
-  } else {
-    double x = KeyTraits<K>::as_float(k);
-    double f;
-    if constexpr (ROOT == K_CUBIC) {
-      f = __builtin_fma(__builtin_fma(__builtin_fma(r.p0, x, r.p1), x, r.p2), x, r.p3);
-    } else {
-      f = __builtin_fma(r.p1, x, r.p0);
-    }
-    f = fmax(0.0, floor(f));          // f64::max(0.0, NaN) == 0.0, as in models/mod.rs:736
-    oob = f > Lm1f;
-    return fmin(f, Lm1f);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_err_tile ("pass B"): last-level error pass + run lengths, tiled through LDS.
-// A 256-thread block loads a tile of 4096 keys coalesced into LDS; each lane then walks 16
-// consecutive keys (conflict-free padded rows), keeps running maxima in registers while the leaf
-// id is unchanged and issues one atomicMax per (lane, leaf) segment -- about N/16 atomics.
-// Runs of length 1 are not reported (k_finalize adds that floor, see `run_floor`).
-// ---------------------------------------------------------------------------------------------
-constexpr int ERR_KPT = 16;                 // keys per lane
-constexpr int ERR_TILE = 256 * ERR_KPT;     // keys per block
-
-__device__ __forceinline__ int err_phys(int a) { return a + (a >> 4); }   // one pad slot per 16 keys
-
-template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(256) k_err_tile(const K* __restrict__ keys, uint64_t n, RootP r,
-                                                  const double* __restrict__ params,
-                                                  unsigned long long* __restrict__ leaf_maxerr,
-                                                  unsigned long long* __restrict__ leaf_run,
-                                                  DevState* __restrict__ st) {
-  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
-  __shared__ K tile[ERR_TILE + 2 + (ERR_TILE + 2) / 16 + 2];
-  const uint64_t base = (uint64_t)blockIdx.x * ERR_TILE;
-  const int tid = threadIdx.x;
-  // logical A[0] = key[base-1], A[1..TILE] = keys, A[TILE+1] = key[base+TILE]
-#pragma unroll
-  for (int it = 0; it < ERR_KPT; it++) {
-    const int q = it * 256 + tid;
-    const uint64_t gi = base + q;
-    if (gi < n) tile[err_phys(q + 1)] = keys[gi];
-  }
-  if (tid == 0 && base > 0) tile[err_phys(0)] = keys[base - 1];
-  if (tid == 1 && base + ERR_TILE < n) tile[err_phys(ERR_TILE + 1)] = keys[base + ERR_TILE];
-  __syncthreads();
-
-  const uint64_t i0 = base + (uint64_t)tid * ERR_KPT;
-  if (i0 >= n) return;
-  const double Lm1f = (double)(r.L - 1);
-  const double nf = (double)n;
-  const int a0 = 1 + tid * ERR_KPT;
-
-  K kprev = (i0 > 0) ? tile[err_phys(a0 - 1)] : K();
-  K k = tile[err_phys(a0)];
-  uint64_t y = (i0 > 0 && kprev == k) ? first_occurrence(keys, i0) : i0;
-  double cur_t = -1.0;
-  double pa[PPL];
-  double maxerr = 0.0;
-  uint64_t maxrun = 0;
-  bool any_oob = false;
-
-#pragma unroll
-  for (int s = 0; s < ERR_KPT; s++) {
-    const uint64_t i = i0 + s;
-    if (i < n) {
-      const bool has_next = (i + 1 < n);
-      const K knext = has_next ? tile[err_phys(a0 + s + 1)] : K();
-      if (s > 0 && !(k == kprev)) y = i;
-      bool oob;
-      const double t = root_target_f<ROOT, K>(r, Lm1f, k, oob);
-      any_oob |= oob;
-      if (t != cur_t) {
-        if (cur_t >= 0.0) {
-          const uint64_t lj = (uint64_t)cur_t;
-          if (maxerr > 0.0) atomicMax(&leaf_maxerr[lj], (unsigned long long)maxerr);
-          if (maxrun > 1) atomicMax(&leaf_run[lj], (unsigned long long)maxrun);
-        }
-        cur_t = t; maxerr = 0.0; maxrun = 0;
-        const uint64_t lj = (uint64_t)t;
-#pragma unroll
-        for (int q = 0; q < PPL; q++) pa[q] = params[lj * PPL + q];
-      }
-      // err = |min(pred, N) - min(y, N)| in the f64 domain (all integers < 2^53)
-      const double x = KeyTraits<K>::as_float(k);
-      double f;
-      if constexpr (LEAF == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(pa[0], x, pa[1]), x, pa[2]), x, pa[3]);
-      else f = __builtin_fma(pa[1], x, pa[0]);
-      const double pf = fmin(fmax(0.0, floor(f)), nf);
-      const double e = fabs(pf - (double)y);
-      maxerr = fmax(maxerr, e);
-      if (has_next && !(knext == k)) { const uint64_t rl = i - y + 1; maxrun = rl > maxrun ? rl : maxrun; }
-      kprev = k; k = knext;
-    }
-  }
-  if (cur_t >= 0.0) {
-    const uint64_t lj = (uint64_t)cur_t;
-    if (maxerr > 0.0) atomicMax(&leaf_maxerr[lj], (unsigned long long)maxerr);
-    if (maxrun > 1) atomicMax(&leaf_run[lj], (unsigned long long)maxrun);
-  }
-  if constexpr (!root_needs_bounds_check<ROOT>()) {
-    if (any_oob) atomicOr(&st->err_flags, EF_ROOT_OOB);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_fit_stream ("pass A"): bucketing scan + exact per-leaf SLR in one streaming pass.
-//
-// The SLR recurrence (linear.rs:24-34) is order dependent, so bit-identical coefficients need the
-// reference order inside a leaf; parallelism is across leaves.  Each lane owns a contiguous chunk
-// of C keys and fits, in key order, every leaf that *starts* inside its chunk (it skips the tail
-// of the leaf it starts in and runs past its chunk end until its last leaf closes), so all 64
-// lanes of a wave advance one key per step in lockstep regardless of leaf sizes.
-//   * HBM reads are coalesced: the wave loads a panel of 64 rows x 16 keys (one row per lane,
-//     4 rows = 4 full 128-B lines per load instruction), stages it through a padded LDS image and
-//     each lane then reads its own row; the next panel is prefetched into registers.
-//   * Everything that happens once per leaf -- the next-first point, the tail duplicate (Q1), the
-//     divisions of the final (alpha, beta) -- is deferred: the lane pushes its running state to
-//     an LDS queue and carries on; the wave drains the queue with all lanes busy.
-// Leaf boundaries are written to leaf_start as a by-product (the bucketing scan).
-// ---------------------------------------------------------------------------------------------
-constexpr int FS_ROW = 16;        // keys per panel row
-constexpr int FS_STRIDE = 17;     // padded row stride (elements): conflict-free lane-per-row reads
-constexpr int FS_QCAP = 96;       // close-record queue capacity per wave (drain at >= 32, <= 64 pushed per step)
-constexpr unsigned long long FS_NO_NEXT = 1ull << 63;
-
-struct SlrState { double mx, my, c, m2, nf; };
-
-__device__ __forceinline__ void slr_push(SlrState& s, double x, double y) {   // linear.rs:25-32
-  s.nf += 1.0;
-  const double dx = x - s.mx;
-  s.mx += dx / s.nf;
-  s.my += (y - s.my) / s.nf;
-  s.c += dx * (y - s.my);
-  const double dx2 = x - s.mx;
-  s.m2 += dx * dx2;
-}
-
-template <int ROOT, typename K>
-__global__ void __launch_bounds__(64) k_fit_stream(const K* __restrict__ keys, uint64_t n, RootP r, uint64_t C,
-                                                   unsigned long long* __restrict__ leaf_start,
-                                                   double* __restrict__ params,
-                                                   DevState* __restrict__ st) {
-  __shared__ K panel[64 * FS_STRIDE];
-  __shared__ double q_mx[FS_QCAP], q_my[FS_QCAP], q_c[FS_QCAP], q_m2[FS_QCAP], q_nf[FS_QCAP];
-  __shared__ unsigned long long q_leaf[FS_QCAP], q_idx[FS_QCAP];
-
-  const int lane = threadIdx.x;
-  const uint64_t wave_base = (uint64_t)blockIdx.x * 64 * C;
-  const uint64_t p0 = wave_base + (uint64_t)lane * C;         // first key of this lane's chunk
-  const uint64_t chunk_end = p0 + C;
-  const double Lm1f = (double)(r.L - 1);
-  const double midf = (double)(r.L / 2);                     // two_layer.rs:131
-
-  // ---- per-lane streaming state ----
-  int phase = (p0 < n) ? 0 : 2;                              // 0 skip, 1 active, 2 done
-  uint64_t i = p0;
-  K kprev = K();
-  double yprev = 0.0, tprev = -1.0;
-  bool prev_was_split = false;
-  double cur_t = -1.0;
-  SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
-  unsigned int flags = 0;
-  if (phase == 0 && p0 > 0) {
-    bool oob;
-    kprev = keys[p0 - 1];
-    yprev = (double)first_occurrence(keys, p0 - 1);
-    tprev = root_target_f<ROOT, K>(r, Lm1f, kprev, oob);
-    if (p0 > 1) {
-      const double tpp = root_target_f<ROOT, K>(r, Lm1f, keys[p0 - 2], oob);
-      prev_was_split = (tpp < midf && tprev >= midf);
-    }
-  }
-  int pending = 0;                                           // wave-uniform
-
-  // drain: every lane finishes one queued leaf (extra points + final divisions)
-  auto drain = [&]() {
-    for (int b = 0; b < pending; b += 64) {
-      const int slot = b + lane;
-      if (slot < pending) {
-        SlrState s2 = {q_mx[slot], q_my[slot], q_c[slot], q_m2[slot], q_nf[slot]};
-        const unsigned long long lj = q_leaf[slot];
-        const unsigned long long qi = q_idx[slot];
-        const uint64_t bi = qi & ~FS_NO_NEXT;
-        double a = 0.0, be = 0.0;
-        bool have = true;
-        if (!(qi & FS_NO_NEXT)) {
-          // next-first point (two_layer.rs:58-59): first key of the next non-empty leaf, y == its index
-          const double x = KeyTraits<K>::as_float(keys[bi]);
-          const double y = (double)bi;
-          slr_push(s2, x, y);
-          slr_push(s2, x, y);                                // Q1 tail duplicate (models/mod.rs:180)
-        } else if (s2.nf > 0.0) {
-          // container ends with the leaf's own last key: duplicate that one
-          const double x = KeyTraits<K>::as_float(keys[bi - 1]);
-          const double y = (double)first_occurrence(keys, bi - 1);
-          slr_push(s2, x, y);
-        } else have = false;                                 // only reachable together with a degenerate split
-        if (have) {
-          const double cov = s2.c / (s2.nf - 1.0);           // linear.rs:46-47
-          const double var = s2.m2 / (s2.nf - 1.0);
-          if (!(var >= 0.0)) flags |= EF_NEG_VARIANCE;
-          if (var == 0.0) { a = s2.my; be = 0.0; }
-          else { be = cov / var; a = s2.my - be * s2.mx; }
-        }
-        params[lj * 2 + 0] = a;
-        params[lj * 2 + 1] = be;
-      }
-    }
-    pending = 0;
-  };
-
-  // ---- panel loop ----
-  K stage[FS_ROW];
-  auto load_panel = [&](uint64_t P) {
-#pragma unroll
-    for (int k = 0; k < FS_ROW; k++) {
-      const int row = k * 4 + (lane >> 4), col = lane & 15;
-      const uint64_t gi = wave_base + (uint64_t)row * C + P * FS_ROW + col;
-      stage[k] = gi < n ? keys[gi] : K();
-    }
-  };
-  uint64_t P = 0;
-  load_panel(0);
-  while (__any(phase != 2)) {
-#pragma unroll
-    for (int k = 0; k < FS_ROW; k++) {
-      const int row = k * 4 + (lane >> 4), col = lane & 15;
-      panel[row * FS_STRIDE + col] = stage[k];
-    }
-    load_panel(P + 1);                                       // prefetch (consumed next iteration)
-#pragma unroll
-    for (int sidx = 0; sidx < FS_ROW; sidx++) {
-      const K k = panel[lane * FS_STRIDE + sidx];
-      bool do_close = false;
-      unsigned long long close_idx = 0;
-      SlrState close_state = sl;
-      double close_leaf = cur_t;
-      if (phase != 2) {
-        if (i >= n) {                                        // end of data: close the open leaf (no next-first)
-          if (phase == 1) { do_close = true; close_idx = n | FS_NO_NEXT; }
-          phase = 2;
-        } else {
-          bool oob;
-          const double t = root_target_f<ROOT, K>(r, Lm1f, k, oob);
-          if constexpr (!root_needs_bounds_check<ROOT>()) { if (oob) flags |= EF_ROOT_OOB; }   // two_layer.rs:45-48
-          const double x = KeyTraits<K>::as_float(k);
-          const double iff = (double)i;
-          const double y = (i > 0 && k == kprev) ? yprev : iff;      // FixDups first-occurrence offset
-          const bool is_split = (tprev < midf && t >= midf);         // i == split_idx (two_layer.rs:132-136)
-          if (t != tprev) {
-            if (t < tprev) flags |= EF_NON_MONOTONE;                 // two_layer.rs:50 / :144
-            if (phase == 1) {                                        // close the leaf this lane is fitting
-              do_close = true;
-              close_idx = is_split ? (i | FS_NO_NEXT) : i;           // Q3: no next-first across the halves
-            }
-            if (i < chunk_end) {                                     // this lane owns the leaf starting at i
-              phase = 1;
-              cur_t = t;
-              leaf_start[(uint64_t)t] = i;
-              if (is_split) {
-                if (i == 0 || i + 1 >= n) flags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
-                st->split_idx = i;
-                st->split_target = (uint64_t)t;
-                sl = {0.0, 0.0, 0.0, 0.0, 0.0};                      // Q2: the key at split_idx is in neither half
-              } else {
-                if (i == 0 || prev_was_split) sl = {0.0, 0.0, 0.0, 0.0, 0.0};   // no prev-last (start of a half / after Q4)
-                else sl = {KeyTraits<K>::as_float(kprev), yprev, 0.0, 0.0, 1.0}; // prev-last (two_layer.rs:74-78)
-                slr_push(sl, x, y);
-              }
-            } else {
-              phase = 2;                                             // the next lane takes over from here
-            }
-          } else if (phase == 1) {
-            slr_push(sl, x, y);
-          } else if (i >= chunk_end) {
-            phase = 2;                                               // no leaf starts in this chunk
-          }
-          kprev = k; yprev = y; tprev = t; prev_was_split = is_split;
-          if (i == n - 1) st->last_target = (uint64_t)t;
-        }
-        i += 1;
-      }
-      // ---- queue the closed leaf (wave-uniform bookkeeping) ----
-      const unsigned long long cm = __ballot(do_close);
-      if (cm) {
-        if (do_close) {
-          const int slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
-          q_mx[slot] = close_state.mx; q_my[slot] = close_state.my; q_c[slot] = close_state.c;
-          q_m2[slot] = close_state.m2; q_nf[slot] = close_state.nf;
-          q_leaf[slot] = (unsigned long long)close_leaf; q_idx[slot] = close_idx;
-        }
-        pending += __popcll(cm);
-        if (pending >= 32) drain();
-      }
-    }
-    P += 1;
-  }
-  if (pending) drain();
-  if (flags) atomicOr(&st->err_flags, flags);
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_finalize: one thread per leaf (O(L)).
 // ---------------------------------------------------------------------------------------------
 template <int LEAF, typename K>

@@ -1,0 +1,493 @@
+// rmi_stream.hip.h -- the two streaming kernels of the leaf hot path (gfx950, wave64).
+//
+//   k_fit_stream  ("pass A")  bucketing scan + exact per-leaf SLR (two_layer.rs:43-90, linear.rs:12-59)
+//   k_err_stream  ("pass B")  last-level error pass + run lengths (two_layer.rs:207-217,
+//                             lower_bound_correction.rs:104-119)
+//
+// Both kernels share one skeleton.  A wave owns 64 consecutive chunks of C keys, one chunk per
+// lane, and all lanes advance one key per step in lockstep.  Per panel of 64 rows x 16 keys:
+//   load     coalesced HBM reads (each load instruction covers 4 rows = 4 full 128-B lines),
+//            transposed through a padded LDS image (row stride 17 slots: lane-per-row accesses are
+//            bank-conflict free); the next panel is prefetched into registers meanwhile.
+//   phase 1  every lane classifies the 16 keys of its own row (root target, leaf-boundary and
+//            duplicate-key bit masks, split point), converts them to f64 in place and leaves the
+//            leaf ids in a second LDS panel.  This is the bucketing scan.
+//   phase 2  16 lockstep steps.  The common step is straight-line code; steps in which some lane
+//            crosses a leaf boundary take a wave-uniform slow path.
+//
+// Why lane-per-chunk: the SLR recurrence (linear.rs:24-34) is order dependent, so bit-identical
+// coefficients need the reference order inside a leaf; the parallelism is across leaves, and
+// chunks (not leaves) per lane keep all 64 lanes busy whatever the leaf sizes are.
+#pragma once
+#include "rmi_device.hip.h"
+
+namespace rmi {
+
+constexpr int FS_ROW = 16;        // keys per panel row
+constexpr int FS_STRIDE = 17;     // padded row stride (slots)
+constexpr int FS_QCAP = 128;      // close-record queue capacity per wave (drain at >= 64, <= 64 pushed per step)
+constexpr int FS_TMAX = 512;      // reciprocal table size
+constexpr unsigned long long FS_NO_NEXT = 1ull << 63;
+
+struct SlrState { double mx, my, c, m2, nf; };
+
+__device__ __forceinline__ void slr_push(SlrState& s, double x, double y) {   // linear.rs:25-32
+  s.nf += 1.0;
+  const double dx = x - s.mx;
+  s.mx += dx / s.nf;
+  s.my += (y - s.my) / s.nf;
+  s.c += dx * (y - s.my);
+  const double dx2 = x - s.mx;
+  s.m2 += dx * dx2;
+}
+
+// RN(a / nf) given r == RN(1 / nf): q0 = RN(a r) is within 2 ulp; one FMA correction round makes
+// it faithful, the second makes it correctly rounded (Markstein's theorem), i.e. exactly what
+// IEEE division returns (checked against `/` by rmi_hip_selftest_div).  No over/underflow can
+// occur for the operands of the recurrence on integer keys (|a| in [2^-84, 2^65] or 0).
+__device__ __forceinline__ double div_by_count(double a, double nf, double r) {
+  double q = a * r;
+  double e = __builtin_fma(-q, nf, a);
+  q = __builtin_fma(e, r, q);
+  e = __builtin_fma(-q, nf, a);
+  return __builtin_fma(e, r, q);
+}
+
+__device__ __forceinline__ void slr_push_r(SlrState& s, double x, double y, double r) {
+  s.nf += 1.0;
+  const double dx = x - s.mx;
+  s.mx += div_by_count(dx, s.nf, r);
+  s.my += div_by_count(y - s.my, s.nf, r);
+  s.c += dx * (y - s.my);
+  const double dx2 = x - s.mx;
+  s.m2 += dx * dx2;
+}
+
+template <typename K> struct UseRecipTable { static constexpr bool value = true; };
+template <> struct UseRecipTable<double> { static constexpr bool value = false; };   // f64 keys: plain IEEE division
+
+template <typename K>
+__device__ __forceinline__ unsigned long long key_to_bits(K k) {
+  if constexpr (sizeof(K) == 8) return __builtin_bit_cast(unsigned long long, k);
+  else return (unsigned long long)__builtin_bit_cast(unsigned int, k);
+}
+template <typename K>
+__device__ __forceinline__ K bits_to_key(unsigned long long b) {
+  if constexpr (sizeof(K) == 8) return __builtin_bit_cast(K, b);
+  else return __builtin_bit_cast(K, (unsigned int)b);
+}
+
+// Coalesced load of panel P of this wave (64 rows x 16 keys) into registers: instruction k
+// covers rows 4k..4k+3, 16 lanes per row.  Indices past the end are clamped to n-1 (no branches
+// around the loads); the duplicated key is masked out by the validity masks downstream.
+template <typename K>
+__device__ __forceinline__ void load_panel(K (&stage)[FS_ROW], const K* __restrict__ keys, uint64_t n,
+                                           uint64_t wave_base, uint64_t C, uint64_t P, int lane) {
+  // wave-uniform base (SGPRs) + one 32-bit lane offset: no per-load 64-bit VGPR address math
+  const uint64_t ubase = wave_base + P * FS_ROW;
+  const unsigned int loff = (unsigned int)(lane >> 4) * (unsigned int)C + (unsigned int)(lane & 15);
+  const uint64_t step = 4 * C;
+  if (wave_base + 63 * C + (P + 1) * FS_ROW <= n) {          // wave-uniform: whole panel in range
+#pragma unroll
+    for (int k = 0; k < FS_ROW; k++) {
+      const K* __restrict__ pk = keys + (ubase + (uint64_t)k * step);
+      stage[k] = pk[loff];
+    }
+  } else {
+    const uint64_t last = n - 1;
+#pragma unroll
+    for (int k = 0; k < FS_ROW; k++) {
+      const uint64_t gi = ubase + (uint64_t)k * step + loff;
+      stage[k] = keys[gi < last ? gi : last];
+    }
+  }
+}
+template <typename K>
+__device__ __forceinline__ void stage_to_lds(const K (&stage)[FS_ROW], unsigned long long* panel, int lane) {
+  const int base = (lane >> 4) * FS_STRIDE + (lane & 15);
+#pragma unroll
+  for (int k = 0; k < FS_ROW; k++) panel[base + k * 4 * FS_STRIDE] = key_to_bits<K>(stage[k]);
+}
+
+// Phase 1: classify the row of this lane -- straight-line code, no branches: all 16 raw keys are
+// read first (one LDS wait), classified, and written back as f64 x plus leaf ids.  Keys past the
+// end of the data are clamped copies of key[n-1]; `vmask` (valid positions) masks their bits.
+// WRITE: pass A additionally publishes leaf_start / the split point / error flags.
+template <int ROOT, typename K, bool WRITE>
+__device__ __forceinline__ void classify_row(unsigned long long* __restrict__ panel, unsigned int* __restrict__ leafp,
+                                             int lane, const RootP& r, double Lm1f, double midf,
+                                             uint64_t row_i, uint64_t n, unsigned int vmask, unsigned int ownmask,
+                                             K& kprev, double& tprev, unsigned int& bmask, unsigned int& dmask,
+                                             int& split_pos, unsigned int& flags,
+                                             unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st) {
+  unsigned int bm = 0, dm = 0, sm = 0, oobm = 0, nm = 0;
+  double tp = tprev;
+  K kp = kprev;
+  double tlast = tprev;
+  K klast = kprev;
+#pragma unroll
+  for (int h = 0; h < FS_ROW; h += 8) {                    // two halves of 8 keys: bounded register pressure
+    K kk[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) kk[q] = bits_to_key<K>(panel[lane * FS_STRIDE + h + q]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int s = h + q;
+      const K k = kk[q];
+      bool oob;
+      const double t = root_target_f<ROOT, K>(r, Lm1f, k, oob);
+      bm |= (t != tp) ? (1u << s) : 0u;
+      sm |= (tp < midf && t >= midf) ? (1u << s) : 0u;     // idx == split_idx (two_layer.rs:132-136)
+      dm |= (k == kp) ? (1u << s) : 0u;
+      if constexpr (WRITE) {
+        nm |= (t < tp) ? (1u << s) : 0u;                   // two_layer.rs:50 / :144
+        oobm |= oob ? (1u << s) : 0u;                      // two_layer.rs:45-48
+      }
+      leafp[lane * FS_STRIDE + s] = (unsigned int)t;
+      panel[lane * FS_STRIDE + s] = __builtin_bit_cast(unsigned long long, KeyTraits<K>::as_float(k));
+      tp = t; kp = k;
+      const bool v = (vmask >> s) & 1u;
+      tlast = v ? t : tlast;
+      klast = v ? k : klast;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (row_i == 0) dm &= ~1u;                               // key 0 has no predecessor
+  bm &= vmask; dm &= vmask; sm &= vmask;
+  bmask = bm; dmask = dm;
+  split_pos = sm ? (__ffs(sm) - 1) : -1;
+  kprev = klast; tprev = tlast;                            // carries = last valid key of the row
+  if constexpr (WRITE) {
+    if (nm & vmask) flags |= EF_NON_MONOTONE;
+    if constexpr (!root_needs_bounds_check<ROOT>()) { if (oobm & vmask) flags |= EF_ROOT_OOB; }
+    unsigned int m = bm & ownmask;                         // leaves that start in this lane's chunk
+    while (m) {
+      const int s = __ffs(m) - 1;
+      m &= m - 1;
+      const uint64_t idx = row_i + s;
+      const unsigned int t = leafp[lane * FS_STRIDE + s];
+      leaf_start[t] = idx;
+      if (s == split_pos) {
+        if (idx == 0 || idx + 1 >= n) flags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
+        st->split_idx = idx;
+        st->split_target = t;
+      }
+    }
+    if (n - 1 >= row_i && n - 1 - row_i < (uint64_t)FS_ROW) st->last_target = leafp[lane * FS_STRIDE + (int)(n - 1 - row_i)];
+  }
+}
+
+// =============================================================================================
+// Pass A.  Block = 4 independent waves (they only share the reciprocal table).
+// =============================================================================================
+constexpr int FA_WAVES = 4;
+constexpr int FS_QDRAIN = 32;     // drain the close queue once this many leaves are pending
+constexpr int FS_QCAP2 = FS_QDRAIN + 64;
+
+template <int ROOT, typename K>
+__global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restrict__ keys, uint64_t n, RootP r, uint64_t C,
+                                                             unsigned long long* __restrict__ leaf_start,
+                                                             double* __restrict__ params,
+                                                             DevState* __restrict__ st, int dbg) {
+  __shared__ unsigned long long s_panel[FA_WAVES][64 * FS_STRIDE];   // raw key bits, then f64 x
+  __shared__ unsigned int s_leafp[FA_WAVES][64 * FS_STRIDE];         // leaf id of every key of the panel
+  __shared__ double rtab[FS_TMAX];
+  __shared__ double s_q[FA_WAVES][5][FS_QCAP2];
+  __shared__ unsigned long long s_qidx[FA_WAVES][FS_QCAP2];
+  __shared__ unsigned int s_qleaf[FA_WAVES][FS_QCAP2];
+
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  unsigned long long* panel = s_panel[wv];
+  unsigned int* leafp = s_leafp[wv];
+  double* q_mx = s_q[wv][0]; double* q_my = s_q[wv][1]; double* q_c = s_q[wv][2];
+  double* q_m2 = s_q[wv][3]; double* q_nf = s_q[wv][4];
+  unsigned long long* q_idx = s_qidx[wv];
+  unsigned int* q_leaf = s_qleaf[wv];
+
+  const uint64_t wave_base = ((uint64_t)blockIdx.x * FA_WAVES + wv) * 64 * C;
+  const uint64_t p0 = wave_base + (uint64_t)lane * C;         // first key of this lane's chunk
+  const uint64_t chunk_end = p0 + C;
+  const double Lm1f = (double)(r.L - 1);
+  const double midf = (double)(r.L / 2);                     // two_layer.rs:131
+
+  for (int q = threadIdx.x; q < FS_TMAX; q += 64 * FA_WAVES) rtab[q] = 1.0 / (double)(q > 0 ? q : 1);
+  __syncthreads();
+
+  // carries of the classification (phase 1)
+  K kprev = K();
+  double tprev = -1.0;
+  bool carry_split = false;                                  // the key just before the row was the split key
+  // carries of the recurrence (phase 2)
+  double xprev = 0.0, yprev = 0.0;
+  bool active = false;
+  unsigned int cur_leaf = 0;
+  unsigned int cnt = 0;                                      // == sl.nf
+  SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
+  unsigned int flags = 0;
+  if (p0 < n && p0 > 0) {
+    bool oob;
+    kprev = keys[p0 - 1];
+    xprev = KeyTraits<K>::as_float(kprev);
+    yprev = (double)first_occurrence(keys, p0 - 1);
+    tprev = root_target_f<ROOT, K>(r, Lm1f, kprev, oob);
+    if (p0 > 1) {
+      const double tpp = root_target_f<ROOT, K>(r, Lm1f, keys[p0 - 2], oob);
+      carry_split = (tpp < midf && tprev >= midf);
+    }
+  }
+  int pending = 0;                                           // wave-uniform
+
+  // drain: every lane finishes one queued leaf (extra points + final divisions)
+  auto drain = [&]() {
+    for (int b = 0; b < pending; b += 64) {
+      const int slot = b + lane;
+      if (slot < pending) {
+        SlrState s2 = {q_mx[slot], q_my[slot], q_c[slot], q_m2[slot], q_nf[slot]};
+        const uint64_t lj = q_leaf[slot];
+        const unsigned long long qi = q_idx[slot];
+        const uint64_t bi = qi & ~FS_NO_NEXT;
+        double a = 0.0, be = 0.0;
+        bool have = true;
+        if (!(qi & FS_NO_NEXT)) {
+          // next-first point (two_layer.rs:58-59): first key of the next non-empty leaf, y == its index
+          const double x = KeyTraits<K>::as_float(keys[bi]);
+          const double y = (double)bi;
+          slr_push(s2, x, y);
+          slr_push(s2, x, y);                                // Q1 tail duplicate (models/mod.rs:180)
+        } else if (s2.nf > 0.0) {
+          // container ends with the leaf's own last key: duplicate that one
+          const double x = KeyTraits<K>::as_float(keys[bi - 1]);
+          const double y = (double)first_occurrence(keys, bi - 1);
+          slr_push(s2, x, y);
+        } else have = false;                                 // only reachable together with a degenerate split
+        if (have) {
+          const double cov = s2.c / (s2.nf - 1.0);           // linear.rs:46-47
+          const double var = s2.m2 / (s2.nf - 1.0);
+          if (!(var >= 0.0)) flags |= EF_NEG_VARIANCE;
+          if (var == 0.0) { a = s2.my; be = 0.0; }
+          else { be = cov / var; a = s2.my - be * s2.mx; }
+        }
+        params[lj * 2 + 0] = a;
+        params[lj * 2 + 1] = be;
+      }
+    }
+    pending = 0;
+  };
+
+  K stage[FS_ROW];
+  uint64_t row_i = p0;                                       // index of the first key of the current row
+  double row_if = (double)p0;
+  bool lane_done = !(p0 < n);
+  uint64_t P = 0;
+  load_panel<K>(stage, keys, n, wave_base, C, 0, lane);
+  while (__any(!lane_done)) {
+    stage_to_lds<K>(stage, panel, lane);
+    load_panel<K>(stage, keys, n, wave_base, C, P + 1, lane);   // prefetch (consumed next iteration)
+
+    // ---------------- phase 1 ----------------
+    unsigned int bmask = 0, dmask = 0;
+    int split_pos = -1;
+    const int end_pos = (row_i >= n) ? 0 : ((n - row_i < (uint64_t)FS_ROW) ? (int)(n - row_i) : FS_ROW);
+    const int own_cnt = (row_i >= chunk_end) ? 0 : ((chunk_end - row_i < (uint64_t)FS_ROW) ? (int)(chunk_end - row_i) : FS_ROW);
+    const bool prev_split_in = carry_split;
+    if (!(dbg & 4)) {
+      const unsigned int vmask = lane_done ? 0u : ((1u << end_pos) - 1u);
+      const unsigned int ownmask = (1u << own_cnt) - 1u;
+      classify_row<ROOT, K, true>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, ownmask,
+                                  kprev, tprev, bmask, dmask, split_pos, flags, leaf_start, st);
+      if (!lane_done && end_pos < FS_ROW) bmask |= 1u << end_pos;   // end of data acts as a final boundary
+      carry_split = (split_pos == FS_ROW - 1);
+    }
+
+    // ---------------- phase 2: 16 lockstep steps of the recurrence ----------------
+    double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
+#pragma unroll 1
+    for (int s = 0; s < FS_ROW; s++) {
+      const double x = xn;
+      xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);   // next step's x
+      double rr = rtab[(cnt + 1) & (FS_TMAX - 1)];
+      const bool bit = (bmask >> s) & 1u;
+      const double idxf = row_if + (double)s;
+      const double y = ((dmask >> s) & 1u) ? yprev : idxf;   // FixDups first-occurrence offset
+      bool do_push = active;
+      if (dbg & 1) do_push = false;
+      if (!(dbg & 2) && __any(bit)) {
+        // close first (queue the running state of the leaf that ends here), then open
+        const bool is_end = (s == end_pos);
+        const bool is_split = (s == split_pos);
+        const uint64_t idx = row_i + s;
+        const bool do_close = bit && active;
+        const unsigned long long cm = __ballot(do_close);
+        if (cm) {
+          if (do_close) {
+            const int slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
+            q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
+            q_leaf[slot] = cur_leaf;
+            q_idx[slot] = (is_end || is_split) ? (idx | FS_NO_NEXT) : idx;   // Q3: no next-first across the halves / at the end
+          }
+          pending += __popcll(cm);
+        }
+        if (bit) {
+          if (!is_end && s < own_cnt) {
+            // open the leaf that starts here
+            active = true;
+            cur_leaf = leafp[lane * FS_STRIDE + s];
+            const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
+            const bool with_prev = !(is_split || idx == 0 || prev_split);   // prev-last (two_layer.rs:74-78), Q3/Q4
+            sl.mx = with_prev ? xprev : 0.0;
+            sl.my = with_prev ? yprev : 0.0;
+            sl.c = 0.0; sl.m2 = 0.0;
+            sl.nf = with_prev ? 1.0 : 0.0;
+            cnt = with_prev ? 1u : 0u;
+            rr = with_prev ? 0.5 : 1.0;                      // 1/(cnt+1)
+            do_push = !is_split;                             // Q2: the key at split_idx is in neither half
+          } else {
+            active = false;                                  // end of data, or the next lane takes over
+            do_push = false;
+          }
+        }
+      }
+      if constexpr (UseRecipTable<K>::value) {
+        if (!__any(do_push && cnt + 1 >= (unsigned)FS_TMAX)) {
+          if (do_push) { cnt += 1; slr_push_r(sl, x, y, rr); }
+        } else {
+          if (do_push) { cnt += 1; slr_push(sl, x, y); }
+        }
+      } else {
+        if (do_push) { cnt += 1; slr_push(sl, x, y); }
+      }
+      xprev = x; yprev = y;
+      if (pending >= FS_QDRAIN) drain();
+    }
+    row_i += FS_ROW;
+    row_if += (double)FS_ROW;
+    if (!active && (row_i >= chunk_end || row_i > n)) lane_done = true;
+    if ((dbg & 4) && row_i >= chunk_end) lane_done = true;
+    P += 1;
+  }
+  if (pending) drain();
+  if (flags) atomicOr(&st->err_flags, flags);
+}
+
+// =============================================================================================
+// Pass B: err = |min(pred, N) - min(y, N)| per key with its leaf's model, max per leaf; longest run of
+// equal keys per leaf (a run is recorded when the next different key arrives, so the globally last
+// run is never recorded: Q5).  A lane walks its chunk keeping the maxima of the current leaf in
+// registers and issues one atomicMax per (lane, leaf) segment: ~N/C + L atomics in total.
+// Runs of length 1 are not reported (k_finalize adds that floor).
+// =============================================================================================
+template <int ROOT, int LEAF, typename K>
+__global__ void __launch_bounds__(64, 4) k_err_stream(const K* __restrict__ keys, uint64_t n, RootP r, uint64_t C,
+                                                   const double* __restrict__ params,
+                                                   unsigned long long* __restrict__ leaf_maxerr,
+                                                   unsigned long long* __restrict__ leaf_run, int dbg) {
+  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
+  __shared__ unsigned long long panel[64 * FS_STRIDE];
+  __shared__ unsigned int leafp[64 * FS_STRIDE];
+
+  const int lane = threadIdx.x;
+  const uint64_t wave_base = (uint64_t)blockIdx.x * 64 * C;
+  const uint64_t p0 = wave_base + (uint64_t)lane * C;
+  const uint64_t chunk_end = (p0 + C < n) ? p0 + C : n;
+  const double Lm1f = (double)(r.L - 1);
+  const double midf = (double)(r.L / 2);
+  const double nf = (double)n;
+  const unsigned int Lm1 = (unsigned int)(r.L - 1);
+
+  K kprev = K();
+  double tprev = -1.0;
+  double yprev = 0.0;
+  unsigned int cur_leaf = 0;
+  bool have_leaf = false;
+  double pa[PPL], pn[PPL];                                   // current leaf, prefetched next leaf
+#pragma unroll
+  for (int q = 0; q < PPL; q++) { pa[q] = 0.0; pn[q] = 0.0; }
+  double maxerr = 0.0, maxrun = 0.0;
+  if (p0 < n && p0 > 0) {
+    bool oob;
+    kprev = keys[p0 - 1];
+    yprev = (double)first_occurrence(keys, p0 - 1);
+    tprev = root_target_f<ROOT, K>(r, Lm1f, kprev, oob);
+    cur_leaf = (unsigned int)tprev;                          // owner of the run that ends at p0-1
+    have_leaf = true;
+#pragma unroll
+    for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)cur_leaf * PPL + q];
+    const unsigned int nx = cur_leaf < Lm1 ? cur_leaf + 1 : cur_leaf;
+#pragma unroll
+    for (int q = 0; q < PPL; q++) pn[q] = params[(uint64_t)nx * PPL + q];
+  }
+  unsigned int flags = 0;
+
+  auto flush = [&]() {
+    if (have_leaf) {
+      if (maxerr > 0.0) atomicMax(&leaf_maxerr[cur_leaf], (unsigned long long)maxerr);
+      if (maxrun > 1.0) atomicMax(&leaf_run[cur_leaf], (unsigned long long)maxrun);
+    }
+  };
+
+  K stage[FS_ROW];
+  uint64_t row_i = p0;
+  double row_if = (double)p0;
+  bool lane_done = !(p0 < n);
+  uint64_t P = 0;
+  load_panel<K>(stage, keys, n, wave_base, C, 0, lane);
+  while (__any(!lane_done)) {
+    stage_to_lds<K>(stage, panel, lane);
+    load_panel<K>(stage, keys, n, wave_base, C, P + 1, lane);
+
+    unsigned int bmask = 0, dmask = 0;
+    int split_pos = -1;
+    const int end_pos = (row_i >= chunk_end) ? 0 : ((chunk_end - row_i < (uint64_t)FS_ROW) ? (int)(chunk_end - row_i) : FS_ROW);
+    const unsigned int vmask = lane_done ? 0u : ((1u << end_pos) - 1u);   // keys of this lane's chunk in the row
+    classify_row<ROOT, K, false>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, 0u,
+                                 kprev, tprev, bmask, dmask, split_pos, flags, nullptr, nullptr);
+
+    double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
+#pragma unroll 1
+    for (int s = 0; s < FS_ROW; s++) {
+      const double x = xn;
+      xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);
+      const bool valid = (vmask >> s) & 1u;
+      const bool dup = (dmask >> s) & 1u;
+      const double idxf = row_if + (double)s;
+      // a new key value ends the previous run: record its length for the leaf of the previous key
+      if (valid && !dup && have_leaf) maxrun = fmax(maxrun, idxf - yprev);
+      const double y = dup ? yprev : idxf;
+      const bool bit = (bmask >> s) & 1u;
+      if (__any(bit)) {
+        if (bit) {
+          flush();
+          const unsigned int nl = leafp[lane * FS_STRIDE + s];
+          if (have_leaf && nl == cur_leaf + 1) {
+#pragma unroll
+            for (int q = 0; q < PPL; q++) pa[q] = pn[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)nl * PPL + q];
+          }
+          cur_leaf = nl; have_leaf = true; maxerr = 0.0; maxrun = 0.0;
+          const unsigned int nx = nl < Lm1 ? nl + 1 : nl;
+#pragma unroll
+          for (int q = 0; q < PPL; q++) pn[q] = params[(uint64_t)nx * PPL + q];
+        }
+      }
+      if (valid) {
+        double f;
+        if constexpr (LEAF == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(pa[0], x, pa[1]), x, pa[2]), x, pa[3]);
+        else f = __builtin_fma(pa[1], x, pa[0]);
+        // err in the f64 domain (all integers < 2^53): |min(pred, N) - y|, y < N
+        const double e = fabs(fmin(fmax(0.0, floor(f)), nf) - y);
+        maxerr = fmax(maxerr, e);
+        yprev = y;
+      }
+    }
+    row_i += FS_ROW;
+    row_if += (double)FS_ROW;
+    if (row_i >= chunk_end) lane_done = true;
+    P += 1;
+  }
+  flush();
+}
+
+}  // namespace rmi
