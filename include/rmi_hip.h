@@ -151,6 +151,9 @@ int rmi_hip_generate_keys(rmi_hip_ctx* ctx, int generator, int dtype, uint64_t n
                           uint64_t start, uint64_t count, uint64_t seed);
 int rmi_hip_download_keys(rmi_hip_ctx* ctx, void* host_out);
 const void* rmi_hip_device_keys(const rmi_hip_ctx* ctx);
+/* Achieved HBM read bandwidth (GB/s) of a read-only streaming kernel over the resident keys:
+ * the measured denominator reported next to the 8 TB/s spec peak. */
+int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* ctx, int iters, double* gb_per_s);
 
 /* ---- root model ---- */
 /* Fit the root exactly as the reference does.  `host_keys` may be NULL, in which case the keys

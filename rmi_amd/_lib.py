@@ -43,6 +43,7 @@ SYMBOLS = [
     ("rmi_hip_generate_keys", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     ("rmi_hip_download_keys", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_device_keys", C.c_void_p, [C.c_void_p]),
+    ("rmi_hip_measure_read_bandwidth", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     ("rmi_hip_fit_root", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(ModelParams)]),
     ("rmi_hip_train_two_layer", C.c_int, [C.c_void_p, C.POINTER(ModelParams), C.c_int, C.c_uint64, C.POINTER(Result)]),
     ("rmi_hip_download_leaf_params", C.c_int, [C.c_void_p, C.c_void_p]),

@@ -46,6 +46,7 @@ struct rmi_hip_ctx {
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
   uint64_t err_threads = 262144;                // lanes of pass B
   int fit_min_chunk = 64;
+  int err_kernel = 1;                           // pass B: 0 = wave-parallel (k_err_wave), 1 = chunk-streaming (k_err_stream)
   int dbg = 0;                                  // ablation switches for profiling (0 = product behaviour)
   // last result
   uint64_t last_L = 0;
@@ -170,6 +171,8 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (ft && *ft) c->fit_threads = std::strtoull(ft, nullptr, 10);
   const char* et = std::getenv("RMI_HIP_ERR_THREADS");
   if (et && *et) c->err_threads = std::strtoull(et, nullptr, 10);
+  const char* ek = std::getenv("RMI_HIP_ERR_KERNEL");
+  if (ek && *ek) c->err_kernel = std::atoi(ek);
   const char* dbg = std::getenv("RMI_HIP_DBG");
   if (dbg && *dbg) c->dbg = std::atoi(dbg);
   const char* fc = std::getenv("RMI_HIP_FIT_MIN_CHUNK");
@@ -262,6 +265,25 @@ int rmi_hip_download_keys(rmi_hip_ctx* c, void* host_out) {
 }
 
 const void* rmi_hip_device_keys(const rmi_hip_ctx* c) { return c ? c->d_keys : nullptr; }
+
+int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* c, int iters, double* gb_per_s) {
+  if (!c || !gb_per_s || iters <= 0) return RMI_ERR_BAD_ARG;
+  if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t bytes = c->n * key_size(c->dtype);
+  const uint64_t n16 = bytes / 16;
+  if (n16 == 0 || ((uintptr_t)c->d_keys & 15)) return RMI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_read_bw, dim3(256 * 8), dim3(256), 0, c->stream, (const uint4*)c->d_keys, n16, (unsigned int*)c->d_state);
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  for (int i = 0; i < iters; i++)
+    hipLaunchKernelGGL(k_read_bw, dim3(256 * 8), dim3(256), 0, c->stream, (const uint4*)c->d_keys, n16, (unsigned int*)c->d_state);
+  HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[9]));
+  *gb_per_s = (double)(n16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+  return RMI_OK;
+}
 
 int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const void* host_keys,
                      rmi_hip_model_params* out) {
@@ -362,6 +384,11 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   if (c->pipeline == 1) {
     const uint64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run);
+  } else if (c->err_kernel == 0) {
+    const uint64_t tiles = (n + 63) / 64;
+    const uint64_t waves = (tiles + EW_UNROLL - 1) / EW_UNROLL;
+    const uint64_t blocks = (waves + 3) / 4;
+    hipLaunchKernelGGL((k_err_wave<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run, c->dbg);
   } else {
     uint64_t C = (n + c->err_threads - 1) / c->err_threads;
     C = ((C + FS_ROW - 1) / FS_ROW) * FS_ROW;

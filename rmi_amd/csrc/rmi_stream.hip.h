@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
 // Runs of length 1 are not reported (k_finalize adds that floor).
 // =============================================================================================
 template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(64, 4) k_err_stream(const K* __restrict__ keys, uint64_t n, RootP r, uint64_t C,
+__global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, uint64_t n, RootP r, uint64_t C,
                                                    const double* __restrict__ params,
                                                    unsigned long long* __restrict__ leaf_maxerr,
                                                    unsigned long long* __restrict__ leaf_run, int dbg) {
@@ -488,6 +488,120 @@ __global__ void __launch_bounds__(64, 4) k_err_stream(const K* __restrict__ keys
     P += 1;
   }
   flush();
+}
+
+
+// =============================================================================================
+// Pass B, wave-parallel form: one key per lane, coalesced loads straight into registers (no LDS),
+// leaf parameters gathered from L2 (a wave touches 1-2 leaves), wave-level DPP max reductions per
+// leaf segment and one atomicMax per (wave, leaf).  Keys of one leaf are contiguous, so a wave
+// of 64 consecutive keys holds one leaf (usual case), two, or -- for leaves shorter than a wave --
+// many; the latter falls back to one atomic per lane.
+// =============================================================================================
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+  // inclusive max-scan inside rows of 16 (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31:
+  // lane 63 ends up with the maximum of all 64 lanes.  0 is the identity.
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return v;
+}
+
+constexpr int EW_UNROLL = 4;      // wave tiles (64 keys each) per wave
+
+template <int ROOT, int LEAF, typename K>
+__global__ void __launch_bounds__(256) k_err_wave(const K* __restrict__ keys, uint64_t n, RootP r,
+                                                  const double* __restrict__ params,
+                                                  unsigned long long* __restrict__ leaf_maxerr,
+                                                  unsigned long long* __restrict__ leaf_run, int dbg) {
+  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const double Lm1f = (double)(r.L - 1);
+  const double nf = (double)n;
+  const bool small = n <= 0xFFFFFFFFull;
+#pragma unroll
+  for (int u = 0; u < EW_UNROLL; u++) {
+    const uint64_t base = (wave_id * EW_UNROLL + u) * 64;
+    if (base >= n) break;                                   // wave-uniform
+    const uint64_t i = base + lane;
+    const bool valid = i < n;
+    const uint64_t ic = valid ? i : n - 1;
+    const K k = keys[ic];
+    // neighbours: previous / next key (lane 0 / lane 63 fetch across the tile edge)
+    K kprev, knext;
+    {
+      unsigned long long kb = key_to_bits<K>(k);
+      unsigned int lo = (unsigned int)kb, hi = (unsigned int)(kb >> 32);
+      unsigned int plo = __shfl_up(lo, 1, 64), phi = __shfl_up(hi, 1, 64);
+      unsigned int nlo = __shfl_down(lo, 1, 64), nhi = __shfl_down(hi, 1, 64);
+      kprev = bits_to_key<K>(((unsigned long long)phi << 32) | plo);
+      knext = bits_to_key<K>(((unsigned long long)nhi << 32) | nlo);
+      if (lane == 0 && i > 0) kprev = keys[i - 1];
+      if (lane == 63 && i + 1 < n) knext = keys[i + 1];
+    }
+    bool oob;
+    const double t = root_target_f<ROOT, K>(r, Lm1f, k, oob);
+    const unsigned int tj = (unsigned int)t;
+    double pa[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)tj * PPL + q];
+    if (dbg & 2) { pa[0] = t; pa[1] = 1e-9; }
+    uint64_t y = i;
+    if (valid && i > 0 && k == kprev) y = first_occurrence(keys, i);
+    const double x = KeyTraits<K>::as_float(k);
+    double f;
+    if constexpr (LEAF == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(pa[0], x, pa[1]), x, pa[2]), x, pa[3]);
+    else f = __builtin_fma(pa[1], x, pa[0]);
+    const double yf = (double)y;
+    double e = fabs(fmin(fmax(0.0, floor(f)), nf) - yf);     // |min(pred, N) - y|, integers < 2^53
+    double rl = (i + 1 < n && !(knext == k)) ? ((double)i - yf + 1.0) : 0.0;   // recorded when the next different key arrives
+    if (!valid) { e = 0.0; rl = 0.0; }
+    if (rl <= 1.0) rl = 0.0;                                 // runs of length 1 are added back by k_finalize
+    if (dbg & 1) { if (e + rl == -1.0) leaf_run[0] = 1; continue; }
+    const unsigned int t_first = __builtin_amdgcn_readfirstlane(tj);
+    const unsigned int t_last = __builtin_amdgcn_readlane(tj, 63);
+    const bool two = __ballot(tj != t_first && tj != t_last) == 0ull;
+    if (small && two) {
+      const unsigned int eu = (unsigned int)e, ru = (unsigned int)rl;
+      const bool inA = (tj == t_first);
+      const unsigned int ea = wave_max_u32(inA ? eu : 0u);
+      const unsigned int ra = wave_max_u32(inA ? ru : 0u);
+      if (lane == 63) {
+        if (ea) atomicMax(&leaf_maxerr[t_first], (unsigned long long)ea);
+        if (ra) atomicMax(&leaf_run[t_first], (unsigned long long)ra);
+      }
+      if (t_first != t_last) {                               // wave-uniform
+        const unsigned int eb = wave_max_u32(inA ? 0u : eu);
+        const unsigned int rb = wave_max_u32(inA ? 0u : ru);
+        if (lane == 63) {
+          if (eb) atomicMax(&leaf_maxerr[t_last], (unsigned long long)eb);
+          if (rb) atomicMax(&leaf_run[t_last], (unsigned long long)rb);
+        }
+      }
+    } else {
+      if (e > 0.0) atomicMax(&leaf_maxerr[tj], (unsigned long long)e);
+      if (rl > 0.0) atomicMax(&leaf_run[tj], (unsigned long long)rl);
+    }
+  }
+}
+
+
+// Read-only streaming kernel: the box's achievable HBM read bandwidth in this harness (the
+// denominator SURVEY.md section 8d asks to report next to the 8 TB/s spec peak).
+__global__ void __launch_bounds__(256) k_read_bw(const uint4* __restrict__ src, uint64_t n16, unsigned int* __restrict__ sink) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned int acc = 0;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  }
+  for (; i < n16; i += stride) { const uint4 a = src[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+  if (acc == 0x12345678u) sink[0] = acc;   // practically never; keeps the loads alive
 }
 
 }  // namespace rmi

@@ -200,6 +200,12 @@ class Trainer:
         self._host_keys = a
         return a
 
+    def measure_read_bandwidth(self, iters: int = 10) -> float:
+        """GB/s of a read-only streaming kernel over the resident keys (the box's achievable HBM rate)."""
+        v = C.c_double()
+        _check(self._lib.rmi_hip_measure_read_bandwidth(self._h, iters, C.byref(v)), self._h)
+        return float(v.value)
+
     def set_stream(self, stream_ptr: int | None):
         _check(self._lib.rmi_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
