@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="keys of the workload the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo for functional tests)")
     return ap.parse_args()
 
 
@@ -75,14 +76,18 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    local_rank = local_rank % max(1, torch.cuda.device_count())   # (functional tests may oversubscribe one GPU with gloo)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from rmi_amd import train as T
     os.environ["RMI_HIP_PROFILE_KERNELS"] = "1"     # per-kernel hipEvents on the library's stream
@@ -129,7 +134,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

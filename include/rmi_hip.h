@@ -114,6 +114,11 @@ typedef struct {
   uint64_t model_max_error_idx;
   uint64_t split_idx;             /* two_layer.rs:132 (== num_rows when there is no split) */
   uint64_t split_target;          /* two_layer.rs:152-156 */
+  /* shard bookkeeping: partial sums over the leaves of this shard, to be combined across ranks:
+   * avg = sum(sum_n_err)/N, avg_l2 = sum(sum_l2), avg_log2 = sum(sum_log2)/N, max over max. */
+  uint64_t shard_leaf_lo, shard_leaves;
+  uint64_t sum_n_err;
+  double sum_l2, sum_log2;
   uint64_t device_ns;             /* hipEvent time of all device work of this call */
   uint64_t kernel_ns[8];          /* per-kernel hipEvent times, see RMI_K_* */
 } rmi_hip_result;
@@ -155,11 +160,44 @@ const void* rmi_hip_device_keys(const rmi_hip_ctx* ctx);
  * the measured denominator reported next to the 8 TB/s spec peak. */
 int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* ctx, int iters, double* gb_per_s);
 
+/* ---- multi-GPU sharding ----
+ * A rank owns the contiguous leaf range [leaf_lo, leaf_hi) and the keys [key_lo, key_hi) that the
+ * root maps to it (key_lo = first index with target >= leaf_lo; key_hi likewise for leaf_hi), and
+ * keeps the keys [read_lo, read_hi) resident: the owned keys plus a halo -- on the left the whole
+ * duplicate run of key[key_lo-1] and one more key, on the right at least key[key_hi].
+ * rmi_hip_upload_keys / attach / generate then refer to exactly the keys [read_lo, read_hi).
+ * split_idx / split_target: the 2-way-join split of two_layer.rs:132-156 (a global property;
+ * UINT64_MAX if no key reaches leaf L/2).  All indices are global.  NULL clears the shard. */
+typedef struct {
+  uint64_t n_global;
+  uint64_t read_lo, read_hi;
+  uint64_t key_lo, key_hi;
+  uint64_t leaf_lo, leaf_hi;
+  uint64_t split_idx, split_target;
+} rmi_hip_shard;
+int rmi_hip_set_shard(rmi_hip_ctx* ctx, const rmi_hip_shard* shard);
+/* Write the packed rows of this shard to a caller-owned device buffer (row 0 of the shard at
+ * `device_rows`) instead of the context's own buffer, e.g. straight into the slot of an
+ * all-gather buffer.  NULL restores the internal buffer. */
+int rmi_hip_set_rows_output(rmi_hip_ctx* ctx, void* device_rows);
+
 /* ---- root model ---- */
 /* Fit the root exactly as the reference does.  `host_keys` may be NULL, in which case the keys
  * are read back from HBM for the order-dependent fits (linear / robust_linear / cubic). */
 int rmi_hip_fit_root(rmi_hip_ctx* ctx, int root_kind, uint64_t num_leaves, const void* host_keys,
                      rmi_hip_model_params* out);
+
+/* min(L-1, root.predict_to_int(key)) evaluated on the host (two_layer.rs:49): lets a caller plan
+ * leaf-aligned shard cuts with exactly the bucketing the kernels use.  key_bits: the key's bits. */
+int rmi_hip_root_target(const rmi_hip_model_params* root, int dtype, uint64_t key_bits,
+                        uint64_t num_leaves, uint64_t* out);
+/* `linear` root fit fed with consecutive chunks of the global key array (same recurrence and
+ * result as rmi_hip_fit_root; for data that is produced or held shard by shard). */
+typedef struct rmi_hip_root_stream rmi_hip_root_stream;
+int rmi_hip_root_stream_begin(int root_kind, int dtype, uint64_t n_global, uint64_t num_leaves,
+                              rmi_hip_root_stream** out);
+int rmi_hip_root_stream_push(rmi_hip_root_stream* rs, const void* host_keys, uint64_t count);
+int rmi_hip_root_stream_finish(rmi_hip_root_stream* rs, rmi_hip_model_params* out);  /* frees rs */
 
 /* ---- the hot path ---- */
 int rmi_hip_train_two_layer(rmi_hip_ctx* ctx, const rmi_hip_model_params* root, int leaf_kind,

@@ -13,6 +13,12 @@ class ModelParams(C.Structure):
     _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("p", C.c_double * 4), ("ip", C.c_uint64 * 2)]
 
 
+class Shard(C.Structure):
+    _fields_ = [("n_global", C.c_uint64), ("read_lo", C.c_uint64), ("read_hi", C.c_uint64),
+                ("key_lo", C.c_uint64), ("key_hi", C.c_uint64), ("leaf_lo", C.c_uint64), ("leaf_hi", C.c_uint64),
+                ("split_idx", C.c_uint64), ("split_target", C.c_uint64)]
+
+
 class Result(C.Structure):
     _fields_ = [
         ("num_rows", C.c_uint64), ("num_leaves", C.c_uint64),
@@ -21,6 +27,8 @@ class Result(C.Structure):
         ("model_avg_log2_error", C.c_double), ("model_max_log2_error", C.c_double),
         ("model_max_error", C.c_uint64), ("model_max_error_idx", C.c_uint64),
         ("split_idx", C.c_uint64), ("split_target", C.c_uint64),
+        ("shard_leaf_lo", C.c_uint64), ("shard_leaves", C.c_uint64),
+        ("sum_n_err", C.c_uint64), ("sum_l2", C.c_double), ("sum_log2", C.c_double),
         ("device_ns", C.c_uint64), ("kernel_ns", C.c_uint64 * 8),
     ]
 
@@ -44,7 +52,13 @@ SYMBOLS = [
     ("rmi_hip_download_keys", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_device_keys", C.c_void_p, [C.c_void_p]),
     ("rmi_hip_measure_read_bandwidth", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    ("rmi_hip_set_shard", C.c_int, [C.c_void_p, C.POINTER(Shard)]),
+    ("rmi_hip_set_rows_output", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_fit_root", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(ModelParams)]),
+    ("rmi_hip_root_target", C.c_int, [C.POINTER(ModelParams), C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("rmi_hip_root_stream_begin", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
+    ("rmi_hip_root_stream_push", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    ("rmi_hip_root_stream_finish", C.c_int, [C.c_void_p, C.POINTER(ModelParams)]),
     ("rmi_hip_train_two_layer", C.c_int, [C.c_void_p, C.POINTER(ModelParams), C.c_int, C.c_uint64, C.POINTER(Result)]),
     ("rmi_hip_download_leaf_params", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_download_leaf_errors", C.c_int, [C.c_void_p, C.c_void_p]),

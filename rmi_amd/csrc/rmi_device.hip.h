@@ -27,6 +27,18 @@ struct RootP {
   uint64_t L;              // number of leaves
 };
 
+// Index space of one launch.  All key indices and leaf ids inside the kernels are GLOBAL; the key
+// and per-leaf array pointers handed to the kernels are pre-offset so that ptr[global_index] is
+// the right element.  One GPU: it = rd = [0, n), leaves [0, L).  A shard of a multi-GPU run owns
+// the leaves [leaf_lo, leaf_hi) and the keys [it_lo, it_hi) that map to them, and can read a
+// small halo around them.
+struct Span {
+  uint64_t it_lo, it_hi;      // keys this launch is responsible for
+  uint64_t rd_lo, rd_hi;      // keys that may be read (rd_lo <= it_lo, it_hi <= rd_hi)
+  uint64_t n;                 // number of keys of the whole data set
+  uint64_t leaf_lo, leaf_hi;  // leaves this launch writes
+};
+
 // Small device-resident state shared between the kernels of one train call.
 struct DevState {
   unsigned long long split_idx;     // two_layer.rs:132-136 ; == n when no key reaches L/2
@@ -128,10 +140,10 @@ __device__ __forceinline__ uint64_t error_between(uint64_t v1, uint64_t v2, uint
 // Offset of the first occurrence of keys[i] (FixDupsIter semantics, models/mod.rs:154-185):
 // lower_bound of keys[i] in [0, i].  O(1) when keys[i-1] != keys[i].
 template <typename K>
-__device__ __forceinline__ uint64_t first_occurrence(const K* __restrict__ keys, uint64_t i) {
+__device__ __forceinline__ uint64_t first_occurrence(const K* __restrict__ keys, uint64_t i, uint64_t rd_lo = 0) {
   K v = keys[i];
-  if (i == 0 || keys[i - 1] != v) return i;
-  uint64_t lo = 0, hi = i - 1;   // keys[hi] == v
+  if (i <= rd_lo || keys[i - 1] != v) return i;
+  uint64_t lo = rd_lo, hi = i - 1;   // keys[hi] == v
   while (lo < hi) {
     uint64_t mid = lo + ((hi - lo) >> 1);
     if (keys[mid] < v) lo = mid + 1; else hi = mid;

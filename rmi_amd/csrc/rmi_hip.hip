@@ -40,6 +40,12 @@ struct rmi_hip_ctx {
   unsigned long long* d_tilemin = nullptr;
   DevState* d_state = nullptr;
   DevState* h_state = nullptr;                  // pinned
+  unsigned long long* h_sentinel = nullptr;     // pinned
+  // shard of a multi-GPU run (rmi_hip_set_shard); keys resident = global [rd_lo, rd_hi)
+  bool have_shard = false;
+  Span shard = {};
+  unsigned long long shard_split_idx = ~0ull, shard_split_target = 0;
+  void* d_rows_ext = nullptr;                   // caller-provided row buffer (e.g. the all-gather buffer)
   hipEvent_t ev[10] = {};
   bool profile_kernels = false;
   int pipeline = 2;                             // 1 = one kernel per reference pass; 2 = tiled/streaming kernels
@@ -162,6 +168,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   c->stream = c->own_stream;
   if (hipMalloc(&c->d_state, sizeof(DevState)) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  if (hipHostMalloc((void**)&c->h_sentinel, 64, hipHostMallocDefault) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   const char* pk = std::getenv("RMI_HIP_PROFILE_KERNELS");
   c->profile_kernels = pk && *pk && *pk != '0';
@@ -197,6 +204,7 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->h_state) (void)hipHostFree(c->h_state);
+  if (c->h_sentinel) (void)hipHostFree(c->h_sentinel);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -232,6 +240,27 @@ int rmi_hip_attach_device_keys(rmi_hip_ctx* c, const void* device_keys, uint64_t
 }
 
 uint64_t rmi_hip_num_keys(const rmi_hip_ctx* c) { return c ? c->n : 0; }
+
+int rmi_hip_set_shard(rmi_hip_ctx* c, const rmi_hip_shard* sh) {
+  if (!c) return RMI_ERR_BAD_ARG;
+  if (!sh) { c->have_shard = false; return RMI_OK; }
+  if (!(sh->read_lo <= sh->key_lo && sh->key_lo <= sh->key_hi && sh->key_hi <= sh->read_hi && sh->read_hi <= sh->n_global &&
+        sh->leaf_lo < sh->leaf_hi)) return RMI_ERR_BAD_ARG;
+  if (sh->key_lo > 0 && sh->read_lo == sh->key_lo) return RMI_ERR_BAD_ARG;         // needs a left halo
+  if (sh->key_hi < sh->n_global && sh->read_hi == sh->key_hi) return RMI_ERR_BAD_ARG;  // needs a right halo
+  c->shard.it_lo = sh->key_lo; c->shard.it_hi = sh->key_hi;
+  c->shard.rd_lo = sh->read_lo; c->shard.rd_hi = sh->read_hi;
+  c->shard.n = sh->n_global; c->shard.leaf_lo = sh->leaf_lo; c->shard.leaf_hi = sh->leaf_hi;
+  c->shard_split_idx = sh->split_idx; c->shard_split_target = sh->split_target;
+  c->have_shard = true;
+  return RMI_OK;
+}
+
+int rmi_hip_set_rows_output(rmi_hip_ctx* c, void* device_rows) {
+  if (!c) return RMI_ERR_BAD_ARG;
+  c->d_rows_ext = device_rows;
+  return RMI_OK;
+}
 
 int rmi_hip_generate_keys(rmi_hip_ctx* c, int generator, int dtype, uint64_t n_global, uint64_t start,
                           uint64_t count, uint64_t seed) {
@@ -310,6 +339,59 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
 
 }  // extern "C"
 
+extern "C" {
+
+int rmi_hip_root_target(const rmi_hip_model_params* root, int dtype, uint64_t key_bits, uint64_t num_leaves, uint64_t* out) {
+  if (!root || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  switch (dtype) {
+    case RMI_KEY_U64: *out = rmi_host::root_target<uint64_t>(*root, (uint64_t)key_bits, num_leaves); return RMI_OK;
+    case RMI_KEY_U32: *out = rmi_host::root_target<uint32_t>(*root, (uint32_t)key_bits, num_leaves); return RMI_OK;
+    case RMI_KEY_F64: { double d; std::memcpy(&d, &key_bits, 8); *out = rmi_host::root_target<double>(*root, d, num_leaves); return RMI_OK; }
+  }
+  return RMI_ERR_BAD_ARG;
+}
+
+struct rmi_hip_root_stream {
+  int dtype;
+  rmi_host::LinearRootStream<uint64_t> s64;
+  rmi_host::LinearRootStream<uint32_t> s32;
+  rmi_host::LinearRootStream<double> sf;
+};
+
+int rmi_hip_root_stream_begin(int root_kind, int dtype, uint64_t n_global, uint64_t num_leaves, rmi_hip_root_stream** out) {
+  if (!out || n_global == 0 || num_leaves == 0 || dtype < 0 || dtype > 2) return RMI_ERR_BAD_ARG;
+  if (root_kind != RMI_MODEL_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
+  rmi_hip_root_stream* r = new rmi_hip_root_stream();
+  r->dtype = dtype;
+  r->s64.begin(n_global, num_leaves); r->s32.begin(n_global, num_leaves); r->sf.begin(n_global, num_leaves);
+  *out = r;
+  return RMI_OK;
+}
+int rmi_hip_root_stream_push(rmi_hip_root_stream* r, const void* host_keys, uint64_t count) {
+  if (!r || (!host_keys && count)) return RMI_ERR_BAD_ARG;
+  switch (r->dtype) {
+    case RMI_KEY_U64: r->s64.push((const uint64_t*)host_keys, count); break;
+    case RMI_KEY_U32: r->s32.push((const uint32_t*)host_keys, count); break;
+    default: r->sf.push((const double*)host_keys, count); break;
+  }
+  return RMI_OK;
+}
+int rmi_hip_root_stream_finish(rmi_hip_root_stream* r, rmi_hip_model_params* out) {
+  if (!r || !out) return RMI_ERR_BAD_ARG;
+  std::memset(out, 0, sizeof *out);
+  out->kind = RMI_MODEL_LINEAR;
+  int rc;
+  switch (r->dtype) {
+    case RMI_KEY_U64: rc = r->s64.finish(out); break;
+    case RMI_KEY_U32: rc = r->s32.finish(out); break;
+    default: rc = r->sf.finish(out); break;
+  }
+  delete r;
+  return rc;
+}
+
+}  // extern "C"
+
 static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   if (L <= c->cap_leaves && ppl <= c->cap_ppl) return RMI_OK;
   free_outputs(c);
@@ -327,91 +409,110 @@ static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
 
 template <int ROOT, int LEAF, typename K>
 static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
-  const K* keys = (const K*)c->d_keys;
-  const uint64_t n = c->n;
   hipStream_t s = c->stream;
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
+  constexpr int ROWB = PPL * 8 + 8;
   const bool pk = c->profile_kernels;
   int evi = 0;
   auto mark = [&]() { if (pk) (void)hipEventRecord(c->ev[1 + evi], s); evi++; };
 
+  // ---- index space of this launch (global indices; see Span) ----
+  Span sp;
+  if (c->have_shard) sp = c->shard;
+  else { sp.it_lo = 0; sp.it_hi = c->n; sp.rd_lo = 0; sp.rd_hi = c->n; sp.n = c->n; sp.leaf_lo = 0; sp.leaf_hi = L; }
+  const uint64_t n_it = sp.it_hi - sp.it_lo;            // keys this launch works on
+  const uint64_t L_own = sp.leaf_hi - sp.leaf_lo;
+  // pointers pre-offset so that ptr[global index] is the right element
+  const K* keys = (const K*)c->d_keys - sp.rd_lo;
+  unsigned long long* leaf_start = c->d_leaf_start - sp.leaf_lo;
+  double* params = c->d_params - sp.leaf_lo * PPL;
+  unsigned long long* maxerr = c->d_maxerr - sp.leaf_lo;
+  unsigned long long* run = c->d_run - sp.leaf_lo;
+  unsigned long long* err = c->d_err - sp.leaf_lo;
+  unsigned long long* count = c->d_count - sp.leaf_lo;
+  unsigned char* rows_base = c->d_rows_ext ? (unsigned char*)c->d_rows_ext : c->d_rows;
+  unsigned char* rows = rows_base - sp.leaf_lo * ROWB;
+
   // --- init ---
   DevState init; std::memset(&init, 0, sizeof init);
-  init.split_idx = n; init.split_target = 0;
+  init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
+  init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
+  init.last_target = ~0ull;
   *c->h_state = init;
+  c->h_sentinel[0] = sp.it_hi;
   HIPCHK(c, hipMemcpyAsync(c->d_state, c->h_state, sizeof(DevState), hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemsetAsync(c->d_leaf_start, 0xFF, (L + 1) * 8, s));
-  HIPCHK(c, hipMemcpyAsync(c->d_leaf_start + L, &c->n, 8, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemsetAsync(c->d_maxerr, 0, L * 8, s));
-  HIPCHK(c, hipMemsetAsync(c->d_run, 0, L * 8, s));
+  HIPCHK(c, hipMemsetAsync(c->d_leaf_start, 0xFF, (L_own + 1) * 8, s));
+  HIPCHK(c, hipMemcpyAsync(c->d_leaf_start + L_own, c->h_sentinel, 8, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->d_maxerr, 0, L_own * 8, s));
+  HIPCHK(c, hipMemsetAsync(c->d_run, 0, L_own * 8, s));
 
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   const bool stream_fit = (c->pipeline != 1) && (LEAF == K_LINEAR);
-  if (!stream_fit) {
+  if (n_it == 0) {
+    mark();                                              // a shard without keys: every leaf is empty
+  } else if (!stream_fit) {
     // --- bucketing scan ---
-    {
-      const uint64_t blocks = (n + 255) / 256;
-      hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_leaf_start, c->d_state);
-    }
+    const uint64_t blocks = (n_it + 255) / 256;
+    hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
     mark();
   } else {
     // --- pass A: bucketing scan + exact per-leaf fit in one streaming pass ---
-    uint64_t C = (n + c->fit_threads - 1) / c->fit_threads;
+    uint64_t C = (n_it + c->fit_threads - 1) / c->fit_threads;
     C = ((C + FS_ROW - 1) / FS_ROW) * FS_ROW;
     if (C < (uint64_t)c->fit_min_chunk) C = c->fit_min_chunk;
-    const uint64_t chunks = (n + C - 1) / C;
+    const uint64_t chunks = (n_it + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
     const uint64_t fblocks = (waves + FA_WAVES - 1) / FA_WAVES;
-    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, n, rp, C, c->d_leaf_start, c->d_params, c->d_state, c->dbg);
+    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, sp, rp, C, leaf_start, params, c->d_state, c->dbg);
     mark();
   }
   // --- fill empty leaves ---
   {
-    const uint64_t count = L + 1;
-    const uint64_t ntiles = (count + FILL_TILE - 1) / FILL_TILE;
-    hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count, c->d_tilemin);
+    const uint64_t count_e = L_own + 1;
+    const uint64_t ntiles = (count_e + FILL_TILE - 1) / FILL_TILE;
+    hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count_e, c->d_tilemin);
     hipLaunchKernelGGL(k_fill_scan_tiles, dim3(1), dim3(1024), 0, s, c->d_tilemin, ntiles);
-    hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count, c->d_tilemin);
+    hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count_e, c->d_tilemin);
   }
   mark();
   if (!stream_fit) {
     // --- per-leaf fit ---
-    const uint64_t blocks = (L + 255) / 256;
-    hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, L, c->d_leaf_start, c->d_state, c->d_params);
+    const uint64_t blocks = (L_own + 255) / 256;
+    hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params);
   }
   mark();
   // --- error pass ---
-  if (c->pipeline == 1) {
-    const uint64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run);
+  if (n_it == 0) {
+  } else if (c->pipeline == 1) {
+    const uint64_t blocks = (n_it + 255) / 256;
+    hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, params, maxerr, run);
   } else if (c->err_kernel == 0) {
-    const uint64_t tiles = (n + 63) / 64;
+    const uint64_t tiles = (n_it + 63) / 64;
     const uint64_t waves = (tiles + EW_UNROLL - 1) / EW_UNROLL;
     const uint64_t blocks = (waves + 3) / 4;
-    hipLaunchKernelGGL((k_err_wave<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, rp, c->d_params, c->d_maxerr, c->d_run, c->dbg);
+    hipLaunchKernelGGL((k_err_wave<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, params, maxerr, run, c->dbg);
   } else {
-    uint64_t C = (n + c->err_threads - 1) / c->err_threads;
+    uint64_t C = (n_it + c->err_threads - 1) / c->err_threads;
     C = ((C + FS_ROW - 1) / FS_ROW) * FS_ROW;
     if (C < (uint64_t)c->fit_min_chunk) C = c->fit_min_chunk;
-    const uint64_t chunks = (n + C - 1) / C;
+    const uint64_t chunks = (n_it + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
-    hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, n, rp, C, c->d_params, c->d_maxerr, c->d_run, c->dbg);
+    hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, params, maxerr, run, c->dbg);
   }
   mark();
   // --- finalize + stats ---
   {
-    const uint64_t blocks = (L + 255) / 256;
-    hipLaunchKernelGGL((k_finalize<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, n, L, c->d_leaf_start, c->d_state,
-                       c->d_params, c->d_maxerr, c->d_run, c->d_err, c->d_count, c->d_rows);
+    const uint64_t blocks = (L_own + 255) / 256;
+    hipLaunchKernelGGL((k_finalize<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state,
+                       params, maxerr, run, err, count, rows);
     const unsigned sb = (unsigned)(blocks < 256 ? blocks : 256);
-    hipLaunchKernelGGL(k_stats, dim3(sb), dim3(256), 0, s, L, n, c->d_err, c->d_count, c->d_state);
-    hipLaunchKernelGGL(k_stats_argmax, dim3(sb), dim3(256), 0, s, L, c->d_err, c->d_state);
+    hipLaunchKernelGGL(k_stats, dim3(sb), dim3(256), 0, s, sp.leaf_lo, sp.leaf_hi, sp.n, err, count, c->d_state);
+    hipLaunchKernelGGL(k_stats_argmax, dim3(sb), dim3(256), 0, s, sp.leaf_lo, sp.leaf_hi, err, c->d_state);
   }
   mark();
   HIPCHK(c, hipEventRecord(c->ev[9], s));
   HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipGetLastError());
-  (void)PPL;
   return RMI_OK;
 }
 
@@ -448,7 +549,13 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (leaf_kind == RMI_MODEL_ROBUST_LINEAR || leaf_kind == RMI_MODEL_CUBIC) return RMI_ERR_UNSUPPORTED_MODEL;
   HIPCHK(c, hipSetDevice(c->device));
   const int ppl = leaf_kind == RMI_MODEL_CUBIC ? 4 : 2;
-  int rc = ensure_outputs(c, num_leaves, ppl);
+  uint64_t L_own = num_leaves;
+  if (c->have_shard) {
+    const Span& sp = c->shard;
+    if (sp.leaf_hi > num_leaves || sp.rd_hi - sp.rd_lo != c->n) return RMI_ERR_BAD_ARG;
+    L_own = sp.leaf_hi - sp.leaf_lo;
+  }
+  int rc = ensure_outputs(c, L_own, ppl);
   if (rc) return rc;
   RootP rp;
   rp.p0 = root->p[0]; rp.p1 = root->p[1]; rp.p2 = root->p[2]; rp.p3 = root->p[3];
@@ -462,7 +569,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   }
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->last_L = num_leaves; c->last_ppl = ppl;
+  c->last_L = L_own; c->last_ppl = ppl;
 
   const DevState& st = *c->h_state;
   if (st.err_flags) {
@@ -474,12 +581,15 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
     return rc;
   }
   std::memset(out, 0, sizeof *out);
-  out->num_rows = c->n; out->num_leaves = num_leaves; out->leaf_kind = leaf_kind;
+  const uint64_t n_glob = c->have_shard ? c->shard.n : c->n;
+  out->num_rows = n_glob; out->num_leaves = num_leaves; out->leaf_kind = leaf_kind;
+  out->shard_leaf_lo = c->have_shard ? c->shard.leaf_lo : 0; out->shard_leaves = L_own;
+  out->sum_n_err = st.sum_n_err; out->sum_l2 = st.sum_l2; out->sum_log2 = st.sum_log2;
   out->params_per_leaf = ppl; out->row_bytes = (uint64_t)ppl * 8 + 8;
   out->model_max_error = st.max_err; out->model_max_error_idx = st.max_err_idx;
-  out->model_avg_error = (double)st.sum_n_err / (double)c->n;
+  out->model_avg_error = (double)st.sum_n_err / (double)n_glob;
   out->model_avg_l2_error = st.sum_l2;
-  out->model_avg_log2_error = st.sum_log2 / (double)c->n;
+  out->model_avg_log2_error = st.sum_log2 / (double)n_glob;
   out->model_max_log2_error = std::log2((double)st.max_err);
   out->split_idx = st.split_idx; out->split_target = st.split_target;
   float ms = 0.f;
@@ -507,7 +617,7 @@ int rmi_hip_download_leaf_params(rmi_hip_ctx* c, double* o) { return dl(c, o, c 
 int rmi_hip_download_leaf_errors(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_err : nullptr, c ? c->last_L * 8 : 0); }
 int rmi_hip_download_leaf_counts(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_count : nullptr, c ? c->last_L * 8 : 0); }
 int rmi_hip_download_leaf_starts(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_leaf_start : nullptr, c ? (c->last_L + 1) * 8 : 0); }
-int rmi_hip_download_rows(rmi_hip_ctx* c, void* o) { return dl(c, o, c ? c->d_rows : nullptr, c ? c->last_L * (c->last_ppl * 8 + 8) : 0); }
-void* rmi_hip_device_rows(rmi_hip_ctx* c) { return c ? c->d_rows : nullptr; }
+int rmi_hip_download_rows(rmi_hip_ctx* c, void* o) { return dl(c, o, c ? (c->d_rows_ext ? (unsigned char*)c->d_rows_ext : c->d_rows) : nullptr, c ? c->last_L * (c->last_ppl * 8 + 8) : 0); }
+void* rmi_hip_device_rows(rmi_hip_ctx* c) { return c ? (c->d_rows_ext ? c->d_rows_ext : (void*)c->d_rows) : nullptr; }
 
 }  // extern "C"

@@ -25,11 +25,12 @@ constexpr unsigned long long NO_START = ~0ull;
 // panics), so leaf_start[j] = first i with target(key[i]) >= j is a boundary detect.
 // ---------------------------------------------------------------------------------------------
 template <int ROOT, typename K>
-__global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, uint64_t n, RootP r,
+__global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, Span sp, RootP r,
                                                     unsigned long long* __restrict__ leaf_start,
                                                     DevState* __restrict__ st) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const uint64_t i = sp.it_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sp.it_hi) return;
+  const uint64_t n = sp.n;
   const uint64_t Lm1 = r.L - 1;
   const uint64_t mid = r.L / 2;                                   // two_layer.rs:131
   const uint64_t p = root_predict<ROOT, K>(r, keys[i]);
@@ -37,15 +38,16 @@ __global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, 
     if (p > Lm1) atomicOr(&st->err_flags, EF_ROOT_OOB);           // two_layer.rs:45-48
   }
   const uint64_t t = p < Lm1 ? p : Lm1;                           // two_layer.rs:49
+  const bool mine = t >= sp.leaf_lo && t < sp.leaf_hi;
   if (i == 0) {
-    leaf_start[t] = 0;
+    if (mine) leaf_start[t] = 0;
     if (t >= mid) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);  // split_idx == 0 -> :27
-  } else {
+  } else if (i > sp.rd_lo) {
     const uint64_t pp = root_predict<ROOT, K>(r, keys[i - 1]);
     const uint64_t tp = pp < Lm1 ? pp : Lm1;
     if (t < tp) atomicOr(&st->err_flags, EF_NON_MONOTONE);        // two_layer.rs:50 / :144
     else if (t > tp) {
-      leaf_start[t] = i;
+      if (mine) leaf_start[t] = i;
       if (tp < mid && t >= mid) {                                 // two_layer.rs:132-136,152-156
         st->split_idx = i;
         st->split_target = t;
@@ -164,12 +166,13 @@ __device__ __forceinline__ int leaf_container(uint64_t j, uint64_t s, uint64_t e
 // dependent, so each leaf is a sequential chain; parallelism is across leaves.)
 // ---------------------------------------------------------------------------------------------
 template <int LEAF, typename K>
-__global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, uint64_t n, uint64_t L,
+__global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, Span sp,
                                                   const unsigned long long* __restrict__ leaf_start,
                                                   DevState* __restrict__ st,
                                                   double* __restrict__ params) {
-  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= L) return;
+  const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= sp.leaf_hi) return;
+  const uint64_t n = sp.n;
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
   uint64_t lo, hi;
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, ui
     // slr: linear.rs:12-59 over C_j.iter(): FixDups offsets + the tail duplicate (Q1)
     double mean_x = 0.0, mean_y = 0.0, c = 0.0, m2 = 0.0;
     uint64_t cnt = 0;
-    uint64_t y = first_occurrence(keys, lo);
+    uint64_t y = first_occurrence(keys, lo, sp.rd_lo);
     K prev = keys[lo];
     double x = 0.0, yf = 0.0;
     for (uint64_t i = lo; i <= hi; i++) {
@@ -229,9 +232,9 @@ __global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, ui
   } else if constexpr (LEAF == K_LINEAR_SPLINE) {
     // linear_splines: linear_spline.rs:13-35 on get(0), get(len-1) of the container
     const K k0 = keys[lo], k1 = keys[hi];
-    const double y0 = (double)first_occurrence(keys, lo);
+    const double y0 = (double)first_occurrence(keys, lo, sp.rd_lo);
     if (lo == hi || k0 == k1) { out[0] = y0; out[1] = 0.0; return; }
-    const double y1 = (double)first_occurrence(keys, hi);
+    const double y1 = (double)first_occurrence(keys, hi, sp.rd_lo);
     const double x0 = KeyTraits<K>::as_float(k0), x1 = KeyTraits<K>::as_float(k1);
     const double slope = (y0 - y1) / (x0 - x1);
     const double intercept = y0 - slope * x0;                        // plain mul+sub
@@ -257,21 +260,22 @@ __device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v
 }
 
 template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, uint64_t n, RootP r,
+__global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, Span sp, RootP r,
                                              const double* __restrict__ params,
                                              unsigned long long* __restrict__ leaf_maxerr,
                                              unsigned long long* __restrict__ leaf_run) {
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t i = sp.it_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & (WAVE - 1);
-  const bool active = i < n;
+  const uint64_t n = sp.n;
+  const bool active = i < sp.it_hi;
   const uint64_t Lm1 = r.L - 1;
   unsigned long long t = ~0ull, err = 0, run = 0;
   if (active) {
     const K k = keys[i];
     const uint64_t p = root_predict<ROOT, K>(r, k);
     t = p < Lm1 ? p : Lm1;
-    const uint64_t y = first_occurrence(keys, i);
+    const uint64_t y = first_occurrence(keys, i, sp.rd_lo);
     const uint64_t pred = leaf_predict<LEAF, K>(params + t * PPL, k);
     err = error_between(pred, y, n);
     if (i + 1 < n && !(keys[i + 1] == k)) run = i - y + 1;   // a run is recorded when the next different item arrives
@@ -296,7 +300,7 @@ __global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, uint64_
 // k_finalize: one thread per leaf (O(L)).
 // ---------------------------------------------------------------------------------------------
 template <int LEAF, typename K>
-__global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, uint64_t n, uint64_t L,
+__global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Span sp, uint64_t L,
                                                   const unsigned long long* __restrict__ leaf_start,
                                                   const DevState* __restrict__ st,
                                                   double* __restrict__ params,
@@ -307,8 +311,9 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, ui
                                                   unsigned char* __restrict__ rows) {
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   constexpr int ROWB = PPL * 8 + 8;
-  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= L) return;
+  const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= sp.leaf_hi) return;
+  const uint64_t n = sp.n;
   const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
   double p[PPL];
   if (s < e) {
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, ui
 // k_stats: aggregates of two_layer.rs:267-287 (parallel reduction; the f64 sums are not
 // bit-identical to the reference's sequential sums -- rmi_hip_stats_exact recomputes on host).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_stats(uint64_t L, uint64_t n,
+__global__ void __launch_bounds__(256) k_stats(uint64_t leaf_lo, uint64_t L, uint64_t n,
                                                const unsigned long long* __restrict__ leaf_err,
                                                const unsigned long long* __restrict__ leaf_count,
                                                DevState* __restrict__ st) {
@@ -363,7 +368,7 @@ __global__ void __launch_bounds__(256) k_stats(uint64_t L, uint64_t n,
   unsigned long long mx = 0, mi = 0, sm = 0;
   double l2 = 0.0, lg = 0.0;
   const double nf = (double)n;
-  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t j = leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
     const unsigned long long e = leaf_err[j], c = leaf_count[j];
     if (e >= mx) { mx = e; mi = j; }                 // max_by_key keeps the last maximum
     const unsigned long long ne = c * e;
@@ -395,10 +400,10 @@ __global__ void __launch_bounds__(256) k_stats(uint64_t L, uint64_t n,
   }
 }
 // second tiny pass: the last index attaining max_err
-__global__ void __launch_bounds__(256) k_stats_argmax(uint64_t L, const unsigned long long* __restrict__ leaf_err,
+__global__ void __launch_bounds__(256) k_stats_argmax(uint64_t leaf_lo, uint64_t L, const unsigned long long* __restrict__ leaf_err,
                                                       DevState* __restrict__ st) {
   const unsigned long long mx = st->max_err;
-  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t j = leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
     if (leaf_err[j] == mx) atomicMax(&st->max_err_idx, (unsigned long long)j);
   }
 }

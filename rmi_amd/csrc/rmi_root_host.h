@@ -226,4 +226,45 @@ inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rm
   }
 }
 
+// Streaming form of the `linear` root fit: the same recurrence, fed with consecutive chunks of
+// the global key array (for data sets that are produced / held shard by shard).
+template <typename K>
+struct LinearRootStream {
+  Slr slr;
+  double scale = 1.0;
+  uint64_t n_global = 0, seen = 0, first = 0;
+  K last_key{};
+  bool have_last = false;
+  void begin(uint64_t n, uint64_t num_leaves) { *this = LinearRootStream(); n_global = n; scale = (double)num_leaves / (double)n; }
+  inline uint64_t scale_y(uint64_t y) const {
+    if (std::fabs(scale - 1.0) > DBL_EPSILON) return sat_u64((double)y * scale);
+    return y;
+  }
+  void push(const K* keys, uint64_t count) {
+    for (uint64_t q = 0; q < count; q++) {
+      const K k = keys[q];
+      if (!have_last || !(k == last_key)) first = seen;       // FixDups first-occurrence offset
+      slr.push(as_float(k), (double)scale_y(first));
+      last_key = k; have_last = true; seen++;
+    }
+  }
+  int finish(rmi_hip_model_params* m) {
+    if (seen != n_global) return RMI_ERR_BAD_ARG;
+    if (have_last) slr.push(as_float(last_key), (double)scale_y(first));   // Q1 tail duplicate
+    return slr.finish(&m->p[0], &m->p[1]);
+  }
+};
+
+// min(L-1, root.predict_to_int(key)) on the host (two_layer.rs:49; used to plan shard cuts)
+template <typename K>
+inline uint64_t root_target(const rmi_hip_model_params& m, K k, uint64_t L) {
+  uint64_t p;
+  switch (m.kind) {
+    case RMI_MODEL_RADIX: p = (as_uint(k) << (m.ip[0] & 63)) >> ((64 - m.ip[1]) & 63); break;
+    case RMI_MODEL_CUBIC: p = sat_u64(std::fmax(0.0, std::floor(cubic_eval(m.p, as_float(k))))); break;
+    default: p = sat_u64(std::fmax(0.0, std::floor(std::fma(m.p[1], as_float(k), m.p[0])))); break;
+  }
+  return p < L - 1 ? p : L - 1;
+}
+
 }  // namespace rmi_host

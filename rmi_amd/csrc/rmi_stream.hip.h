@@ -185,7 +185,7 @@ constexpr int FS_QDRAIN = 32;     // drain the close queue once this many leaves
 constexpr int FS_QCAP2 = FS_QDRAIN + 64;
 
 template <int ROOT, typename K>
-__global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restrict__ keys, uint64_t n, RootP r, uint64_t C,
+__global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
                                                              unsigned long long* __restrict__ leaf_start,
                                                              double* __restrict__ params,
                                                              DevState* __restrict__ st, int dbg) {
@@ -205,9 +205,11 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   unsigned long long* q_idx = s_qidx[wv];
   unsigned int* q_leaf = s_qleaf[wv];
 
-  const uint64_t wave_base = ((uint64_t)blockIdx.x * FA_WAVES + wv) * 64 * C;
+  const uint64_t n = sp.n;                                   // global key count
+  const uint64_t rd_hi = sp.rd_hi;                           // one past the last readable key
+  const uint64_t wave_base = sp.it_lo + ((uint64_t)blockIdx.x * FA_WAVES + wv) * 64 * C;
   const uint64_t p0 = wave_base + (uint64_t)lane * C;         // first key of this lane's chunk
-  const uint64_t chunk_end = p0 + C;
+  const uint64_t chunk_end = (p0 + C < sp.it_hi) ? p0 + C : sp.it_hi;
   const double Lm1f = (double)(r.L - 1);
   const double midf = (double)(r.L / 2);                     // two_layer.rs:131
 
@@ -225,13 +227,13 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   unsigned int cnt = 0;                                      // == sl.nf
   SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
   unsigned int flags = 0;
-  if (p0 < n && p0 > 0) {
+  if (p0 < sp.it_hi && p0 > sp.rd_lo) {
     bool oob;
     kprev = keys[p0 - 1];
     xprev = KeyTraits<K>::as_float(kprev);
-    yprev = (double)first_occurrence(keys, p0 - 1);
+    yprev = (double)first_occurrence(keys, p0 - 1, sp.rd_lo);
     tprev = root_target_f<ROOT, K>(r, Lm1f, kprev, oob);
-    if (p0 > 1) {
+    if (p0 > sp.rd_lo + 1) {
       const double tpp = root_target_f<ROOT, K>(r, Lm1f, keys[p0 - 2], oob);
       carry_split = (tpp < midf && tprev >= midf);
     }
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         } else if (s2.nf > 0.0) {
           // container ends with the leaf's own last key: duplicate that one
           const double x = KeyTraits<K>::as_float(keys[bi - 1]);
-          const double y = (double)first_occurrence(keys, bi - 1);
+          const double y = (double)first_occurrence(keys, bi - 1, sp.rd_lo);
           slr_push(s2, x, y);
         } else have = false;                                 // only reachable together with a degenerate split
         if (have) {
@@ -278,17 +280,17 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   K stage[FS_ROW];
   uint64_t row_i = p0;                                       // index of the first key of the current row
   double row_if = (double)p0;
-  bool lane_done = !(p0 < n);
+  bool lane_done = !(p0 < sp.it_hi);
   uint64_t P = 0;
-  load_panel<K>(stage, keys, n, wave_base, C, 0, lane);
+  load_panel<K>(stage, keys, rd_hi, wave_base, C, 0, lane);
   while (__any(!lane_done)) {
     stage_to_lds<K>(stage, panel, lane);
-    load_panel<K>(stage, keys, n, wave_base, C, P + 1, lane);   // prefetch (consumed next iteration)
+    load_panel<K>(stage, keys, rd_hi, wave_base, C, P + 1, lane);   // prefetch (consumed next iteration)
 
     // ---------------- phase 1 ----------------
     unsigned int bmask = 0, dmask = 0;
     int split_pos = -1;
-    const int end_pos = (row_i >= n) ? 0 : ((n - row_i < (uint64_t)FS_ROW) ? (int)(n - row_i) : FS_ROW);
+    const int end_pos = (row_i >= rd_hi) ? 0 : ((rd_hi - row_i < (uint64_t)FS_ROW) ? (int)(rd_hi - row_i) : FS_ROW);
     const int own_cnt = (row_i >= chunk_end) ? 0 : ((chunk_end - row_i < (uint64_t)FS_ROW) ? (int)(chunk_end - row_i) : FS_ROW);
     const bool prev_split_in = carry_split;
     if (!(dbg & 4)) {
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     }
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
-    if (!active && (row_i >= chunk_end || row_i > n)) lane_done = true;
+    if (!active && (row_i >= chunk_end || row_i >= rd_hi)) lane_done = true;
     if ((dbg & 4) && row_i >= chunk_end) lane_done = true;
     P += 1;
   }
@@ -378,7 +380,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
 // Runs of length 1 are not reported (k_finalize adds that floor).
 // =============================================================================================
 template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, uint64_t n, RootP r, uint64_t C,
+__global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
                                                    const double* __restrict__ params,
                                                    unsigned long long* __restrict__ leaf_maxerr,
                                                    unsigned long long* __restrict__ leaf_run, int dbg) {
@@ -387,9 +389,10 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, u
   __shared__ unsigned int leafp[64 * FS_STRIDE];
 
   const int lane = threadIdx.x;
-  const uint64_t wave_base = (uint64_t)blockIdx.x * 64 * C;
+  const uint64_t n = sp.n;
+  const uint64_t wave_base = sp.it_lo + (uint64_t)blockIdx.x * 64 * C;
   const uint64_t p0 = wave_base + (uint64_t)lane * C;
-  const uint64_t chunk_end = (p0 + C < n) ? p0 + C : n;
+  const uint64_t chunk_end = (p0 + C < sp.it_hi) ? p0 + C : sp.it_hi;
   const double Lm1f = (double)(r.L - 1);
   const double midf = (double)(r.L / 2);
   const double nf = (double)n;
@@ -404,10 +407,10 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, u
 #pragma unroll
   for (int q = 0; q < PPL; q++) { pa[q] = 0.0; pn[q] = 0.0; }
   double maxerr = 0.0, maxrun = 0.0;
-  if (p0 < n && p0 > 0) {
+  if (p0 < sp.it_hi && p0 > sp.rd_lo) {
     bool oob;
     kprev = keys[p0 - 1];
-    yprev = (double)first_occurrence(keys, p0 - 1);
+    yprev = (double)first_occurrence(keys, p0 - 1, sp.rd_lo);
     tprev = root_target_f<ROOT, K>(r, Lm1f, kprev, oob);
     cur_leaf = (unsigned int)tprev;                          // owner of the run that ends at p0-1
     have_leaf = true;
@@ -420,7 +423,8 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, u
   unsigned int flags = 0;
 
   auto flush = [&]() {
-    if (have_leaf) {
+    // the leaf of the halo key before a shard belongs to another rank: nothing to report for it
+    if (have_leaf && cur_leaf >= sp.leaf_lo && cur_leaf < sp.leaf_hi) {
       if (maxerr > 0.0) atomicMax(&leaf_maxerr[cur_leaf], (unsigned long long)maxerr);
       if (maxrun > 1.0) atomicMax(&leaf_run[cur_leaf], (unsigned long long)maxrun);
     }
@@ -429,12 +433,12 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, u
   K stage[FS_ROW];
   uint64_t row_i = p0;
   double row_if = (double)p0;
-  bool lane_done = !(p0 < n);
+  bool lane_done = !(p0 < sp.it_hi);
   uint64_t P = 0;
-  load_panel<K>(stage, keys, n, wave_base, C, 0, lane);
+  load_panel<K>(stage, keys, sp.rd_hi, wave_base, C, 0, lane);
   while (__any(!lane_done)) {
     stage_to_lds<K>(stage, panel, lane);
-    load_panel<K>(stage, keys, n, wave_base, C, P + 1, lane);
+    load_panel<K>(stage, keys, sp.rd_hi, wave_base, C, P + 1, lane);
 
     unsigned int bmask = 0, dmask = 0;
     int split_pos = -1;
@@ -487,6 +491,9 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, u
     if (row_i >= chunk_end) lane_done = true;
     P += 1;
   }
+  // The key right after a shard starts another leaf (hence another key value): it ends the run of
+  // this shard's last key, but it is processed by the next rank, so account for it here.
+  if (p0 < sp.it_hi && chunk_end == sp.it_hi && sp.it_hi < sp.n && have_leaf) maxrun = fmax(maxrun, (double)sp.it_hi - yprev);
   flush();
 }
 
@@ -513,23 +520,24 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
 constexpr int EW_UNROLL = 4;      // wave tiles (64 keys each) per wave
 
 template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(256) k_err_wave(const K* __restrict__ keys, uint64_t n, RootP r,
+__global__ void __launch_bounds__(256) k_err_wave(const K* __restrict__ keys, Span sp, RootP r,
                                                   const double* __restrict__ params,
                                                   unsigned long long* __restrict__ leaf_maxerr,
                                                   unsigned long long* __restrict__ leaf_run, int dbg) {
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   const int lane = threadIdx.x & 63;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t n = sp.n;
   const double Lm1f = (double)(r.L - 1);
   const double nf = (double)n;
   const bool small = n <= 0xFFFFFFFFull;
 #pragma unroll
   for (int u = 0; u < EW_UNROLL; u++) {
-    const uint64_t base = (wave_id * EW_UNROLL + u) * 64;
-    if (base >= n) break;                                   // wave-uniform
+    const uint64_t base = sp.it_lo + (wave_id * EW_UNROLL + u) * 64;
+    if (base >= sp.it_hi) break;                            // wave-uniform
     const uint64_t i = base + lane;
-    const bool valid = i < n;
-    const uint64_t ic = valid ? i : n - 1;
+    const bool valid = i < sp.it_hi;
+    const uint64_t ic = valid ? i : sp.it_hi - 1;
     const K k = keys[ic];
     // neighbours: previous / next key (lane 0 / lane 63 fetch across the tile edge)
     K kprev, knext;
@@ -540,8 +548,8 @@ __global__ void __launch_bounds__(256) k_err_wave(const K* __restrict__ keys, ui
       unsigned int nlo = __shfl_down(lo, 1, 64), nhi = __shfl_down(hi, 1, 64);
       kprev = bits_to_key<K>(((unsigned long long)phi << 32) | plo);
       knext = bits_to_key<K>(((unsigned long long)nhi << 32) | nlo);
-      if (lane == 0 && i > 0) kprev = keys[i - 1];
-      if (lane == 63 && i + 1 < n) knext = keys[i + 1];
+      if (lane == 0 && i > sp.rd_lo) kprev = keys[i - 1];
+      if (lane == 63 && i + 1 < sp.rd_hi) knext = keys[i + 1];
     }
     bool oob;
     const double t = root_target_f<ROOT, K>(r, Lm1f, k, oob);
@@ -551,7 +559,7 @@ __global__ void __launch_bounds__(256) k_err_wave(const K* __restrict__ keys, ui
     for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)tj * PPL + q];
     if (dbg & 2) { pa[0] = t; pa[1] = 1e-9; }
     uint64_t y = i;
-    if (valid && i > 0 && k == kprev) y = first_occurrence(keys, i);
+    if (valid && i > sp.rd_lo && k == kprev) y = first_occurrence(keys, i, sp.rd_lo);
     const double x = KeyTraits<K>::as_float(k);
     double f;
     if constexpr (LEAF == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(pa[0], x, pa[1]), x, pa[2]), x, pa[3]);

@@ -1,0 +1,235 @@
+"""Multi-GPU form of the leaf hot path: one process per GPU, leaf-aligned contiguous shards, one
+all-gather of the packed leaf rows over RCCL (``torch.distributed`` backend ``nccl``).
+
+Given the root parameters every leaf's container, fit and error bound depend only on a contiguous
+key range plus a one/two-key halo and on global indices.  Rank r owns the leaves
+``[r*L/G, (r+1)*L/G)`` and the keys the root maps to them; the cut points are found by binary
+search with exactly the bucketing the kernels use (``rmi_hip_root_target``).  The G-GPU result is
+byte-identical to the 1-GPU result.
+
+The reference has no distributed path at all (one process, Rayon threads: two_layer.rs:161-169);
+this module is the MI355X-side replacement of that 2-way join, not a translation of anything.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from . import train as T
+
+NO_SPLIT = (1 << 64) - 1
+
+
+@dataclass
+class ShardPlan:
+    n_global: int
+    num_leaves: int
+    rank: int
+    world: int
+    leaf_lo: int
+    leaf_hi: int
+    key_lo: int
+    key_hi: int
+    read_lo: int
+    read_hi: int
+    split_idx: int
+    split_target: int
+
+    def c_struct(self) -> _lib.Shard:
+        s = _lib.Shard()
+        s.n_global, s.read_lo, s.read_hi = self.n_global, self.read_lo, self.read_hi
+        s.key_lo, s.key_hi, s.leaf_lo, s.leaf_hi = self.key_lo, self.key_hi, self.leaf_lo, self.leaf_hi
+        s.split_idx, s.split_target = self.split_idx, self.split_target
+        return s
+
+
+def _key_bits(k, np_dtype) -> int:
+    if np.dtype(np_dtype) == np.float64:
+        return int(np.array([k], dtype=np.float64).view(np.uint64)[0])
+    return int(k)
+
+
+class Planner:
+    """Host-side shard planning over any global key source ``key_at(i) -> key`` (a closed-form
+    synthetic generator, or an mmap'd key file): O(G log N) probes, no pass over the data."""
+
+    def __init__(self, key_at, n_global: int, np_dtype, root: T.Model, num_leaves: int):
+        self.key_at = key_at
+        self.n = int(n_global)
+        self.np_dtype = np.dtype(np_dtype)
+        self.dt = T._DTYPES[self.np_dtype]
+        self.root = root
+        self.L = int(num_leaves)
+        self._lib = _lib.load()
+        self._rootc = root._c()
+
+    def target(self, i: int) -> int:
+        out = C.c_uint64()
+        rc = self._lib.rmi_hip_root_target(C.byref(self._rootc), self.dt, _key_bits(self.key_at(i), self.np_dtype),
+                                           self.L, C.byref(out))
+        if rc:
+            raise T.RMIError(rc)
+        return int(out.value)
+
+    def first_index_with_target_ge(self, leaf: int) -> int:
+        """lower_bound over the (monotone) targets -- the search of two_layer.rs:132-136."""
+        lo, hi = 0, self.n
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if self.target(mid) < leaf:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo
+
+    def first_occurrence(self, i: int) -> int:
+        v = self.key_at(i)
+        if i == 0 or self.key_at(i - 1) != v:
+            return i
+        lo, hi = 0, i - 1
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if self.key_at(mid) < v:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo
+
+    def plan(self, world: int):
+        if self.L % world != 0:
+            raise ValueError("the number of leaves must be divisible by the number of GPUs")
+        per = self.L // world
+        cuts = [0] + [self.first_index_with_target_ge(r * per) for r in range(1, world)] + [self.n]
+        cuts[0] = 0
+        split = self.first_index_with_target_ge(self.L // 2)
+        if split >= self.n:
+            split_idx, split_target = NO_SPLIT, 0
+        else:
+            split_idx, split_target = split, self.target(split)
+        plans = []
+        for r in range(world):
+            key_lo, key_hi = cuts[r], cuts[r + 1]
+            # left halo: the whole duplicate run of key[key_lo-1] plus one more key (prev-last point
+            # with its first-occurrence offset; "was the previous key the split key" needs key_lo-2)
+            if key_lo == 0:
+                read_lo = 0
+            else:
+                read_lo = max(0, min(self.first_occurrence(key_lo - 1), key_lo - 1) - 1)
+            # right halo: key[key_hi] (next-first point / upper lower-bound error) plus one spare
+            read_hi = min(self.n, key_hi + 2)
+            plans.append(ShardPlan(self.n, self.L, r, world, r * per, (r + 1) * per, key_lo, key_hi,
+                                   read_lo, read_hi, split_idx, split_target))
+        return plans
+
+
+def run_shard(tr: T.Trainer, plan: ShardPlan, root: T.Model, leaf, rows_ptr: int | None = None):
+    """Train the leaves of one shard on the trainer's device (keys [read_lo, read_hi) resident)."""
+    lib = tr._lib
+    sh = plan.c_struct()
+    T._check(lib.rmi_hip_set_shard(tr._h, C.byref(sh)), tr._h)
+    T._check(lib.rmi_hip_set_rows_output(tr._h, C.c_void_p(rows_ptr or 0)), tr._h)
+    try:
+        return tr.train_leaves(root, leaf, plan.num_leaves)
+    finally:
+        lib.rmi_hip_set_shard(tr._h, None)
+
+
+def combine_stats(parts, n_global: int) -> dict:
+    """Aggregates of two_layer.rs:267-287 from per-shard partial sums (rmi_hip_result)."""
+    mx, idx = 0, 0
+    for p in parts:
+        if p["max_error"] > mx or (p["max_error"] == mx and p["max_error_idx"] >= idx):
+            mx, idx = p["max_error"], p["max_error_idx"]
+    s_err = sum(p["sum_n_err"] for p in parts) & ((1 << 64) - 1)
+    return {
+        "model_max_error": mx, "model_max_error_idx": idx,
+        "model_avg_error": s_err / n_global,
+        "model_avg_l2_error": float(sum(p["sum_l2"] for p in parts)),
+        "model_avg_log2_error": float(sum(p["sum_log2"] for p in parts)) / n_global,
+    }
+
+
+def exchange_rows(dist, full_rows, rank: int, world: int):
+    """One all-gather of the packed rows: every rank contributes its slice of `full_rows`
+    (a flat uint8 tensor of L*row_bytes) in place.  nccl == RCCL over xGMI; gloo on CPU tests."""
+    per = full_rows.numel() // world
+    mine = full_rows[rank * per:(rank + 1) * per]
+    if dist.get_backend() == "gloo":
+        parts = [full_rows[r * per:(r + 1) * per] if r != rank else mine.clone() for r in range(world)]
+        outs = [full_rows.new_empty(per) for _ in range(world)]
+        dist.all_gather(outs, mine.clone())
+        for r in range(world):
+            full_rows[r * per:(r + 1) * per] = outs[r]
+        del parts
+    else:
+        dist.all_gather_into_tensor(full_rows, mine)
+    return full_rows
+
+
+class ShardedTrainer:
+    """Weak-scaling driver used by bench.py: every rank generates its own shard of the global
+    synthetic key array in HBM, rank 0 fits the root exactly (streamed) and broadcasts it."""
+
+    def __init__(self, tr: T.Trainer, dist, rank: int, world: int, dataset: str, np_dtype,
+                 n_global: int, num_leaves: int, spec: str, chunk: int = 50_000_000):
+        import torch
+        from . import datagen
+        self.tr, self.dist, self.rank, self.world = tr, dist, rank, world
+        self.n_global, self.L = n_global, num_leaves
+        root_kind, self.leaf_kind = T.parse_spec(spec)
+        lib = tr._lib
+        np_dtype = np.dtype(np_dtype)
+        dt = T._DTYPES[np_dtype]
+        t0 = time.perf_counter()
+        # ---- exact root fit, streamed on rank 0 (the recurrence is sequential: SURVEY.md section 7, H1) ----
+        on_gpu = dist.get_backend() != "gloo"
+        pbuf = torch.zeros(6, dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        if rank == 0:
+            rs = C.c_void_p()
+            T._check(lib.rmi_hip_root_stream_begin(root_kind, dt, n_global, num_leaves, C.byref(rs)))
+            gen = T.Trainer(device=torch.cuda.current_device())
+            done = 0
+            while done < n_global:
+                cnt = min(chunk, n_global - done)
+                gen.generate_keys(dataset, np_dtype, n_global, done, cnt)
+                host = gen.download_keys()
+                T._check(lib.rmi_hip_root_stream_push(rs, host.ctypes.data, cnt))
+                gen._host_keys = None
+                done += cnt
+            gen.close()
+            m = _lib.ModelParams()
+            T._check(lib.rmi_hip_root_stream_finish(rs, C.byref(m)))
+            root = T.Model._from_c(m)
+            pbuf.copy_(torch.tensor(list(root.p) + [float(root.ip[0]), float(root.ip[1])], dtype=torch.float64))
+        dist.broadcast(pbuf, src=0)
+        vals = pbuf.cpu().tolist()
+        self.root = T.Model(root_kind, tuple(vals[:4]), (int(vals[4]), int(vals[5])))
+        self.root_seconds = time.perf_counter() - t0
+        # ---- plan + resident keys ----
+        gen_fn = {("uniform", np.dtype(np.uint64)): datagen.uniform_u64, ("dups", np.dtype(np.uint64)): datagen.dups_u64,
+                  ("uniform", np.dtype(np.uint32)): datagen.uniform_u32, ("dups", np.dtype(np.uint32)): datagen.dups_u32}
+        if dataset == "uniform":
+            f = gen_fn[(dataset, np_dtype)]
+            key_at = lambda i: f(n_global, start=i, count=1)[0]
+        else:
+            raise ValueError("sharded bench supports the closed-form 'uniform' generator")
+        self.plan = Planner(key_at, n_global, np_dtype, self.root, num_leaves).plan(world)[rank]
+        tr.generate_keys(dataset, np_dtype, n_global, self.plan.read_lo, self.plan.read_hi - self.plan.read_lo)
+        self.row_bytes = 24
+        self.full_rows = torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda")
+        self.rows_ptr = self.full_rows.data_ptr() + self.plan.leaf_lo * self.row_bytes
+        self._host_rows = None if on_gpu else torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8)
+
+    def step(self):
+        res = run_shard(self.tr, self.plan, self.root, self.leaf_kind, self.rows_ptr)
+        if self._host_rows is None:
+            exchange_rows(self.dist, self.full_rows, self.rank, self.world)      # RCCL all-gather, device to device
+        else:                                                                    # gloo functional path: host bounce
+            self._host_rows.copy_(self.full_rows)
+            exchange_rows(self.dist, self._host_rows, self.rank, self.world)
+            self.full_rows.copy_(self._host_rows)
+        return res

@@ -94,6 +94,9 @@ class TrainedRMI:
     kernel_ns: tuple = ()
     split_idx: int = 0
     split_target: int = 0
+    shard_leaf_lo: int = 0          # multi-GPU: this object covers leaves [shard_leaf_lo, +shard_leaves)
+    shard_leaves: int = 0
+    partial: dict = field(default_factory=dict)   # per-shard partial sums of the aggregates
     cache_fix: object = None
     _trainer: object = field(default=None, repr=False)
     _cache: dict = field(default_factory=dict, repr=False)
@@ -233,7 +236,11 @@ class Trainer:
             models=f"{root.name},{MODEL_NAMES[leaf_kind]}", branching_factor=int(num_leaves), root=root,
             leaf_kind=leaf_kind, params_per_leaf=int(res.params_per_leaf),
             device_ns=int(res.device_ns), kernel_ns=tuple(int(x) for x in res.kernel_ns),
-            split_idx=int(res.split_idx), split_target=int(res.split_target), _trainer=self)
+            split_idx=int(res.split_idx), split_target=int(res.split_target),
+            shard_leaf_lo=int(res.shard_leaf_lo), shard_leaves=int(res.shard_leaves),
+            partial={"max_error": int(res.model_max_error), "max_error_idx": int(res.model_max_error_idx),
+                     "sum_n_err": int(res.sum_n_err), "sum_l2": float(res.sum_l2), "sum_log2": float(res.sum_log2)},
+            _trainer=self)
 
     def train(self, model_spec: str, branch_factor: int) -> TrainedRMI:
         """rmi_lib::train (train/mod.rs:100-126)."""
@@ -245,7 +252,7 @@ class Trainer:
         return out
 
     def _download(self, what: str, rmi: TrainedRMI):
-        L, ppl = rmi.branching_factor, rmi.params_per_leaf
+        L, ppl = (rmi.shard_leaves or rmi.branching_factor), rmi.params_per_leaf
         if what == "params":
             a = np.empty((L, ppl), dtype=np.float64)
             _check(self._lib.rmi_hip_download_leaf_params(self._h, a.ctypes.data), self._h)

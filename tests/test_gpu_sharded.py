@@ -1,0 +1,59 @@
+"""Multi-GPU row on one GPU: the shards of a G-way split are run one after the
+other on the same device, each with only its own keys + halo resident, and the concatenation must
+be byte-identical to the unsharded result (and therefore to the oracle)."""
+import numpy as np
+import pytest
+
+from rmi_amd import datagen as dg
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_sharded(train, sharded, keys, root_name, leaf, L, G):
+    tr = train.Trainer(keys)
+    root = tr.fit_root(root_name, L)
+    full = tr.train_leaves(root, leaf, L)
+    full_rows = full.rows.copy()
+    full_params, full_err = full.leaf_params.copy(), full.last_layer_max_l1s.copy()
+    full_counts, full_starts = full.leaf_counts.copy(), full.leaf_starts.copy()
+    tr.close()
+    plans = sharded.Planner(lambda i: keys[i], len(keys), keys.dtype, root, L).plan(G)
+    rows, params, errs, counts, starts, parts = [], [], [], [], [], []
+    for pl in plans:
+        assert pl.key_lo == full_starts[pl.leaf_lo] and pl.key_hi == full_starts[pl.leaf_hi]
+        t = train.Trainer(np.ascontiguousarray(keys[pl.read_lo:pl.read_hi]))
+        res = sharded.run_shard(t, pl, root, leaf)
+        rows.append(res.rows.copy()); params.append(res.leaf_params.copy()); errs.append(res.last_layer_max_l1s.copy())
+        counts.append(res.leaf_counts.copy()); starts.append(res.leaf_starts[:-1].copy()); parts.append(res.partial)
+        t.close()
+    assert np.array_equal(np.concatenate(starts), full_starts[:-1])
+    assert np.array_equal(np.concatenate(params), full_params)
+    assert np.array_equal(np.concatenate(errs), full_err)
+    assert np.array_equal(np.concatenate(counts), full_counts)
+    assert np.array_equal(np.concatenate(rows), full_rows), "sharded rows differ from the 1-GPU rows"
+    st = sharded.combine_stats(parts, len(keys))
+    assert st["model_max_error"] == full.model_max_error
+    assert st["model_max_error_idx"] == full.model_max_error_idx
+    assert st["model_avg_error"] == full.model_avg_error
+    assert abs(st["model_avg_log2_error"] - full.model_avg_log2_error) <= 1e-9 * max(1.0, abs(full.model_avg_log2_error))
+    return full
+
+
+@pytest.mark.parametrize("pipeline", ["2", "1"])
+@pytest.mark.parametrize("gen", ["uniform_u64", "books_u64", "dups_u64", "dups_u32"])
+@pytest.mark.parametrize("G", [2, 8])
+def test_sharded_equals_single(monkeypatch, pipeline, gen, G):
+    monkeypatch.setenv("RMI_HIP_PIPELINE", pipeline)
+    from rmi_amd import train, sharded
+    keys = dg.GENERATORS[gen](200_000)
+    _run_sharded(train, sharded, keys, "linear", "linear", 4096, G)
+    _run_sharded(train, sharded, keys, "radix", "linear_spline", 8192, G)
+
+
+def test_sharded_matches_oracle(oracle):
+    from rmi_amd import train, sharded
+    keys = dg.books_u64(150_000)
+    full = _run_sharded(train, sharded, keys, "linear", "linear", 1024, 4)
+    o = oracle.train_two_layer("linear", "linear", keys, 1024)
+    assert np.array_equal(full.leaf_params, o.leaf_params)
+    assert np.array_equal(full.last_layer_max_l1s, o.leaf_err)
