@@ -396,7 +396,6 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, S
   const double Lm1f = (double)(r.L - 1);
   const double midf = (double)(r.L / 2);
   const double nf = (double)n;
-  const unsigned int Lm1 = (unsigned int)(r.L - 1);
 
   K kprev = K();
   double tprev = -1.0;
@@ -407,6 +406,7 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, S
 #pragma unroll
   for (int q = 0; q < PPL; q++) { pa[q] = 0.0; pn[q] = 0.0; }
   double maxerr = 0.0, maxrun = 0.0;
+  bool pn_ok = false;                                        // pn holds the parameters of leaf cur_leaf + 1
   if (p0 < sp.it_hi && p0 > sp.rd_lo) {
     bool oob;
     kprev = keys[p0 - 1];
@@ -414,11 +414,14 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, S
     tprev = root_target_f<ROOT, K>(r, Lm1f, kprev, oob);
     cur_leaf = (unsigned int)tprev;                          // owner of the run that ends at p0-1
     have_leaf = true;
+    if (cur_leaf >= sp.leaf_lo && cur_leaf < sp.leaf_hi) {   // (the halo key before a shard belongs to another rank)
 #pragma unroll
-    for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)cur_leaf * PPL + q];
-    const unsigned int nx = cur_leaf < Lm1 ? cur_leaf + 1 : cur_leaf;
+      for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)cur_leaf * PPL + q];
+      const unsigned int nx = cur_leaf + 1 < (unsigned int)sp.leaf_hi ? cur_leaf + 1 : cur_leaf;
 #pragma unroll
-    for (int q = 0; q < PPL; q++) pn[q] = params[(uint64_t)nx * PPL + q];
+      for (int q = 0; q < PPL; q++) pn[q] = params[(uint64_t)nx * PPL + q];
+      pn_ok = true;
+    }
   }
   unsigned int flags = 0;
 
@@ -463,7 +466,7 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, S
         if (bit) {
           flush();
           const unsigned int nl = leafp[lane * FS_STRIDE + s];
-          if (have_leaf && nl == cur_leaf + 1) {
+          if (have_leaf && pn_ok && nl == cur_leaf + 1) {
 #pragma unroll
             for (int q = 0; q < PPL; q++) pa[q] = pn[q];
           } else {
@@ -471,9 +474,10 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, S
             for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)nl * PPL + q];
           }
           cur_leaf = nl; have_leaf = true; maxerr = 0.0; maxrun = 0.0;
-          const unsigned int nx = nl < Lm1 ? nl + 1 : nl;
+          const unsigned int nx = nl + 1 < (unsigned int)sp.leaf_hi ? nl + 1 : nl;   // stay inside this launch's leaf range
 #pragma unroll
           for (int q = 0; q < PPL; q++) pn[q] = params[(uint64_t)nx * PPL + q];
+          pn_ok = (nx == nl + 1);
         }
       }
       if (valid) {

@@ -50,6 +50,15 @@ def test_sharded_equals_single(monkeypatch, pipeline, gen, G):
     _run_sharded(train, sharded, keys, "radix", "linear_spline", 8192, G)
 
 
+def test_sharded_tiny_leaves_split_at_cut():
+    """More leaves than keys per wave row, and the 2-way-join split exactly on a shard cut."""
+    from rmi_amd import train, sharded
+    keys = dg.uniform_u64(300_000)
+    _run_sharded(train, sharded, keys, "linear", "linear", 1 << 17, 2)
+    _run_sharded(train, sharded, keys, "linear", "linear", 1 << 17, 4)
+    _run_sharded(train, sharded, dg.dups_u64(300_000), "linear", "linear", 1 << 16, 8)
+
+
 def test_sharded_matches_oracle(oracle):
     from rmi_amd import train, sharded
     keys = dg.books_u64(150_000)
