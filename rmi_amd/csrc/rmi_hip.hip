@@ -52,7 +52,7 @@ struct rmi_hip_ctx {
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
   uint64_t err_threads = 262144;                // lanes of pass B
   int fit_min_chunk = 64;
-  int err_kernel = 1;                           // pass B: 0 = wave-parallel (k_err_wave), 1 = chunk-streaming (k_err_stream)
+  int err_kernel = 1;                           // pass B: 0 = k_err_wave, 1 = k_err_range (leaf_start-driven), 2 = k_err_stream
   int dbg = 0;                                  // ablation switches for profiling (0 = product behaviour)
   // last result
   uint64_t last_L = 0;
@@ -497,7 +497,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     if (C < (uint64_t)c->fit_min_chunk) C = c->fit_min_chunk;
     const uint64_t chunks = (n_it + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
-    hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, params, maxerr, run, c->dbg);
+    if constexpr (ROOT != K_RADIX) {
+      if (c->err_kernel == 2)
+        hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, params, maxerr, run, c->dbg);
+      else
+        hipLaunchKernelGGL((k_err_range<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, leaf_start, params, maxerr, run);
+    } else {
+      hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, params, maxerr, run, c->dbg);
+    }
   }
   mark();
   // --- finalize + stats ---

@@ -19,6 +19,8 @@
 // coefficients need the reference order inside a leaf; the parallelism is across leaves, and
 // chunks (not leaves) per lane keep all 64 lanes busy whatever the leaf sizes are.
 #pragma once
+#include <type_traits>
+
 #include "rmi_device.hip.h"
 
 namespace rmi {
@@ -501,6 +503,217 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, S
   flush();
 }
 
+
+// =============================================================================================
+// Pass B driven by leaf_start ("k_err_range").  After pass A and the fill, every leaf boundary is
+// known, so pass B needs no root evaluation per key: a lane walks its chunk, compares the running
+// index with the end of its current leaf, and at a boundary switches to the next leaf whose
+// parameters and end index were prefetched when the previous leaf was entered.  Phase 1 shrinks to
+// "convert 16 keys to f64 + duplicate mask".  One atomicMax per (lane, leaf) segment.
+// (Radix roots keep k_err_stream: their leaf ids need the raw key bits.)
+// =============================================================================================
+template <typename K>
+__device__ __forceinline__ void convert_row(unsigned long long* __restrict__ panel, int lane, uint64_t row_i,
+                                            K& kprev, unsigned int& dmask) {
+  unsigned int dm = 0;
+  K kp = kprev;
+#pragma unroll
+  for (int h = 0; h < FS_ROW; h += 8) {
+    K kk[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) kk[q] = bits_to_key<K>(panel[lane * FS_STRIDE + h + q]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const K k = kk[q];
+      dm |= (k == kp) ? (1u << (h + q)) : 0u;
+      panel[lane * FS_STRIDE + h + q] = __builtin_bit_cast(unsigned long long, KeyTraits<K>::as_float(k));
+      kp = k;
+    }
+  }
+  if (row_i == 0) dm &= ~1u;                               // key 0 has no predecessor
+  dmask = dm;
+  kprev = kp;
+}
+
+constexpr int ER_QCAP = 128;      // result queue per wave (drained in bursts of >= 64)
+
+template <int ROOT, int LEAF, typename K>
+__global__ void __launch_bounds__(64) k_err_range(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
+                                                  const unsigned long long* __restrict__ leaf_start,
+                                                  const double* __restrict__ params,
+                                                  unsigned long long* __restrict__ leaf_maxerr,
+                                                  unsigned long long* __restrict__ leaf_run) {
+  static_assert(ROOT != K_RADIX, "radix roots use k_err_stream");
+  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
+  __shared__ unsigned long long panel[64 * FS_STRIDE];
+  __shared__ unsigned int q_leaf[ER_QCAP];
+  __shared__ double q_err[ER_QCAP], q_run[ER_QCAP];
+
+  const int lane = threadIdx.x;
+  const uint64_t n = sp.n;
+  const uint64_t wave_base = sp.it_lo + (uint64_t)blockIdx.x * 64 * C;
+  const uint64_t p0 = wave_base + (uint64_t)lane * C;
+  const uint64_t chunk_end = (p0 + C < sp.it_hi) ? p0 + C : sp.it_hi;
+  const double Lm1f = (double)(r.L - 1);
+  const double nf = (double)n;
+  const unsigned int leaf_last = (unsigned int)(sp.leaf_hi - 1);
+
+  K kprev = K();
+  double yprev = 0.0;
+  unsigned int cur_leaf = 0;
+  bool have_leaf = false;                                    // cur_leaf is a leaf of this launch
+  double e_cur = (double)p0;                                 // index at which the current leaf ends
+  double e_next = 0.0;                                       // end of leaf cur_leaf + 1 (prefetched)
+  // Prefetch of (params, end) of leaf cur_leaf+1 is issued at a panel top, right before the key
+  // prefetch, so that the one vmcnt wait per panel covers it: need -> inflight -> ok.
+  bool pn_need = false, pn_inflight = false, pn_ok = false;
+  double pa[PPL], pn[PPL], pn_l[PPL];
+  unsigned long long e_next_l = 0;
+#pragma unroll
+  for (int q = 0; q < PPL; q++) { pa[q] = 0.0; pn[q] = 0.0; pn_l[q] = 0.0; }
+  double maxerr = 0.0, maxrun = 0.0;
+  if (p0 < sp.it_hi && p0 > sp.rd_lo) {
+    bool oob;
+    kprev = keys[p0 - 1];
+    yprev = (double)first_occurrence(keys, p0 - 1, sp.rd_lo);
+    const unsigned int tl = (unsigned int)root_target_f<ROOT, K>(r, Lm1f, kprev, oob);   // owner of the run ending at p0-1
+    if (tl >= sp.leaf_lo && tl < sp.leaf_hi) {               // (the halo key before a shard belongs to another rank)
+      cur_leaf = tl; have_leaf = true;
+      e_cur = (double)leaf_start[tl + 1];
+#pragma unroll
+      for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)tl * PPL + q];
+      pn_need = tl < leaf_last;
+    }
+  }
+  int pending = 0;                                           // wave-uniform
+
+  auto drain = [&]() {
+    for (int b = 0; b < pending; b += 64) {
+      const int slot = b + lane;
+      if (slot < pending) {
+        const unsigned int lj = q_leaf[slot];
+        const double e = q_err[slot], rn = q_run[slot];
+        if (e > 0.0) atomicMax(&leaf_maxerr[lj], (unsigned long long)e);
+        if (rn > 1.0) atomicMax(&leaf_run[lj], (unsigned long long)rn);
+      }
+    }
+    pending = 0;
+  };
+  // queue the maxima of the leaf this lane leaves (wave-uniform bookkeeping)
+  auto flush = [&](bool leaving) {
+    const bool push = leaving && have_leaf && (maxerr > 0.0 || maxrun > 1.0);
+    const unsigned long long pm = __ballot(push);
+    if (pm) {
+      if (push) {
+        const int slot = pending + __popcll(pm & ((1ull << lane) - 1ull));
+        q_leaf[slot] = cur_leaf; q_err[slot] = maxerr; q_run[slot] = maxrun;
+      }
+      pending += __popcll(pm);
+    }
+  };
+
+  K stage[FS_ROW];
+  uint64_t row_i = p0;
+  double row_if = (double)p0;
+  bool lane_done = !(p0 < sp.it_hi);
+  uint64_t P = 0;
+  load_panel<K>(stage, keys, sp.rd_hi, wave_base, C, 0, lane);
+  while (__any(!lane_done)) {
+    stage_to_lds<K>(stage, panel, lane);                     // (waits for every outstanding load)
+    // the prefetch issued one panel ago has landed (same wait): move it to plain registers so that
+    // the step loop never waits on the vector-memory counter
+    if (pn_inflight) {
+#pragma unroll
+      for (int q = 0; q < PPL; q++) pn[q] = pn_l[q];
+      e_next = (double)e_next_l;
+      pn_ok = true; pn_inflight = false;
+    }
+    if (pn_need) {
+#pragma unroll
+      for (int q = 0; q < PPL; q++) pn_l[q] = params[(uint64_t)(cur_leaf + 1) * PPL + q];
+      e_next_l = leaf_start[cur_leaf + 2];
+      pn_need = false; pn_inflight = true;
+    }
+    load_panel<K>(stage, keys, sp.rd_hi, wave_base, C, P + 1, lane);
+
+    unsigned int dmask = 0;
+    convert_row<K>(panel, lane, row_i, kprev, dmask);
+    const int end_pos = (row_i >= chunk_end) ? 0 : ((chunk_end - row_i < (uint64_t)FS_ROW) ? (int)(chunk_end - row_i) : FS_ROW);
+    const unsigned int vmask = lane_done ? 0u : ((1u << end_pos) - 1u);   // keys of this lane's chunk in the row
+
+    // Will some lane cross a boundary in this row for which the prefetched next leaf cannot be used
+    // (not landed yet, next leaf empty, or a second boundary inside the row)?  Then the whole wave
+    // takes the general step loop for this panel; otherwise the fast one, which contains no
+    // vector-memory instruction at all (so the compiler places no vmcnt wait in it).
+    const double row_endf = row_if + (double)end_pos;
+    const bool crosses = !lane_done && end_pos > 0 && e_cur < row_endf;
+    const bool general = crosses && !(have_leaf && pn_ok && e_next > e_cur && e_next >= row_endf);
+    auto steps = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+      double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
+#pragma unroll 2
+      for (int s = 0; s < FS_ROW; s++) {
+        const double x = xn;
+        xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);
+        const bool valid = (vmask >> s) & 1u;
+        const bool dup = (dmask >> s) & 1u;
+        const double idxf = row_if + (double)s;
+        // a new key value ends the previous run: record its length for the leaf of the previous key
+        if (valid && !dup && have_leaf) maxrun = fmax(maxrun, idxf - yprev);
+        const double y = dup ? yprev : idxf;
+        const bool bit = valid && (idxf >= e_cur);           // first key of another leaf
+        if (__any(bit)) {
+          flush(bit);
+          if (bit) {
+            bool use_prefetch = true;
+            if constexpr (!FAST) use_prefetch = have_leaf && pn_ok && e_next > idxf;
+            if (use_prefetch) {
+              // the next leaf is not empty: the prefetched parameters and end index are the ones
+              cur_leaf += 1;
+#pragma unroll
+              for (int q = 0; q < PPL; q++) pa[q] = pn[q];
+              e_cur = e_next;
+            } else {
+              if constexpr (!FAST) {
+                // empty leaves in between, first leaf of this lane, or leaves shorter than two rows
+                bool oob;
+                cur_leaf = (unsigned int)root_target_f<ROOT, K>(r, Lm1f, keys[row_i + s], oob);
+#pragma unroll
+                for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)cur_leaf * PPL + q];
+                e_cur = (double)leaf_start[cur_leaf + 1];
+              }
+            }
+            have_leaf = true; maxerr = 0.0; maxrun = 0.0;
+            pn_ok = false; pn_inflight = false;
+            pn_need = cur_leaf < leaf_last;
+          }
+          if constexpr (!FAST) { if (pending >= 64) drain(); }
+        }
+        if (valid) {
+          double f;
+          if constexpr (LEAF == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(pa[0], x, pa[1]), x, pa[2]), x, pa[3]);
+          else f = __builtin_fma(pa[1], x, pa[0]);
+          // err in the f64 domain (all integers < 2^53): |min(pred, N) - y|, y < N
+          const double e = fabs(fmin(fmax(0.0, floor(f)), nf) - y);
+          maxerr = fmax(maxerr, e);
+          yprev = y;
+        }
+      }
+    };
+    if (__any(general)) steps(std::false_type{});
+    else steps(std::true_type{});
+    if (pending >= 64) drain();                              // (at most 64 more can arrive per panel in the fast loop)
+    row_i += FS_ROW;
+    row_if += (double)FS_ROW;
+    if (row_i >= chunk_end) lane_done = true;
+    P += 1;
+  }
+  // The key right after a shard starts another leaf (hence another key value): it ends the run of
+  // this shard's last key, but it is processed by the next rank, so account for it here.
+  if (p0 < sp.it_hi && chunk_end == sp.it_hi && sp.it_hi < sp.n && have_leaf) maxrun = fmax(maxrun, (double)sp.it_hi - yprev);
+  flush(true);
+  if (pending) drain();
+}
 
 // =============================================================================================
 // Pass B, wave-parallel form: one key per lane, coalesced loads straight into registers (no LDS),

@@ -153,18 +153,16 @@ def combine_stats(parts, n_global: int) -> dict:
     }
 
 
-def exchange_rows(dist, full_rows, rank: int, world: int):
-    """One all-gather of the packed rows: every rank contributes its slice of `full_rows`
-    (a flat uint8 tensor of L*row_bytes) in place.  nccl == RCCL over xGMI; gloo on CPU tests."""
+def exchange_rows(dist, full_rows, mine, rank: int, world: int):
+    """One all-gather of the packed rows: every rank contributes `mine` (its L/G rows) and receives
+    the full table in `full_rows` (flat uint8 tensors).  nccl == RCCL over xGMI; gloo on CPU tests."""
     per = full_rows.numel() // world
-    mine = full_rows[rank * per:(rank + 1) * per]
+    assert mine.numel() == per
     if dist.get_backend() == "gloo":
-        parts = [full_rows[r * per:(r + 1) * per] if r != rank else mine.clone() for r in range(world)]
         outs = [full_rows.new_empty(per) for _ in range(world)]
-        dist.all_gather(outs, mine.clone())
+        dist.all_gather(outs, mine.contiguous())
         for r in range(world):
             full_rows[r * per:(r + 1) * per] = outs[r]
-        del parts
     else:
         dist.all_gather_into_tensor(full_rows, mine)
     return full_rows
@@ -221,15 +219,21 @@ class ShardedTrainer:
         tr.generate_keys(dataset, np_dtype, n_global, self.plan.read_lo, self.plan.read_hi - self.plan.read_lo)
         self.row_bytes = 24
         self.full_rows = torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda")
-        self.rows_ptr = self.full_rows.data_ptr() + self.plan.leaf_lo * self.row_bytes
-        self._host_rows = None if on_gpu else torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8)
+        per = (self.plan.leaf_hi - self.plan.leaf_lo) * self.row_bytes
+        self.my_rows = torch.empty(per, dtype=torch.uint8, device="cuda")     # the kernels write this rank's rows here
+        self.rows_ptr = self.my_rows.data_ptr()
+        self._host = None if on_gpu else (torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8),
+                                          torch.empty(per, dtype=torch.uint8))
+        self._torch = torch
 
     def step(self):
-        res = run_shard(self.tr, self.plan, self.root, self.leaf_kind, self.rows_ptr)
-        if self._host_rows is None:
-            exchange_rows(self.dist, self.full_rows, self.rank, self.world)      # RCCL all-gather, device to device
+        res = run_shard(self.tr, self.plan, self.root, self.leaf_kind, self.rows_ptr)   # (synchronises its stream)
+        if self._host is None:
+            exchange_rows(self.dist, self.full_rows, self.my_rows, self.rank, self.world)   # RCCL all-gather, device to device
+            self._torch.cuda.current_stream().synchronize()    # the step ends when every rank holds the full table
         else:                                                                    # gloo functional path: host bounce
-            self._host_rows.copy_(self.full_rows)
-            exchange_rows(self.dist, self._host_rows, self.rank, self.world)
-            self.full_rows.copy_(self._host_rows)
+            full_h, mine_h = self._host
+            mine_h.copy_(self.my_rows)
+            exchange_rows(self.dist, full_h, mine_h, self.rank, self.world)
+            self.full_rows.copy_(full_h)
         return res

@@ -36,8 +36,8 @@ def _worker(rank, world, port, L, q):
     ref_bytes = ref_rows.view(np.uint8).reshape(-1)
     full = torch.zeros(L * 24, dtype=torch.uint8)
     lo, hi = plan.leaf_lo * 24, plan.leaf_hi * 24
-    full[lo:hi] = torch.from_numpy(ref_bytes[lo:hi].copy())       # stand-in for this rank's device rows
-    sharded.exchange_rows(dist, full, rank, world)
+    mine = torch.from_numpy(ref_bytes[lo:hi].copy())              # stand-in for this rank's device rows
+    sharded.exchange_rows(dist, full, mine, rank, world)
     ok = bool(np.array_equal(full.numpy(), ref_bytes))
     q.put((rank, ok))
     dist.destroy_process_group()
