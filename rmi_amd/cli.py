@@ -1,0 +1,106 @@
+"""`rmi`-compatible command line (reference: src/main.rs:33-340).
+
+    python -m rmi_amd.cli <input> [namespace] [models] [branching factor] [flags]
+
+Same positional arguments and the flags that concern the single-train and param-grid modes:
+--no-code, --no-errors, -d/--data-path, -t/--threads (accepted, unused: the work runs on the GPU),
+--zero-build-time, --param-grid, --disable-parallel-training.  The data type comes from a substring
+of the input path (uint64 / uint32 / f64, src/main.rs:122-132).  --optimize, --max-size and
+--bounded belong to components outside this round's scope and are rejected.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+
+import numpy as np
+
+from . import codegen, datagen, train
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="rmi", description="MI355X-native RMI trainer (two-layer)")
+    ap.add_argument("input", help="Path to input file containing data")
+    ap.add_argument("namespace", nargs="?", help="Namespace to use in generated code")
+    ap.add_argument("models", nargs="?", help='Comma-separated list of model layers, e.g. linear,linear')
+    ap.add_argument("branching_factor", nargs="?", type=int, help="Branching factor between each model level")
+    ap.add_argument("--no-code", action="store_true", help="Skip code generation")
+    ap.add_argument("--no-errors", action="store_true", help="Do not save last-level errors, and modify the RMI function signature")
+    ap.add_argument("-d", "--data-path", default="rmi_data", help="exports parameters to files stored in this directory")
+    ap.add_argument("-t", "--threads", type=int, default=4, help="accepted for compatibility")
+    ap.add_argument("--zero-build-time", action="store_true", help="zero out the model build time field")
+    ap.add_argument("--param-grid", help="train the RMIs specified in the JSON file and report their errors")
+    ap.add_argument("--disable-parallel-training", action="store_true", help="accepted for compatibility")
+    ap.add_argument("--optimize", help="(not in this build)")
+    ap.add_argument("--max-size", help="(not in this build)")
+    ap.add_argument("--bounded", help="(not in this build)")
+    ap.add_argument("--device", type=int, default=0)
+    return ap
+
+
+def _stats(rmi: train.TrainedRMI, n: int) -> dict:
+    # src/main.rs:207-221
+    return {"layers": rmi.models, "branching factor": rmi.branching_factor,
+            "average error": rmi.model_avg_error, "average error %": rmi.model_avg_error / n * 100.0,
+            "average l2 error": rmi.model_avg_l2_error, "average log2 error": rmi.model_avg_log2_error,
+            "max error": rmi.model_max_error, "max error %": rmi.model_max_error / n * 100.0,
+            "max log2 error": rmi.model_max_log2_error,
+            "size binary search": codegen.rmi_size(rmi.root.kind, rmi.leaf_kind, rmi.branching_factor, True),
+            "build time": rmi.build_time}
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    for flag in ("optimize", "max_size", "bounded"):
+        if getattr(args, flag):
+            print(f"--{flag.replace('_', '-')} is outside this build's scope (see DESIGN.md)", file=sys.stderr)
+            return 2
+    if args.namespace and args.param_grid:
+        print("Can only specify one of namespace or param-grid", file=sys.stderr)      # src/main.rs:116-118
+        return 2
+    keys = datagen.read_keys(args.input)                                              # src/load.rs:132-157
+    key_c = "double" if keys.dtype == np.float64 else "uint64_t"                       # src/main.rs:122-132
+    tr = train.Trainer(np.ascontiguousarray(keys), device=args.device)
+    n = len(keys)
+    try:
+        if args.param_grid:                                                            # src/main.rs:171-261
+            grid = json.load(open(args.param_grid))
+            results = []
+            for cfg in grid["configs"]:
+                rmi = tr.train(cfg["layers"], int(cfg["branching factor"]))
+                res = _stats(rmi, n)
+                if "namespace" in cfg:
+                    res["namespace"] = cfg["namespace"]
+                    codegen.output_rmi(cfg["namespace"], rmi, args.data_path, key_type=key_c, include_errors=not args.no_errors,
+                                       build_time_ns=0 if args.zero_build_time else None)
+                results.append(res)
+            with open(f"{args.param_grid}_results", "w") as f:
+                json.dump(results, f)
+            return 0
+        if not args.namespace:
+            print("Must specify either a name space or a parameter grid.", file=sys.stderr)
+            return 2
+        if not args.models or args.branching_factor is None:
+            print("models and branching factor are required", file=sys.stderr)
+            return 2
+        rmi = tr.train(args.models, args.branching_factor)
+        print(f"Model build time: {rmi.build_time // 1_000_000} ms (device {rmi.device_ns / 1e6:.3f} ms)")
+        print(f"Average model error: {rmi.model_avg_error} ({rmi.model_avg_error / n * 100.0}%)")
+        print(f"Average model L2 error: {rmi.model_avg_l2_error}")
+        print(f"Average model log2 error: {rmi.model_avg_log2_error}")
+        print(f"Max model log2 error: {rmi.model_max_log2_error}")
+        print(f"Max model error on model {rmi.model_max_error_idx}: {rmi.model_max_error} ({rmi.model_max_error / n * 100.0}%)")
+        if not args.no_code:
+            codegen.output_rmi(args.namespace, rmi, args.data_path, key_type=key_c, include_errors=not args.no_errors,
+                               build_time_ns=0 if args.zero_build_time else None)
+        return 0
+    except train.RMIError as e:
+        print(f"error: {e}", file=sys.stderr)
+        return 1
+    finally:
+        tr.close()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

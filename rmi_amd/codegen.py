@@ -1,0 +1,211 @@
+"""Emission of the trained RMI: `<ns>.cpp`, `<ns>.h`, `<ns>_data.h` and the binary parameter files
+`<data_dir>/<ns>_L{i}_PARAMETERS` -- the reference's artefact format, so the output is a drop-in
+(SURVEY.md section 8b "wire format", section 8f-1).
+
+Reference: rmi_lib/src/codegen.rs (LayerParams :24-333, rmi_size :375-394, generate_code :450-754,
+output_rmi :757-788) and rmi_lib/src/models/mod.rs:510-674 (ModelParam: c_val, write_to) plus the
+`code()` / `function_name()` of the plugins (linear.rs:103-114, cubic_spline.rs:169-183,
+radix.rs:64-74).  The reference iterates HashSets when it emits declarations, so its text order
+varies run to run; this writer emits them in a fixed order.  What must match is the
+binary parameter file (byte for byte: it is the `rows` buffer the kernels produce) and the
+behaviour of `load()` / `lookup()` / `cleanup()`.
+"""
+from __future__ import annotations
+
+import os
+from decimal import Decimal
+
+import numpy as np
+
+LINEAR, LINEAR_SPLINE, CUBIC, RADIX, ROBUST_LINEAR = 0, 1, 2, 3, 4
+
+_MODEL_CODE = {
+    "linear": """
+inline double linear(double alpha, double beta, double inp) {
+    return std::fma(beta, inp, alpha);
+}""",
+    "cubic": """
+inline double cubic(double a, double b, double c, double d, double x) {
+    auto v1 = std::fma(a, x, b);
+    auto v2 = std::fma(v1, x, c);
+    auto v3 = std::fma(v2, x, d);
+    return v3;
+}""",
+    "radix": """
+inline uint64_t radix(uint64_t prefix_length, uint64_t bits, uint64_t inp) {
+    return (inp << prefix_length) >> (64 - bits);
+}""",
+}
+
+
+def _fn_name(kind: int) -> str:
+    return {LINEAR: "linear", LINEAR_SPLINE: "linear", ROBUST_LINEAR: "linear", CUBIC: "cubic", RADIX: "radix"}[kind]
+
+
+def _output_is_float(kind: int) -> bool:
+    return kind != RADIX
+
+
+def _needs_bounds_check(kind: int) -> bool:
+    return kind not in (CUBIC, RADIX)          # cubic_spline.rs:184-186, radix.rs:72-74
+
+
+def c_float(v: float) -> str:
+    """ModelParam::Float::c_val (models/mod.rs:568-574): Rust's Display for f64 -- shortest digits
+    that round-trip, positional notation, never an exponent -- with ".0" appended if there is no '.'."""
+    v = float(v)
+    if v != v:
+        return "NaN"
+    if v in (float("inf"), float("-inf")):
+        return "inf" if v > 0 else "-inf"
+    s = format(Decimal(repr(v)), "f")
+    if s.startswith("-") and float(s) == 0.0:
+        s = "-0"
+    if "." not in s:
+        s += ".0"
+    return s
+
+
+def rmi_size(root_kind: int, leaf_kind: int, num_leaves: int, with_errors: bool) -> int:
+    """codegen.rs:375-394 (two layers, no cache-fix)."""
+    root_bytes = {CUBIC: 32, RADIX: 16}.get(root_kind, 16)
+    leaf_bytes = 32 if leaf_kind == CUBIC else 16
+    return root_bytes + leaf_bytes * num_leaves + (8 * num_leaves if with_errors else 0)
+
+
+def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", include_errors: bool = True,
+               out_dir: str = ".", build_time_ns: int | None = None) -> dict:
+    """`rmi`: an object with .root (kind, p, ip), .leaf_kind, .params_per_leaf, .branching_factor,
+    .num_rmi_rows, .leaf_params [L, ppl] f64, .last_layer_max_l1s [L] u64 and (optionally) .rows,
+    .build_time -- i.e. rmi_amd.train.TrainedRMI.  Returns the paths written."""
+    L = int(rmi.branching_factor)
+    n = int(rmi.num_rmi_rows)
+    root = rmi.root
+    ppl = int(rmi.params_per_leaf)
+    leaf_kind = int(rmi.leaf_kind)
+    os.makedirs(data_dir, exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
+    paths = {}
+
+    data_h = [f"namespace {namespace} {{"]
+    read_code = ["bool load(char const* dataPath) {"]
+    free_code = ["void cleanup() {"]
+
+    # ---- layer 0: a single model; all-same-typed, <= 4096 bytes -> Constant (codegen.rs:45-63) ----
+    if root.kind == RADIX:
+        root_vals = [f"{int(root.ip[0])}UL", f"{int(root.ip[1])}UL"]
+        root_ctype = "uint64_t"
+    else:
+        nroot = 4 if root.kind == CUBIC else 2
+        root_vals = [c_float(root.p[i]) for i in range(nroot)]
+        root_ctype = "double"
+    for i, v in enumerate(root_vals):
+        data_h.append(f"const {root_ctype} L0_PARAMETER{i} = {v};")
+
+    # ---- layer 1 ----
+    errs = np.ascontiguousarray(rmi.last_layer_max_l1s, dtype=np.uint64)
+    params = np.ascontiguousarray(rmi.leaf_params, dtype=np.float64).reshape(L, ppl)
+    fname = f"{namespace}_L1_PARAMETERS"
+    fpath = os.path.join(data_dir, fname)
+    if include_errors and L > 1:
+        # with_zipped_errors (codegen.rs:288-315): rows (params..., Int err) -> mixed -> MixedArray
+        rows = getattr(rmi, "rows", None)
+        if rows is None:
+            buf = np.empty((L, ppl + 1), dtype="<u8")
+            buf[:, :ppl] = params.view(np.uint64)
+            buf[:, ppl] = errs
+            rows = buf.view(np.uint8).reshape(-1)
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        row_bytes = ppl * 8 + 8
+        assert rows.size == L * row_bytes
+        with open(fpath, "wb") as f:
+            f.write(rows.tobytes())
+        layer1_size = L * row_bytes
+        data_h.append("char* L1_PARAMETERS;")
+        ptr_type = "char"
+        malloc = True
+
+        def acc(p_idx: int) -> str:                         # access_by_ref, MixedArray (codegen.rs:259-282)
+            ctype = "uint64_t" if p_idx == ppl else "double"
+            return f"*(({ctype}*) (L1_PARAMETERS + (modelIndex * {row_bytes}) + {p_idx * 8}))"
+        err_line = f"  *err = {acc(ppl)};"
+    else:
+        with open(fpath, "wb") as f:
+            f.write(params.astype("<f8").tobytes())
+        layer1_size = L * ppl * 8
+        malloc = layer1_size >= 4 * 1024                    # requires_malloc (codegen.rs:104-113)
+        ptr_type = "double"
+        data_h.append("double* L1_PARAMETERS;" if malloc else f"double L1_PARAMETERS[{L * ppl}];")
+
+        def acc(p_idx: int) -> str:                         # access_by_ref, Array (codegen.rs:250-257)
+            return f"L1_PARAMETERS[{ppl}*modelIndex + {p_idx}]"
+        err_line = f"  *err = {int(errs[0])};" if (include_errors and L == 1) else ""
+    paths["L1_PARAMETERS"] = fpath
+    read_code += [
+        "  {",
+        f"    std::ifstream infile(std::filesystem::path(dataPath) / \"{fname}\", std::ios::in | std::ios::binary);",
+        "    if (!infile.good()) return false;",
+    ]
+    if malloc:
+        read_code += [f"    L1_PARAMETERS = ({ptr_type}*) malloc({layer1_size});",
+                      "    if (L1_PARAMETERS == NULL) return false;"]
+        free_code.append("    free(L1_PARAMETERS);")
+    read_code += [f"    infile.read((char*)L1_PARAMETERS, {layer1_size});",
+                  "    if (!infile.good()) return false;", "  }"]
+    read_code += ["  return true;", "}"]
+    free_code.append("}")
+    data_h.append("} // namespace")
+
+    # ---- code ----
+    report_errors = include_errors
+    sig = f"uint64_t lookup({key_type} key, size_t* err)" if report_errors else f"uint64_t lookup({key_type} key)"
+    code = [f'#include "{namespace}.h"', f'#include "{namespace}_data.h"', "#include <math.h>", "#include <cmath>",
+            "#include <fstream>", "#include <filesystem>", "#include <iostream>", f"namespace {namespace} {{"]
+    code += read_code + free_code
+    fns = []
+    for k in (root.kind, leaf_kind):
+        c = _MODEL_CODE[_fn_name(k)]
+        if c not in fns:
+            fns.append(c)
+    code += fns
+    code.append("""
+inline size_t FCLAMP(double inp, double bound) {
+  if (inp < 0.0) return 0;
+  return (inp > bound ? bound : (size_t)inp);
+}
+""")
+    code.append(f"{sig} {{")
+    code.append("  size_t modelIndex;")
+    if _output_is_float(root.kind) or _output_is_float(leaf_kind):
+        code.append("  double fpred;")
+    if not _output_is_float(root.kind):
+        code.append("  uint64_t ipred;")
+    root_in = "double" if root.kind != RADIX else "uint64_t"
+    root_var = "fpred" if _output_is_float(root.kind) else "ipred"
+    args = ", ".join(f"L0_PARAMETER{i}" for i in range(len(root_vals)))
+    code.append(f"  {root_var} = {_fn_name(root.kind)}({args}, ({root_in})key);")
+    # model_index_from_output! (codegen.rs:346-373)
+    if _output_is_float(root.kind):
+        mi = f"FCLAMP(fpred, {L}.0 - 1.0)" if _needs_bounds_check(root.kind) else "(uint64_t) fpred"
+    else:
+        mi = f"(ipred > {L} - 1 ? {L} - 1 : ipred)" if _needs_bounds_check(root.kind) else "ipred"
+    code.append(f"  modelIndex = {mi};")
+    largs = ", ".join(acc(i) for i in range(ppl))
+    code.append(f"  fpred = {_fn_name(leaf_kind)}({largs}, (double)key);")
+    code.append(err_line)
+    code.append(f"  return FCLAMP(fpred, {n}.0 - 1.0);")       # always bounds-checked (codegen.rs:713-717)
+    code.append("}")
+    code.append("} // namespace")
+
+    bt = int(getattr(rmi, "build_time", 0) if build_time_ns is None else build_time_ns)
+    header = ["#include <cstddef>", "#include <cstdint>", f"namespace {namespace} {{",
+              "bool load(char const* dataPath);", "void cleanup();",
+              f"const size_t RMI_SIZE = {rmi_size(root.kind, leaf_kind, L, include_errors)};",
+              f"const uint64_t BUILD_TIME_NS = {bt};", f'const char NAME[] = "{namespace}";', f"{sig};", "}"]
+
+    for name, lines in ((f"{namespace}.cpp", code), (f"{namespace}_data.h", data_h), (f"{namespace}.h", header)):
+        pth = os.path.join(out_dir, name)
+        with open(pth, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        paths[name] = pth
+    return paths

@@ -93,6 +93,13 @@ def clustered_u64(n: int, seed: int = 48, base: int = 1 << 62) -> np.ndarray:
         return _U64(base) + np.cumsum(gap, dtype=np.uint64)
 
 
+def uniform_f64(n: int, seed: int = 49) -> np.ndarray:
+    """f64 keys (file names containing "f64", src/main.rs:127-129): the 53 high bits of the uniform
+    u64 set scaled by 2^-20 -- exact, monotone, non-integer values."""
+    k = uniform_u64(n, seed) >> _U64(11)
+    return k.astype(np.float64) * (2.0 ** -20)
+
+
 GENERATORS = {
     "uniform_u64": uniform_u64,
     "books_u64": books_u64,
@@ -100,6 +107,7 @@ GENERATORS = {
     "uniform_u32": uniform_u32,
     "dups_u32": dups_u32,
     "clustered_u64": clustered_u64,
+    "uniform_f64": uniform_f64,
 }
 
 

@@ -87,6 +87,15 @@ def test_parity_small(trainer_mod, oracle, gen, root, leaf, L):
     _compare(trainer_mod, oracle, keys, root, leaf, L)
 
 
+@pytest.mark.parametrize("root,leaf,L", [("linear", "linear", 2048), ("linear", "linear_spline", 2048),
+                                         ("cubic", "linear", 1024), ("linear_spline", "linear", 512)])
+def test_parity_f64_keys(trainer_mod, oracle, root, leaf, L):
+    """f64 key files (src/load.rs:71-95): as_float is the identity, +-epsilon widening (models/mod.rs:101-111)."""
+    keys = dg.uniform_f64(200_000)
+    assert keys.dtype == np.float64 and (keys[1:] > keys[:-1]).all()
+    _compare(trainer_mod, oracle, keys, root, leaf, L)
+
+
 def test_parity_config1(trainer_mod, oracle):
     """BASELINE config 1: linear,linear 1024 on 1M synthetic sorted uint64."""
     keys = dg.uniform_u64(1_000_000)

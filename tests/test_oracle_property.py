@@ -17,7 +17,7 @@ SPECS = [
 ]
 
 
-@pytest.mark.parametrize("gen", ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "uniform_u32", "dups_u32"])
+@pytest.mark.parametrize("gen", ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "uniform_u32", "dups_u32", "uniform_f64"])
 @pytest.mark.parametrize("root,leaf,L", SPECS)
 def test_lookup_property(oracle, gen, root, leaf, L):
     keys = dg.GENERATORS[gen](200_000)
