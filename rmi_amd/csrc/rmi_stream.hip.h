@@ -28,7 +28,7 @@ namespace rmi {
 constexpr int FS_ROW = 16;        // keys per panel row
 constexpr int FS_STRIDE = 17;     // padded row stride (slots)
 constexpr int FS_QCAP = 128;      // close-record queue capacity per wave (drain at >= 64, <= 64 pushed per step)
-constexpr int FS_TMAX = 512;      // reciprocal table size
+constexpr int FS_TMAX = 512;      // reciprocal table size (leaves with more points divide with `/`)
 constexpr unsigned long long FS_NO_NEXT = 1ull << 63;
 
 struct SlrState { double mx, my, c, m2, nf; };
@@ -115,7 +115,23 @@ __device__ __forceinline__ void stage_to_lds(const K (&stage)[FS_ROW], unsigned 
 // read first (one LDS wait), classified, and written back as f64 x plus leaf ids.  Keys past the
 // end of the data are clamped copies of key[n-1]; `vmask` (valid positions) masks their bits.
 // WRITE: pass A additionally publishes leaf_start / the split point / error flags.
-template <int ROOT, typename K, bool WRITE>
+// Leaf id of the key at row position s: from the leaf-id panel (radix roots: the id needs the raw
+// key bits) or recomputed from the f64 x that phase 1 left in the key panel (float roots).
+template <int ROOT, bool LEAFP>
+__device__ __forceinline__ unsigned int leaf_id_at(const unsigned long long* __restrict__ panel,
+                                                   const unsigned int* __restrict__ leafp, int lane, int s,
+                                                   const RootP& r, double Lm1f) {
+  if constexpr (LEAFP) return leafp[lane * FS_STRIDE + s];
+  else {
+    const double x = __builtin_bit_cast(double, panel[lane * FS_STRIDE + s]);
+    double f;
+    if constexpr (ROOT == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(r.p0, x, r.p1), x, r.p2), x, r.p3);
+    else f = __builtin_fma(r.p1, x, r.p0);
+    return (unsigned int)fmin(fmax(0.0, floor(f)), Lm1f);
+  }
+}
+
+template <int ROOT, typename K, bool WRITE, bool LEAFP>
 __device__ __forceinline__ void classify_row(unsigned long long* __restrict__ panel, unsigned int* __restrict__ leafp,
                                              int lane, const RootP& r, double Lm1f, double midf,
                                              uint64_t row_i, uint64_t n, unsigned int vmask, unsigned int ownmask,
@@ -145,7 +161,7 @@ __device__ __forceinline__ void classify_row(unsigned long long* __restrict__ pa
         nm |= (t < tp) ? (1u << s) : 0u;                   // two_layer.rs:50 / :144
         oobm |= oob ? (1u << s) : 0u;                      // two_layer.rs:45-48
       }
-      leafp[lane * FS_STRIDE + s] = (unsigned int)t;
+      if constexpr (LEAFP) leafp[lane * FS_STRIDE + s] = (unsigned int)t;
       panel[lane * FS_STRIDE + s] = __builtin_bit_cast(unsigned long long, KeyTraits<K>::as_float(k));
       tp = t; kp = k;
       const bool v = (vmask >> s) & 1u;
@@ -167,7 +183,7 @@ __device__ __forceinline__ void classify_row(unsigned long long* __restrict__ pa
       const int s = __ffs(m) - 1;
       m &= m - 1;
       const uint64_t idx = row_i + s;
-      const unsigned int t = leafp[lane * FS_STRIDE + s];
+      const unsigned int t = leaf_id_at<ROOT, LEAFP>(panel, leafp, lane, s, r, Lm1f);
       leaf_start[t] = idx;
       if (s == split_pos) {
         if (idx == 0 || idx + 1 >= n) flags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
@@ -175,7 +191,8 @@ __device__ __forceinline__ void classify_row(unsigned long long* __restrict__ pa
         st->split_target = t;
       }
     }
-    if (n - 1 >= row_i && n - 1 - row_i < (uint64_t)FS_ROW) st->last_target = leafp[lane * FS_STRIDE + (int)(n - 1 - row_i)];
+    if (n - 1 >= row_i && n - 1 - row_i < (uint64_t)FS_ROW && ((vmask >> (int)(n - 1 - row_i)) & 1u))
+      st->last_target = leaf_id_at<ROOT, LEAFP>(panel, leafp, lane, (int)(n - 1 - row_i), r, Lm1f);
   }
 }
 
@@ -192,7 +209,8 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
                                                              double* __restrict__ params,
                                                              DevState* __restrict__ st, int dbg) {
   __shared__ unsigned long long s_panel[FA_WAVES][64 * FS_STRIDE];   // raw key bits, then f64 x
-  __shared__ unsigned int s_leafp[FA_WAVES][64 * FS_STRIDE];         // leaf id of every key of the panel
+  constexpr bool LEAFP = (ROOT == K_RADIX);
+  __shared__ unsigned int s_leafp[FA_WAVES][LEAFP ? 64 * FS_STRIDE : 1];   // leaf ids (radix roots only)
   __shared__ double rtab[FS_TMAX];
   __shared__ double s_q[FA_WAVES][5][FS_QCAP2];
   __shared__ unsigned long long s_qidx[FA_WAVES][FS_QCAP2];
@@ -298,7 +316,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     if (!(dbg & 4)) {
       const unsigned int vmask = lane_done ? 0u : ((1u << end_pos) - 1u);
       const unsigned int ownmask = (1u << own_cnt) - 1u;
-      classify_row<ROOT, K, true>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, ownmask,
+      classify_row<ROOT, K, true, LEAFP>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, ownmask,
                                   kprev, tprev, bmask, dmask, split_pos, flags, leaf_start, st);
       if (!lane_done && end_pos < FS_ROW) bmask |= 1u << end_pos;   // end of data acts as a final boundary
       carry_split = (split_pos == FS_ROW - 1);
@@ -336,7 +354,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
           if (!is_end && s < own_cnt) {
             // open the leaf that starts here
             active = true;
-            cur_leaf = leafp[lane * FS_STRIDE + s];
+            cur_leaf = leaf_id_at<ROOT, LEAFP>(panel, leafp, lane, s, r, Lm1f);
             const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
             const bool with_prev = !(is_split || idx == 0 || prev_split);   // prev-last (two_layer.rs:74-78), Q3/Q4
             sl.mx = with_prev ? xprev : 0.0;
@@ -449,7 +467,7 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, S
     int split_pos = -1;
     const int end_pos = (row_i >= chunk_end) ? 0 : ((chunk_end - row_i < (uint64_t)FS_ROW) ? (int)(chunk_end - row_i) : FS_ROW);
     const unsigned int vmask = lane_done ? 0u : ((1u << end_pos) - 1u);   // keys of this lane's chunk in the row
-    classify_row<ROOT, K, false>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, 0u,
+    classify_row<ROOT, K, false, true>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, 0u,
                                  kprev, tprev, bmask, dmask, split_pos, flags, nullptr, nullptr);
 
     double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
@@ -538,7 +556,7 @@ __device__ __forceinline__ void convert_row(unsigned long long* __restrict__ pan
 constexpr int ER_QCAP = 128;      // result queue per wave (drained in bursts of >= 64)
 
 template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(64) k_err_range(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
+__global__ void __launch_bounds__(64, 3) k_err_range(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
                                                   const unsigned long long* __restrict__ leaf_start,
                                                   const double* __restrict__ params,
                                                   unsigned long long* __restrict__ leaf_maxerr,
