@@ -452,8 +452,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     mark();                                              // a shard without keys: every leaf is empty
   } else if (!stream_fit) {
     // --- bucketing scan ---
-    const uint64_t blocks = (n_it + 255) / 256;
-    hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
+    if (c->pipeline == 1) {
+      const uint64_t blocks = (n_it + 255) / 256;
+      hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
+    } else {
+      constexpr uint64_t V = 16 / sizeof(K);
+      const uint64_t blocks = ((n_it + V - 1) / V + 255) / 256;
+      hipLaunchKernelGGL((k_bounds_vec<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
+    }
     mark();
   } else {
     // --- pass A: bucketing scan + exact per-leaf fit in one streaming pass ---
@@ -497,14 +503,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     if (C < (uint64_t)c->fit_min_chunk) C = c->fit_min_chunk;
     const uint64_t chunks = (n_it + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
-    if constexpr (ROOT != K_RADIX) {
-      if (c->err_kernel == 2)
-        hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, params, maxerr, run, c->dbg);
-      else
-        hipLaunchKernelGGL((k_err_range<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, leaf_start, params, maxerr, run);
-    } else {
+    if (c->err_kernel == 2)
       hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, params, maxerr, run, c->dbg);
-    }
+    else
+      hipLaunchKernelGGL((k_err_range<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, leaf_start, params, maxerr, run);
   }
   mark();
   // --- finalize + stats ---

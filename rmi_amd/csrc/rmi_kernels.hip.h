@@ -59,6 +59,64 @@ __global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_bounds_vec: the same bucketing scan with 16 bytes per lane (2 x 8-byte or 4 x 4-byte keys),
+// fully coalesced; the key before a lane's first key comes from the previous lane (shuffle) or,
+// for lane 0, from memory.  One root evaluation per key (+1 per lane for the predecessor).
+// ---------------------------------------------------------------------------------------------
+template <int ROOT, typename K>
+__global__ void __launch_bounds__(256) k_bounds_vec(const K* __restrict__ keys, Span sp, RootP r,
+                                                    unsigned long long* __restrict__ leaf_start,
+                                                    DevState* __restrict__ st) {
+  constexpr int V = 16 / sizeof(K);
+  const uint64_t base = sp.it_lo + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (base >= sp.it_hi) return;
+  const uint64_t n = sp.n;
+  const uint64_t Lm1 = r.L - 1;
+  const uint64_t mid = r.L / 2;                                   // two_layer.rs:131
+  K kk[V];
+  if (base + V <= sp.it_hi && (((uintptr_t)(keys + base)) & 15) == 0) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(keys + base);
+    __builtin_memcpy(kk, &raw, 16);
+  } else {
+#pragma unroll
+    for (int q = 0; q < V; q++) kk[q] = keys[(base + q < sp.it_hi) ? base + q : sp.it_hi - 1];
+  }
+  unsigned int flags = 0;
+  uint64_t tp = ~0ull;                                            // target of the previous key (none yet)
+  if (base > sp.rd_lo) {
+    const uint64_t pp = root_predict<ROOT, K>(r, keys[base - 1]);
+    tp = pp < Lm1 ? pp : Lm1;
+  }
+#pragma unroll
+  for (int q = 0; q < V; q++) {
+    const uint64_t i = base + q;
+    if (i < sp.it_hi) {
+      const uint64_t p = root_predict<ROOT, K>(r, kk[q]);
+      if constexpr (!root_needs_bounds_check<ROOT>()) { if (p > Lm1) flags |= EF_ROOT_OOB; }    // two_layer.rs:45-48
+      const uint64_t t = p < Lm1 ? p : Lm1;                      // two_layer.rs:49
+      const bool mine = t >= sp.leaf_lo && t < sp.leaf_hi;
+      if (i == 0) {
+        if (mine) leaf_start[t] = 0;
+        if (t >= mid) flags |= EF_DEGENERATE_SPLIT;              // split_idx == 0 -> :27
+      } else if (tp != ~0ull) {
+        if (t < tp) flags |= EF_NON_MONOTONE;                    // two_layer.rs:50 / :144
+        else if (t > tp) {
+          if (mine) leaf_start[t] = i;
+          if (tp < mid && t >= mid) {                            // two_layer.rs:132-136,152-156
+            st->split_idx = i;
+            st->split_target = t;
+            if (i + 1 >= n) flags |= EF_DEGENERATE_SPLIT;        // second half empty -> :27
+          }
+        }
+      }
+      if (i == n - 1) st->last_target = t;
+      tp = t;
+    }
+  }
+  if (flags) atomicOr(&st->err_flags, flags);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Suffix-min fill: leaf_start[j] = min_{j' >= j} leaf_start[j'] with leaf_start[L] = n.
 // Three small kernels over L+1 entries (tile = 2048 entries per block).
 // ---------------------------------------------------------------------------------------------

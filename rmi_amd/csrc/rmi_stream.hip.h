@@ -28,7 +28,7 @@ namespace rmi {
 constexpr int FS_ROW = 16;        // keys per panel row
 constexpr int FS_STRIDE = 17;     // padded row stride (slots)
 constexpr int FS_QCAP = 128;      // close-record queue capacity per wave (drain at >= 64, <= 64 pushed per step)
-constexpr int FS_TMAX = 512;      // reciprocal table size (leaves with more points divide with `/`)
+constexpr int FS_TMAX = 1024;     // reciprocal table size (leaves with more points divide with `/`)
 constexpr unsigned long long FS_NO_NEXT = 1ull << 63;
 
 struct SlrState { double mx, my, c, m2, nf; };
@@ -323,65 +323,70 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     }
 
     // ---------------- phase 2: 16 lockstep steps of the recurrence ----------------
-    double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
-#pragma unroll 1
-    for (int s = 0; s < FS_ROW; s++) {
-      const double x = xn;
-      xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);   // next step's x
-      double rr = rtab[(cnt + 1) & (FS_TMAX - 1)];
-      const bool bit = (bmask >> s) & 1u;
-      const double idxf = row_if + (double)s;
-      const double y = ((dmask >> s) & 1u) ? yprev : idxf;   // FixDups first-occurrence offset
-      bool do_push = active;
-      if (dbg & 1) do_push = false;
-      if (!(dbg & 2) && __any(bit)) {
-        // close first (queue the running state of the leaf that ends here), then open
-        const bool is_end = (s == end_pos);
-        const bool is_split = (s == split_pos);
-        const uint64_t idx = row_i + s;
-        const bool do_close = bit && active;
-        const unsigned long long cm = __ballot(do_close);
-        if (cm) {
-          if (do_close) {
-            const int slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
-            q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
-            q_leaf[slot] = cur_leaf;
-            q_idx[slot] = (is_end || is_split) ? (idx | FS_NO_NEXT) : idx;   // Q3: no next-first across the halves / at the end
+    // Two instances of the step loop: the usual one divides through the reciprocal table; if some
+    // lane's running count may leave the table during this panel the whole wave takes the
+    // instance with plain IEEE division (same results, see div_by_count).
+    auto steps = [&](auto table_tag) {
+      constexpr bool TABLE = decltype(table_tag)::value;
+      double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
+#pragma unroll 2
+      for (int s = 0; s < FS_ROW; s++) {
+        const double x = xn;
+        xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);   // next step's x
+        double rr = 0.0;
+        if constexpr (TABLE) rr = rtab[(cnt + 1) & (FS_TMAX - 1)];
+        const bool bit = (bmask >> s) & 1u;
+        const double idxf = row_if + (double)s;
+        const double y = ((dmask >> s) & 1u) ? yprev : idxf;   // FixDups first-occurrence offset
+        bool do_push = active;
+        if (dbg & 1) do_push = false;
+        if (!(dbg & 2) && __any(bit)) {
+          // close first (queue the running state of the leaf that ends here), then open
+          const bool is_end = (s == end_pos);
+          const bool is_split = (s == split_pos);
+          const uint64_t idx = row_i + s;
+          const bool do_close = bit && active;
+          const unsigned long long cm = __ballot(do_close);
+          if (cm) {
+            if (do_close) {
+              const int slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
+              q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
+              q_leaf[slot] = cur_leaf;
+              q_idx[slot] = (is_end || is_split) ? (idx | FS_NO_NEXT) : idx;   // Q3: no next-first across the halves / at the end
+            }
+            pending += __popcll(cm);
           }
-          pending += __popcll(cm);
-        }
-        if (bit) {
-          if (!is_end && s < own_cnt) {
-            // open the leaf that starts here
-            active = true;
-            cur_leaf = leaf_id_at<ROOT, LEAFP>(panel, leafp, lane, s, r, Lm1f);
-            const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
-            const bool with_prev = !(is_split || idx == 0 || prev_split);   // prev-last (two_layer.rs:74-78), Q3/Q4
-            sl.mx = with_prev ? xprev : 0.0;
-            sl.my = with_prev ? yprev : 0.0;
-            sl.c = 0.0; sl.m2 = 0.0;
-            sl.nf = with_prev ? 1.0 : 0.0;
-            cnt = with_prev ? 1u : 0u;
-            rr = with_prev ? 0.5 : 1.0;                      // 1/(cnt+1)
-            do_push = !is_split;                             // Q2: the key at split_idx is in neither half
-          } else {
-            active = false;                                  // end of data, or the next lane takes over
-            do_push = false;
+          if (bit) {
+            if (!is_end && s < own_cnt) {
+              // open the leaf that starts here
+              active = true;
+              cur_leaf = leaf_id_at<ROOT, LEAFP>(panel, leafp, lane, s, r, Lm1f);
+              const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
+              const bool with_prev = !(is_split || idx == 0 || prev_split);   // prev-last (two_layer.rs:74-78), Q3/Q4
+              sl.mx = with_prev ? xprev : 0.0;
+              sl.my = with_prev ? yprev : 0.0;
+              sl.c = 0.0; sl.m2 = 0.0;
+              sl.nf = with_prev ? 1.0 : 0.0;
+              cnt = with_prev ? 1u : 0u;
+              rr = with_prev ? 0.5 : 1.0;                    // 1/(cnt+1)
+              do_push = !is_split;                           // Q2: the key at split_idx is in neither half
+            } else {
+              active = false;                                // end of data, or the next lane takes over
+              do_push = false;
+            }
           }
         }
-      }
-      if constexpr (UseRecipTable<K>::value) {
-        if (!__any(do_push && cnt + 1 >= (unsigned)FS_TMAX)) {
-          if (do_push) { cnt += 1; slr_push_r(sl, x, y, rr); }
-        } else {
-          if (do_push) { cnt += 1; slr_push(sl, x, y); }
+        if (do_push) {
+          cnt += 1;
+          if constexpr (TABLE) slr_push_r(sl, x, y, rr);
+          else slr_push(sl, x, y);
         }
-      } else {
-        if (do_push) { cnt += 1; slr_push(sl, x, y); }
+        xprev = x; yprev = y;
+        if (pending >= FS_QDRAIN) drain();
       }
-      xprev = x; yprev = y;
-      if (pending >= FS_QDRAIN) drain();
-    }
+    };
+    if (UseRecipTable<K>::value && !__any(active && cnt + FS_ROW + 2 >= (unsigned)FS_TMAX)) steps(std::true_type{});
+    else steps(std::false_type{});
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
     if (!active && (row_i >= chunk_end || row_i >= rd_hi)) lane_done = true;
@@ -528,7 +533,6 @@ __global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, S
 // index with the end of its current leaf, and at a boundary switches to the next leaf whose
 // parameters and end index were prefetched when the previous leaf was entered.  Phase 1 shrinks to
 // "convert 16 keys to f64 + duplicate mask".  One atomicMax per (lane, leaf) segment.
-// (Radix roots keep k_err_stream: their leaf ids need the raw key bits.)
 // =============================================================================================
 template <typename K>
 __device__ __forceinline__ void convert_row(unsigned long long* __restrict__ panel, int lane, uint64_t row_i,
@@ -561,7 +565,6 @@ __global__ void __launch_bounds__(64, 3) k_err_range(const K* __restrict__ keys,
                                                   const double* __restrict__ params,
                                                   unsigned long long* __restrict__ leaf_maxerr,
                                                   unsigned long long* __restrict__ leaf_run) {
-  static_assert(ROOT != K_RADIX, "radix roots use k_err_stream");
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   __shared__ unsigned long long panel[64 * FS_STRIDE];
   __shared__ unsigned int q_leaf[ER_QCAP];
