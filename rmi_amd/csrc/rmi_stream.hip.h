@@ -138,11 +138,14 @@ __device__ __forceinline__ void classify_row(unsigned long long* __restrict__ pa
                                              K& kprev, double& tprev, unsigned int& bmask, unsigned int& dmask,
                                              int& split_pos, unsigned int& flags,
                                              unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st) {
-  unsigned int bm = 0, dm = 0, sm = 0, oobm = 0, nm = 0;
+  // Per key: convert, evaluate the root, two compares.  Everything that only matters at a leaf
+  // boundary (split point, monotonicity, leaf_start) is derived afterwards from the boundary bits.
+  // Positions past the readable end hold clamped copies of the last key, so the carries below are
+  // right without per-key selects.
+  unsigned int bm = 0, dm = 0, oobm = 0;
+  const double tin = tprev;
   double tp = tprev;
   K kp = kprev;
-  double tlast = tprev;
-  K klast = kprev;
 #pragma unroll
   for (int h = 0; h < FS_ROW; h += 8) {                    // two halves of 8 keys: bounded register pressure
     K kk[8];
@@ -155,41 +158,42 @@ __device__ __forceinline__ void classify_row(unsigned long long* __restrict__ pa
       bool oob;
       const double t = root_target_f<ROOT, K>(r, Lm1f, k, oob);
       bm |= (t != tp) ? (1u << s) : 0u;
-      sm |= (tp < midf && t >= midf) ? (1u << s) : 0u;     // idx == split_idx (two_layer.rs:132-136)
       dm |= (k == kp) ? (1u << s) : 0u;
-      if constexpr (WRITE) {
-        nm |= (t < tp) ? (1u << s) : 0u;                   // two_layer.rs:50 / :144
-        oobm |= oob ? (1u << s) : 0u;                      // two_layer.rs:45-48
-      }
+      if constexpr (WRITE && !root_needs_bounds_check<ROOT>()) oobm |= oob ? (1u << s) : 0u;   // two_layer.rs:45-48
       if constexpr (LEAFP) leafp[lane * FS_STRIDE + s] = (unsigned int)t;
       panel[lane * FS_STRIDE + s] = __builtin_bit_cast(unsigned long long, KeyTraits<K>::as_float(k));
       tp = t; kp = k;
-      const bool v = (vmask >> s) & 1u;
-      tlast = v ? t : tlast;
-      klast = v ? k : klast;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   if (row_i == 0) dm &= ~1u;                               // key 0 has no predecessor
-  bm &= vmask; dm &= vmask; sm &= vmask;
+  bm &= vmask; dm &= vmask;
   bmask = bm; dmask = dm;
-  split_pos = sm ? (__ffs(sm) - 1) : -1;
-  kprev = klast; tprev = tlast;                            // carries = last valid key of the row
+  kprev = kp; tprev = tp;
+  split_pos = -1;
   if constexpr (WRITE) {
-    if (nm & vmask) flags |= EF_NON_MONOTONE;
-    if constexpr (!root_needs_bounds_check<ROOT>()) { if (oobm & vmask) flags |= EF_ROOT_OOB; }
-    unsigned int m = bm & ownmask;                         // leaves that start in this lane's chunk
+    if (oobm & vmask) flags |= EF_ROOT_OOB;
+    // walk the boundaries of this row in order (targets only change there)
+    const unsigned int midu = (unsigned int)midf;
+    long long tc = (tin < 0.0) ? -1ll : (long long)(unsigned int)tin;   // target before the row (-1: none)
+    unsigned int m = bm;
     while (m) {
       const int s = __ffs(m) - 1;
       m &= m - 1;
       const uint64_t idx = row_i + s;
       const unsigned int t = leaf_id_at<ROOT, LEAFP>(panel, leafp, lane, s, r, Lm1f);
-      leaf_start[t] = idx;
-      if (s == split_pos) {
-        if (idx == 0 || idx + 1 >= n) flags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
-        st->split_idx = idx;
-        st->split_target = t;
+      if ((long long)t < tc) flags |= EF_NON_MONOTONE;     // two_layer.rs:50 / :144
+      const bool is_split = (tc < (long long)midu && t >= midu);       // idx == split_idx (two_layer.rs:132-136)
+      if (is_split) split_pos = s;
+      if ((ownmask >> s) & 1u) {                           // this lane owns the leaf starting here
+        leaf_start[t] = idx;
+        if (is_split) {
+          if (idx == 0 || idx + 1 >= n) flags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
+          st->split_idx = idx;
+          st->split_target = t;
+        }
       }
+      tc = (long long)t;
     }
     if (n - 1 >= row_i && n - 1 - row_i < (uint64_t)FS_ROW && ((vmask >> (int)(n - 1 - row_i)) & 1u))
       st->last_target = leaf_id_at<ROOT, LEAFP>(panel, leafp, lane, (int)(n - 1 - row_i), r, Lm1f);
@@ -214,7 +218,6 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   __shared__ double rtab[FS_TMAX];
   __shared__ double s_q[FA_WAVES][5][FS_QCAP2];
   __shared__ unsigned long long s_qidx[FA_WAVES][FS_QCAP2];
-  __shared__ unsigned int s_qleaf[FA_WAVES][FS_QCAP2];
 
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -223,7 +226,6 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   double* q_mx = s_q[wv][0]; double* q_my = s_q[wv][1]; double* q_c = s_q[wv][2];
   double* q_m2 = s_q[wv][3]; double* q_nf = s_q[wv][4];
   unsigned long long* q_idx = s_qidx[wv];
-  unsigned int* q_leaf = s_qleaf[wv];
 
   const uint64_t n = sp.n;                                   // global key count
   const uint64_t rd_hi = sp.rd_hi;                           // one past the last readable key
@@ -243,7 +245,6 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   // carries of the recurrence (phase 2)
   double xprev = 0.0, yprev = 0.0;
   bool active = false;
-  unsigned int cur_leaf = 0;
   unsigned int cnt = 0;                                      // == sl.nf
   SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
   unsigned int flags = 0;
@@ -266,9 +267,10 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
       const int slot = b + lane;
       if (slot < pending) {
         SlrState s2 = {q_mx[slot], q_my[slot], q_c[slot], q_m2[slot], q_nf[slot]};
-        const uint64_t lj = q_leaf[slot];
         const unsigned long long qi = q_idx[slot];
-        const uint64_t bi = qi & ~FS_NO_NEXT;
+        const uint64_t bi = qi & ~FS_NO_NEXT;                // the boundary index; the leaf is that of key[bi-1]
+        bool oob_;
+        const uint64_t lj = (uint64_t)root_target_f<ROOT, K>(r, Lm1f, keys[bi - 1], oob_);
         double a = 0.0, be = 0.0;
         bool have = true;
         if (!(qi & FS_NO_NEXT)) {
@@ -351,7 +353,6 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
             if (do_close) {
               const int slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
               q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
-              q_leaf[slot] = cur_leaf;
               q_idx[slot] = (is_end || is_split) ? (idx | FS_NO_NEXT) : idx;   // Q3: no next-first across the halves / at the end
             }
             pending += __popcll(cm);
@@ -360,7 +361,6 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
             if (!is_end && s < own_cnt) {
               // open the leaf that starts here
               active = true;
-              cur_leaf = leaf_id_at<ROOT, LEAFP>(panel, leafp, lane, s, r, Lm1f);
               const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
               const bool with_prev = !(is_split || idx == 0 || prev_split);   // prev-last (two_layer.rs:74-78), Q3/Q4
               sl.mx = with_prev ? xprev : 0.0;
