@@ -325,18 +325,39 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     }
 
     // ---------------- phase 2: 16 lockstep steps of the recurrence ----------------
-    // Two instances of the step loop: the usual one divides through the reciprocal table; if some
-    // lane's running count may leave the table during this panel the whole wave takes the
-    // instance with plain IEEE division (same results, see div_by_count).
-    auto steps = [&](auto table_tag) {
-      constexpr bool TABLE = decltype(table_tag)::value;
+    // Two instances of the step loop.  FAST (the usual one): divisions through the reciprocal
+    // table, and at most one leaf closes per lane in this row, so the queue slots are assigned
+    // once per panel and the loop body has no cross-lane operation besides the boundary vote.
+    // GENERAL: plain IEEE division (running counts beyond the table) and/or several closes per lane
+    // (leaves shorter than a row); slots by ballot, drain inside the loop.  Same results.
+    int my_closes = 0;
+    {
+      bool act = active;
+      unsigned int m = bmask;
+      while (m) {
+        const int s = __ffs(m) - 1;
+        m &= m - 1;
+        if (act) my_closes++;
+        act = (s != end_pos) && (s < own_cnt);
+      }
+    }
+    const bool general = !UseRecipTable<K>::value || __any(my_closes > 1) ||
+                         __any(active && cnt + FS_ROW + 2 >= (unsigned)FS_TMAX);
+    auto steps = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+      int my_slot = 0;
+      if constexpr (FAST) {
+        const unsigned long long cmask = __ballot(my_closes == 1);
+        my_slot = pending + __popcll(cmask & ((1ull << lane) - 1ull));
+        pending += __popcll(cmask);
+      }
       double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
 #pragma unroll 2
       for (int s = 0; s < FS_ROW; s++) {
         const double x = xn;
         xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);   // next step's x
         double rr = 0.0;
-        if constexpr (TABLE) rr = rtab[(cnt + 1) & (FS_TMAX - 1)];
+        if constexpr (FAST) rr = rtab[(cnt + 1) & (FS_TMAX - 1)];
         const bool bit = (bmask >> s) & 1u;
         const double idxf = row_if + (double)s;
         const double y = ((dmask >> s) & 1u) ? yprev : idxf;   // FixDups first-occurrence offset
@@ -348,14 +369,15 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
           const bool is_split = (s == split_pos);
           const uint64_t idx = row_i + s;
           const bool do_close = bit && active;
-          const unsigned long long cm = __ballot(do_close);
-          if (cm) {
-            if (do_close) {
-              const int slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
-              q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
-              q_idx[slot] = (is_end || is_split) ? (idx | FS_NO_NEXT) : idx;   // Q3: no next-first across the halves / at the end
-            }
+          int slot = my_slot;
+          if constexpr (!FAST) {
+            const unsigned long long cm = __ballot(do_close);
+            slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
             pending += __popcll(cm);
+          }
+          if (do_close) {
+            q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
+            q_idx[slot] = (is_end || is_split) ? (idx | FS_NO_NEXT) : idx;   // Q3: no next-first across the halves / at the end
           }
           if (bit) {
             if (!is_end && s < own_cnt) {
@@ -378,15 +400,16 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         }
         if (do_push) {
           cnt += 1;
-          if constexpr (TABLE) slr_push_r(sl, x, y, rr);
+          if constexpr (FAST) slr_push_r(sl, x, y, rr);
           else slr_push(sl, x, y);
         }
         xprev = x; yprev = y;
-        if (pending >= FS_QDRAIN) drain();
+        if constexpr (!FAST) { if (pending >= FS_QDRAIN) drain(); }
       }
     };
-    if (UseRecipTable<K>::value && !__any(active && cnt + FS_ROW + 2 >= (unsigned)FS_TMAX)) steps(std::true_type{});
-    else steps(std::false_type{});
+    if (general) steps(std::false_type{});
+    else steps(std::true_type{});
+    if (pending >= FS_QDRAIN) drain();
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
     if (!active && (row_i >= chunk_end || row_i >= rd_hi)) lane_done = true;
