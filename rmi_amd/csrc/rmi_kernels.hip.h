@@ -151,13 +151,14 @@ __global__ void __launch_bounds__(1024) k_fill_scan_tiles(unsigned long long* __
   for (uint64_t k = hi; k-- > lo;) { unsigned long long v = tile_min[k]; m = v < m ? v : m; }
   sm[threadIdx.x] = m;
   __syncthreads();
-  // carry for thread t = min over threads > t (serial over 1024 entries by one thread: tiny)
-  if (threadIdx.x == 0) {
-    unsigned long long run = NO_START;
-    for (int k = 1023; k >= 0; k--) { unsigned long long v = sm[k]; sm[k] = run; run = v < run ? v : run; }
+  // carry for thread t = min over threads > t: inclusive suffix-min by doubling, then shift by one
+  for (int d = 1; d < 1024; d <<= 1) {
+    unsigned long long o = ((int)threadIdx.x + d < 1024) ? sm[threadIdx.x + d] : NO_START;
+    __syncthreads();
+    if (o < sm[threadIdx.x]) sm[threadIdx.x] = o;
+    __syncthreads();
   }
-  __syncthreads();
-  unsigned long long carry = sm[threadIdx.x];
+  unsigned long long carry = (threadIdx.x + 1 < 1024) ? sm[threadIdx.x + 1] : NO_START;
   for (uint64_t k = hi; k-- > lo;) {
     unsigned long long v = tile_min[k];
     tile_min[k] = carry;              // exclusive: min of all tiles to the right
@@ -370,8 +371,9 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   constexpr int ROWB = PPL * 8 + 8;
   const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= sp.leaf_hi) return;
+  const bool in_range = j < sp.leaf_hi;
   const uint64_t n = sp.n;
+  if (in_range) {
   const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
   double p[PPL];
   if (s < e) {
@@ -405,12 +407,14 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
   if (run == 0 && s < e && !(e == n && keys[s] == keys[n - 1])) run = 1;
   const uint64_t final_err = m + run;                                      // two_layer.rs:250-251
   leaf_err[j] = final_err;
-  leaf_count[j] = (e - s) + (st->last_target == j ? 1ull : 0ull);          // Q7: tail duplicate
+  const uint64_t cnt_j = (e - s) + (st->last_target == j ? 1ull : 0ull);   // Q7: tail duplicate
+  leaf_count[j] = cnt_j;
   // packed row = the reference's L1_PARAMETERS record (codegen.rs:288-315)
   double* rp = reinterpret_cast<double*>(rows + j * ROWB);
 #pragma unroll
   for (int q = 0; q < PPL; q++) rp[q] = p[q];
   *reinterpret_cast<unsigned long long*>(rows + j * ROWB + PPL * 8) = final_err;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
