@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--spec", default="linear,linear")
     ap.add_argument("--dataset", default="uniform", choices=["uniform", "dups"])
     ap.add_argument("--dtype", default="uint64", choices=["uint64", "uint32"])
-    ap.add_argument("--cpu-sample", type=int, default=100_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=200_000_000,
                     help="keys of the workload the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo for functional tests)")
@@ -168,6 +168,14 @@ def main():
                 "pipeline_frac": pipeline_gbs / HBM_PEAK_GBS,
             },
         }
+        tpath = os.path.join(ROOT, "profiles", "traffic_calibrated.json")
+        if os.path.exists(tpath) and world == 1 and args.keys == 200_000_000 and args.leaves == (1 << 20) and args.spec == "linear,linear":
+            try:
+                tj = json.load(open(tpath))
+                out["roofline"]["traffic"] = tj.get(KERNEL_NAMES[dom], {}).get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_note"] = tj.get("note")
+            except Exception:
+                pass
         if not args.no_cpu_baseline and args.cpu_sample > 0 and world == 1:
             sample = keys_np[: min(args.cpu_sample, len(keys_np))]
             out["cpu_baseline"] = cpu_baseline(sample, args.spec, L_global, n_global)
