@@ -692,18 +692,26 @@ __global__ void __launch_bounds__(64, 3) k_err_range(const K* __restrict__ keys,
     const double row_endf = row_if + (double)end_pos;
     const bool crosses = !lane_done && end_pos > 0 && e_cur < row_endf;
     const bool general = crosses && !(have_leaf && pn_ok && e_next > e_cur && e_next >= row_endf);
-    auto steps = [&](auto fast_tag) {
+    // PLAIN: every lane has a full row, no duplicate keys in the panel and no open duplicate run:
+    // y is the running index and run lengths are all 1 (never reported), so the step is just
+    // "predict, compare, max".
+    const bool plain_ok = !__any(lane_done || end_pos < FS_ROW || dmask != 0u || (row_i > sp.rd_lo && yprev != row_if - 1.0));
+    auto steps = [&](auto fast_tag, auto plain_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
+      constexpr bool PLAIN = decltype(plain_tag)::value;
       double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
 #pragma unroll 2
       for (int s = 0; s < FS_ROW; s++) {
         const double x = xn;
         xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);
-        const bool valid = (vmask >> s) & 1u;
-        const bool dup = (dmask >> s) & 1u;
         const double idxf = row_if + (double)s;
-        // a new key value ends the previous run: record its length for the leaf of the previous key
-        if (valid && !dup && have_leaf) maxrun = fmax(maxrun, idxf - yprev);
+        bool valid = true, dup = false;
+        if constexpr (!PLAIN) {
+          valid = (vmask >> s) & 1u;
+          dup = (dmask >> s) & 1u;
+          // a new key value ends the previous run: record its length for the leaf of the previous key
+          if (valid && !dup && have_leaf) maxrun = fmax(maxrun, idxf - yprev);
+        }
         const double y = dup ? yprev : idxf;
         const bool bit = valid && (idxf >= e_cur);           // first key of another leaf
         if (__any(bit)) {
@@ -740,12 +748,14 @@ __global__ void __launch_bounds__(64, 3) k_err_range(const K* __restrict__ keys,
           // err in the f64 domain (all integers < 2^53): |min(pred, N) - y|, y < N
           const double e = fabs(fmin(fmax(0.0, floor(f)), nf) - y);
           maxerr = fmax(maxerr, e);
-          yprev = y;
+          if constexpr (!PLAIN) yprev = y;
         }
       }
+      if constexpr (PLAIN) yprev = row_if + (double)(FS_ROW - 1);
     };
-    if (__any(general)) steps(std::false_type{});
-    else steps(std::true_type{});
+    if (__any(general)) steps(std::false_type{}, std::false_type{});
+    else if (plain_ok) steps(std::true_type{}, std::true_type{});
+    else steps(std::true_type{}, std::false_type{});
     if (pending >= 64) drain();                              // (at most 64 more can arrive per panel in the fast loop)
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
