@@ -379,24 +379,22 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
             q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
             q_idx[slot] = (is_end || is_split) ? (idx | FS_NO_NEXT) : idx;   // Q3: no next-first across the halves / at the end
           }
-          if (bit) {
-            if (!is_end && s < own_cnt) {
-              // open the leaf that starts here
-              active = true;
-              const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
-              const bool with_prev = !(is_split || idx == 0 || prev_split);   // prev-last (two_layer.rs:74-78), Q3/Q4
-              sl.mx = with_prev ? xprev : 0.0;
-              sl.my = with_prev ? yprev : 0.0;
-              sl.c = 0.0; sl.m2 = 0.0;
-              sl.nf = with_prev ? 1.0 : 0.0;
-              cnt = with_prev ? 1u : 0u;
-              rr = with_prev ? 0.5 : 1.0;                    // 1/(cnt+1)
-              do_push = !is_split;                           // Q2: the key at split_idx is in neither half
-            } else {
-              active = false;                                // end of data, or the next lane takes over
-              do_push = false;
-            }
-          }
+          // open the leaf that starts here (selects, so that the running state stays in place):
+          // prev-last point (two_layer.rs:74-78) unless at the start of a half / after Q4 (Q3/Q4);
+          // Q2: the key at split_idx is in neither half.
+          const bool open = bit && !is_end && (s < own_cnt);
+          const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
+          const bool with_prev = !(is_split || idx == 0 || prev_split);
+          const double ini_n = with_prev ? 1.0 : 0.0;
+          sl.mx = open ? (with_prev ? xprev : 0.0) : sl.mx;
+          sl.my = open ? (with_prev ? yprev : 0.0) : sl.my;
+          sl.c = open ? 0.0 : sl.c;
+          sl.m2 = open ? 0.0 : sl.m2;
+          sl.nf = open ? ini_n : sl.nf;
+          cnt = open ? (with_prev ? 1u : 0u) : cnt;
+          rr = open ? (with_prev ? 0.5 : 1.0) : rr;          // 1/(cnt+1)
+          active = bit ? open : active;                      // end of data / the next lane takes over: inactive
+          do_push = bit ? (open && !is_split) : do_push;
         }
         if (do_push) {
           cnt += 1;
