@@ -343,8 +343,9 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     }
     const bool general = !UseRecipTable<K>::value || __any(my_closes > 1) ||
                          __any(active && cnt + FS_ROW + 2 >= (unsigned)FS_TMAX);
-    auto steps = [&](auto fast_tag) {
+    auto steps = [&](auto fast_tag, auto nodup_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
+      constexpr bool NODUP = decltype(nodup_tag)::value;   // no duplicate key in this panel: y == index
       int my_slot = 0;
       if constexpr (FAST) {
         const unsigned long long cmask = __ballot(my_closes == 1);
@@ -360,7 +361,8 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         if constexpr (FAST) rr = rtab[(cnt + 1) & (FS_TMAX - 1)];
         const bool bit = (bmask >> s) & 1u;
         const double idxf = row_if + (double)s;
-        const double y = ((dmask >> s) & 1u) ? yprev : idxf;   // FixDups first-occurrence offset
+        double y = idxf;                                     // FixDups first-occurrence offset
+        if constexpr (!NODUP) y = ((dmask >> s) & 1u) ? yprev : idxf;
         bool do_push = active;
         if (dbg & 1) do_push = false;
         if (!(dbg & 2) && __any(bit)) {
@@ -387,7 +389,9 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
           const bool with_prev = !(is_split || idx == 0 || prev_split);
           const double ini_n = with_prev ? 1.0 : 0.0;
           sl.mx = open ? (with_prev ? xprev : 0.0) : sl.mx;
-          sl.my = open ? (with_prev ? yprev : 0.0) : sl.my;
+          double yp = yprev;                                   // y of the previous key
+          if constexpr (NODUP) yp = (s == 0) ? yprev : idxf - 1.0;
+          sl.my = open ? (with_prev ? yp : 0.0) : sl.my;
           sl.c = open ? 0.0 : sl.c;
           sl.m2 = open ? 0.0 : sl.m2;
           sl.nf = open ? ini_n : sl.nf;
@@ -401,12 +405,15 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
           if constexpr (FAST) slr_push_r(sl, x, y, rr);
           else slr_push(sl, x, y);
         }
-        xprev = x; yprev = y;
+        xprev = x;
+        if constexpr (!NODUP) yprev = y;
         if constexpr (!FAST) { if (pending >= FS_QDRAIN) drain(); }
       }
+      if constexpr (NODUP) yprev = row_if + (double)(FS_ROW - 1);
     };
-    if (general) steps(std::false_type{});
-    else steps(std::true_type{});
+    if (general) steps(std::false_type{}, std::false_type{});
+    else if (!__any(dmask != 0u)) steps(std::true_type{}, std::true_type{});
+    else steps(std::true_type{}, std::false_type{});
     if (pending >= FS_QDRAIN) drain();
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
