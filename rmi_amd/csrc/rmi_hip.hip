@@ -438,13 +438,11 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
-  *c->h_state = init;
-  c->h_sentinel[0] = sp.it_hi;
-  HIPCHK(c, hipMemcpyAsync(c->d_state, c->h_state, sizeof(DevState), hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemsetAsync(c->d_leaf_start, 0xFF, (L_own + 1) * 8, s));
-  HIPCHK(c, hipMemcpyAsync(c->d_leaf_start + L_own, c->h_sentinel, 8, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemsetAsync(c->d_maxerr, 0, L_own * 8, s));
-  HIPCHK(c, hipMemsetAsync(c->d_run, 0, L_own * 8, s));
+  {
+    const uint64_t ib = (L_own + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, c->d_leaf_start, c->d_maxerr, c->d_run,
+                       L_own, (unsigned long long)sp.it_hi, c->d_state, init);
+  }
 
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   const bool stream_fit = (c->pipeline != 1) && (LEAF == K_LINEAR);

@@ -59,6 +59,22 @@ __global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_init: one launch instead of four memsets and two small copies: leaf_start := "no start" with
+// the sentinel entry leaf_start[L_own] = it_hi, maxerr := run := 0, device state := initial state.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_init(unsigned long long* __restrict__ leaf_start,
+                                              unsigned long long* __restrict__ maxerr,
+                                              unsigned long long* __restrict__ run, uint64_t L_own,
+                                              unsigned long long sentinel, DevState* __restrict__ st, DevState init) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= L_own; j += stride) {
+    leaf_start[j] = (j == L_own) ? sentinel : NO_START;
+    if (j < L_own) { maxerr[j] = 0; run[j] = 0; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *st = init;
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_bounds_vec: the same bucketing scan with 16 bytes per lane (2 x 8-byte or 4 x 4-byte keys),
 // fully coalesced; the key before a lane's first key comes from the previous lane (shuffle) or,
 // for lane 0, from memory.  One root evaluation per key (+1 per lane for the predecessor).
