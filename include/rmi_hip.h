@@ -156,6 +156,9 @@ int rmi_hip_generate_keys(rmi_hip_ctx* ctx, int generator, int dtype, uint64_t n
                           uint64_t start, uint64_t count, uint64_t seed);
 int rmi_hip_download_keys(rmi_hip_ctx* ctx, void* host_out);
 const void* rmi_hip_device_keys(const rmi_hip_ctx* ctx);
+/* Device self-test: the reciprocal-table division used inside the SLR recurrence against IEEE
+ * division, on `trials` pseudo-random and near-midpoint operands; *mismatches must come back 0. */
+int rmi_hip_selftest_div(rmi_hip_ctx* ctx, uint64_t trials, uint64_t seed, uint64_t* mismatches);
 /* Achieved HBM read bandwidth (GB/s) of a read-only streaming kernel over the resident keys:
  * the measured denominator reported next to the 8 TB/s spec peak. */
 int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* ctx, int iters, double* gb_per_s);

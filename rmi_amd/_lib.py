@@ -51,6 +51,7 @@ SYMBOLS = [
     ("rmi_hip_generate_keys", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     ("rmi_hip_download_keys", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_device_keys", C.c_void_p, [C.c_void_p]),
+    ("rmi_hip_selftest_div", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rmi_hip_measure_read_bandwidth", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     ("rmi_hip_set_shard", C.c_int, [C.c_void_p, C.POINTER(Shard)]),
     ("rmi_hip_set_rows_output", C.c_int, [C.c_void_p, C.c_void_p]),

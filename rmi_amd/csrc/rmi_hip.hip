@@ -295,6 +295,23 @@ int rmi_hip_download_keys(rmi_hip_ctx* c, void* host_out) {
 
 const void* rmi_hip_device_keys(const rmi_hip_ctx* c) { return c ? c->d_keys : nullptr; }
 
+int rmi_hip_selftest_div(rmi_hip_ctx* c, uint64_t trials, uint64_t seed, uint64_t* mismatches) {
+  if (!c || !mismatches || trials == 0) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long* d = nullptr;
+  HIPCHK(c, hipMalloc(&d, 8));
+  HIPCHK(c, hipMemsetAsync(d, 0, 8, c->stream));
+  const unsigned blocks = 2048, threads = 256;
+  const unsigned long long per = (trials + (unsigned long long)blocks * threads - 1) / ((unsigned long long)blocks * threads);
+  hipLaunchKernelGGL(k_selftest_div, dim3(blocks), dim3(threads), 0, c->stream, per, (unsigned long long)seed, d);
+  unsigned long long h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  *mismatches = h;
+  return RMI_OK;
+}
+
 int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* c, int iters, double* gb_per_s) {
   if (!c || !gb_per_s || iters <= 0) return RMI_ERR_BAD_ARG;
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;

@@ -43,15 +43,19 @@ __device__ __forceinline__ void slr_push(SlrState& s, double x, double y) {   //
   s.m2 += dx * dx2;
 }
 
-// RN(a / nf) given r == RN(1 / nf): q0 = RN(a r) is within 2 ulp; one FMA correction round makes
-// it faithful, the second makes it correctly rounded (Markstein's theorem), i.e. exactly what
-// IEEE division returns (checked against `/` by rmi_hip_selftest_div).  No over/underflow can
+// RN(a / nf) for an integer-valued nf < 2^40, given r == RN(1 / nf)  [one Markstein round].
+//   q0 = RN(a r) = t (1 + e1)(1 + e2), t = a / nf, |e1|, |e2| <= 2^-53
+//   rem = a - q0 nf  is exact: it is a multiple of ulp(q0) and below 2 ulp(a) ~ 2 nf ulp(q0)
+//   v = q0 + rem r = t + (t - q0) e1, so |v - t| <= |t| 2^-105, and the FMA returns RN(v).
+// RN(v) == RN(t) unless a rounding boundary (a midpoint m of two doubles) lies between them.  But
+// a - nf m is a non-zero multiple of half an ulp of t (a tie a == nf m would need more than 53
+// significand bits), so |t - m| >= |t| 2^-53 / nf >> |t| 2^-105.  Hence the result is the
+// correctly rounded quotient -- bit for bit what IEEE division returns.  No over/underflow can
 // occur for the operands of the recurrence on integer keys (|a| in [2^-84, 2^65] or 0).
+// rmi_hip_selftest_div checks it against `/` on random and near-midpoint operands.
 __device__ __forceinline__ double div_by_count(double a, double nf, double r) {
-  double q = a * r;
-  double e = __builtin_fma(-q, nf, a);
-  q = __builtin_fma(e, r, q);
-  e = __builtin_fma(-q, nf, a);
+  const double q = a * r;
+  const double e = __builtin_fma(-q, nf, a);
   return __builtin_fma(e, r, q);
 }
 
@@ -886,6 +890,44 @@ __global__ void __launch_bounds__(256) k_read_bw(const uint4* __restrict__ src, 
   }
   for (; i < n16; i += stride) { const uint4 a = src[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
   if (acc == 0x12345678u) sink[0] = acc;   // practically never; keeps the loads alive
+}
+
+
+// Self-test of div_by_count against IEEE division: every count 1..FS_TMAX-1 with pseudo-random
+// numerators and with numerators constructed next to rounding midpoints of the quotient.
+__global__ void __launch_bounds__(256) k_selftest_div(unsigned long long trials_per_thread, unsigned long long seed,
+                                                      unsigned long long* __restrict__ mismatches) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long bad = 0;
+  unsigned long long state = seed + tid * 0x9E3779B97F4A7C15ull;
+  for (unsigned long long it = 0; it < trials_per_thread; it++) {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    unsigned long long z = state ^ (state >> 29);
+    z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    const unsigned int n = 1u + (unsigned int)(z % (unsigned long long)(FS_TMAX - 1));
+    const double nf = (double)n;
+    const double r = 1.0 / nf;
+    double a;
+    const unsigned int mode = (unsigned int)(z >> 60) & 3u;
+    // exponent range of the recurrence's operands (and some margin): 2^-100 .. 2^+100
+    const int ex = (int)((z >> 40) % 201ull) - 100;
+    const double frac = 1.0 + (double)((z >> 8) & 0xFFFFFFFFFFFFFull) * 0x1p-52;
+    if (mode == 0) {
+      a = ldexp(frac, ex);
+    } else {
+      // q a random double; a = RN(nf * (q +- half an ulp +- tiny)): quotients next to a midpoint
+      const double q = ldexp(frac, ex);
+      const double half = ldexp(1.0, ex - 53);
+      const double qm = (mode & 1u) ? q + half : q - half;          // exact: q has 53 bits, half is 2^-53 below
+      a = qm * nf;                                                  // rounded: lands within an ulp of nf * midpoint
+      if (mode == 3) a = nextafter(a, (z & 1ull) ? 1e300 : -1e300);
+    }
+    if ((z >> 7) & 1ull) a = -a;
+    const double want = a / nf;
+    const double got = div_by_count(a, nf, r);
+    if (__builtin_bit_cast(unsigned long long, want) != __builtin_bit_cast(unsigned long long, got)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
 }
 
 }  // namespace rmi

@@ -129,6 +129,17 @@ def test_parity_tiny(trainer_mod, oracle):
         _compare(trainer_mod, oracle, keys, "linear", "linear_spline", L)
 
 
+def test_division_by_count_is_ieee(trainer_mod):
+    """The table-reciprocal division of the SLR step == IEEE division, bit for bit (random and
+    near-midpoint numerators, every count of the table)."""
+    import ctypes as C
+    tr = trainer_mod.Trainer()
+    bad = C.c_uint64(123)
+    rc = tr._lib.rmi_hip_selftest_div(tr._h, 4_000_000_000, 7, C.byref(bad))
+    assert rc == 0 and bad.value == 0, f"{bad.value} mismatching quotients"
+    tr.close()
+
+
 def test_device_generators_match_numpy(trainer_mod):
     for gen, dt, ref in [("uniform", np.uint64, dg.uniform_u64), ("dups", np.uint64, dg.dups_u64),
                          ("uniform", np.uint32, dg.uniform_u32), ("dups", np.uint32, dg.dups_u32)]:
