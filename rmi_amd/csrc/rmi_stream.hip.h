@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   // carries of the recurrence (phase 2)
   double xprev = 0.0, yprev = 0.0;
   bool active = false;
-  unsigned int cnt = 0;                                      // == sl.nf
+  unsigned int roff = 8;                                     // byte offset of 1/(count+1) in the reciprocal table
   SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
   unsigned int flags = 0;
   if (p0 < sp.it_hi && p0 > sp.rd_lo) {
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
       }
     }
     const bool general = !UseRecipTable<K>::value || __any(my_closes > 1) ||
-                         __any(active && cnt + FS_ROW + 2 >= (unsigned)FS_TMAX);
+                         __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
     auto steps = [&](auto fast_tag, auto nodup_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
       constexpr bool NODUP = decltype(nodup_tag)::value;   // no duplicate key in this panel: y == index
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         const double x = xn;
         xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);   // next step's x
         double rr = 0.0;
-        if constexpr (FAST) rr = rtab[(cnt + 1) & (FS_TMAX - 1)];
+        if constexpr (FAST) rr = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rtab) + (roff & (FS_TMAX * 8 - 1)));
         const bool bit = (bmask >> s) & 1u;
         const double idxf = row_if + (double)s;
         double y = idxf;                                     // FixDups first-occurrence offset
@@ -399,13 +399,13 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
           sl.c = open ? 0.0 : sl.c;
           sl.m2 = open ? 0.0 : sl.m2;
           sl.nf = open ? ini_n : sl.nf;
-          cnt = open ? (with_prev ? 1u : 0u) : cnt;
+          roff = open ? (with_prev ? 16u : 8u) : roff;
           rr = open ? (with_prev ? 0.5 : 1.0) : rr;          // 1/(cnt+1)
           active = bit ? open : active;                      // end of data / the next lane takes over: inactive
           do_push = bit ? (open && !is_split) : do_push;
         }
         if (do_push) {
-          cnt += 1;
+          roff += 8;
           if constexpr (FAST) slr_push_r(sl, x, y, rr);
           else slr_push(sl, x, y);
         }
