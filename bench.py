@@ -37,7 +37,8 @@ def parse_args():
     ap.add_argument("--keys", type=int, default=200_000_000, help="keys per GPU")
     ap.add_argument("--leaves", type=int, default=1 << 20, help="leaves per GPU")
     ap.add_argument("--spec", default="linear,linear")
-    ap.add_argument("--dataset", default="uniform", choices=["uniform", "dups"])
+    ap.add_argument("--dataset", default="uniform", choices=["uniform", "dups", "books"],
+                    help="uniform / dups are generated in HBM; books (heavy-tailed, books_200M-shaped) on the host")
     ap.add_argument("--dtype", default="uint64", choices=["uint64", "uint32"])
     ap.add_argument("--cpu-sample", type=int, default=200_000_000,
                     help="keys of the workload the CPU baseline is timed on (0 = skip)")
@@ -101,7 +102,11 @@ def main():
 
     tr = T.Trainer(device=local_rank)
     if world == 1:
-        tr.generate_keys(args.dataset, np_dtype, n_global, 0, n_local)
+        if args.dataset == "books":
+            from rmi_amd import datagen
+            tr.set_keys(datagen.books_u64(n_local))
+        else:
+            tr.generate_keys(args.dataset, np_dtype, n_global, 0, n_local)
         root_kind, leaf_kind = T.parse_spec(args.spec)
         t0 = time.perf_counter()
         keys_np = tr.download_keys()

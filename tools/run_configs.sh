@@ -6,3 +6,5 @@ python bench.py --steps 5 --warmup 1 --no-cpu-baseline --spec cubic,linear --lea
 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --spec linear,linear --leaves 2097152 --keys 800000000 2>&1 | tail -1 | python -c "$P"
 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --spec radix,linear_spline --leaves 4194304 --keys 400000000 --dtype uint32 2>&1 | tail -1 | python -c "$P"
 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --spec linear,linear --leaves 1048576 --dataset dups 2>&1 | tail -1 | python -c "$P"
+python bench.py --steps 5 --warmup 1 --no-cpu-baseline --spec linear,linear --leaves 262144 --dataset books 2>&1 | tail -1 | python -c "$P"
+python bench.py --steps 5 --warmup 1 --no-cpu-baseline --spec linear,linear --leaves 1048576 --dataset books 2>&1 | tail -1 | python -c "$P"
