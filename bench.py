@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-KERNEL_NAMES = ["k_fit_stream", "k_fill", "(unused)", "k_err_range", "k_finalize+stats"]
+KERNEL_NAMES = ["k_fit_stream", "k_fill", "k_fit_long", "k_err_range", "k_finalize+stats"]
 
 
 def parse_args():

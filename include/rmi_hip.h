@@ -121,6 +121,8 @@ typedef struct {
   double sum_l2, sum_log2;
   uint64_t device_ns;             /* hipEvent time of all device work of this call */
   uint64_t kernel_ns[8];          /* per-kernel hipEvent times, see RMI_K_* */
+  uint64_t long_leaves;           /* leaves too long for the lockstep fit pass, fitted one lane each
+                                   * (skew diagnostic: each is a sequential chain of its own length) */
 } rmi_hip_result;
 
 enum { RMI_K_BOUNDARIES = 0, RMI_K_FILL = 1, RMI_K_FIT = 2, RMI_K_ERR = 3, RMI_K_FINALIZE = 4 };
@@ -159,6 +161,9 @@ const void* rmi_hip_device_keys(const rmi_hip_ctx* ctx);
 /* Device self-test: the reciprocal-table division used inside the SLR recurrence against IEEE
  * division, on `trials` pseudo-random and near-midpoint operands; *mismatches must come back 0. */
 int rmi_hip_selftest_div(rmi_hip_ctx* ctx, uint64_t trials, uint64_t seed, uint64_t* mismatches);
+/* The computed reciprocal used for counts beyond the table: checks RN(1/n) == 1.0/n for every
+ * integer n in [n_lo, n_hi), 1 <= n_lo < n_hi <= 2^40. */
+int rmi_hip_selftest_recip(rmi_hip_ctx* ctx, uint64_t n_lo, uint64_t n_hi, uint64_t* mismatches);
 /* Achieved HBM read bandwidth (GB/s) of a read-only streaming kernel over the resident keys:
  * the measured denominator reported next to the 8 TB/s spec peak. */
 int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* ctx, int iters, double* gb_per_s);

@@ -30,6 +30,7 @@ class Result(C.Structure):
         ("shard_leaf_lo", C.c_uint64), ("shard_leaves", C.c_uint64),
         ("sum_n_err", C.c_uint64), ("sum_l2", C.c_double), ("sum_log2", C.c_double),
         ("device_ns", C.c_uint64), ("kernel_ns", C.c_uint64 * 8),
+        ("long_leaves", C.c_uint64),
     ]
 
 
@@ -52,6 +53,7 @@ SYMBOLS = [
     ("rmi_hip_download_keys", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_device_keys", C.c_void_p, [C.c_void_p]),
     ("rmi_hip_selftest_div", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("rmi_hip_selftest_recip", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rmi_hip_measure_read_bandwidth", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     ("rmi_hip_set_shard", C.c_int, [C.c_void_p, C.POINTER(Shard)]),
     ("rmi_hip_set_rows_output", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -80,8 +82,12 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{SO} is missing: build it with `python -m rmi_amd.build` (hipcc --offload-arch=gfx950). "
             "rmi_amd has no CPU fallback for the training hot path.")
-    L = C.CDLL(SO)
+    # RMI_HIP_LIB: development aid for A/B timing against another build of the same ABI
+    alt = os.environ.get("RMI_HIP_LIB")
+    L = C.CDLL(alt or SO)
     for name, res, args in SYMBOLS:
+        if alt and not hasattr(L, name):
+            continue
         fn = getattr(L, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -52,6 +52,9 @@ struct DevState {
   unsigned long long sum_n_err;     // sum(n*err) wrapping u64
   double sum_l2;                    // sum((n*err)^2 / N)
   double sum_log2;                  // sum(n * log2(2 err + 2))
+  // leaves too long for the lockstep pass (see k_fit_long): number of entries in the long list
+  unsigned long long long_count;
+  unsigned long long long_cap;
 };
 
 template <typename K> struct KeyTraits;

@@ -38,6 +38,8 @@ struct rmi_hip_ctx {
   unsigned long long* d_count = nullptr;        // L
   unsigned char* d_rows = nullptr;              // L*(ppl*8+8)
   unsigned long long* d_tilemin = nullptr;
+  unsigned long long* d_long = nullptr;         // long-leaf hand-over list (pass A -> k_fit_long)
+  uint64_t long_cap = 0;
   DevState* d_state = nullptr;
   DevState* h_state = nullptr;                  // pinned
   unsigned long long* h_sentinel = nullptr;     // pinned
@@ -54,6 +56,7 @@ struct rmi_hip_ctx {
   int fit_min_chunk = 64;
   int err_kernel = 1;                           // pass B: 0 = k_err_wave, 1 = k_err_range (leaf_start-driven), 2 = k_err_stream
   int dbg = 0;                                  // ablation switches for profiling (0 = product behaviour)
+  unsigned int long_min = 4096;                 // leaves with more points go to k_fit_long (>= FS_TMAX)
   // last result
   uint64_t last_L = 0;
   int last_ppl = 2;
@@ -182,6 +185,8 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (ek && *ek) c->err_kernel = std::atoi(ek);
   const char* dbg = std::getenv("RMI_HIP_DBG");
   if (dbg && *dbg) c->dbg = std::atoi(dbg);
+  const char* lm = std::getenv("RMI_HIP_LONG_MIN");
+  if (lm && *lm) { long v = std::atol(lm); if (v >= FS_TMAX) c->long_min = (unsigned int)v; }
   const char* fc = std::getenv("RMI_HIP_FIT_MIN_CHUNK");
   if (fc && *fc) c->fit_min_chunk = std::atoi(fc);
   *out = c;
@@ -191,6 +196,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
 static void free_outputs(rmi_hip_ctx* c) {
   (void)hipFree(c->d_leaf_start); (void)hipFree(c->d_params); (void)hipFree(c->d_maxerr); (void)hipFree(c->d_run);
   (void)hipFree(c->d_err); (void)hipFree(c->d_count); (void)hipFree(c->d_rows); (void)hipFree(c->d_tilemin);
+  if (c->d_long) { (void)hipFree(c->d_long); c->d_long = nullptr; c->long_cap = 0; }
   c->d_leaf_start = nullptr; c->d_params = nullptr; c->d_maxerr = nullptr; c->d_run = nullptr;
   c->d_err = nullptr; c->d_count = nullptr; c->d_rows = nullptr; c->d_tilemin = nullptr;
   c->cap_leaves = 0; c->cap_ppl = 0;
@@ -304,6 +310,21 @@ int rmi_hip_selftest_div(rmi_hip_ctx* c, uint64_t trials, uint64_t seed, uint64_
   const unsigned blocks = 2048, threads = 256;
   const unsigned long long per = (trials + (unsigned long long)blocks * threads - 1) / ((unsigned long long)blocks * threads);
   hipLaunchKernelGGL(k_selftest_div, dim3(blocks), dim3(threads), 0, c->stream, per, (unsigned long long)seed, d);
+  unsigned long long h = 0;
+  HIPCHK(c, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  *mismatches = h;
+  return RMI_OK;
+}
+
+int rmi_hip_selftest_recip(rmi_hip_ctx* c, uint64_t n_lo, uint64_t n_hi, uint64_t* mismatches) {
+  if (!c || !mismatches || n_lo == 0 || n_hi <= n_lo || n_hi > (1ull << 40)) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long* d = nullptr;
+  HIPCHK(c, hipMalloc(&d, 8));
+  HIPCHK(c, hipMemsetAsync(d, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_selftest_recip, dim3(4096), dim3(256), 0, c->stream, (unsigned long long)n_lo, (unsigned long long)n_hi, d);
   unsigned long long h = 0;
   HIPCHK(c, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -451,7 +472,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   unsigned char* rows = rows_base - sp.leaf_lo * ROWB;
 
   // --- init ---
+  // long-leaf list: a long leaf has at least long_min points, so n/long_min entries always suffice
+  const uint64_t need_long = n_it / c->long_min + 1024;
+  if (c->long_cap < need_long) {
+    if (c->d_long) (void)hipFree(c->d_long);
+    c->d_long = nullptr; c->long_cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_long, need_long * 8));
+    c->long_cap = need_long;
+  }
   DevState init; std::memset(&init, 0, sizeof init);
+  init.long_cap = c->long_cap;
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
@@ -484,7 +514,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     const uint64_t chunks = (n_it + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
     const uint64_t fblocks = (waves + FA_WAVES - 1) / FA_WAVES;
-    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, sp, rp, C, leaf_start, params, c->d_state, c->dbg);
+    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, sp, rp, C, leaf_start, params, c->d_state, c->d_long, c->long_min, c->dbg);
     mark();
   }
   // --- fill empty leaves ---
@@ -496,10 +526,15 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count_e, c->d_tilemin);
   }
   mark();
-  if (!stream_fit) {
+  if (n_it == 0) {
+  } else if (!stream_fit) {
     // --- per-leaf fit ---
     const uint64_t blocks = (L_own + 255) / 256;
     hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params);
+  } else {
+    // --- leaves handed over by pass A (more than long_min points): one wave each ---
+    const uint64_t blocks = c->long_cap < 2048 ? c->long_cap : 2048;   // ~2 waves per SIMD saturate its f64 issue
+    hipLaunchKernelGGL((k_fit_long<ROOT, K>), dim3((unsigned)blocks), dim3(64), 0, s, keys, sp, rp, leaf_start, c->d_state, params, c->d_long);
   }
   mark();
   // --- error pass ---
@@ -616,6 +651,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   out->model_avg_log2_error = st.sum_log2 / (double)n_glob;
   out->model_max_log2_error = std::log2((double)st.max_err);
   out->split_idx = st.split_idx; out->split_target = st.split_target;
+  out->long_leaves = st.long_count;
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[9]));
   out->device_ns = (uint64_t)((double)ms * 1e6);

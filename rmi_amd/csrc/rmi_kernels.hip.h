@@ -241,12 +241,9 @@ __device__ __forceinline__ int leaf_container(uint64_t j, uint64_t s, uint64_t e
 // dependent, so each leaf is a sequential chain; parallelism is across leaves.)
 // ---------------------------------------------------------------------------------------------
 template <int LEAF, typename K>
-__global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, Span sp,
-                                                  const unsigned long long* __restrict__ leaf_start,
-                                                  DevState* __restrict__ st,
-                                                  double* __restrict__ params) {
-  const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= sp.leaf_hi) return;
+__device__ __forceinline__ void fit_one_leaf(uint64_t j, const K* __restrict__ keys, const Span& sp,
+                                             const unsigned long long* __restrict__ leaf_start,
+                                             DevState* __restrict__ st, double* __restrict__ params) {
   const uint64_t n = sp.n;
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
@@ -316,6 +313,17 @@ __global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, Sp
     out[0] = intercept; out[1] = slope;
   }
 }
+
+template <int LEAF, typename K>
+__global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, Span sp,
+                                                  const unsigned long long* __restrict__ leaf_start,
+                                                  DevState* __restrict__ st,
+                                                  double* __restrict__ params) {
+  const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= sp.leaf_hi) return;
+  fit_one_leaf<LEAF, K>(j, keys, sp, leaf_start, st, params);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // k_err: one thread per key: err = |min(pred,N) - min(y,N)| with the leaf's model

@@ -59,6 +59,20 @@ __device__ __forceinline__ double div_by_count(double a, double nf, double r) {
   return __builtin_fma(e, r, q);
 }
 
+// RN(1 / nf) for an integer-valued nf in [1, 2^40): hardware estimate, Newton steps, and a last
+// Markstein step  y + y (1 - nf y)  which rounds correctly once y is within an ulp (the only
+// exception, a significand of all ones, cannot occur for nf < 2^53).  rmi_hip_selftest_recip
+// checks it against 1.0 / nf exhaustively over ranges of nf.
+__device__ __forceinline__ double recip_exact(double nf) {
+  double y = __builtin_amdgcn_rcp(nf);
+  double e = __builtin_fma(-nf, y, 1.0);
+  y = __builtin_fma(e, y, y);
+  e = __builtin_fma(-nf, y, 1.0);
+  y = __builtin_fma(e, y, y);
+  e = __builtin_fma(-nf, y, 1.0);
+  return __builtin_fma(e, y, y);
+}
+
 __device__ __forceinline__ void slr_push_r(SlrState& s, double x, double y, double r) {
   s.nf += 1.0;
   const double dx = x - s.mx;
@@ -215,7 +229,9 @@ template <int ROOT, typename K>
 __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
                                                              unsigned long long* __restrict__ leaf_start,
                                                              double* __restrict__ params,
-                                                             DevState* __restrict__ st, int dbg) {
+                                                             DevState* __restrict__ st,
+                                                             unsigned long long* __restrict__ long_idx,
+                                                             unsigned int long_min, int dbg) {
   __shared__ unsigned long long s_panel[FA_WAVES][64 * FS_STRIDE];   // raw key bits, then f64 x
   constexpr bool LEAFP = (ROOT == K_RADIX);
   __shared__ unsigned int s_leafp[FA_WAVES][LEAFP ? 64 * FS_STRIDE : 1];   // leaf ids (radix roots only)
@@ -334,6 +350,20 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     // once per panel and the loop body has no cross-lane operation besides the boundary vote.
     // GENERAL: plain IEEE division (running counts beyond the table) and/or several closes per lane
     // (leaves shorter than a row); slots by ballot, drain inside the loop.  Same results.
+    // Counts that may leave the reciprocal table during this row (wave-uniform, rare): the row's
+    // reciprocals are computed instead.  And a leaf of more than `long_min` points leaves the
+    // lockstep pass altogether (its lane would walk far beyond its chunk, alone, at the cost of a
+    // whole wave): the lane hands it over to k_fit_long (by the index of its previous key) and goes
+    // on looking for the next leaf start.
+    bool beyond = __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
+    if (beyond) {
+      if (active && (roff >> 3) >= long_min) {
+        const unsigned long long pos = atomicAdd(&st->long_count, 1ull);
+        if (pos < st->long_cap) long_idx[pos] = row_i - 1;
+        active = false;
+      }
+      beyond = __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
+    }
     int my_closes = 0;
     {
       bool act = active;
@@ -345,11 +375,11 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         act = (s != end_pos) && (s < own_cnt);
       }
     }
-    const bool general = !UseRecipTable<K>::value || __any(my_closes > 1) ||
-                         __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
-    auto steps = [&](auto fast_tag, auto nodup_tag) {
+    const bool general = !UseRecipTable<K>::value || __any(my_closes > 1);
+    auto steps = [&](auto fast_tag, auto nodup_tag, auto tab_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
       constexpr bool NODUP = decltype(nodup_tag)::value;   // no duplicate key in this panel: y == index
+      constexpr bool TAB = decltype(tab_tag)::value;       // 1/(count+1) from the LDS table
       int my_slot = 0;
       if constexpr (FAST) {
         const unsigned long long cmask = __ballot(my_closes == 1);
@@ -362,7 +392,8 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         const double x = xn;
         xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);   // next step's x
         double rr = 0.0;
-        if constexpr (FAST) rr = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rtab) + (roff & (FS_TMAX * 8 - 1)));
+        if constexpr (FAST && TAB) rr = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rtab) + (roff & (FS_TMAX * 8 - 1)));
+        if constexpr (FAST && !TAB) rr = recip_exact(sl.nf + 1.0);
         const bool bit = (bmask >> s) & 1u;
         const double idxf = row_if + (double)s;
         double y = idxf;                                     // FixDups first-occurrence offset
@@ -415,9 +446,10 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
       }
       if constexpr (NODUP) yprev = row_if + (double)(FS_ROW - 1);
     };
-    if (general) steps(std::false_type{}, std::false_type{});
-    else if (!__any(dmask != 0u)) steps(std::true_type{}, std::true_type{});
-    else steps(std::true_type{}, std::false_type{});
+    if (general) steps(std::false_type{}, std::false_type{}, std::false_type{});
+    else if (beyond) steps(std::true_type{}, std::false_type{}, std::false_type{});
+    else if (!__any(dmask != 0u)) steps(std::true_type{}, std::true_type{}, std::true_type{});
+    else steps(std::true_type{}, std::false_type{}, std::true_type{});
     if (pending >= FS_QDRAIN) drain();
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
@@ -904,9 +936,12 @@ __global__ void __launch_bounds__(256) k_selftest_div(unsigned long long trials_
     state = state * 6364136223846793005ull + 1442695040888963407ull;
     unsigned long long z = state ^ (state >> 29);
     z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
-    const unsigned int n = 1u + (unsigned int)(z % (unsigned long long)(FS_TMAX - 1));
+    // counts of the table (reciprocal as the table holds it), or any count below 2^40 (computed)
+    const bool big = (z >> 6) & 1ull;
+    const unsigned long long n = big ? 1ull + ((state >> 11) % ((1ull << 40) - 1ull))
+                                     : 1ull + (z % (unsigned long long)(FS_TMAX - 1));
     const double nf = (double)n;
-    const double r = 1.0 / nf;
+    const double r = big ? recip_exact(nf) : 1.0 / nf;
     double a;
     const unsigned int mode = (unsigned int)(z >> 60) & 3u;
     // exponent range of the recurrence's operands (and some margin): 2^-100 .. 2^+100
@@ -926,6 +961,113 @@ __global__ void __launch_bounds__(256) k_selftest_div(unsigned long long trials_
     const double want = a / nf;
     const double got = div_by_count(a, nf, r);
     if (__builtin_bit_cast(unsigned long long, want) != __builtin_bit_cast(unsigned long long, got)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+
+// =============================================================================================
+// k_fit_long: the leaves pass A hands over (more than `long_min` points).  The recurrence of one
+// leaf is a sequential chain of its length, so what matters is the latency of a step: ONE WAVE per
+// leaf.  64 keys at a time the lanes prepare, in parallel, everything that does not depend on the
+// chain -- x = f64(key), y = FixDups first-occurrence index, RN(1/count) -- into LDS; then the
+// wave walks the 64 steps with nothing but the recurrence itself in the loop (all lanes compute
+// the same values; the LDS reads are broadcasts).  Same operations in the same order as
+// linear.rs:12-59 on the container of the leaf, so the coefficients are bit-identical.
+// =============================================================================================
+constexpr int FL_TILE = 64;
+
+template <int ROOT, typename K>
+__global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Span sp, RootP r,
+                                                 const unsigned long long* __restrict__ leaf_start,
+                                                 DevState* __restrict__ st, double* __restrict__ params,
+                                                 const unsigned long long* __restrict__ long_idx) {
+  __shared__ double s_x[2][FL_TILE], s_y[2][FL_TILE], s_r[2][FL_TILE];
+  const uint64_t cnt = st->long_count < st->long_cap ? st->long_count : st->long_cap;
+  const int lane = threadIdx.x;
+  for (uint64_t t = blockIdx.x; t < cnt; t += gridDim.x) {
+    bool oob;
+    const uint64_t j = (uint64_t)root_target_f<ROOT, K>(r, (double)(r.L - 1), keys[long_idx[t]], oob);
+    const uint64_t n = sp.n;
+    const uint64_t s0 = leaf_start[j], e0 = leaf_start[j + 1];
+    uint64_t lo, hi;
+    const int ck = leaf_container(j, s0, e0, n, st->split_idx, st->split_target, lo, hi);
+    if (ck != 2) continue;                                   // cannot happen for a handed-over leaf
+    double carry_y = (double)first_occurrence(keys, lo, sp.rd_lo);
+    SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double last_x = 0.0, last_y = 0.0;
+    // prepare(tile at `base`) -> LDS buffer b
+    auto prepare = [&](uint64_t base, int b, K k, K kp) {
+      const uint64_t i = base + lane;
+      const bool valid = i <= hi;
+      const bool newrun = valid && i > lo && !(k == kp);
+      const unsigned long long m = __ballot(newrun);
+      const unsigned long long below = m & ((2ull << lane) - 1ull);     // lane 63: (2<<63) wraps to 0, minus 1 = all ones
+      const double y = below ? (double)(base + (uint64_t)(63 - __builtin_clzll(below))) : carry_y;
+      s_x[b][lane] = KeyTraits<K>::as_float(k);
+      s_y[b][lane] = y;
+      const double nn = (double)(i - lo + 1);
+      if constexpr (UseRecipTable<K>::value) s_r[b][lane] = recip_exact(nn);
+      // the first-occurrence index carried into the next tile: that of this tile's last key
+      if (m) carry_y = (double)(base + (uint64_t)(63 - __builtin_clzll(m)));
+    };
+    auto load = [&](uint64_t base, K& k, K& kp) {
+      uint64_t i = base + lane;
+      i = i <= hi ? i : hi;
+      k = keys[i];
+      kp = keys[i > lo ? i - 1 : i];
+    };
+    K k, kp;
+    load(lo, k, kp);
+    int b = 0;
+    for (uint64_t base = lo; base <= hi; base += FL_TILE, b ^= 1) {
+      prepare(base, b, k, kp);
+      if (base + FL_TILE <= hi) load(base + FL_TILE, k, kp);             // next tile's keys: in flight during the chain
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int steps = (hi - base + 1 < (uint64_t)FL_TILE) ? (int)(hi - base + 1) : FL_TILE;
+      if (steps == FL_TILE) {
+#pragma unroll 8
+        for (int u = 0; u < FL_TILE; u++) {
+          if constexpr (UseRecipTable<K>::value) slr_push_r(sl, s_x[b][u], s_y[b][u], s_r[b][u]);
+          else slr_push(sl, s_x[b][u], s_y[b][u]);
+        }
+      } else {
+        for (int u = 0; u < steps; u++) {
+          if constexpr (UseRecipTable<K>::value) slr_push_r(sl, s_x[b][u], s_y[b][u], s_r[b][u]);
+          else slr_push(sl, s_x[b][u], s_y[b][u]);
+        }
+      }
+      last_x = s_x[b][steps - 1];
+      last_y = s_y[b][steps - 1];
+    }
+    // Q1: the tail duplicate of the FixDups iterator (models/mod.rs:180)
+    if constexpr (UseRecipTable<K>::value) slr_push_r(sl, last_x, last_y, recip_exact(sl.nf + 1.0));
+    else slr_push(sl, last_x, last_y);
+    if (lane == 0) {
+      double* out = params + j * 2;
+      const double cov = sl.c / (sl.nf - 1.0);
+      const double var = sl.m2 / (sl.nf - 1.0);
+      if (!(var >= 0.0)) atomicOr(&st->err_flags, EF_NEG_VARIANCE);       // linear.rs:48
+      if (var == 0.0) { out[0] = sl.my; out[1] = 0.0; }                     // linear.rs:50-53
+      else {
+        const double beta = cov / var;
+        out[0] = sl.my - beta * sl.mx;                                      // no fma: linear.rs:56
+        out[1] = beta;
+      }
+    }
+  }
+}
+
+// recip_exact(n) == 1.0 / n for every integer n in [n_lo, n_hi)
+__global__ void __launch_bounds__(256) k_selftest_recip(unsigned long long n_lo, unsigned long long n_hi,
+                                                        unsigned long long* __restrict__ mismatches) {
+  unsigned long long bad = 0;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long v = n_lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; v < n_hi; v += stride) {
+    const double nf = (double)v;
+    if (__builtin_bit_cast(unsigned long long, 1.0 / nf) != __builtin_bit_cast(unsigned long long, recip_exact(nf))) bad++;
   }
   if (bad) atomicAdd(mismatches, bad);
 }

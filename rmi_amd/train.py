@@ -92,6 +92,7 @@ class TrainedRMI:
     build_time: int = 0            # ns, train/mod.rs:103-118
     device_ns: int = 0
     kernel_ns: tuple = ()
+    long_leaves: int = 0           # leaves handed to the one-lane-per-leaf kernel (skew diagnostic)
     split_idx: int = 0
     split_target: int = 0
     shard_leaf_lo: int = 0          # multi-GPU: this object covers leaves [shard_leaf_lo, +shard_leaves)
@@ -235,7 +236,7 @@ class Trainer:
             model_max_error_idx=int(res.model_max_error_idx), model_max_log2_error=res.model_max_log2_error,
             models=f"{root.name},{MODEL_NAMES[leaf_kind]}", branching_factor=int(num_leaves), root=root,
             leaf_kind=leaf_kind, params_per_leaf=int(res.params_per_leaf),
-            device_ns=int(res.device_ns), kernel_ns=tuple(int(x) for x in res.kernel_ns),
+            device_ns=int(res.device_ns), kernel_ns=tuple(int(x) for x in res.kernel_ns), long_leaves=int(res.long_leaves),
             split_idx=int(res.split_idx), split_target=int(res.split_target),
             shard_leaf_lo=int(res.shard_leaf_lo), shard_leaves=int(res.shard_leaves),
             partial={"max_error": int(res.model_max_error), "max_error_idx": int(res.model_max_error_idx),

@@ -122,6 +122,16 @@ def test_parity_chunk_geometry(trainer_mod, oracle, monkeypatch, threads, min_ch
         _compare(trainer_mod, oracle, keys, "linear", "linear", 50_000)
 
 
+@pytest.mark.parametrize("gen", ["uniform_u64", "books_u64", "dups_u64", "dups_u32"])
+def test_parity_long_leaves(trainer_mod, oracle, gen):
+    """Leaves far longer than pass A's reciprocal table (1024 counts): handed over to k_fit_long."""
+    keys = dg.GENERATORS[gen](400_000)
+    for L in (2, 16, 128, 300):
+        _compare(trainer_mod, oracle, keys, "linear", "linear", L)
+    _compare(trainer_mod, oracle, keys, "linear", "linear_spline", 16)
+    _compare(trainer_mod, oracle, keys, "cubic", "linear", 64)
+
+
 def test_parity_tiny(trainer_mod, oracle):
     keys = np.array([10, 11, 12, 20, 21, 30, 30, 31, 40, 41, 42, 50], dtype=np.uint64)
     for L in (2, 3, 4, 7):
@@ -137,6 +147,18 @@ def test_division_by_count_is_ieee(trainer_mod):
     bad = C.c_uint64(123)
     rc = tr._lib.rmi_hip_selftest_div(tr._h, 4_000_000_000, 7, C.byref(bad))
     assert rc == 0 and bad.value == 0, f"{bad.value} mismatching quotients"
+    tr.close()
+
+
+def test_computed_reciprocal_is_ieee(trainer_mod):
+    """Counts beyond the table: the computed reciprocal == 1.0 / n bit for bit, for every n below
+    2^32 and for ranges up to the 2^40 the division proof covers."""
+    import ctypes as C
+    tr = trainer_mod.Trainer()
+    for lo, hi in [(1, 1 << 32), ((1 << 36) - (1 << 28), (1 << 36) + (1 << 28)), ((1 << 40) - (1 << 30), 1 << 40)]:
+        bad = C.c_uint64(123)
+        rc = tr._lib.rmi_hip_selftest_recip(tr._h, lo, hi, C.byref(bad))
+        assert rc == 0 and bad.value == 0, f"{bad.value} mismatching reciprocals in [{lo}, {hi})"
     tr.close()
 
 

@@ -59,6 +59,16 @@ def test_sharded_tiny_leaves_split_at_cut():
     _run_sharded(train, sharded, dg.dups_u64(300_000), "linear", "linear", 1 << 16, 8)
 
 
+def test_sharded_long_leaves():
+    """Leaves longer than pass A's table (k_fit_long) inside shards, incl. a long leaf at a shard cut."""
+    from rmi_amd import train, sharded
+    for gen in ("dups_u64", "books_u64"):
+        keys = dg.GENERATORS[gen](300_000)
+        _run_sharded(train, sharded, keys, "linear", "linear", 16, 2)
+        _run_sharded(train, sharded, keys, "linear", "linear", 64, 8)
+        _run_sharded(train, sharded, keys, "linear", "linear_spline", 32, 4)
+
+
 def test_sharded_matches_oracle(oracle):
     from rmi_amd import train, sharded
     keys = dg.books_u64(150_000)
