@@ -73,6 +73,15 @@ __device__ __forceinline__ double recip_exact(double nf) {
   return __builtin_fma(e, y, y);
 }
 
+// RN(a / nf) with a dependent chain of two instead of three operations, given the reciprocal of
+// the integer nf < 2^40 as an unevaluated sum r + rl:  r = RN(1/nf),  rl = RN((1 - nf r) r)
+// (1 - nf r is exact in an FMA), so 1/nf = (r + rl)(1 + O(2^-105)).  Then
+//   a r + RN(a rl) = (a / nf)(1 + eta),  |eta| < 2^-103,
+// and the FMA rounds that sum once.  As in div_by_count, a / nf is at least 2^-53 / nf > 2^-93
+// (relative) away from every rounding boundary, so the result is the correctly rounded quotient.
+__device__ __forceinline__ double recip_tail(double nf, double r) { return __builtin_fma(-nf, r, 1.0) * r; }
+__device__ __forceinline__ double div_by_count2(double a, double r, double rl) { return __builtin_fma(a, r, a * rl); }
+
 __device__ __forceinline__ void slr_push_r(SlrState& s, double x, double y, double r) {
   s.nf += 1.0;
   const double dx = x - s.mx;
@@ -960,7 +969,9 @@ __global__ void __launch_bounds__(256) k_selftest_div(unsigned long long trials_
     if ((z >> 7) & 1ull) a = -a;
     const double want = a / nf;
     const double got = div_by_count(a, nf, r);
+    const double got2 = div_by_count2(a, r, recip_tail(nf, r));
     if (__builtin_bit_cast(unsigned long long, want) != __builtin_bit_cast(unsigned long long, got)) bad++;
+    if (__builtin_bit_cast(unsigned long long, want) != __builtin_bit_cast(unsigned long long, got2)) bad++;
   }
   if (bad) atomicAdd(mismatches, bad);
 }
@@ -970,21 +981,36 @@ __global__ void __launch_bounds__(256) k_selftest_div(unsigned long long trials_
 // k_fit_long: the leaves pass A hands over (more than `long_min` points).  The recurrence of one
 // leaf is a sequential chain of its length, so what matters is the latency of a step: ONE WAVE per
 // leaf.  64 keys at a time the lanes prepare, in parallel, everything that does not depend on the
-// chain -- x = f64(key), y = FixDups first-occurrence index, RN(1/count) -- into LDS; then the
-// wave walks the 64 steps with nothing but the recurrence itself in the loop (all lanes compute
-// the same values; the LDS reads are broadcasts).  Same operations in the same order as
-// linear.rs:12-59 on the container of the leaf, so the coefficients are bit-identical.
+// chain -- x = f64(key), y = FixDups first-occurrence index, count and RN(1/count) -- into LDS;
+// then the wave walks the 64 steps with nothing but the recurrence itself in the loop.  An f64
+// instruction costs a wave the same 4 cycles whatever it does in its lanes, so the two mean
+// updates of a step share their instructions: even lanes carry (x, mean_x, m2), odd lanes
+// (y, mean_y, c); the one cross term, c += dx * (y - mean_y'), gets dx from the even neighbour by
+// DPP.  9 vector instructions per step, next to a dependent chain of 4 (sub, mul, fma, add: the
+// quotient by the count comes from a two-term reciprocal, div_by_count2).  Same operations in
+// the same order as linear.rs:12-59 on the container of the leaf: bit-identical coefficients.
+// (f64 keys divide with `/`: every lane runs the whole recurrence.)
 // =============================================================================================
 constexpr int FL_TILE = 64;
+
+__device__ __forceinline__ double dpp_from_even_lane(double v) {           // quad_perm [0,0,2,2]
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned int)b, 0xA0, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned int)(b >> 32), 0xA0, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
 
 template <int ROOT, typename K>
 __global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Span sp, RootP r,
                                                  const unsigned long long* __restrict__ leaf_start,
                                                  DevState* __restrict__ st, double* __restrict__ params,
                                                  const unsigned long long* __restrict__ long_idx) {
-  __shared__ double s_x[2][FL_TILE], s_y[2][FL_TILE], s_r[2][FL_TILE];
+  constexpr bool SPLIT = UseRecipTable<K>::value;          // two-lane form with reciprocal division
+  __shared__ double s_v[2][2][FL_TILE];                    // [buffer][x | y][step]
+  __shared__ double s_rn[2][FL_TILE][2];                   // [buffer][step][1/count: head, tail]
   const uint64_t cnt = st->long_count < st->long_cap ? st->long_count : st->long_cap;
   const int lane = threadIdx.x;
+  const int half = lane & 1;
   for (uint64_t t = blockIdx.x; t < cnt; t += gridDim.x) {
     bool oob;
     const uint64_t j = (uint64_t)root_target_f<ROOT, K>(r, (double)(r.L - 1), keys[long_idx[t]], oob);
@@ -994,22 +1020,24 @@ __global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Spa
     const int ck = leaf_container(j, s0, e0, n, st->split_idx, st->split_target, lo, hi);
     if (ck != 2) continue;                                   // cannot happen for a handed-over leaf
     double carry_y = (double)first_occurrence(keys, lo, sp.rd_lo);
-    SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
-    double last_x = 0.0, last_y = 0.0;
-    // prepare(tile at `base`) -> LDS buffer b
+    SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};                 // !SPLIT: the whole state in every lane
+    double m = 0.0, acc = 0.0;                               // SPLIT: mean_x | mean_y,  m2 | c
     auto prepare = [&](uint64_t base, int b, K k, K kp) {
       const uint64_t i = base + lane;
-      const bool valid = i <= hi;
-      const bool newrun = valid && i > lo && !(k == kp);
-      const unsigned long long m = __ballot(newrun);
-      const unsigned long long below = m & ((2ull << lane) - 1ull);     // lane 63: (2<<63) wraps to 0, minus 1 = all ones
+      const bool newrun = i <= hi && i > lo && !(k == kp);
+      const unsigned long long mk = __ballot(newrun);
+      const unsigned long long below = mk & ((2ull << lane) - 1ull);      // lane 63: 2<<63 wraps to 0, minus 1 = all ones
       const double y = below ? (double)(base + (uint64_t)(63 - __builtin_clzll(below))) : carry_y;
-      s_x[b][lane] = KeyTraits<K>::as_float(k);
-      s_y[b][lane] = y;
-      const double nn = (double)(i - lo + 1);
-      if constexpr (UseRecipTable<K>::value) s_r[b][lane] = recip_exact(nn);
+      s_v[b][0][lane] = KeyTraits<K>::as_float(k);
+      s_v[b][1][lane] = y;
+      if constexpr (SPLIT) {
+        const double nn = (double)(i - lo + 1);
+        const double rr = recip_exact(nn);
+        s_rn[b][lane][0] = rr;
+        s_rn[b][lane][1] = recip_tail(nn, rr);
+      }
       // the first-occurrence index carried into the next tile: that of this tile's last key
-      if (m) carry_y = (double)(base + (uint64_t)(63 - __builtin_clzll(m)));
+      if (mk) carry_y = (double)(base + (uint64_t)(63 - __builtin_clzll(mk)));
     };
     auto load = [&](uint64_t base, K& k, K& kp) {
       uint64_t i = base + lane;
@@ -1017,9 +1045,16 @@ __global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Spa
       k = keys[i];
       kp = keys[i > lo ? i - 1 : i];
     };
+    auto step = [&](double v, double rr, double rl) {      // v: x | y of this step
+      const double d = v - m;
+      m += div_by_count2(d, rr, rl);
+      const double d2 = v - m;                              // x - mean_x' | y - mean_y'
+      acc += dpp_from_even_lane(d) * d2;                    // m2 += dx dx2 | c += dx dy2
+    };
     K k, kp;
     load(lo, k, kp);
     int b = 0;
+    double last_v = 0.0, last_x = 0.0, last_y = 0.0;
     for (uint64_t base = lo; base <= hi; base += FL_TILE, b ^= 1) {
       prepare(base, b, k, kp);
       if (base + FL_TILE <= hi) load(base + FL_TILE, k, kp);             // next tile's keys: in flight during the chain
@@ -1027,24 +1062,32 @@ __global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Spa
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int steps = (hi - base + 1 < (uint64_t)FL_TILE) ? (int)(hi - base + 1) : FL_TILE;
-      if (steps == FL_TILE) {
+      if constexpr (SPLIT) {
+        const double* __restrict__ pv = s_v[b][half];
+        if (steps == FL_TILE) {
 #pragma unroll 8
-        for (int u = 0; u < FL_TILE; u++) {
-          if constexpr (UseRecipTable<K>::value) slr_push_r(sl, s_x[b][u], s_y[b][u], s_r[b][u]);
-          else slr_push(sl, s_x[b][u], s_y[b][u]);
+          for (int u = 0; u < FL_TILE; u++) step(pv[u], s_rn[b][u][0], s_rn[b][u][1]);
+        } else {
+          for (int u = 0; u < steps; u++) step(pv[u], s_rn[b][u][0], s_rn[b][u][1]);
         }
+        last_v = pv[steps - 1];
       } else {
-        for (int u = 0; u < steps; u++) {
-          if constexpr (UseRecipTable<K>::value) slr_push_r(sl, s_x[b][u], s_y[b][u], s_r[b][u]);
-          else slr_push(sl, s_x[b][u], s_y[b][u]);
-        }
+        for (int u = 0; u < steps; u++) slr_push(sl, s_v[b][0][u], s_v[b][1][u]);
+        last_x = s_v[b][0][steps - 1];
+        last_y = s_v[b][1][steps - 1];
       }
-      last_x = s_x[b][steps - 1];
-      last_y = s_y[b][steps - 1];
     }
     // Q1: the tail duplicate of the FixDups iterator (models/mod.rs:180)
-    if constexpr (UseRecipTable<K>::value) slr_push_r(sl, last_x, last_y, recip_exact(sl.nf + 1.0));
-    else slr_push(sl, last_x, last_y);
+    if constexpr (SPLIT) {
+      const double nn = (double)(hi - lo + 2);
+      const double rr = recip_exact(nn);
+      step(last_v, rr, recip_tail(nn, rr));
+      sl.mx = __shfl(m, 0); sl.my = __shfl(m, 1);
+      sl.m2 = __shfl(acc, 0); sl.c = __shfl(acc, 1);
+      sl.nf = nn;
+    } else {
+      slr_push(sl, last_x, last_y);
+    }
     if (lane == 0) {
       double* out = params + j * 2;
       const double cov = sl.c / (sl.nf - 1.0);
