@@ -48,8 +48,10 @@ extern "C" {
 /* src/load.rs:15-19 */
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
 
-/* model registry, train/mod.rs:37-54.  Ids 0-4 are implemented on the device path; the rest
- * of the registry is recognised by name and rejected with RMI_ERR_UNSUPPORTED_MODEL. */
+/* model registry, train/mod.rs:37-54.  Ids 0-4 are implemented on the device path (roots: all
+ * five; leaves: linear, linear_spline, cubic -- radix is top-only in the reference, robust_linear
+ * as a leaf is rejected); the rest of the registry is recognised by name and rejected with
+ * RMI_ERR_UNSUPPORTED_MODEL. */
 enum rmi_hip_model_kind {
   RMI_MODEL_LINEAR = 0,
   RMI_MODEL_LINEAR_SPLINE = 1,

@@ -18,6 +18,7 @@ enum : uint32_t {
   EF_DEGENERATE_SPLIT = 1u << 1,
   EF_ROOT_OOB = 1u << 2,
   EF_NEG_VARIANCE = 1u << 3,
+  EF_CUBIC_DEGENERATE = 1u << 4,   // cubic_spline.rs:46-65: `.unwrap()` on an empty search (distinct keys, one f64)
 };
 
 // Root model parameters + branching factor, passed by value to kernels.

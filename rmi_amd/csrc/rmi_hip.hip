@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rmi_hip.h"
@@ -38,6 +40,9 @@ struct rmi_hip_ctx {
   unsigned long long* d_count = nullptr;        // L
   unsigned char* d_rows = nullptr;              // L*(ppl*8+8)
   unsigned long long* d_tilemin = nullptr;
+  double* d_cube = nullptr;                     // cubic leaves: span, then pow(span, 3.0), per leaf
+  uint64_t cube_cap = 0;
+  std::vector<double> h_cube;
   unsigned long long* d_long = nullptr;         // long-leaf hand-over list (pass A -> k_fit_long)
   uint64_t long_cap = 0;
   DevState* d_state = nullptr;
@@ -197,6 +202,7 @@ static void free_outputs(rmi_hip_ctx* c) {
   (void)hipFree(c->d_leaf_start); (void)hipFree(c->d_params); (void)hipFree(c->d_maxerr); (void)hipFree(c->d_run);
   (void)hipFree(c->d_err); (void)hipFree(c->d_count); (void)hipFree(c->d_rows); (void)hipFree(c->d_tilemin);
   if (c->d_long) { (void)hipFree(c->d_long); c->d_long = nullptr; c->long_cap = 0; }
+  if (c->d_cube) { (void)hipFree(c->d_cube); c->d_cube = nullptr; c->cube_cap = 0; }
   c->d_leaf_start = nullptr; c->d_params = nullptr; c->d_maxerr = nullptr; c->d_run = nullptr;
   c->d_err = nullptr; c->d_count = nullptr; c->d_rows = nullptr; c->d_tilemin = nullptr;
   c->cap_leaves = 0; c->cap_ppl = 0;
@@ -445,6 +451,22 @@ static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   return RMI_OK;
 }
 
+// pow(x, 3.0) with the host's libm, a few threads
+static void host_cubes(double* v, uint64_t n) {
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+  if (n < 65536) nt = 1;
+  auto work = [v](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) v[i] = std::pow(v[i], 3.0); };
+  if (nt == 1) { work(0, n); return; }
+  std::vector<std::thread> th;
+  const uint64_t per = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; t++) {
+    const uint64_t a = (uint64_t)t * per, b = a + per < n ? a + per : n;
+    if (a < b) th.emplace_back(work, a, b);
+  }
+  for (auto& x : th) x.join();
+}
+
 template <int ROOT, int LEAF, typename K>
 static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   hipStream_t s = c->stream;
@@ -530,7 +552,25 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   } else if (!stream_fit) {
     // --- per-leaf fit ---
     const uint64_t blocks = (L_own + 255) / 256;
-    hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params);
+    const double* cube = nullptr;
+    if constexpr (LEAF == K_CUBIC) {
+      // The cube of every container's key range is the platform libm's pow on the host (that is
+      // what the reference's coefficient is defined by); the kernels do everything else.
+      if (c->cube_cap < L_own) {
+        if (c->d_cube) (void)hipFree(c->d_cube);
+        c->d_cube = nullptr; c->cube_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_cube, L_own * 8));
+        c->cube_cap = L_own;
+      }
+      c->h_cube.resize(L_own);
+      hipLaunchKernelGGL((k_cubic_span<K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, c->d_cube - sp.leaf_lo);
+      HIPCHK(c, hipMemcpyAsync(c->h_cube.data(), c->d_cube, L_own * 8, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      host_cubes(c->h_cube.data(), L_own);
+      HIPCHK(c, hipMemcpyAsync(c->d_cube, c->h_cube.data(), L_own * 8, hipMemcpyHostToDevice, s));
+      cube = c->d_cube - sp.leaf_lo;
+    }
+    hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, cube);
   } else {
     // --- leaves handed over by pass A (more than long_min points): one wave each ---
     const uint64_t blocks = c->long_cap < 2048 ? c->long_cap : 2048;   // ~2 waves per SIMD saturate its f64 issue
@@ -580,6 +620,7 @@ static int dispatch_leaf(rmi_hip_ctx* c, const RootP& rp, int leaf_kind, uint64_
   switch (leaf_kind) {
     case RMI_MODEL_LINEAR: return launch_pipeline<ROOT, K_LINEAR, K>(c, rp, L);
     case RMI_MODEL_LINEAR_SPLINE: return launch_pipeline<ROOT, K_LINEAR_SPLINE, K>(c, rp, L);
+    case RMI_MODEL_CUBIC: return launch_pipeline<ROOT, K_CUBIC, K>(c, rp, L);
     default: return RMI_ERR_UNSUPPORTED_MODEL;
   }
 }
@@ -605,7 +646,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (must_be_top(leaf_kind)) return RMI_ERR_RESTRICTION;
   if (root->kind > RMI_MODEL_ROBUST_LINEAR || leaf_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
   // robust_linear as a leaf trims 0.01% tails of each container (linear.rs:247-252); not on the device path yet
-  if (leaf_kind == RMI_MODEL_ROBUST_LINEAR || leaf_kind == RMI_MODEL_CUBIC) return RMI_ERR_UNSUPPORTED_MODEL;
+  if (leaf_kind == RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
   HIPCHK(c, hipSetDevice(c->device));
   const int ppl = leaf_kind == RMI_MODEL_CUBIC ? 4 : 2;
   uint64_t L_own = num_leaves;
@@ -636,6 +677,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
     else if (st.err_flags & EF_ROOT_OOB) rc = RMI_ERR_ROOT_OUT_OF_BOUNDS;
     else if (st.err_flags & EF_DEGENERATE_SPLIT) rc = RMI_ERR_DEGENERATE_SPLIT;
     else if (st.err_flags & EF_NEG_VARIANCE) rc = RMI_ERR_NEGATIVE_VARIANCE;
+    else if (st.err_flags & EF_CUBIC_DEGENERATE) rc = RMI_ERR_CUBIC_DEGENERATE;
     set_err(c, "%s", rmi_hip_strerror(rc));
     return rc;
   }

@@ -243,7 +243,8 @@ __device__ __forceinline__ int leaf_container(uint64_t j, uint64_t s, uint64_t e
 template <int LEAF, typename K>
 __device__ __forceinline__ void fit_one_leaf(uint64_t j, const K* __restrict__ keys, const Span& sp,
                                              const unsigned long long* __restrict__ leaf_start,
-                                             DevState* __restrict__ st, double* __restrict__ params) {
+                                             DevState* __restrict__ st, double* __restrict__ params,
+                                             const double* __restrict__ cube = nullptr) {
   const uint64_t n = sp.n;
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
@@ -311,17 +312,95 @@ __device__ __forceinline__ void fit_one_leaf(uint64_t j, const K* __restrict__ k
     const double slope = (y0 - y1) / (x0 - x1);
     const double intercept = y0 - slope * x0;                        // plain mul+sub
     out[0] = intercept; out[1] = slope;
+  } else if constexpr (LEAF == K_CUBIC) {
+    // CubicSplineModel::new (cubic_spline.rs:108-136) on the container [lo, hi]; the points a
+    // container stores carry FixDups first-occurrence offsets, for get() as well as for iter().
+    // cube[j] = pow(xmax - xmin, 3.0) comes from the host: the reference's value IS the platform
+    // libm's (`powf(3.0)`, cubic_spline.rs:76-93), see k_cubic_span.
+    const K k0 = keys[lo], kl = keys[hi];
+    const double y0 = (double)first_occurrence(keys, lo, sp.rd_lo);
+    if (k0 == kl) { out[0] = 0.0; out[1] = 0.0; out[2] = 0.0; out[3] = y0; return; }   // :28-36 (sorted: all equal)
+    const double xmin = KeyTraits<K>::as_float(k0), ymin = y0;
+    const double xmax = KeyTraits<K>::as_float(kl), ymax = (double)first_occurrence(keys, hi, sp.rd_lo);
+    const double xr = xmax - xmin, yr = ymax - ymin;
+    double m1, m2;
+    {  // :46-54 first item of iter() whose scaled x is > 0
+      bool found = false;
+      uint64_t yn = 0; double xn = 0.0;
+      uint64_t first = (uint64_t)y0;
+      for (uint64_t i = lo; i <= hi; i++) {
+        const K k = keys[i];
+        if (i > lo && !(k == keys[i - 1])) first = i;
+        const double x = KeyTraits<K>::as_float(k);
+        if ((x - xmin) / xr > 0.0) { xn = x; yn = first; found = true; break; }
+      }
+      if (!found) { atomicOr(&st->err_flags, EF_CUBIC_DEGENERATE); out[0] = out[1] = out[2] = out[3] = 0.0; return; }
+      const double sxn = (xn - xmin) / xr, syn = ((double)yn - ymin) / yr;
+      m1 = (syn - 0.0) / (sxn - 0.0);
+    }
+    {  // :56-65 last index (get) whose scaled x is < 1
+      bool found = false;
+      uint64_t ip = 0; double xp = 0.0;
+      for (uint64_t i = hi + 1; i-- > lo;) {
+        const double x = KeyTraits<K>::as_float(keys[i]);
+        if ((x - xmin) / xr < 1.0) { xp = x; ip = i; found = true; break; }
+      }
+      if (!found) { atomicOr(&st->err_flags, EF_CUBIC_DEGENERATE); out[0] = out[1] = out[2] = out[3] = 0.0; return; }
+      const double yp = (double)first_occurrence(keys, ip, sp.rd_lo);
+      const double sxp = (xp - xmin) / xr, syp = (yp - ymin) / yr;
+      m2 = (1.0 - syp) / (1.0 - sxp);
+    }
+    if (m1 * m1 + m2 * m2 > 9.0) {                                     // :68-72
+      const double tau = 3.0 / sqrt(m1 * m1 + m2 * m2);
+      m1 *= tau; m2 *= tau;
+    }
+    const double den = cube[j];
+    double a = (m1 + m2 - 2.0) / den;                                                        // :76
+    double b = -(xmax * (2.0 * m1 + m2 - 3.0) + xmin * (m1 + 2.0 * m2 - 3.0)) / den;         // :80-81
+    double c = (m1 * (xmax * xmax) + m2 * (xmin * xmin) + xmax * xmin * (2.0 * m1 + 2.0 * m2 - 6.0)) / den;   // :86-88
+    double d = -xmin * (m1 * (xmax * xmax) + xmax * xmin * (m2 - 3.0) + (xmin * xmin)) / den;   // :92-93
+    a *= yr; b *= yr; c *= yr; d *= yr; d += ymin;                                            // :95-99
+    // the line through the end points (linear_spline.rs:13-35) and the comparison pass over iter()
+    const double slope = (ymin - ymax) / (xmin - xmax);
+    const double icept = ymin - slope * xmin;
+    double our_error = 0.0, lin_error = 0.0;
+    uint64_t y = (uint64_t)y0;
+    double x = 0.0, yf = 0.0;
+    for (uint64_t i = lo; i <= hi; i++) {
+      const K k = keys[i];
+      if (i > lo && !(k == keys[i - 1])) y = i;
+      x = KeyTraits<K>::as_float(k);
+      yf = (double)y;
+      our_error += fabs(__builtin_fma(__builtin_fma(__builtin_fma(a, x, b), x, c), x, d) - yf);
+      lin_error += fabs(__builtin_fma(slope, x, icept) - yf);
+    }
+    our_error += fabs(__builtin_fma(__builtin_fma(__builtin_fma(a, x, b), x, c), x, d) - yf);   // Q1: tail duplicate
+    lin_error += fabs(__builtin_fma(slope, x, icept) - yf);
+    if (lin_error < our_error) { out[0] = 0.0; out[1] = 0.0; out[2] = slope; out[3] = icept; }
+    else { out[0] = a; out[1] = b; out[2] = c; out[3] = d; }
   }
+}
+
+// Cubic leaves: xmax - xmin of every container, for the host's pow(., 3.0) (0 where no cube is needed).
+template <typename K>
+__global__ void __launch_bounds__(256) k_cubic_span(const K* __restrict__ keys, Span sp,
+                                                    const unsigned long long* __restrict__ leaf_start,
+                                                    const DevState* __restrict__ st, double* __restrict__ span) {
+  const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= sp.leaf_hi) return;
+  uint64_t lo, hi;
+  const int ck = leaf_container(j, leaf_start[j], leaf_start[j + 1], sp.n, st->split_idx, st->split_target, lo, hi);
+  span[j] = (ck == 2) ? KeyTraits<K>::as_float(keys[hi]) - KeyTraits<K>::as_float(keys[lo]) : 0.0;
 }
 
 template <int LEAF, typename K>
 __global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, Span sp,
                                                   const unsigned long long* __restrict__ leaf_start,
                                                   DevState* __restrict__ st,
-                                                  double* __restrict__ params) {
+                                                  double* __restrict__ params, const double* __restrict__ cube) {
   const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= sp.leaf_hi) return;
-  fit_one_leaf<LEAF, K>(j, keys, sp, leaf_start, st, params);
+  fit_one_leaf<LEAF, K>(j, keys, sp, leaf_start, st, params, cube);
 }
 
 

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("gen,spec,L", [("books_u64", "linear,linear", 4096), ("dups_u32", "radix,linear_spline", 1024),
-                                        ("uniform_u64", "cubic,linear", 2048)])
+                                        ("uniform_u64", "cubic,linear", 2048), ("dups_u64", "linear,cubic", 1024)])
 def test_cli_end_to_end(tmp_path, oracle, gen, spec, L):
     from tests.test_codegen import MAIN_CPP
     keys = dg.GENERATORS[gen](150_000)
@@ -30,9 +30,10 @@ def test_cli_end_to_end(tmp_path, oracle, gen, spec, L):
     # parameter file == oracle rows, byte for byte
     root, leaf = spec.split(",")
     o = oracle.train_two_layer(root, leaf, keys, L)
-    raw = np.fromfile(str(tmp_path / "rmi_data" / "rmi_L1_PARAMETERS"), dtype="<u8").reshape(L, 3)
-    assert np.array_equal(raw[:, :2], o.leaf_params.view(np.uint64))
-    assert np.array_equal(raw[:, 2], o.leaf_err)
+    ppl = o.leaf_params.shape[1]
+    raw = np.fromfile(str(tmp_path / "rmi_data" / "rmi_L1_PARAMETERS"), dtype="<u8").reshape(L, ppl + 1)
+    assert np.array_equal(raw[:, :ppl], o.leaf_params.view(np.uint64))
+    assert np.array_equal(raw[:, ppl], o.leaf_err)
     assert "const uint64_t BUILD_TIME_NS = 0;" in (tmp_path / "rmi.h").read_text()
     if shutil.which("g++"):
         kt = "uint64_t" if suffix == "uint64" else "uint32_t"

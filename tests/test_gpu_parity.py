@@ -96,6 +96,23 @@ def test_parity_f64_keys(trainer_mod, oracle, root, leaf, L):
     _compare(trainer_mod, oracle, keys, root, leaf, L)
 
 
+@pytest.mark.parametrize("gen", ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "dups_u32"])
+@pytest.mark.parametrize("root,L", [("linear", 4096), ("cubic", 1024), ("radix", 8192), ("linear", 40_000), ("linear", 8)])
+def test_parity_cubic_leaves(trainer_mod, oracle, gen, root, L):
+    """leaf = cubic (cubic_spline.rs:108-136 on every container; SURVEY 8a row a8''): 4 coefficients per
+    leaf, rows of 40 bytes, the cube of the key range from the host's libm like the reference's."""
+    keys = dg.GENERATORS[gen](200_000)
+    g, o = _compare(trainer_mod, oracle, keys, root, "cubic", L)
+    if g is not None:
+        assert g.params_per_leaf == 4 and g.rows.size == L * 40
+
+
+def test_parity_cubic_leaves_f64(trainer_mod, oracle):
+    keys = dg.uniform_f64(100_000)
+    _compare(trainer_mod, oracle, keys, "linear", "cubic", 2048)
+    _compare(trainer_mod, oracle, keys, "cubic", "cubic", 256)
+
+
 def test_parity_config1(trainer_mod, oracle):
     """BASELINE config 1: linear,linear 1024 on 1M synthetic sorted uint64."""
     keys = dg.uniform_u64(1_000_000)

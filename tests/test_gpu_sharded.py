@@ -69,6 +69,13 @@ def test_sharded_long_leaves():
         _run_sharded(train, sharded, keys, "linear", "linear_spline", 32, 4)
 
 
+def test_sharded_cubic_leaves():
+    from rmi_amd import train, sharded
+    keys = dg.dups_u64(200_000)
+    _run_sharded(train, sharded, keys, "linear", "cubic", 4096, 4)
+    _run_sharded(train, sharded, keys, "cubic", "cubic", 512, 2)
+
+
 def test_sharded_matches_oracle(oracle):
     from rmi_amd import train, sharded
     keys = dg.books_u64(150_000)
