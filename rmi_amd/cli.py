@@ -4,19 +4,21 @@
 
 Same positional arguments and the flags that concern the single-train and param-grid modes:
 --no-code, --no-errors, -d/--data-path, -t/--threads (accepted, unused: the work runs on the GPU),
---zero-build-time, --param-grid, --disable-parallel-training.  The data type comes from a substring
-of the input path (uint64 / uint32 / f64, src/main.rs:122-132).  --optimize, --max-size and
---bounded belong to components outside this round's scope and are rejected.
+--zero-build-time, --param-grid, --disable-parallel-training, --optimize <file> (Pareto search,
+src/main.rs:134-163) and --max-size <bytes> (train_for_size, :276-294).  The data type comes from a
+substring of the input path (uint64 / uint32 / f64, src/main.rs:122-132).  --bounded (cache-fix) is
+outside this build's scope and is rejected.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import os
 import sys
 
 import numpy as np
 
-from . import codegen, datagen, train
+from . import codegen, datagen, optimizer, train
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -28,12 +30,12 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--no-code", action="store_true", help="Skip code generation")
     ap.add_argument("--no-errors", action="store_true", help="Do not save last-level errors, and modify the RMI function signature")
     ap.add_argument("-d", "--data-path", default="rmi_data", help="exports parameters to files stored in this directory")
-    ap.add_argument("-t", "--threads", type=int, default=4, help="accepted for compatibility")
+    ap.add_argument("-t", "--threads", type=int, default=4, help="host threads for the optimizer's root fits, default = 4")
     ap.add_argument("--zero-build-time", action="store_true", help="zero out the model build time field")
     ap.add_argument("--param-grid", help="train the RMIs specified in the JSON file and report their errors")
     ap.add_argument("--disable-parallel-training", action="store_true", help="accepted for compatibility")
-    ap.add_argument("--optimize", help="(not in this build)")
-    ap.add_argument("--max-size", help="(not in this build)")
+    ap.add_argument("--optimize", metavar="file", help="Search for Pareto efficient RMI configurations. Specify the name of the output file.")
+    ap.add_argument("--max-size", metavar="BYTES", type=int, help="uses the optimizer to find an RMI with a size less than specified")
     ap.add_argument("--bounded", help="(not in this build)")
     ap.add_argument("--device", type=int, default=0)
     return ap
@@ -52,10 +54,9 @@ def _stats(rmi: train.TrainedRMI, n: int) -> dict:
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
-    for flag in ("optimize", "max_size", "bounded"):
-        if getattr(args, flag):
-            print(f"--{flag.replace('_', '-')} is outside this build's scope (see DESIGN.md)", file=sys.stderr)
-            return 2
+    if args.bounded:
+        print("--bounded is outside this build's scope (see DESIGN.md)", file=sys.stderr)
+        return 2
     if args.namespace and args.param_grid:
         print("Can only specify one of namespace or param-grid", file=sys.stderr)      # src/main.rs:116-118
         return 2
@@ -64,6 +65,16 @@ def main(argv=None) -> int:
     tr = train.Trainer(np.ascontiguousarray(keys), device=args.device)
     n = len(keys)
     try:
+        if args.optimize:                                                              # src/main.rs:134-163
+            if optimizer.skipped_models():
+                print("not on the device path, left out of the search: " + ", ".join(optimizer.skipped_models()), file=sys.stderr)
+            results = optimizer.find_pareto_efficient_configs(tr, 10, threads=args.threads)
+            optimizer.display_table(results)
+            prefix = args.namespace or os.path.basename(args.input) or "rmi"
+            specs = [r.to_grid_spec(f"{prefix}_{i}") for i, r in enumerate(results)]
+            with open(args.optimize, "w") as f:
+                json.dump({"configs": specs}, f)
+            return 0
         if args.param_grid:                                                            # src/main.rs:171-261
             grid = json.load(open(args.param_grid))
             results = []
@@ -81,10 +92,15 @@ def main(argv=None) -> int:
         if not args.namespace:
             print("Must specify either a name space or a parameter grid.", file=sys.stderr)
             return 2
-        if not args.models or args.branching_factor is None:
+        if args.max_size is not None:                                                  # src/main.rs:286-292
+            print(f"Constructing RMI with size less than {args.max_size}")
+            rmi = optimizer.train_for_size(tr, args.max_size, threads=args.threads)
+            print(f"Found RMI config {rmi.models} {rmi.branching_factor}")
+        elif not args.models or args.branching_factor is None:
             print("models and branching factor are required", file=sys.stderr)
             return 2
-        rmi = tr.train(args.models, args.branching_factor)
+        else:
+            rmi = tr.train(args.models, args.branching_factor)
         print(f"Model build time: {rmi.build_time // 1_000_000} ms (device {rmi.device_ns / 1e6:.3f} ms)")
         print(f"Average model error: {rmi.model_avg_error} ({rmi.model_avg_error / n * 100.0}%)")
         print(f"Average model L2 error: {rmi.model_avg_l2_error}")

@@ -571,6 +571,12 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       cube = c->d_cube - sp.leaf_lo;
     }
     hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, cube);
+    if constexpr (LEAF == K_CUBIC) {
+      if (n_it + 2 > (uint64_t)CUBIC_LONG) {                 // long containers are possible
+        const uint64_t wb = L_own < 4096 ? L_own : 4096;
+        hipLaunchKernelGGL((k_fit_cubic_long<K>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, cube);
+      }
+    }
   } else {
     // --- leaves handed over by pass A (more than long_min points): one wave each ---
     const uint64_t blocks = c->long_cap < 2048 ? c->long_cap : 2048;   // ~2 waves per SIMD saturate its f64 issue

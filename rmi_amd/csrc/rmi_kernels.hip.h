@@ -237,6 +237,81 @@ __device__ __forceinline__ int leaf_container(uint64_t j, uint64_t s, uint64_t e
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cubic leaves (CubicSplineModel::new, cubic_spline.rs:108-136, on the container [lo, hi]).  The
+// points a container stores carry FixDups first-occurrence offsets, for get() as well as for
+// iter().  cube = pow(xmax - xmin, 3.0) comes from the host: the reference's value IS the
+// platform libm's (`powf(3.0)`, cubic_spline.rs:76-93), see k_cubic_span.
+// ---------------------------------------------------------------------------------------------
+constexpr int CUBIC_LONG = 1024;      // containers longer than this: one wave per leaf (k_fit_cubic_long)
+
+struct CubicFit {
+  double a, b, c, d;                  // cubic()
+  double slope, icept;                // the line through the end points (linear_spline.rs:13-35)
+  double ymin;
+  __device__ __forceinline__ double eval(double x) const {
+    return __builtin_fma(__builtin_fma(__builtin_fma(a, x, b), x, c), x, d);
+  }
+  __device__ __forceinline__ void store(double* out, bool line_wins) const {      // :133-135
+    if (line_wins) { out[0] = 0.0; out[1] = 0.0; out[2] = slope; out[3] = icept; }
+    else { out[0] = a; out[1] = b; out[2] = c; out[3] = d; }
+  }
+};
+
+// Everything before the comparison pass.  Returns false when the model is already decided (written
+// to `out`): all keys equal, or the reference's `.unwrap()` on an empty search (error flag).
+template <typename K>
+__device__ __forceinline__ bool cubic_prolog(const K* __restrict__ keys, uint64_t lo, uint64_t hi, const Span& sp,
+                                             DevState* __restrict__ st, double den, double* __restrict__ out, CubicFit& cf) {
+  const K k0 = keys[lo], kl = keys[hi];
+  const double y0 = (double)first_occurrence(keys, lo, sp.rd_lo);
+  if (k0 == kl) { out[0] = 0.0; out[1] = 0.0; out[2] = 0.0; out[3] = y0; return false; }   // :28-36 (sorted: all equal)
+  const double xmin = KeyTraits<K>::as_float(k0), ymin = y0;
+  const double xmax = KeyTraits<K>::as_float(kl), ymax = (double)first_occurrence(keys, hi, sp.rd_lo);
+  const double xr = xmax - xmin, yr = ymax - ymin;
+  double m1, m2;
+  {  // :46-54 first item of iter() whose scaled x is > 0
+    bool found = false;
+    uint64_t yn = 0; double xn = 0.0;
+    uint64_t first = (uint64_t)y0;
+    for (uint64_t i = lo; i <= hi; i++) {
+      const K k = keys[i];
+      if (i > lo && !(k == keys[i - 1])) first = i;
+      const double x = KeyTraits<K>::as_float(k);
+      if ((x - xmin) / xr > 0.0) { xn = x; yn = first; found = true; break; }
+    }
+    if (!found) { atomicOr(&st->err_flags, EF_CUBIC_DEGENERATE); out[0] = out[1] = out[2] = out[3] = 0.0; return false; }
+    const double sxn = (xn - xmin) / xr, syn = ((double)yn - ymin) / yr;
+    m1 = (syn - 0.0) / (sxn - 0.0);
+  }
+  {  // :56-65 last index (get) whose scaled x is < 1
+    bool found = false;
+    uint64_t ip = 0; double xp = 0.0;
+    for (uint64_t i = hi + 1; i-- > lo;) {
+      const double x = KeyTraits<K>::as_float(keys[i]);
+      if ((x - xmin) / xr < 1.0) { xp = x; ip = i; found = true; break; }
+    }
+    if (!found) { atomicOr(&st->err_flags, EF_CUBIC_DEGENERATE); out[0] = out[1] = out[2] = out[3] = 0.0; return false; }
+    const double yp = (double)first_occurrence(keys, ip, sp.rd_lo);
+    const double sxp = (xp - xmin) / xr, syp = (yp - ymin) / yr;
+    m2 = (1.0 - syp) / (1.0 - sxp);
+  }
+  if (m1 * m1 + m2 * m2 > 9.0) {                                     // :68-72
+    const double tau = 3.0 / sqrt(m1 * m1 + m2 * m2);
+    m1 *= tau; m2 *= tau;
+  }
+  double a = (m1 + m2 - 2.0) / den;                                                        // :76
+  double b = -(xmax * (2.0 * m1 + m2 - 3.0) + xmin * (m1 + 2.0 * m2 - 3.0)) / den;         // :80-81
+  double c = (m1 * (xmax * xmax) + m2 * (xmin * xmin) + xmax * xmin * (2.0 * m1 + 2.0 * m2 - 6.0)) / den;   // :86-88
+  double d = -xmin * (m1 * (xmax * xmax) + xmax * xmin * (m2 - 3.0) + (xmin * xmin)) / den;   // :92-93
+  a *= yr; b *= yr; c *= yr; d *= yr; d += ymin;                                            // :95-99
+  cf.a = a; cf.b = b; cf.c = c; cf.d = d;
+  cf.slope = (ymin - ymax) / (xmin - xmax);
+  cf.icept = ymin - cf.slope * xmin;
+  cf.ymin = ymin;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fit_leaf: one lane per leaf, reference order.  (Exact mode: the SLR recurrence is order
 // dependent, so each leaf is a sequential chain; parallelism is across leaves.)
 // ---------------------------------------------------------------------------------------------
@@ -313,71 +388,24 @@ __device__ __forceinline__ void fit_one_leaf(uint64_t j, const K* __restrict__ k
     const double intercept = y0 - slope * x0;                        // plain mul+sub
     out[0] = intercept; out[1] = slope;
   } else if constexpr (LEAF == K_CUBIC) {
-    // CubicSplineModel::new (cubic_spline.rs:108-136) on the container [lo, hi]; the points a
-    // container stores carry FixDups first-occurrence offsets, for get() as well as for iter().
-    // cube[j] = pow(xmax - xmin, 3.0) comes from the host: the reference's value IS the platform
-    // libm's (`powf(3.0)`, cubic_spline.rs:76-93), see k_cubic_span.
-    const K k0 = keys[lo], kl = keys[hi];
-    const double y0 = (double)first_occurrence(keys, lo, sp.rd_lo);
-    if (k0 == kl) { out[0] = 0.0; out[1] = 0.0; out[2] = 0.0; out[3] = y0; return; }   // :28-36 (sorted: all equal)
-    const double xmin = KeyTraits<K>::as_float(k0), ymin = y0;
-    const double xmax = KeyTraits<K>::as_float(kl), ymax = (double)first_occurrence(keys, hi, sp.rd_lo);
-    const double xr = xmax - xmin, yr = ymax - ymin;
-    double m1, m2;
-    {  // :46-54 first item of iter() whose scaled x is > 0
-      bool found = false;
-      uint64_t yn = 0; double xn = 0.0;
-      uint64_t first = (uint64_t)y0;
-      for (uint64_t i = lo; i <= hi; i++) {
-        const K k = keys[i];
-        if (i > lo && !(k == keys[i - 1])) first = i;
-        const double x = KeyTraits<K>::as_float(k);
-        if ((x - xmin) / xr > 0.0) { xn = x; yn = first; found = true; break; }
-      }
-      if (!found) { atomicOr(&st->err_flags, EF_CUBIC_DEGENERATE); out[0] = out[1] = out[2] = out[3] = 0.0; return; }
-      const double sxn = (xn - xmin) / xr, syn = ((double)yn - ymin) / yr;
-      m1 = (syn - 0.0) / (sxn - 0.0);
-    }
-    {  // :56-65 last index (get) whose scaled x is < 1
-      bool found = false;
-      uint64_t ip = 0; double xp = 0.0;
-      for (uint64_t i = hi + 1; i-- > lo;) {
-        const double x = KeyTraits<K>::as_float(keys[i]);
-        if ((x - xmin) / xr < 1.0) { xp = x; ip = i; found = true; break; }
-      }
-      if (!found) { atomicOr(&st->err_flags, EF_CUBIC_DEGENERATE); out[0] = out[1] = out[2] = out[3] = 0.0; return; }
-      const double yp = (double)first_occurrence(keys, ip, sp.rd_lo);
-      const double sxp = (xp - xmin) / xr, syp = (yp - ymin) / yr;
-      m2 = (1.0 - syp) / (1.0 - sxp);
-    }
-    if (m1 * m1 + m2 * m2 > 9.0) {                                     // :68-72
-      const double tau = 3.0 / sqrt(m1 * m1 + m2 * m2);
-      m1 *= tau; m2 *= tau;
-    }
-    const double den = cube[j];
-    double a = (m1 + m2 - 2.0) / den;                                                        // :76
-    double b = -(xmax * (2.0 * m1 + m2 - 3.0) + xmin * (m1 + 2.0 * m2 - 3.0)) / den;         // :80-81
-    double c = (m1 * (xmax * xmax) + m2 * (xmin * xmin) + xmax * xmin * (2.0 * m1 + 2.0 * m2 - 6.0)) / den;   // :86-88
-    double d = -xmin * (m1 * (xmax * xmax) + xmax * xmin * (m2 - 3.0) + (xmin * xmin)) / den;   // :92-93
-    a *= yr; b *= yr; c *= yr; d *= yr; d += ymin;                                            // :95-99
-    // the line through the end points (linear_spline.rs:13-35) and the comparison pass over iter()
-    const double slope = (ymin - ymax) / (xmin - xmax);
-    const double icept = ymin - slope * xmin;
+    if (hi - lo + 1 > (uint64_t)CUBIC_LONG) return;          // k_fit_cubic_long's
+    CubicFit cf;
+    if (!cubic_prolog<K>(keys, lo, hi, sp, st, cube[j], out, cf)) return;
+    // the comparison pass over iter() (cubic_spline.rs:117-131), in iteration order
     double our_error = 0.0, lin_error = 0.0;
-    uint64_t y = (uint64_t)y0;
+    uint64_t y = (uint64_t)cf.ymin;
     double x = 0.0, yf = 0.0;
     for (uint64_t i = lo; i <= hi; i++) {
       const K k = keys[i];
       if (i > lo && !(k == keys[i - 1])) y = i;
       x = KeyTraits<K>::as_float(k);
       yf = (double)y;
-      our_error += fabs(__builtin_fma(__builtin_fma(__builtin_fma(a, x, b), x, c), x, d) - yf);
-      lin_error += fabs(__builtin_fma(slope, x, icept) - yf);
+      our_error += fabs(cf.eval(x) - yf);
+      lin_error += fabs(__builtin_fma(cf.slope, x, cf.icept) - yf);
     }
-    our_error += fabs(__builtin_fma(__builtin_fma(__builtin_fma(a, x, b), x, c), x, d) - yf);   // Q1: tail duplicate
-    lin_error += fabs(__builtin_fma(slope, x, icept) - yf);
-    if (lin_error < our_error) { out[0] = 0.0; out[1] = 0.0; out[2] = slope; out[3] = icept; }
-    else { out[0] = a; out[1] = b; out[2] = c; out[3] = d; }
+    our_error += fabs(cf.eval(x) - yf);                        // Q1: tail duplicate
+    lin_error += fabs(__builtin_fma(cf.slope, x, cf.icept) - yf);
+    cf.store(out, lin_error < our_error);
   }
 }
 
@@ -391,6 +419,61 @@ __global__ void __launch_bounds__(256) k_cubic_span(const K* __restrict__ keys, 
   uint64_t lo, hi;
   const int ck = leaf_container(j, leaf_start[j], leaf_start[j + 1], sp.n, st->split_idx, st->split_target, lo, hi);
   span[j] = (ck == 2) ? KeyTraits<K>::as_float(keys[hi]) - KeyTraits<K>::as_float(keys[lo]) : 0.0;
+}
+
+// Long cubic leaves, one wave per leaf: the two error sums of the comparison pass are sequential
+// (floating-point sums in iteration order), but their terms are not -- 64 keys at a time the lanes
+// compute |cubic(x) - y| and |line(x) - y| (y: first-occurrence index by ballot) into LDS, then
+// every lane adds the 64 pairs in order (broadcast reads).
+template <typename K>
+__global__ void __launch_bounds__(64) k_fit_cubic_long(const K* __restrict__ keys, Span sp,
+                                                       const unsigned long long* __restrict__ leaf_start,
+                                                       DevState* __restrict__ st, double* __restrict__ params,
+                                                       const double* __restrict__ cube) {
+  __shared__ double s_e[2][64][2];
+  const int lane = threadIdx.x;
+  for (uint64_t j = sp.leaf_lo + blockIdx.x; j < sp.leaf_hi; j += gridDim.x) {
+    uint64_t lo, hi;
+    const int ck = leaf_container(j, leaf_start[j], leaf_start[j + 1], sp.n, st->split_idx, st->split_target, lo, hi);
+    if (ck != 2 || hi - lo + 1 <= (uint64_t)CUBIC_LONG) continue;
+    double* out = params + j * 4;
+    CubicFit cf;
+    double scratch[4];
+    if (!cubic_prolog<K>(keys, lo, hi, sp, st, cube[j], lane == 0 ? out : scratch, cf)) continue;
+    double our_error = 0.0, lin_error = 0.0;
+    double carry_y = cf.ymin, last_c = 0.0, last_l = 0.0;
+    int b = 0;
+    for (uint64_t base = lo; base <= hi; base += 64, b ^= 1) {
+      uint64_t i = base + lane;
+      const bool valid = i <= hi;
+      i = valid ? i : hi;
+      const K k = keys[i];
+      const K kp = keys[i > lo ? i - 1 : i];
+      const bool newrun = valid && i > lo && !(k == kp);
+      const unsigned long long mk = __ballot(newrun);
+      const unsigned long long below = mk & ((2ull << lane) - 1ull);
+      const double y = below ? (double)(base + (uint64_t)(63 - __builtin_clzll(below))) : carry_y;
+      if (mk) carry_y = (double)(base + (uint64_t)(63 - __builtin_clzll(mk)));
+      const double x = KeyTraits<K>::as_float(k);
+      s_e[b][lane][0] = fabs(cf.eval(x) - y);
+      s_e[b][lane][1] = fabs(__builtin_fma(cf.slope, x, cf.icept) - y);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int steps = (hi - base + 1 < 64ull) ? (int)(hi - base + 1) : 64;
+      if (steps == 64) {
+#pragma unroll 16
+        for (int u = 0; u < 64; u++) { our_error += s_e[b][u][0]; lin_error += s_e[b][u][1]; }
+      } else {
+        for (int u = 0; u < steps; u++) { our_error += s_e[b][u][0]; lin_error += s_e[b][u][1]; }
+      }
+      last_c = s_e[b][steps - 1][0];
+      last_l = s_e[b][steps - 1][1];
+    }
+    our_error += last_c;                                       // Q1: tail duplicate
+    lin_error += last_l;
+    if (lane == 0) cf.store(out, lin_error < our_error);
+  }
 }
 
 template <int LEAF, typename K>

@@ -58,3 +58,38 @@ def test_cli_param_grid(tmp_path):
     res = json.loads((tmp_path / "grid.json_results").read_text())
     assert len(res) == 2 and res[0]["layers"] == "linear,linear" and res[1]["namespace"] == "g2"
     assert (tmp_path / "g2.cpp").exists() and (tmp_path / "rmi_data" / "g2_L1_PARAMETERS").exists()
+
+
+def test_optimizer_fast_profile(tmp_path, oracle, monkeypatch):
+    """--optimize (src/main.rs:134-163) with the `fast` profile, whose model lists are entirely on the
+    device path: every configuration on the returned front carries the oracle's statistics."""
+    import json
+    from rmi_amd import codegen, optimizer, train
+    monkeypatch.setenv("RMI_OPTIMIZER_PROFILE", "fast")
+    keys = dg.books_u64(60_000)
+    tr = train.Trainer(keys)
+    seen = []
+    front = optimizer.find_pareto_efficient_configs(tr, 10, threads=4, progress=lambda s, r: seen.append(s))
+    tr.close()
+    assert 2 <= len(front) <= 10 and len(seen) > len(optimizer.first_phase_configs())
+    assert front == sorted(front, key=lambda r: r.average_log2_error)
+    assert not any(a.dominated_by(b) for a in front for b in front)
+    for st in front[:4]:
+        root, leaf = st.models.split(",")
+        o = oracle.train_two_layer(root, leaf, keys, st.branching_factor)
+        assert abs(o.model_avg_log2_error - st.average_log2_error) <= 1e-12 * max(1.0, abs(st.average_log2_error))
+        assert st.size == codegen.rmi_size(train.parse_spec(st.models)[0], train.parse_spec(st.models)[1], st.branching_factor, True)
+    # the command line writes the grid spec the reference's --param-grid mode reads back
+    kfile = str(tmp_path / "opt_uint64")
+    dg.write_keys(kfile, keys)
+    r = subprocess.run([sys.executable, "-m", "rmi_amd.cli", kfile, "--optimize", "front.json"], cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONPATH=ROOT, RMI_OPTIMIZER_PROFILE="fast"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Models" in r.stdout and "AvgLg2" in r.stdout
+    cfgs = json.loads((tmp_path / "front.json").read_text())["configs"]
+    assert [c["layers"] for c in cfgs] == [s.models for s in front]
+    assert [c["branching factor"] for c in cfgs] == [s.branching_factor for s in front]
+    assert cfgs[0]["namespace"] == "opt_uint64_0" and cfgs[0]["binary"] is True
+    r = subprocess.run([sys.executable, "-m", "rmi_amd.cli", kfile, "sized", "--max-size", "200000", "--no-code"], cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONPATH=ROOT, RMI_OPTIMIZER_PROFILE="fast"), capture_output=True, text=True)
+    assert r.returncode == 0 and "Found RMI config" in r.stdout, r.stdout + r.stderr

@@ -97,7 +97,8 @@ def test_parity_f64_keys(trainer_mod, oracle, root, leaf, L):
 
 
 @pytest.mark.parametrize("gen", ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "dups_u32"])
-@pytest.mark.parametrize("root,L", [("linear", 4096), ("cubic", 1024), ("radix", 8192), ("linear", 40_000), ("linear", 8)])
+@pytest.mark.parametrize("root,L", [("linear", 4096), ("cubic", 1024), ("radix", 8192), ("linear", 40_000), ("linear", 8),
+                                    ("linear", 150)])
 def test_parity_cubic_leaves(trainer_mod, oracle, gen, root, L):
     """leaf = cubic (cubic_spline.rs:108-136 on every container; SURVEY 8a row a8''): 4 coefficients per
     leaf, rows of 40 bytes, the cube of the key range from the host's libm like the reference's."""
