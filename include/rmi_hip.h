@@ -48,10 +48,10 @@ extern "C" {
 /* src/load.rs:15-19 */
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
 
-/* model registry, train/mod.rs:37-54.  Ids 0-4 are implemented on the device path (roots: all
- * five; leaves: linear, linear_spline, cubic -- radix is top-only in the reference, robust_linear
- * as a leaf is rejected); the rest of the registry is recognised by name and rejected with
- * RMI_ERR_UNSUPPORTED_MODEL. */
+/* model registry, train/mod.rs:37-54.  On the device path: roots linear, linear_spline, cubic,
+ * radix, robust_linear and the radix tables (ids 8-12); leaves linear, linear_spline, cubic
+ * (radix is top-only in the reference; robust_linear and radix tables as leaves are rejected).
+ * The rest of the registry is recognised by name and rejected with RMI_ERR_UNSUPPORTED_MODEL. */
 enum rmi_hip_model_kind {
   RMI_MODEL_LINEAR = 0,
   RMI_MODEL_LINEAR_SPLINE = 1,
@@ -201,6 +201,16 @@ int rmi_hip_fit_root(rmi_hip_ctx* ctx, int root_kind, uint64_t num_leaves, const
  * leaf-aligned shard cuts with exactly the bucketing the kernels use.  key_bits: the key's bits. */
 int rmi_hip_root_target(const rmi_hip_model_params* root, int dtype, uint64_t key_bits,
                         uint64_t num_leaves, uint64_t* out);
+/* Radix-table roots (radix8/18/22/26/28 = RadixTable::new(data, bits), radix.rs:83-121): the
+ * parameters are ip = (prefix_bits, table_bits) plus the hint table of 2^table_bits u32, which
+ * lives in the context.  rmi_hip_fit_root stores it there; these calls read it back (for the
+ * emitted L0_PARAMETERS file) or install one (a cached root, another rank of a multi-GPU job).
+ * rmi_hip_train_two_layer uses the table of the context for such a root; rmi_hip_root_target
+ * has no context and returns RMI_ERR_UNSUPPORTED_MODEL for them. */
+int rmi_hip_root_table_entries(const rmi_hip_ctx* ctx, uint64_t* entries);
+int rmi_hip_download_root_table(const rmi_hip_ctx* ctx, uint32_t* host_out);
+int rmi_hip_set_root_table(rmi_hip_ctx* ctx, const uint32_t* host_table, uint64_t entries);
+
 /* `linear` root fit fed with consecutive chunks of the global key array (same recurrence and
  * result as rmi_hip_fit_root; for data that is produced or held shard by shard). */
 typedef struct rmi_hip_root_stream rmi_hip_root_stream;

@@ -24,6 +24,7 @@ MODEL_IDS = {
     "cubic": MODEL_CUBIC,
     "radix": MODEL_RADIX,
     "robust_linear": MODEL_ROBUST_LINEAR,
+    "radix8": 8, "radix18": 9, "radix22": 10, "radix26": 11, "radix28": 12,      # RadixTable (train/mod.rs:46-50)
 }
 ERRORS = {
     -1: "unknown model (train/mod.rs:53)",
@@ -46,7 +47,8 @@ class OracleError(RuntimeError):
 
 
 class _Model(C.Structure):
-    _fields_ = [("kind", C.c_int), ("p", C.c_double * 4), ("ip", C.c_uint64 * 2)]
+    _fields_ = [("kind", C.c_int), ("p", C.c_double * 4), ("ip", C.c_uint64 * 2),
+                ("table", C.POINTER(C.c_uint32)), ("table_len", C.c_uint64)]
 
 
 class _Trained(C.Structure):
@@ -109,6 +111,8 @@ def lib() -> C.CDLL:
         L.orc_bucket_ids.restype = C.c_int
         L.orc_check_lookup_property.argtypes = [C.POINTER(_Trained), C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_check_lookup_property.restype = C.c_uint64
+        L.orc_model_free.argtypes = [C.POINTER(_Model)]
+        L.orc_model_free.restype = None
         L.orc_version.restype = C.c_char_p
         _lib = L
     return _lib
@@ -137,6 +141,7 @@ class Model:
     kind: int
     p: tuple
     ip: tuple
+    table: np.ndarray | None = None       # radix tables: hint_table (u32), radix.rs:83-88
 
     def _c(self) -> _Model:
         m = _Model()
@@ -145,6 +150,9 @@ class Model:
             m.p[i] = self.p[i]
         for i in range(2):
             m.ip[i] = self.ip[i]
+        if self.table is not None:
+            m.table = self.table.ctypes.data_as(C.POINTER(C.c_uint32))     # borrowed: self keeps it alive
+            m.table_len = self.table.size
         return m
 
     def predict_to_int(self, key, dtype=KEY_U64) -> int:
@@ -160,8 +168,13 @@ def _key_bits(key, dtype) -> int:
     return int(key)
 
 
-def _from_c(m: _Model) -> Model:
-    return Model(int(m.kind), tuple(float(x) for x in m.p), tuple(int(x) for x in m.ip))
+def _from_c(m: _Model, own_table: bool = False) -> Model:
+    table = None
+    if m.table_len:
+        table = np.ctypeslib.as_array(m.table, shape=(int(m.table_len),)).copy()
+        if own_table:
+            lib().orc_model_free(C.byref(m))
+    return Model(int(m.kind), tuple(float(x) for x in m.p), tuple(int(x) for x in m.ip), table)
 
 
 def fit_pairs(kind, keys, ys, scale: float = 1.0) -> Model:
@@ -171,7 +184,7 @@ def fit_pairs(kind, keys, ys, scale: float = 1.0) -> Model:
     rc = lib().orc_fit_pairs(_kind(kind), dtype_of(keys), keys.ctypes.data, ys.ctypes.data, len(keys), scale, C.byref(m))
     if rc:
         raise OracleError(rc)
-    return _from_c(m)
+    return _from_c(m, own_table=True)
 
 
 def fit_root(kind, keys: np.ndarray, num_leaves: int) -> Model:
@@ -180,7 +193,7 @@ def fit_root(kind, keys: np.ndarray, num_leaves: int) -> Model:
     rc = lib().orc_fit_root(_kind(kind), dtype_of(keys), keys.ctypes.data, len(keys), num_leaves, C.byref(m))
     if rc:
         raise OracleError(rc)
-    return _from_c(m)
+    return _from_c(m, own_table=True)
 
 
 def num_bits(t: int) -> int:
@@ -235,18 +248,20 @@ def train_two_layer(root_kind, leaf_kind, keys: np.ndarray, num_leaves: int,
     t.leaf_err = leaf_err.ctypes.data_as(C.POINTER(C.c_uint64))
     t.leaf_count = leaf_count.ctypes.data_as(C.POINTER(C.c_uint64))
     t.leaf_start = leaf_start.ctypes.data_as(C.POINTER(C.c_uint64))
+    if root is None and 8 <= _kind(root_kind) <= 12:
+        root = fit_root(root_kind, keys, L)              # the table then lives in numpy, not in C
     rootc = root._c() if root is not None else None
     rc = lib().orc_train_two_layer(_kind(root_kind), lk, dtype_of(keys), keys.ctypes.data, len(keys), L,
                                    C.byref(rootc) if rootc is not None else None, threads, C.byref(t))
     if rc:
         raise OracleError(rc)
     return TrainedRMI(
-        n=int(t.n), num_leaves=L, root=_from_c(t.root), leaf_kind=lk, params_per_leaf=ppl,
+        n=int(t.n), num_leaves=L, root=(root if root is not None and root.table is not None else _from_c(t.root)), leaf_kind=lk, params_per_leaf=ppl,
         leaf_params=leaf_params, leaf_err=leaf_err, leaf_count=leaf_count, leaf_start=leaf_start,
         model_avg_error=float(t.model_avg_error), model_avg_l2_error=float(t.model_avg_l2_error),
         model_avg_log2_error=float(t.model_avg_log2_error), model_max_error=int(t.model_max_error),
         model_max_error_idx=int(t.model_max_error_idx), model_max_log2_error=float(t.model_max_log2_error),
-        _c=t,
+        _c=(t, root, leaf_params, leaf_err, leaf_count, leaf_start),
     )
 
 
@@ -254,5 +269,5 @@ def check_lookup_property(rmi: TrainedRMI, keys: np.ndarray):
     """Returns (num_violations, first_bad_index)."""
     keys = np.ascontiguousarray(keys)
     fb = C.c_uint64(0)
-    bad = lib().orc_check_lookup_property(C.byref(rmi._c), dtype_of(keys), keys.ctypes.data, len(keys), C.byref(fb))
+    bad = lib().orc_check_lookup_property(C.byref(rmi._c[0]), dtype_of(keys), keys.ctypes.data, len(keys), C.byref(fb))
     return int(bad), int(fb.value)

@@ -366,6 +366,40 @@ static int fit_radix(const otd* d, orc_model* m) {
   return ORC_OK;
 }
 
+/* RadixTable::new: radix.rs:90-121 */
+static inline int is_radix_table(int kind) { return kind >= ORC_MODEL_RADIX8 && kind <= ORC_MODEL_RADIX28; }
+static inline int radix_table_bits(int kind) {
+  static const int bits[5] = { 8, 18, 22, 26, 28 };
+  return bits[kind - ORC_MODEL_RADIX8];
+}
+static inline uint64_t radix_table_slot(uint64_t prefix, uint64_t bits, uint64_t x) {
+  /* radix.rs:98-99 / :125-131; release-mode masked shifts */
+  uint64_t num_bits = (prefix + bits > 64) ? 0 : 64 - (prefix + bits);
+  return (((x << (prefix & 63)) >> (prefix & 63)) >> (num_bits & 63));
+}
+static int fit_radix_table(const otd* d, int kind, orc_model* m) {
+  const uint64_t bits = (uint64_t)radix_table_bits(kind);
+  const uint64_t prefix = (uint64_t)(uint8_t)common_prefix_size_td(d);
+  const uint64_t len = 1ull << bits;
+  uint32_t* t = (uint32_t*)calloc(len, sizeof(uint32_t));
+  if (!t) return ORC_ERR_BAD_ARG;
+  uint64_t last_radix = 0;
+  fixdups_it it; fd_init(&it, d); okey k; size_t y;
+  while (fd_next(&it, &k, &y)) {
+    uint64_t x = key_as_uint(d->dtype, k);
+    uint64_t cur = radix_table_slot(prefix, bits, x);
+    if (cur == last_radix) continue;
+    if (cur >= len) { free(t); return ORC_ERR_BAD_ARG; }     /* assert!, radix.rs:101 (cannot fire) */
+    t[cur] = (uint32_t)y;
+    for (uint64_t i = last_radix + 1; i < cur; i++) t[i] = (uint32_t)y;
+    last_radix = cur;
+  }
+  for (uint64_t i = last_radix + 1; i < len; i++) t[i] = (uint32_t)len;
+  m->kind = kind; m->ip[0] = prefix; m->ip[1] = bits; m->table = t; m->table_len = len;
+  return ORC_OK;
+}
+void orc_model_free(orc_model* m) { if (m && m->table) { free(m->table); m->table = NULL; m->table_len = 0; } }
+
 /* train_model: train/mod.rs:35-57 */
 static int train_model(int kind, const otd* d, orc_model* m) {
   memset(m, 0, sizeof *m);
@@ -375,13 +409,15 @@ static int train_model(int kind, const otd* d, orc_model* m) {
     case ORC_MODEL_LINEAR_SPLINE: return fit_linear_spline(d, m);
     case ORC_MODEL_CUBIC: return fit_cubic(d, m);
     case ORC_MODEL_RADIX: return fit_radix(d, m);
+    case ORC_MODEL_RADIX8: case ORC_MODEL_RADIX18: case ORC_MODEL_RADIX22: case ORC_MODEL_RADIX26:
+    case ORC_MODEL_RADIX28: return fit_radix_table(d, kind, m);
     default: return ORC_ERR_UNKNOWN_MODEL;
   }
 }
 
 static inline int model_needs_bounds_check(int kind) {
   /* default true (mod.rs:751-753); cubic false (cubic_spline.rs:184-186); radix false (radix.rs:72-74) */
-  return !(kind == ORC_MODEL_CUBIC || kind == ORC_MODEL_RADIX);
+  return !(kind == ORC_MODEL_CUBIC || kind == ORC_MODEL_RADIX || is_radix_table(kind));   /* radix.rs:160-162 */
 }
 static inline int model_params_per(int kind) { return kind == ORC_MODEL_CUBIC ? 4 : 2; }
 
@@ -398,6 +434,9 @@ static inline double model_predict_float_k(const orc_model* m, int dtype, okey k
       uint64_t r = (v << (m->ip[0] & 63)) >> ((64 - m->ip[1]) & 63);
       return (double)r;
     }
+    case ORC_MODEL_RADIX8: case ORC_MODEL_RADIX18: case ORC_MODEL_RADIX22: case ORC_MODEL_RADIX26:
+    case ORC_MODEL_RADIX28:
+      return (double)m->table[radix_table_slot(m->ip[0], m->ip[1], key_as_uint(dtype, k))];
   }
   return 0.0;
 }
@@ -407,6 +446,8 @@ static inline uint64_t model_predict_int_k(const orc_model* m, int dtype, okey k
     uint64_t v = key_as_uint(dtype, k);
     return (v << (m->ip[0] & 63)) >> ((64 - m->ip[1]) & 63);  /* release-mode masked shifts */
   }
+  if (is_radix_table(m->kind))                                /* radix.rs:124-134 */
+    return (uint64_t)m->table[radix_table_slot(m->ip[0], m->ip[1], key_as_uint(dtype, k))];
   double f = floor(model_predict_float_k(m, dtype, k));
   return sat_f64_to_u64(fmax(0.0, f));
 }
@@ -447,6 +488,12 @@ static int validate(int root_kind, int leaf_kind) {
       case ORC_MODEL_LINEAR: case ORC_MODEL_ROBUST_LINEAR: case ORC_MODEL_LINEAR_SPLINE:
       case ORC_MODEL_CUBIC: break;
       case ORC_MODEL_RADIX: if (idx != 0) return ORC_ERR_RESTRICTION; break;
+      case ORC_MODEL_RADIX8: case ORC_MODEL_RADIX18: case ORC_MODEL_RADIX22: case ORC_MODEL_RADIX26:
+      case ORC_MODEL_RADIX28:
+        /* ModelRestriction::None (radix.rs:163-165); as a leaf its parameters are a table per leaf,
+         * which this restatement does not carry */
+        if (idx != 0) return ORC_ERR_BAD_ARG;
+        break;
       default: return ORC_ERR_UNKNOWN_MODEL;
     }
   }
@@ -787,7 +834,7 @@ static uint64_t emitted_lookup(const orc_trained_rmi* r, int dtype, okey key, ui
   size_t model_index;
   const orc_model* top = &r->root;
   /* key C type: uint64_t for u64/u32 files, double for f64 (main.rs:122-132) */
-  if (top->kind == ORC_MODEL_RADIX) {
+  if (top->kind == ORC_MODEL_RADIX || is_radix_table(top->kind)) {
     uint64_t ipred = model_predict_int_k(top, dtype, key);
     model_index = (size_t)ipred;                                   /* no bounds check: radix.rs:72-74 */
   } else {

@@ -32,7 +32,13 @@ enum {
   ORC_MODEL_LINEAR_SPLINE = 1,
   ORC_MODEL_CUBIC = 2,
   ORC_MODEL_RADIX = 3,
-  ORC_MODEL_ROBUST_LINEAR = 4
+  ORC_MODEL_ROBUST_LINEAR = 4,
+  /* RadixTable::new(data, bits), train/mod.rs:46-50: same ids as include/rmi_hip.h */
+  ORC_MODEL_RADIX8 = 8,
+  ORC_MODEL_RADIX18 = 9,
+  ORC_MODEL_RADIX22 = 10,
+  ORC_MODEL_RADIX26 = 11,
+  ORC_MODEL_RADIX28 = 12
 };
 
 /* return codes: 0 ok; negative = the reference would have panicked at the cited line */
@@ -56,7 +62,13 @@ typedef struct {
   int kind;
   double p[4];
   uint64_t ip[2];
+  /* radix tables (radix.rs:83-121): ip = (prefix_bits, table_bits), hint_table of 2^table_bits u32.
+   * malloc'd by the fit (release with orc_model_free) or borrowed from the caller. */
+  uint32_t* table;
+  uint64_t table_len;
 } orc_model;
+
+void orc_model_free(orc_model* m);
 
 /* Result of train_two_layer: the fields of TrainedRMI (train/mod.rs:18-33) that the
  * hot path produces, plus diagnostics (leaf_start = bucket assignment). */

@@ -48,7 +48,8 @@ def _stats(rmi: train.TrainedRMI, n: int) -> dict:
             "average l2 error": rmi.model_avg_l2_error, "average log2 error": rmi.model_avg_log2_error,
             "max error": rmi.model_max_error, "max error %": rmi.model_max_error / n * 100.0,
             "max log2 error": rmi.model_max_log2_error,
-            "size binary search": codegen.rmi_size(rmi.root.kind, rmi.leaf_kind, rmi.branching_factor, True),
+            "size binary search": codegen.rmi_size(rmi.root.kind, rmi.leaf_kind, rmi.branching_factor, True,
+                                                      0 if rmi.root.table is None else len(rmi.root.table)),
             "build time": rmi.build_time}
 
 

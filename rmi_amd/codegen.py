@@ -18,6 +18,7 @@ from decimal import Decimal
 import numpy as np
 
 LINEAR, LINEAR_SPLINE, CUBIC, RADIX, ROBUST_LINEAR = 0, 1, 2, 3, 4
+RADIX_TABLES = (8, 9, 10, 11, 12)            # radix8/18/22/26/28 (RadixTable, radix.rs:83-170)
 
 _MODEL_CODE = {
     "linear": """
@@ -39,15 +40,25 @@ inline uint64_t radix(uint64_t prefix_length, uint64_t bits, uint64_t inp) {
 
 
 def _fn_name(kind: int) -> str:
+    if kind in RADIX_TABLES:
+        return "radix_table"
     return {LINEAR: "linear", LINEAR_SPLINE: "linear", ROBUST_LINEAR: "linear", CUBIC: "cubic", RADIX: "radix"}[kind]
 
 
 def _output_is_float(kind: int) -> bool:
-    return kind != RADIX
+    return kind != RADIX and kind not in RADIX_TABLES
 
 
 def _needs_bounds_check(kind: int) -> bool:
-    return kind not in (CUBIC, RADIX)          # cubic_spline.rs:184-186, radix.rs:72-74
+    return kind not in (CUBIC, RADIX) and kind not in RADIX_TABLES     # cubic_spline.rs:184-186, radix.rs:72-74, :160-162
+
+
+def _radix_table_code(prefix: int, table_bits: int) -> str:              # radix.rs:140-153
+    num_bits = 0 if prefix + table_bits > 64 else 64 - (prefix + table_bits)
+    return f"""
+inline uint64_t radix_table(const uint32_t* table, const uint64_t inp) {{
+    return table[((inp << {prefix}) >> {prefix}) >> {num_bits}];
+}}"""
 
 
 def c_float(v: float) -> str:
@@ -66,9 +77,9 @@ def c_float(v: float) -> str:
     return s
 
 
-def rmi_size(root_kind: int, leaf_kind: int, num_leaves: int, with_errors: bool) -> int:
-    """codegen.rs:375-394 (two layers, no cache-fix)."""
-    root_bytes = {CUBIC: 32, RADIX: 16}.get(root_kind, 16)
+def rmi_size(root_kind: int, leaf_kind: int, num_leaves: int, with_errors: bool, root_table_entries: int = 0) -> int:
+    """codegen.rs:375-394 (two layers, no cache-fix).  A radix-table root is its hint table (4 B per entry)."""
+    root_bytes = 4 * root_table_entries if root_kind in RADIX_TABLES else {CUBIC: 32, RADIX: 16}.get(root_kind, 16)
     leaf_bytes = 32 if leaf_kind == CUBIC else 16
     return root_bytes + leaf_bytes * num_leaves + (8 * num_leaves if with_errors else 0)
 
@@ -92,7 +103,30 @@ def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", i
     free_code = ["void cleanup() {"]
 
     # ---- layer 0: a single model; all-same-typed, <= 4096 bytes -> Constant (codegen.rs:45-63) ----
-    if root.kind == RADIX:
+    root_table_args = None
+    if root.kind in RADIX_TABLES:
+        table = np.ascontiguousarray(root.table, dtype="<u4")
+        if table.size * 4 <= 4096:                           # Constant: literal array (codegen.rs:68-77, mod.rs:594-597)
+            lits = ", ".join(f"{int(v)}UL" for v in table)
+            data_h.append(f"const uint32_t L0_PARAMETER0[] = {{ {lits} }};")
+            root_table_args = "L0_PARAMETER0"
+        else:                                                # Array: binary file, malloc'd (codegen.rs:79-93, 104-113)
+            f0 = f"{namespace}_L0_PARAMETERS"
+            with open(os.path.join(data_dir, f0), "wb") as f:
+                f.write(table.tobytes())
+            paths["L0_PARAMETERS"] = os.path.join(data_dir, f0)
+            data_h.append("uint32_t* L0_PARAMETERS;")
+            read_code += ["  {",
+                          f"    std::ifstream infile(std::filesystem::path(dataPath) / \"{f0}\", std::ios::in | std::ios::binary);",
+                          "    if (!infile.good()) return false;",
+                          f"    L0_PARAMETERS = (uint32_t*) malloc({table.size * 4});",
+                          "    if (L0_PARAMETERS == NULL) return false;",
+                          f"    infile.read((char*)L0_PARAMETERS, {table.size * 4});",
+                          "    if (!infile.good()) return false;", "  }"]
+            free_code.append("    free(L0_PARAMETERS);")
+            root_table_args = "L0_PARAMETERS"
+        root_vals, root_ctype = [], "uint32_t"
+    elif root.kind == RADIX:
         root_vals = [f"{int(root.ip[0])}UL", f"{int(root.ip[1])}UL"]
         root_ctype = "uint64_t"
     else:
@@ -164,7 +198,7 @@ def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", i
     code += read_code + free_code
     fns = []
     for k in (root.kind, leaf_kind):
-        c = _MODEL_CODE[_fn_name(k)]
+        c = _radix_table_code(int(root.ip[0]), int(root.ip[1])) if k in RADIX_TABLES else _MODEL_CODE[_fn_name(k)]
         if c not in fns:
             fns.append(c)
     code += fns
@@ -180,9 +214,9 @@ inline size_t FCLAMP(double inp, double bound) {
         code.append("  double fpred;")
     if not _output_is_float(root.kind):
         code.append("  uint64_t ipred;")
-    root_in = "double" if root.kind != RADIX else "uint64_t"
+    root_in = "double" if _output_is_float(root.kind) else "uint64_t"
     root_var = "fpred" if _output_is_float(root.kind) else "ipred"
-    args = ", ".join(f"L0_PARAMETER{i}" for i in range(len(root_vals)))
+    args = root_table_args or ", ".join(f"L0_PARAMETER{i}" for i in range(len(root_vals)))
     code.append(f"  {root_var} = {_fn_name(root.kind)}({args}, ({root_in})key);")
     # model_index_from_output! (codegen.rs:346-373)
     if _output_is_float(root.kind):
@@ -200,7 +234,7 @@ inline size_t FCLAMP(double inp, double bound) {
     bt = int(getattr(rmi, "build_time", 0) if build_time_ns is None else build_time_ns)
     header = ["#include <cstddef>", "#include <cstdint>", f"namespace {namespace} {{",
               "bool load(char const* dataPath);", "void cleanup();",
-              f"const size_t RMI_SIZE = {rmi_size(root.kind, leaf_kind, L, include_errors)};",
+              f"const size_t RMI_SIZE = {rmi_size(root.kind, leaf_kind, L, include_errors, 0 if root.table is None else len(root.table))};",
               f"const uint64_t BUILD_TIME_NS = {bt};", f'const char NAME[] = "{namespace}";', f"{sig};", "}"]
 
     for name, lines in ((f"{namespace}.cpp", code), (f"{namespace}_data.h", data_h), (f"{namespace}.h", header)):

@@ -10,7 +10,8 @@
 
 namespace rmi {
 
-enum : int { K_LINEAR = 0, K_LINEAR_SPLINE = 1, K_CUBIC = 2, K_RADIX = 3, K_ROBUST_LINEAR = 4 };
+enum : int { K_LINEAR = 0, K_LINEAR_SPLINE = 1, K_CUBIC = 2, K_RADIX = 3, K_ROBUST_LINEAR = 4,
+             K_RADIX_TABLE = 5 };    // RadixTable (radix8/18/22/26/28): roots only
 
 // error bits raised by kernels (host maps them to rmi_hip_error codes)
 enum : uint32_t {
@@ -24,9 +25,15 @@ enum : uint32_t {
 // Root model parameters + branching factor, passed by value to kernels.
 struct RootP {
   double p0, p1, p2, p3;   // linear-like: (alpha, beta); cubic: (a, b, c, d)
-  uint32_t prefix, bits;   // radix
+  uint32_t prefix, bits;   // radix: (prefix, bits); radix table: (prefix, shift = 64 - prefix - table_bits or 0)
   uint64_t L;              // number of leaves
+  const uint32_t* table;   // radix table: hint_table in HBM (2^table_bits entries), else null
 };
+
+// radix.rs:125-131 (release-mode masked shifts)
+__device__ __forceinline__ uint64_t radix_table_slot(const RootP& r, uint64_t v) {
+  return ((v << (r.prefix & 63u)) >> (r.prefix & 63u)) >> (r.bits & 63u);
+}
 
 // Index space of one launch.  All key indices and leaf ids inside the kernels are GLOBAL; the key
 // and per-leaf array pointers handed to the kernels are pre-offset so that ptr[global_index] is
@@ -103,6 +110,8 @@ __device__ __forceinline__ uint64_t root_predict(const RootP& r, K k) {
     // radix.rs:43-50 (release-mode masked shifts)
     uint64_t v = KeyTraits<K>::as_uint(k);
     return (v << (r.prefix & 63u)) >> ((64u - r.bits) & 63u);
+  } else if constexpr (ROOT == K_RADIX_TABLE) {
+    return (uint64_t)r.table[radix_table_slot(r, KeyTraits<K>::as_uint(k))];   // radix.rs:124-134
   } else if constexpr (ROOT == K_CUBIC) {
     double x = KeyTraits<K>::as_float(k);
     double v1 = __builtin_fma(r.p0, x, r.p1);     // cubic_spline.rs:146-148
@@ -117,7 +126,7 @@ __device__ __forceinline__ uint64_t root_predict(const RootP& r, K k) {
 
 template <int ROOT>
 __device__ __forceinline__ constexpr bool root_needs_bounds_check() {
-  return !(ROOT == K_CUBIC || ROOT == K_RADIX);   // cubic_spline.rs:184-186, radix.rs:72-74
+  return !(ROOT == K_CUBIC || ROOT == K_RADIX || ROOT == K_RADIX_TABLE);   // cubic_spline.rs:184-186, radix.rs:72-74, :160-162
 }
 
 // Leaf prediction (predict_to_int) from a row of parameters.
@@ -165,6 +174,11 @@ __device__ __forceinline__ double root_target_f(const RootP& r, double Lm1f, K k
   if constexpr (ROOT == K_RADIX) {
     uint64_t v = KeyTraits<K>::as_uint(k);
     uint64_t p = (v << (r.prefix & 63u)) >> ((64u - r.bits) & 63u);
+    oob = p > (uint64_t)Lm1f;
+    p = p < r.L - 1 ? p : r.L - 1;
+    return (double)p;
+  } else if constexpr (ROOT == K_RADIX_TABLE) {
+    uint64_t p = (uint64_t)r.table[radix_table_slot(r, KeyTraits<K>::as_uint(k))];
     oob = p > (uint64_t)Lm1f;
     p = p < r.L - 1 ? p : r.L - 1;
     return (double)p;

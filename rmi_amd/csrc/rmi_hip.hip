@@ -40,6 +40,10 @@ struct rmi_hip_ctx {
   unsigned long long* d_count = nullptr;        // L
   unsigned char* d_rows = nullptr;              // L*(ppl*8+8)
   unsigned long long* d_tilemin = nullptr;
+  // radix-table root (radix8/18/22/26/28): hint_table of the last rmi_hip_fit_root / rmi_hip_set_root_table
+  std::vector<uint32_t> h_table;
+  uint32_t* d_table = nullptr;
+  uint64_t d_table_cap = 0;
   double* d_cube = nullptr;                     // cubic leaves: span, then pow(span, 3.0), per leaf
   uint64_t cube_cap = 0;
   std::vector<double> h_cube;
@@ -133,10 +137,10 @@ const char* rmi_hip_model_name(int kind) {
 }
 
 static bool must_be_top(int kind) {
-  // radix.rs:75-80, radix.rs:166-168 (RadixTable), balanced_radix.rs, histogram.rs (MustBeTop)
+  // radix.rs:75-80, balanced_radix.rs:167-169, histogram.rs:102 (MustBeTop).  RadixTable has no
+  // restriction (radix.rs:163-165).
   switch (kind) {
-    case RMI_MODEL_RADIX: case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22:
-    case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28: case RMI_MODEL_BRADIX: case RMI_MODEL_HISTOGRAM:
+    case RMI_MODEL_RADIX: case RMI_MODEL_BRADIX: case RMI_MODEL_HISTOGRAM:
       return true;
     default: return false;
   }
@@ -213,6 +217,7 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_outputs(c);
+  if (c->d_table) (void)hipFree(c->d_table);       // the root table is an input, not an output: it outlives re-sizing
   if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->h_state) (void)hipHostFree(c->h_state);
@@ -362,7 +367,8 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
                      rmi_hip_model_params* out) {
   if (!c || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
   if (root_kind < 0 || root_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
-  if (root_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
+  const bool is_table = rmi_host::radix_table_bits(root_kind) > 0;
+  if (root_kind > RMI_MODEL_ROBUST_LINEAR && !is_table) return RMI_ERR_UNSUPPORTED_MODEL;
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
   std::vector<unsigned char> tmp;
   const void* hk = host_keys;
@@ -373,12 +379,42 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
     HIPCHK(c, hipMemcpy(tmp.data(), c->d_keys, tmp.size(), hipMemcpyDeviceToHost));
     hk = tmp.data();
   }
+  std::vector<uint32_t> table;
+  int rc = RMI_ERR_BAD_ARG;
   switch (c->dtype) {
-    case RMI_KEY_U64: return rmi_host::fit_root<uint64_t>(root_kind, (const uint64_t*)hk, c->n, num_leaves, out);
-    case RMI_KEY_U32: return rmi_host::fit_root<uint32_t>(root_kind, (const uint32_t*)hk, c->n, num_leaves, out);
-    case RMI_KEY_F64: return rmi_host::fit_root<double>(root_kind, (const double*)hk, c->n, num_leaves, out);
+    case RMI_KEY_U64: rc = rmi_host::fit_root<uint64_t>(root_kind, (const uint64_t*)hk, c->n, num_leaves, out, &table); break;
+    case RMI_KEY_U32: rc = rmi_host::fit_root<uint32_t>(root_kind, (const uint32_t*)hk, c->n, num_leaves, out, &table); break;
+    case RMI_KEY_F64: rc = rmi_host::fit_root<double>(root_kind, (const double*)hk, c->n, num_leaves, out, &table); break;
   }
-  return RMI_ERR_BAD_ARG;
+  if (rc == RMI_OK && is_table) rc = rmi_hip_set_root_table(c, table.data(), table.size());
+  return rc;
+}
+
+// The hint table of a radix-table root lives in the context (host copy + HBM copy): it is set by
+// rmi_hip_fit_root, or by the caller (another process of a multi-GPU job, a cached root).
+int rmi_hip_set_root_table(rmi_hip_ctx* c, const uint32_t* table, uint64_t entries) {
+  if (!c || !table || entries == 0 || (entries & (entries - 1))) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->d_table_cap < entries) {
+    if (c->d_table) (void)hipFree(c->d_table);
+    c->d_table = nullptr; c->d_table_cap = 0;
+    HIPCHK(c, hipMalloc(&c->d_table, entries * 4));
+    c->d_table_cap = entries;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));                  // a train call may still be reading the old table
+  if (table != c->h_table.data()) c->h_table.assign(table, table + entries);
+  HIPCHK(c, hipMemcpy(c->d_table, c->h_table.data(), entries * 4, hipMemcpyHostToDevice));
+  return RMI_OK;
+}
+int rmi_hip_root_table_entries(const rmi_hip_ctx* c, uint64_t* entries) {
+  if (!c || !entries) return RMI_ERR_BAD_ARG;
+  *entries = c->h_table.size();
+  return RMI_OK;
+}
+int rmi_hip_download_root_table(const rmi_hip_ctx* c, uint32_t* out) {
+  if (!c || !out || c->h_table.empty()) return RMI_ERR_BAD_ARG;
+  std::memcpy(out, c->h_table.data(), c->h_table.size() * 4);
+  return RMI_OK;
 }
 
 }  // extern "C"
@@ -387,6 +423,7 @@ extern "C" {
 
 int rmi_hip_root_target(const rmi_hip_model_params* root, int dtype, uint64_t key_bits, uint64_t num_leaves, uint64_t* out) {
   if (!root || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  if (rmi_host::radix_table_bits(root->kind) > 0) return RMI_ERR_UNSUPPORTED_MODEL;   // needs the table: plan on the caller's side
   switch (dtype) {
     case RMI_KEY_U64: *out = rmi_host::root_target<uint64_t>(*root, (uint64_t)key_bits, num_leaves); return RMI_OK;
     case RMI_KEY_U32: *out = rmi_host::root_target<uint32_t>(*root, (uint32_t)key_bits, num_leaves); return RMI_OK;
@@ -638,6 +675,8 @@ static int dispatch_root(rmi_hip_ctx* c, int root_kind, const RootP& rp, int lea
       return dispatch_leaf<K_LINEAR, K>(c, rp, leaf_kind, L);     // all three predict with fma(beta, x, alpha)
     case RMI_MODEL_CUBIC: return dispatch_leaf<K_CUBIC, K>(c, rp, leaf_kind, L);
     case RMI_MODEL_RADIX: return dispatch_leaf<K_RADIX, K>(c, rp, leaf_kind, L);
+    case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22: case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28:
+      return dispatch_leaf<K_RADIX_TABLE, K>(c, rp, leaf_kind, L);
     default: return RMI_ERR_UNSUPPORTED_MODEL;
   }
 }
@@ -650,7 +689,10 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
   if (root->kind < 0 || root->kind >= kNumModels || leaf_kind < 0 || leaf_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
   if (must_be_top(leaf_kind)) return RMI_ERR_RESTRICTION;
-  if (root->kind > RMI_MODEL_ROBUST_LINEAR || leaf_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
+  const int table_bits = rmi_host::radix_table_bits(root->kind);
+  if ((root->kind > RMI_MODEL_ROBUST_LINEAR && table_bits < 0) || leaf_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
+  if (table_bits > 0 && (c->h_table.size() != (1ull << table_bits) || root->ip[1] != (uint64_t)table_bits || !c->d_table))
+    return RMI_ERR_BAD_ARG;                                    // no (matching) table in this context: rmi_hip_set_root_table
   // robust_linear as a leaf trims 0.01% tails of each container (linear.rs:247-252); not on the device path yet
   if (leaf_kind == RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
   HIPCHK(c, hipSetDevice(c->device));
@@ -667,6 +709,11 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   rp.p0 = root->p[0]; rp.p1 = root->p[1]; rp.p2 = root->p[2]; rp.p3 = root->p[3];
   rp.prefix = (uint32_t)root->ip[0]; rp.bits = (uint32_t)root->ip[1];
   rp.L = num_leaves;
+  rp.table = nullptr;
+  if (table_bits > 0) {                                        // radix.rs:125-131: slot = ((x << p) >> p) >> shift
+    rp.table = c->d_table;
+    rp.bits = (root->ip[0] + root->ip[1] > 64) ? 0u : (uint32_t)(64 - (root->ip[0] + root->ip[1]));
+  }
   switch (c->dtype) {
     case RMI_KEY_U64: rc = dispatch_root<uint64_t>(c, root->kind, rp, leaf_kind, num_leaves); break;
     case RMI_KEY_U32: rc = dispatch_root<uint32_t>(c, root->kind, rp, leaf_kind, num_leaves); break;

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "../../include/rmi_hip.h"
 
@@ -211,8 +212,49 @@ inline int fit_radix(const Data<K>& d, rmi_hip_model_params* m) {          // ra
   return RMI_OK;
 }
 
+// RadixTable::new (radix.rs:90-121): hint_table[radix] = scaled first-occurrence offset of the first
+// key with that radix; gaps take the value of the next present radix, the tail takes table.len().
+inline int radix_table_bits(int kind) {
+  switch (kind) {
+    case RMI_MODEL_RADIX8: return 8;
+    case RMI_MODEL_RADIX18: return 18;
+    case RMI_MODEL_RADIX22: return 22;
+    case RMI_MODEL_RADIX26: return 26;
+    case RMI_MODEL_RADIX28: return 28;
+    default: return -1;
+  }
+}
+inline uint64_t radix_table_slot(uint64_t prefix, uint64_t bits, uint64_t x) {   // radix.rs:98-99, :125-131
+  const uint64_t num_bits = (prefix + bits > 64) ? 0 : 64 - (prefix + bits);
+  return ((x << (prefix & 63)) >> (prefix & 63)) >> (num_bits & 63);           // release-mode masked shifts
+}
 template <typename K>
-inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rmi_hip_model_params* m) {
+inline int fit_radix_table(const Data<K>& d, int kind, rmi_hip_model_params* m, std::vector<uint32_t>& table) {
+  const uint64_t bits = (uint64_t)radix_table_bits(kind);
+  uint64_t any_ones = 0, no_ones = ~0ull;                                      // common_prefix_size, utils.rs:23-36
+  for (uint64_t i = 0; i < d.n; i++) { const uint64_t v = as_uint(d.keys[i]); any_ones |= v; no_ones &= v; }
+  const uint64_t inv = ~((~no_ones) ^ any_ones);
+  const uint64_t prefix = inv == 0 ? 64 : (uint64_t)__builtin_clzll(inv);
+  const uint64_t len = 1ull << bits;
+  table.assign(len, 0u);
+  uint64_t last_radix = 0;
+  int rc = RMI_OK;
+  for_each_fixdups(d, 0, UINT64_MAX, [&](K k, uint64_t y) {
+    const uint64_t cur = radix_table_slot(prefix, bits, as_uint(k));
+    if (cur == last_radix) return;
+    if (cur >= len) { rc = RMI_ERR_BAD_ARG; return; }                         // assert!, radix.rs:101
+    table[cur] = (uint32_t)y;
+    for (uint64_t i = last_radix + 1; i < cur; i++) table[i] = (uint32_t)y;
+    last_radix = cur;
+  });
+  for (uint64_t i = last_radix + 1; i < len; i++) table[i] = (uint32_t)len;
+  m->ip[0] = prefix; m->ip[1] = bits;
+  return rc;
+}
+
+template <typename K>
+inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rmi_hip_model_params* m,
+                    std::vector<uint32_t>* table = nullptr) {
   std::memset(m, 0, sizeof *m);
   m->kind = kind;
   Data<K> d{keys, n, (double)num_leaves / (double)n};                       // two_layer.rs:109
@@ -222,6 +264,9 @@ inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rm
     case RMI_MODEL_LINEAR_SPLINE: linear_splines(d, &m->p[0], &m->p[1]); return RMI_OK;
     case RMI_MODEL_CUBIC: return fit_cubic(d, m);
     case RMI_MODEL_RADIX: return fit_radix(d, m);
+    case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22: case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28:
+      if (!table) return RMI_ERR_BAD_ARG;
+      return fit_radix_table(d, kind, m, *table);
     default: return RMI_ERR_UNSUPPORTED_MODEL;
   }
 }
@@ -257,9 +302,11 @@ struct LinearRootStream {
 
 // min(L-1, root.predict_to_int(key)) on the host (two_layer.rs:49; used to plan shard cuts)
 template <typename K>
-inline uint64_t root_target(const rmi_hip_model_params& m, K k, uint64_t L) {
+inline uint64_t root_target(const rmi_hip_model_params& m, K k, uint64_t L, const uint32_t* table = nullptr) {
   uint64_t p;
   switch (m.kind) {
+    case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22: case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28:
+      p = table[radix_table_slot(m.ip[0], m.ip[1], as_uint(k))]; break;
     case RMI_MODEL_RADIX: p = (as_uint(k) << (m.ip[0] & 63)) >> ((64 - m.ip[1]) & 63); break;
     case RMI_MODEL_CUBIC: p = sat_u64(std::fmax(0.0, std::floor(cubic_eval(m.p, as_float(k))))); break;
     default: p = sat_u64(std::fmax(0.0, std::floor(std::fma(m.p[1], as_float(k), m.p[0])))); break;

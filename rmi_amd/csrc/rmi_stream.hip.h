@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
                                                              unsigned long long* __restrict__ long_idx,
                                                              unsigned int long_min, int dbg) {
   __shared__ unsigned long long s_panel[FA_WAVES][64 * FS_STRIDE];   // raw key bits, then f64 x
-  constexpr bool LEAFP = (ROOT == K_RADIX);
+  constexpr bool LEAFP = (ROOT == K_RADIX || ROOT == K_RADIX_TABLE);
   __shared__ unsigned int s_leafp[FA_WAVES][LEAFP ? 64 * FS_STRIDE : 1];   // leaf ids (radix roots only)
   __shared__ double rtab[FS_TMAX];
   __shared__ double s_q[FA_WAVES][5][FS_QCAP2];

@@ -9,8 +9,8 @@ work left is the exact, sequential root fit (rmi_hip_fit_root) -- computed once 
 (root, branching factor), shared by all leaf types, and overlapped across configurations on a few
 host threads (the reference's `par_iter` over whole trainings, optimizer.rs:220-231).
 
-Models the device path does not implement (radix18 / radix22 tables, normal, lognormal, loglinear)
-are left out of the lists; `skipped_models()` names them.
+Models the device path does not implement (normal, lognormal, loglinear: the `disk` profile's extra
+tops) are left out of the lists; `skipped_models()` names them.
 """
 from __future__ import annotations
 
@@ -24,7 +24,7 @@ from . import codegen, train
 
 EPSILON = sys.float_info.epsilon
 
-SUPPORTED_TOP = ("linear", "robust_linear", "linear_spline", "cubic", "radix")
+SUPPORTED_TOP = ("linear", "robust_linear", "linear_spline", "cubic", "radix", "radix8", "radix18", "radix22", "radix26", "radix28")
 SUPPORTED_LEAF = ("linear", "linear_spline", "cubic")
 
 
@@ -79,7 +79,8 @@ class RMIStatistics:                                                          # 
         return RMIStatistics(models=rmi.models, branching_factor=int(rmi.branching_factor),
                              average_log2_error=float(rmi.model_avg_log2_error),
                              max_log2_error=float(rmi.model_max_log2_error),
-                             size=codegen.rmi_size(rmi.root.kind, rmi.leaf_kind, rmi.branching_factor, True))
+                             size=codegen.rmi_size(rmi.root.kind, rmi.leaf_kind, rmi.branching_factor, True,
+                                                   0 if rmi.root.table is None else len(rmi.root.table)))
 
     def dominated_by(self, other: "RMIStatistics") -> bool:                   # :170-185
         if self.size < other.size:

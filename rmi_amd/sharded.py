@@ -68,6 +68,13 @@ class Planner:
         self._rootc = root._c()
 
     def target(self, i: int) -> int:
+        if self.root.is_radix_table:                      # radix.rs:124-134, clamp two_layer.rs:49 (the table is host data)
+            k = self.key_at(i)
+            v = min(max(int(k), 0), (1 << 64) - 1)
+            prefix, bits = int(self.root.ip[0]), int(self.root.ip[1])
+            nb = 0 if prefix + bits > 64 else 64 - (prefix + bits)
+            slot = (((v << (prefix & 63)) & ((1 << 64) - 1)) >> (prefix & 63)) >> (nb & 63)
+            return min(int(self.root.table[slot]), self.L - 1)
         out = C.c_uint64()
         rc = self._lib.rmi_hip_root_target(C.byref(self._rootc), self.dt, _key_bits(self.key_at(i), self.np_dtype),
                                            self.L, C.byref(out))

@@ -7,6 +7,7 @@ models/mod.rs:233-317.  The arithmetic runs in the HIP kernels behind include/rm
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import time
 from dataclasses import dataclass, field
 
@@ -54,10 +55,15 @@ class Model:
     kind: int
     p: tuple = (0.0, 0.0, 0.0, 0.0)
     ip: tuple = (0, 0)
+    table: object = field(default=None, repr=False, compare=False)   # radix tables: hint_table, np.uint32 (radix.rs:83-88)
 
     @property
     def name(self) -> str:
         return MODEL_NAMES[self.kind]
+
+    @property
+    def is_radix_table(self) -> bool:
+        return 8 <= self.kind <= 12
 
     def _c(self) -> _lib.ModelParams:
         m = _lib.ModelParams()
@@ -140,6 +146,8 @@ class Trainer:
         self._h = h
         self._host_keys = None
         self._keepalive = None
+        self._table_in_ctx = None
+        self._ctx_lock = threading.RLock()
         self.n = 0
         if keys is not None:
             self.set_keys(keys)
@@ -219,13 +227,33 @@ class Trainer:
             raise RMIError(kind)
         m = _lib.ModelParams()
         hk = C.c_void_p(self._host_keys.ctypes.data) if self._host_keys is not None else None
-        _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
-        return Model._from_c(m)
+        if not (8 <= kind <= 12):
+            _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
+            return Model._from_c(m)
+        with self._ctx_lock:                        # a table root's fit writes the context's table
+            _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
+            root = Model._from_c(m)
+            ent = C.c_uint64()
+            _check(self._lib.rmi_hip_root_table_entries(self._h, C.byref(ent)))
+            root.table = np.empty(int(ent.value), dtype=np.uint32)
+            _check(self._lib.rmi_hip_download_root_table(self._h, root.table.ctypes.data))
+            self._table_in_ctx = root.table
+        return root
 
     def train_leaves(self, root: Model, leaf: str | int, num_leaves: int) -> TrainedRMI:
         leaf_kind = leaf if isinstance(leaf, int) else self._lib.rmi_hip_model_from_name(leaf.encode())
         if leaf_kind < 0:
             raise RMIError(leaf_kind)
+        with self._ctx_lock:
+            return self._train_leaves_locked(root, leaf_kind, num_leaves)
+
+    def _train_leaves_locked(self, root: Model, leaf_kind: int, num_leaves: int) -> TrainedRMI:
+        if root.is_radix_table and self._table_in_ctx is not root.table:
+            if root.table is None:
+                raise ValueError("a radix-table root needs its hint table (Model.table)")
+            t = np.ascontiguousarray(root.table, dtype=np.uint32)
+            _check(self._lib.rmi_hip_set_root_table(self._h, t.ctypes.data, t.size), self._h)
+            self._table_in_ctx = root.table
         res = _lib.Result()
         rc = self._lib.rmi_hip_train_two_layer(self._h, C.byref(root._c()), leaf_kind, num_leaves, C.byref(res))
         _check(rc, self._h)

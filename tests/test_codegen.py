@@ -42,7 +42,7 @@ def _as_rmi(o, n):
     """Adapter: oracle result -> the attributes codegen.output_rmi reads (a TrainedRMI look-alike)."""
     return types.SimpleNamespace(
         branching_factor=o.num_leaves, num_rmi_rows=n,
-        root=types.SimpleNamespace(kind=o.root.kind, p=o.root.p, ip=o.root.ip),
+        root=types.SimpleNamespace(kind=o.root.kind, p=o.root.p, ip=o.root.ip, table=o.root.table),
         leaf_kind=o.leaf_kind, params_per_leaf=o.params_per_leaf,
         leaf_params=o.leaf_params, last_layer_max_l1s=o.leaf_err, build_time=123)
 
@@ -53,6 +53,9 @@ def _as_rmi(o, n):
     ("uniform_u32", "radix", "linear_spline", 1024, True),
     ("uniform_u64", "radix", "linear", 1024, True),       # tests/radix_model_wiki
     ("uniform_f64", "linear", "linear", 512, True),
+    ("books_u64", "radix18", "linear", 2048, True),       # hint table in <ns>_L0_PARAMETERS (radix.rs:83-170)
+    ("dups_u32", "radix8", "linear_spline", 256, True),   # 1 KiB table: literal array in <ns>_data.h
+    ("uniform_u64", "radix22", "cubic", 512, True),
 ])
 def test_emitted_code_compiles_and_is_sound(oracle, tmp_path, gen, root, leaf, L, with_err):
     if shutil.which("g++") is None:
@@ -71,7 +74,10 @@ def test_emitted_code_compiles_and_is_sound(oracle, tmp_path, gen, root, leaf, L
     assert np.array_equal(raw[:, :-1], o.leaf_params.view(np.uint64))
     assert np.array_equal(raw[:, -1], o.leaf_err)
     hdr = open(paths[f"{ns}.h"]).read()
-    assert f"const size_t RMI_SIZE = {codegen.rmi_size(o.root.kind, o.leaf_kind, L, True)};" in hdr
+    tlen = 0 if o.root.table is None else len(o.root.table)
+    assert f"const size_t RMI_SIZE = {codegen.rmi_size(o.root.kind, o.leaf_kind, L, True, tlen)};" in hdr
+    if tlen * 4 > 4096:
+        assert np.array_equal(np.fromfile(paths["L0_PARAMETERS"], dtype="<u4"), o.root.table)
     assert "bool load(char const* dataPath);" in hdr and "void cleanup();" in hdr and 'const char NAME[] = "rmi";' in hdr
     kt = {"uint64": "uint64_t", "uint32": "uint32_t", "f64": "double"}[suffix]
     main = MAIN_CPP.replace("NS", ns).replace("LKEYT", key_c).replace("KEYT", kt)

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("gen,spec,L", [("books_u64", "linear,linear", 4096), ("dups_u32", "radix,linear_spline", 1024),
-                                        ("uniform_u64", "cubic,linear", 2048), ("dups_u64", "linear,cubic", 1024)])
+                                        ("uniform_u64", "cubic,linear", 2048), ("dups_u64", "linear,cubic", 1024),
+                                        ("books_u64", "radix18,linear", 8192)])
 def test_cli_end_to_end(tmp_path, oracle, gen, spec, L):
     from tests.test_codegen import MAIN_CPP
     keys = dg.GENERATORS[gen](150_000)

@@ -35,6 +35,9 @@ def _compare(trainer_mod, oracle, keys, root, leaf, L, exact_root=True):
     o_root = oracle.fit_root(root, keys, L)
     g_root = tr.fit_root(root, L)
     assert g_root.p == o_root.p and g_root.ip == o_root.ip, f"root params differ: {g_root} vs {o_root}"
+    assert (g_root.table is None) == (o_root.table is None)
+    if o_root.table is not None:
+        assert np.array_equal(g_root.table, o_root.table), "hint table differs"
     try:
         o = oracle.train_two_layer(root, leaf, keys, L)
     except oracle.OracleError as oe:
@@ -81,6 +84,9 @@ GENS = ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "uniform_u32", 
     ("linear_spline", "linear", 4096),
     ("robust_linear", "linear", 4096),
     ("linear", "linear_spline", 4096),
+    ("radix18", "linear", 4096),
+    ("radix8", "linear_spline", 200),
+    ("radix22", "cubic", 32768),
 ])
 def test_parity_small(trainer_mod, oracle, gen, root, leaf, L):
     keys = dg.GENERATORS[gen](300_000)

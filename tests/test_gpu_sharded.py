@@ -69,6 +69,14 @@ def test_sharded_long_leaves():
         _run_sharded(train, sharded, keys, "linear", "linear_spline", 32, 4)
 
 
+def test_sharded_radix_table_root():
+    """Radix-table root: the hint table travels with the root (rmi_hip_set_root_table per shard context)."""
+    from rmi_amd import train, sharded
+    keys = dg.dups_u64(200_000)
+    _run_sharded(train, sharded, keys, "radix18", "linear", 4096, 4)
+    _run_sharded(train, sharded, dg.dups_u32(200_000), "radix8", "linear_spline", 128, 2)
+
+
 def test_sharded_cubic_leaves():
     from rmi_amd import train, sharded
     keys = dg.dups_u64(200_000)

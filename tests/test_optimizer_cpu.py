@@ -12,10 +12,10 @@ def test_branching_factors_and_lists(monkeypatch):
     assert opt.get_branching_factors() == [2 ** i for i in range(6, 25)]            # optimizer.rs:45
     assert opt._reference_top_only_layers() == ["radix", "radix18", "radix22", "robust_linear"]
     assert opt.anywhere_layers() == ["linear", "cubic", "linear_spline"]
-    assert opt.skipped_models() == ["radix18", "radix22"]
+    assert opt.skipped_models() == [] and opt.top_only_layers() == opt._reference_top_only_layers()
     # (tops + anywhere) x anywhere x every 5th branching factor (6, 11, 16, 21)
     cfgs = opt.first_phase_configs()
-    assert len(cfgs) == (2 + 3) * 3 * 4
+    assert len(cfgs) == (4 + 3) * 3 * 4
     assert cfgs[0] == ("radix,linear", 64) and cfgs[1] == ("radix,linear", 2 ** 11)
     monkeypatch.setenv("RMI_OPTIMIZER_PROFILE", "fast")
     assert opt.get_branching_factors() == [2 ** i for i in range(6, 25, 2)]
@@ -23,6 +23,7 @@ def test_branching_factors_and_lists(monkeypatch):
     assert len(opt.first_phase_configs()) == 3 * 2 * 2 and opt.skipped_models() == []
     monkeypatch.setenv("RMI_OPTIMIZER_PROFILE", "disk")
     assert opt.get_branching_factors()[-1] == 2 ** 27
+    assert opt.skipped_models() == ["normal", "lognormal", "loglinear"]
     monkeypatch.setenv("RMI_OPTIMIZER_PROFILE", "bogus")
     with pytest.raises(ValueError):
         opt.get_branching_factors()

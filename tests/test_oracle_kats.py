@@ -136,3 +136,52 @@ def test_worked_example_survey(oracle):
     # leaf 3: empty and last (Q6) -> stays (0,0)
     assert r.leaf_params[3].tolist() == [0.0, 0.0]
     assert oracle.check_lookup_property(r, keys)[0] == 0
+
+
+def test_radix_table_against_direct_restatement(oracle):
+    """RadixTable::new (radix.rs:90-121) has no unit test in the reference; pin the oracle's table
+    against a direct, independent transcription of those lines on small inputs."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n = int(rng.integers(2, 400))
+        keys = np.sort(rng.integers(1, 1 << int(rng.integers(10, 64)), size=n, dtype=np.uint64))
+        if trial % 2:
+            keys[n // 2:n // 2 + 3] = keys[n // 2]           # duplicate run
+            keys = np.sort(keys)
+        L = int(rng.integers(2, 300))
+        m = oracle.fit_root("radix8", keys, L)
+        ks = [int(k) for k in keys]
+        any_ones, no_ones = 0, (1 << 64) - 1
+        for k in ks:
+            any_ones |= k
+            no_ones &= k
+        agree = ((~no_ones) ^ any_ones) & ((1 << 64) - 1)     # bits on which all keys agree
+        prefix = 64
+        for b in range(64):
+            if not (agree >> (63 - b)) & 1:
+                prefix = b
+                break
+        bits, scale = 8, L / n
+        table = [0] * (1 << bits)
+        nb = 0 if prefix + bits > 64 else 64 - (prefix + bits)
+        last = 0
+        items, first = [], 0
+        for i, k in enumerate(ks):                            # FixDups: first-occurrence offsets, tail duplicate
+            if i == 0 or k != ks[i - 1]:
+                first = i
+            items.append((k, first))
+        items.append(items[-1])
+        for k, y in items:
+            ys = int(float(y) * scale) if abs(scale - 1.0) > 2.220446049250313e-16 else y
+            cur = (((k << (prefix & 63)) & ((1 << 64) - 1)) >> (prefix & 63)) >> (nb & 63)
+            if cur == last:
+                continue
+            table[cur] = ys
+            for j in range(last + 1, cur):
+                table[j] = ys
+            last = cur
+        for j in range(last + 1, len(table)):
+            table[j] = len(table)
+        assert m.ip == (prefix, bits)
+        assert [int(v) for v in m.table] == table
