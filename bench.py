@@ -181,6 +181,18 @@ def main():
                 out["roofline"]["traffic_note"] = tj.get("note")
             except Exception:
                 pass
+        if world == 1 and keys_np is not None:
+            # The boundary also takes host buffers (rmi_hip_upload_keys): the PCIe-inclusive rate of
+            # "pageable host keys -> HBM -> one pass of the hot path".  Reported beside, never as, `value`.
+            t0 = time.perf_counter()
+            tr.set_keys(keys_np)
+            t1 = time.perf_counter()
+            run_step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            out["pcie_inclusive"] = {"value": n_local / (t2 - t0), "unit": "keys/s", "upload_ms": (t1 - t0) * 1e3,
+                                     "upload_GBps": n_local * key_bytes / (t1 - t0) / 1e9, "step_ms": (t2 - t1) * 1e3,
+                                     "note": "pageable host buffer, hipMemcpy, then one step; not the headline value"}
         if not args.no_cpu_baseline and args.cpu_sample > 0 and world == 1:
             sample = keys_np[: min(args.cpu_sample, len(keys_np))]
             out["cpu_baseline"] = cpu_baseline(sample, args.spec, L_global, n_global)
