@@ -49,8 +49,8 @@ extern "C" {
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
 
 /* model registry, train/mod.rs:37-54.  On the device path: roots linear, linear_spline, cubic,
- * radix, robust_linear and the radix tables (ids 8-12); leaves linear, linear_spline, cubic
- * (radix is top-only in the reference; robust_linear and radix tables as leaves are rejected).
+ * radix, robust_linear and the radix tables (ids 8-12); leaves linear, linear_spline, cubic,
+ * robust_linear (radix is top-only in the reference; radix tables as leaves are rejected).
  * The rest of the registry is recognised by name and rejected with RMI_ERR_UNSUPPORTED_MODEL. */
 enum rmi_hip_model_kind {
   RMI_MODEL_LINEAR = 0,

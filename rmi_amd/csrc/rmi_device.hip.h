@@ -19,6 +19,7 @@ enum : uint32_t {
   EF_DEGENERATE_SPLIT = 1u << 1,
   EF_ROOT_OOB = 1u << 2,
   EF_NEG_VARIANCE = 1u << 3,
+  EF_ROBUST_TOO_SMALL = 1u << 5,   // linear.rs:248: assert!(bnd*2+1 < data.len()) on a leaf container
   EF_CUBIC_DEGENERATE = 1u << 4,   // cubic_spline.rs:46-65: `.unwrap()` on an empty search (distinct keys, one f64)
 };
 
@@ -67,7 +68,12 @@ struct DevState {
 
 template <typename K> struct KeyTraits;
 template <> struct KeyTraits<uint64_t> {
-  static __device__ __forceinline__ double as_float(uint64_t k) { return (double)k; }   // mod.rs:83
+  // `key as f64` (mod.rs:83): round-to-nearest-even of the integer.  hi * 2^32 + lo is the integer
+  // exactly and the FMA rounds it once, so this is the same value as the compiler's
+  // cvt/ldexp/cvt/add sequence in one operation fewer (it is on the per-key path of every pass).
+  static __device__ __forceinline__ double as_float(uint64_t k) {
+    return __builtin_fma((double)(uint32_t)(k >> 32), 4294967296.0, (double)(uint32_t)k);
+  }
   static __device__ __forceinline__ uint64_t as_uint(uint64_t k) { return k; }
   static __device__ __forceinline__ uint64_t minus_eps(uint64_t k) { return k - 1ull; }  // mod.rs:78
   static __device__ __forceinline__ uint64_t plus_eps(uint64_t k) { return k + 1ull; }   // mod.rs:80

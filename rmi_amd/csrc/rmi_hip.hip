@@ -64,6 +64,7 @@ struct rmi_hip_ctx {
   uint64_t err_threads = 196608;                // lanes of pass B (3 waves/SIMD)
   int fit_min_chunk = 64;
   int err_kernel = 1;                           // pass B: 0 = k_err_wave, 1 = k_err_range (leaf_start-driven), 2 = k_err_stream
+  bool robust_leaf = false;                     // this call's leaves are robust_linear (fitted by k_fit_leaf; predict like linear)
   int dbg = 0;                                  // ablation switches for profiling (0 = product behaviour)
   unsigned int long_min = 4096;                 // leaves with more points go to k_fit_long (>= FS_TMAX)
   // last result
@@ -551,7 +552,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   }
 
   HIPCHK(c, hipEventRecord(c->ev[0], s));
-  const bool stream_fit = (c->pipeline != 1) && (LEAF == K_LINEAR);
+  const bool stream_fit = (c->pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
   if (n_it == 0) {
     mark();                                              // a shard without keys: every leaf is empty
   } else if (!stream_fit) {
@@ -607,7 +608,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       HIPCHK(c, hipMemcpyAsync(c->d_cube, c->h_cube.data(), L_own * 8, hipMemcpyHostToDevice, s));
       cube = c->d_cube - sp.leaf_lo;
     }
-    hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, cube);
+    hipLaunchKernelGGL((k_fit_leaf<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, cube, c->robust_leaf);
     if constexpr (LEAF == K_CUBIC) {
       if (n_it + 2 > (uint64_t)CUBIC_LONG) {                 // long containers are possible
         const uint64_t wb = L_own < 4096 ? L_own : 4096;
@@ -661,7 +662,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
 template <int ROOT, typename K>
 static int dispatch_leaf(rmi_hip_ctx* c, const RootP& rp, int leaf_kind, uint64_t L) {
   switch (leaf_kind) {
-    case RMI_MODEL_LINEAR: return launch_pipeline<ROOT, K_LINEAR, K>(c, rp, L);
+    case RMI_MODEL_LINEAR: case RMI_MODEL_ROBUST_LINEAR: return launch_pipeline<ROOT, K_LINEAR, K>(c, rp, L);
     case RMI_MODEL_LINEAR_SPLINE: return launch_pipeline<ROOT, K_LINEAR_SPLINE, K>(c, rp, L);
     case RMI_MODEL_CUBIC: return launch_pipeline<ROOT, K_CUBIC, K>(c, rp, L);
     default: return RMI_ERR_UNSUPPORTED_MODEL;
@@ -693,8 +694,8 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if ((root->kind > RMI_MODEL_ROBUST_LINEAR && table_bits < 0) || leaf_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
   if (table_bits > 0 && (c->h_table.size() != (1ull << table_bits) || root->ip[1] != (uint64_t)table_bits || !c->d_table))
     return RMI_ERR_BAD_ARG;                                    // no (matching) table in this context: rmi_hip_set_root_table
-  // robust_linear as a leaf trims 0.01% tails of each container (linear.rs:247-252); not on the device path yet
-  if (leaf_kind == RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
+  // robust_linear as a leaf trims 0.01 % tails of each container (linear.rs:247-252): its own fit, then a linear leaf
+  c->robust_leaf = (leaf_kind == RMI_MODEL_ROBUST_LINEAR);
   HIPCHK(c, hipSetDevice(c->device));
   const int ppl = leaf_kind == RMI_MODEL_CUBIC ? 4 : 2;
   uint64_t L_own = num_leaves;
@@ -730,6 +731,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
     else if (st.err_flags & EF_ROOT_OOB) rc = RMI_ERR_ROOT_OUT_OF_BOUNDS;
     else if (st.err_flags & EF_DEGENERATE_SPLIT) rc = RMI_ERR_DEGENERATE_SPLIT;
     else if (st.err_flags & EF_NEG_VARIANCE) rc = RMI_ERR_NEGATIVE_VARIANCE;
+    else if (st.err_flags & EF_ROBUST_TOO_SMALL) rc = RMI_ERR_ROBUST_TOO_SMALL;
     else if (st.err_flags & EF_CUBIC_DEGENERATE) rc = RMI_ERR_CUBIC_DEGENERATE;
     set_err(c, "%s", rmi_hip_strerror(rc));
     return rc;

@@ -319,7 +319,7 @@ template <int LEAF, typename K>
 __device__ __forceinline__ void fit_one_leaf(uint64_t j, const K* __restrict__ keys, const Span& sp,
                                              const unsigned long long* __restrict__ leaf_start,
                                              DevState* __restrict__ st, double* __restrict__ params,
-                                             const double* __restrict__ cube = nullptr) {
+                                             const double* __restrict__ cube = nullptr, bool robust = false) {
   const uint64_t n = sp.n;
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
@@ -330,6 +330,44 @@ __device__ __forceinline__ void fit_one_leaf(uint64_t j, const K* __restrict__ k
     if constexpr (LEAF == K_CUBIC) { out[0] = 0.0; out[1] = 0.0; out[2] = 1.0; out[3] = 0.0; }  // cubic_spline.rs:19-21
     else { out[0] = 0.0; out[1] = 0.0; }                                                         // linear.rs:37-39
     return;
+  }
+  if constexpr (LEAF == K_LINEAR) {
+    if (robust) {
+      // RobustLinearModel::new (linear.rs:239-260) on the container: drop max(1, 0.01 %) items at each
+      // end of iter() -- the Q1 duplicate is never reached -- and run slr over the rest.
+      const uint64_t len = hi - lo + 1;
+      uint64_t bnd = (uint64_t)((double)len * 0.0001);
+      if (bnd < 1) bnd = 1;
+      if (!(bnd * 2 + 1 < len)) {                                      // assert!, linear.rs:248
+        atomicOr(&st->err_flags, EF_ROBUST_TOO_SMALL);
+        out[0] = 0.0; out[1] = 0.0;
+        return;
+      }
+      const uint64_t a = lo + bnd, b = hi - bnd;                       // items [bnd, len - bnd) of the container
+      double mean_x = 0.0, mean_y = 0.0, c = 0.0, m2 = 0.0;
+      uint64_t cnt = 0;
+      uint64_t y = first_occurrence(keys, a, sp.rd_lo);
+      for (uint64_t i = a; i <= b; i++) {
+        const K k = keys[i];
+        if (i > a && !(k == keys[i - 1])) y = i;
+        const double x = KeyTraits<K>::as_float(k), yf = (double)y;
+        cnt += 1;
+        const double nf = (double)cnt;
+        const double dx = x - mean_x;
+        mean_x += dx / nf;
+        mean_y += (yf - mean_y) / nf;
+        c += dx * (yf - mean_y);
+        m2 += dx * (x - mean_x);
+      }
+      if (cnt == 1) { out[0] = mean_y; out[1] = 0.0; return; }         // linear.rs:41-43
+      const double cov = c / (double)(cnt - 1);
+      const double var = m2 / (double)(cnt - 1);
+      if (!(var >= 0.0)) atomicOr(&st->err_flags, EF_NEG_VARIANCE);
+      if (var == 0.0) { out[0] = mean_y; out[1] = 0.0; return; }
+      const double beta = cov / var;
+      out[0] = mean_y - beta * mean_x; out[1] = beta;
+      return;
+    }
   }
   if (ck == 1) {
     // single point (key[lo], y = lo): its key differs from key[lo-1] (different leaf) so y == lo
@@ -480,10 +518,11 @@ template <int LEAF, typename K>
 __global__ void __launch_bounds__(256) k_fit_leaf(const K* __restrict__ keys, Span sp,
                                                   const unsigned long long* __restrict__ leaf_start,
                                                   DevState* __restrict__ st,
-                                                  double* __restrict__ params, const double* __restrict__ cube) {
+                                                  double* __restrict__ params, const double* __restrict__ cube,
+                                                  bool robust) {
   const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= sp.leaf_hi) return;
-  fit_one_leaf<LEAF, K>(j, keys, sp, leaf_start, st, params, cube);
+  fit_one_leaf<LEAF, K>(j, keys, sp, leaf_start, st, params, cube, robust);
 }
 
 

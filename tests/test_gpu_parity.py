@@ -120,6 +120,16 @@ def test_parity_cubic_leaves_f64(trainer_mod, oracle):
     _compare(trainer_mod, oracle, keys, "cubic", "cubic", 256)
 
 
+@pytest.mark.parametrize("gen,root,L", [("uniform_u64", "linear", 512), ("dups_u64", "robust_linear", 2048),
+                                        ("books_u64", "linear", 64), ("dups_u32", "radix", 1024),
+                                        ("books_u64", "linear", 20_000)])
+def test_parity_robust_linear_leaves(trainer_mod, oracle, gen, root, L):
+    """leaf = robust_linear (linear.rs:239-260 on every container): 0.01 % tails trimmed; containers of
+    fewer than 4 points trip the reference's assert -> RMI_ERR_ROBUST_TOO_SMALL (last case)."""
+    keys = dg.GENERATORS[gen](250_000)
+    _compare(trainer_mod, oracle, keys, root, "robust_linear", L)
+
+
 def test_parity_config1(trainer_mod, oracle):
     """BASELINE config 1: linear,linear 1024 on 1M synthetic sorted uint64."""
     keys = dg.uniform_u64(1_000_000)
