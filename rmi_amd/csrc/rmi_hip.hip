@@ -61,7 +61,7 @@ struct rmi_hip_ctx {
   bool profile_kernels = false;
   int pipeline = 2;                             // 1 = one kernel per reference pass; 2 = tiled/streaming kernels
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
-  uint64_t err_threads = 196608;                // lanes of pass B (3 waves/SIMD)
+  uint64_t err_threads = 262144;                // lanes of pass B (4 waves/SIMD)
   int fit_min_chunk = 64;
   int err_kernel = 1;                           // pass B: 0 = k_err_wave, 1 = k_err_range (leaf_start-driven), 2 = k_err_stream
   bool robust_leaf = false;                     // this call's leaves are robust_linear (fitted by k_fit_leaf; predict like linear)

@@ -630,10 +630,12 @@ __device__ __forceinline__ void convert_row(unsigned long long* __restrict__ pan
   kprev = kp;
 }
 
-constexpr int ER_QCAP = 128;      // result queue per wave (drained in bursts of >= 64)
+constexpr int ER_QDRAIN = 8;      // drain the result queue once this many (lane, leaf) maxima are pending
+constexpr int ER_QCAP = ER_QDRAIN + 64;   // at most 64 more arrive per panel in the fast loop; 4 waves/SIMD need <= 10 KB LDS per wave
+      // result queue per wave (drained in bursts of >= 64)
 
 template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(64, 3) k_err_range(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
+__global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
                                                   const unsigned long long* __restrict__ leaf_start,
                                                   const double* __restrict__ params,
                                                   unsigned long long* __restrict__ leaf_maxerr,
@@ -789,7 +791,7 @@ __global__ void __launch_bounds__(64, 3) k_err_range(const K* __restrict__ keys,
             pn_ok = false; pn_inflight = false;
             pn_need = cur_leaf < leaf_last;
           }
-          if constexpr (!FAST) { if (pending >= 64) drain(); }
+          if constexpr (!FAST) { if (pending >= ER_QDRAIN) drain(); }
         }
         if (valid) {
           double f;
@@ -806,7 +808,7 @@ __global__ void __launch_bounds__(64, 3) k_err_range(const K* __restrict__ keys,
     if (__any(general)) steps(std::false_type{}, std::false_type{});
     else if (plain_ok) steps(std::true_type{}, std::true_type{});
     else steps(std::true_type{}, std::false_type{});
-    if (pending >= 64) drain();                              // (at most 64 more can arrive per panel in the fast loop)
+    if (pending >= ER_QDRAIN) drain();                       // (at most 64 more can arrive per panel in the fast loop)
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
     if (row_i >= chunk_end) lane_done = true;
