@@ -106,36 +106,54 @@ __device__ __forceinline__ K bits_to_key(unsigned long long b) {
   else return __builtin_bit_cast(K, (unsigned int)b);
 }
 
-// Coalesced load of panel P of this wave (64 rows x 16 keys) into registers: instruction k
-// covers rows 4k..4k+3, 16 lanes per row.  Indices past the end are clamped to n-1 (no branches
-// around the loads); the duplicated key is masked out by the validity masks downstream.
+// Coalesced load of panel P of this wave (64 rows x 16 keys) into registers with 16-byte loads:
+// a lane fetches V = 16/sizeof(K) consecutive keys of one row, LPR = 16/V lanes cover a row (one
+// full 128-B line for 8-byte keys), an instruction covers 64/LPR rows, LPR instructions cover the
+// panel.  Near the end of the readable keys the panel is fetched key by key instead, indices past
+// the end clamped to n-1 (no branches around the loads); the duplicated key is masked out by the
+// validity masks downstream.
+template <typename K> struct PanelGeom {
+  static constexpr int V = 16 / (int)sizeof(K);      // keys per lane per load
+  static constexpr int LPR = FS_ROW / V;              // lanes per row == loads per panel
+  static constexpr int RPI = 64 / LPR;                // rows per load instruction
+};
 template <typename K>
 __device__ __forceinline__ void load_panel(K (&stage)[FS_ROW], const K* __restrict__ keys, uint64_t n,
                                            uint64_t wave_base, uint64_t C, uint64_t P, int lane) {
+  using G = PanelGeom<K>;
+  struct alignas(8) Vec { K v[G::V]; };                 // 16 bytes; the address is only key-aligned in a shard
   // wave-uniform base (SGPRs) + one 32-bit lane offset: no per-load 64-bit VGPR address math
   const uint64_t ubase = wave_base + P * FS_ROW;
-  const unsigned int loff = (unsigned int)(lane >> 4) * (unsigned int)C + (unsigned int)(lane & 15);
-  const uint64_t step = 4 * C;
+  const unsigned int loff = (unsigned int)(lane / G::LPR) * (unsigned int)C + (unsigned int)(lane % G::LPR) * G::V;
+  const uint64_t step = (uint64_t)G::RPI * C;
   if (wave_base + 63 * C + (P + 1) * FS_ROW <= n) {          // wave-uniform: whole panel in range
 #pragma unroll
-    for (int k = 0; k < FS_ROW; k++) {
+    for (int k = 0; k < G::LPR; k++) {
       const K* __restrict__ pk = keys + (ubase + (uint64_t)k * step);
-      stage[k] = pk[loff];
+      const Vec t = *reinterpret_cast<const Vec*>(pk + loff);
+#pragma unroll
+      for (int q = 0; q < G::V; q++) stage[k * G::V + q] = t.v[q];
     }
   } else {
     const uint64_t last = n - 1;
 #pragma unroll
-    for (int k = 0; k < FS_ROW; k++) {
-      const uint64_t gi = ubase + (uint64_t)k * step + loff;
-      stage[k] = keys[gi < last ? gi : last];
+    for (int k = 0; k < G::LPR; k++) {
+#pragma unroll
+      for (int q = 0; q < G::V; q++) {
+        const uint64_t gi = ubase + (uint64_t)k * step + loff + q;
+        stage[k * G::V + q] = keys[gi < last ? gi : last];
+      }
     }
   }
 }
 template <typename K>
 __device__ __forceinline__ void stage_to_lds(const K (&stage)[FS_ROW], unsigned long long* panel, int lane) {
-  const int base = (lane >> 4) * FS_STRIDE + (lane & 15);
+  using G = PanelGeom<K>;
+  const int base = (lane / G::LPR) * FS_STRIDE + (lane % G::LPR) * G::V;
 #pragma unroll
-  for (int k = 0; k < FS_ROW; k++) panel[base + k * 4 * FS_STRIDE] = key_to_bits<K>(stage[k]);
+  for (int k = 0; k < G::LPR; k++)
+#pragma unroll
+    for (int q = 0; q < G::V; q++) panel[base + k * G::RPI * FS_STRIDE + q] = key_to_bits<K>(stage[k * G::V + q]);
 }
 
 // Phase 1: classify the row of this lane -- straight-line code, no branches: all 16 raw keys are
