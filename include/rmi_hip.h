@@ -211,6 +211,13 @@ int rmi_hip_root_table_entries(const rmi_hip_ctx* ctx, uint64_t* entries);
 int rmi_hip_download_root_table(const rmi_hip_ctx* ctx, uint32_t* host_out);
 int rmi_hip_set_root_table(rmi_hip_ctx* ctx, const uint32_t* host_table, uint64_t entries);
 
+/* Error-bounded mode (`--bounded line_size`, train_bounded train/mod.rs:156-184): cache_fix
+ * (cache_fix.rs:109-150) is a greedy, sequential pass over the unique u64 keys on the host; the RMI
+ * is then trained, on the device as usual, over the spline keys (upload them as a key set of their
+ * own).  The spline ((key, offset) pairs, 16 B each) stays in the context until the next call. */
+int rmi_hip_cache_fix(rmi_hip_ctx* ctx, const uint64_t* host_keys, uint64_t n, uint64_t line_size, uint64_t* num_points);
+int rmi_hip_download_cache_fix(const rmi_hip_ctx* ctx, uint64_t* host_out_pairs /* 2 * num_points */);
+
 /* `linear` root fit fed with consecutive chunks of the global key array (same recurrence and
  * result as rmi_hip_fit_root; for data that is produced or held shard by shard). */
 typedef struct rmi_hip_root_stream rmi_hip_root_stream;

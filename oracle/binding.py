@@ -111,6 +111,13 @@ def lib() -> C.CDLL:
         L.orc_bucket_ids.restype = C.c_int
         L.orc_check_lookup_property.argtypes = [C.POINTER(_Trained), C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_check_lookup_property.restype = C.c_uint64
+        L.orc_cache_fix.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+        L.orc_cache_fix.restype = C.c_int
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_free.restype = None
+        L.orc_check_bounded_property.argtypes = [C.POINTER(_Trained), C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                 C.POINTER(C.c_uint64)]
+        L.orc_check_bounded_property.restype = C.c_uint64
         L.orc_model_free.argtypes = [C.POINTER(_Model)]
         L.orc_model_free.restype = None
         L.orc_version.restype = C.c_char_p
@@ -270,4 +277,32 @@ def check_lookup_property(rmi: TrainedRMI, keys: np.ndarray):
     keys = np.ascontiguousarray(keys)
     fb = C.c_uint64(0)
     bad = lib().orc_check_lookup_property(C.byref(rmi._c[0]), dtype_of(keys), keys.ctypes.data, len(keys), C.byref(fb))
+    return int(bad), int(fb.value)
+
+
+def cache_fix(keys: np.ndarray, line_size: int) -> np.ndarray:
+    """cache_fix.rs:109-150 -> [m, 2] uint64 (key, offset) spline points."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    ptr = C.POINTER(C.c_uint64)()
+    cnt = C.c_uint64(0)
+    rc = lib().orc_cache_fix(keys.ctypes.data, len(keys), line_size, C.byref(ptr), C.byref(cnt))
+    if rc:
+        raise OracleError(rc)
+    out = np.ctypeslib.as_array(ptr, shape=(int(cnt.value) * 2,)).copy().reshape(-1, 2)
+    lib().orc_free(ptr)
+    return out
+
+
+def train_bounded(root_kind, leaf_kind, keys: np.ndarray, num_leaves: int, line_size: int):
+    """train_bounded (train/mod.rs:156-184): RMI over the re-indexed spline points.  Returns (rmi, spline)."""
+    spline = cache_fix(keys, line_size)
+    rmi = train_two_layer(root_kind, leaf_kind, np.ascontiguousarray(spline[:, 0]), num_leaves)
+    return rmi, spline
+
+
+def check_bounded_property(rmi: TrainedRMI, spline: np.ndarray, line_size: int, keys: np.ndarray):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    sp = np.ascontiguousarray(spline, dtype=np.uint64)
+    fb = C.c_uint64(0)
+    bad = lib().orc_check_bounded_property(C.byref(rmi._c[0]), sp.ctypes.data, len(sp), line_size, keys.ctypes.data, len(keys), C.byref(fb))
     return int(bad), int(fb.value)

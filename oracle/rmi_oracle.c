@@ -862,3 +862,121 @@ uint64_t orc_check_lookup_property(const orc_trained_rmi* rmi, int dtype, const 
   }
   return bad;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * cache_fix.rs
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint64_t from_x, from_y, to_x, to_y; } cf_spline;
+
+static inline uint64_t cf_predict(const cf_spline* s, uint64_t inp) {      /* cache_fix.rs:37-43 */
+  double v0 = (double)s->from_y, v1 = (double)s->to_y;
+  double t = ((double)(inp - s->from_x)) / (double)(s->to_x - s->from_x);
+  return sat_f64_to_u64(fma(1.0 - t, v0, t * v1));                          /* `as usize` */
+}
+
+typedef struct {
+  int has; cf_spline sp;
+  uint64_t* px; uint64_t* py; size_t np, cap;      /* curr_pts */
+  uint64_t line;
+} cf_fit;
+
+static int cf_push_pt(cf_fit* f, uint64_t x, uint64_t y) {
+  if (f->np == f->cap) {
+    size_t nc = f->cap ? f->cap * 2 : 64;
+    uint64_t* nx = (uint64_t*)realloc(f->px, nc * 8); uint64_t* ny = (uint64_t*)realloc(f->py, nc * 8);
+    if (!nx || !ny) return -1;
+    f->px = nx; f->py = ny; f->cap = nc;
+  }
+  f->px[f->np] = x; f->py[f->np] = y; f->np++;
+  return 0;
+}
+
+/* SplineFit::add_point (cache_fix.rs:60-86): 1 = emitted a point into (*ox,*oy), 0 = none, <0 = assert */
+static int cf_add_point(cf_fit* f, uint64_t x, uint64_t y, uint64_t* ox, uint64_t* oy) {
+  if (!f->has) { f->has = 1; f->sp.from_x = f->sp.to_x = x; f->sp.from_y = f->sp.to_y = y; *ox = x; *oy = y; return 1; }
+  cf_spline last = f->sp;
+  if (!(x >= last.from_x) || !(y >= last.from_y)) return ORC_ERR_BAD_ARG;   /* with_new_dest asserts */
+  cf_spline prop = last; prop.to_x = x; prop.to_y = y;
+  if (cf_push_pt(f, last.to_x, last.to_y)) return ORC_ERR_BAD_ARG;
+  int ok = 1;
+  for (size_t i = 0; i < f->np; i++) {                                      /* check_spline :95-102 */
+    if (cf_predict(&prop, f->px[i]) / f->line != f->py[i] / f->line) { ok = 0; break; }
+  }
+  if (ok) { f->sp = prop; return 0; }
+  if (!(x > last.to_x)) return ORC_ERR_BAD_ARG;                              /* assert :77 */
+  if (!(last.to_x <= x) || !(last.to_y <= y)) return ORC_ERR_BAD_ARG;        /* Spline::from asserts */
+  f->sp.from_x = last.to_x; f->sp.from_y = last.to_y; f->sp.to_x = x; f->sp.to_y = y;
+  f->np = 0;
+  if (cf_push_pt(f, x, y)) return ORC_ERR_BAD_ARG;
+  *ox = last.to_x; *oy = last.to_y;
+  return 1;
+}
+
+int orc_cache_fix(const uint64_t* keys, uint64_t n, uint64_t line_size, uint64_t** pairs_out, uint64_t* count_out) {
+  if (!keys || !pairs_out || !count_out || line_size == 0) return ORC_ERR_BAD_ARG;
+  if (!(n > line_size)) return ORC_ERR_BAD_ARG;                              /* assert :110 */
+  cf_fit f; memset(&f, 0, sizeof f); f.line = line_size;
+  size_t cap = 1024, cnt = 0;
+  uint64_t* out = (uint64_t*)malloc(cap * 16);
+  if (!out) return ORC_ERR_BAD_ARG;
+#define CF_EMIT(X, Y) do { if (cnt == cap) { cap *= 2; uint64_t* t_ = (uint64_t*)realloc(out, cap * 16); if (!t_) { free(out); free(f.px); free(f.py); return ORC_ERR_BAD_ARG; } out = t_; } \
+                           out[2 * cnt] = (X); out[2 * cnt + 1] = (Y); cnt++; } while (0)
+  uint64_t last_key = 0;
+  int rc = 0;
+  for (uint64_t i = 0; i < n; i++) {                                         /* iter_unique(): first occurrences */
+    if (i > 0 && keys[i] == keys[i - 1]) continue;
+    const uint64_t key = keys[i], off = i;
+    if (key == 0 || !(key - 1 >= last_key)) { rc = ORC_ERR_BAD_ARG; break; } /* minus_epsilon / assert :122 */
+    uint64_t ox, oy;
+    if (key - 1 != last_key) {
+      rc = cf_add_point(&f, key - 1, off, &ox, &oy);
+      if (rc < 0) break;
+      if (rc == 1) CF_EMIT(ox, oy);
+    }
+    rc = cf_add_point(&f, key, off, &ox, &oy);
+    if (rc < 0) break;
+    if (rc == 1) CF_EMIT(ox, oy);
+    rc = 0;
+    last_key = key;
+  }
+  if (rc == 0 && f.has) CF_EMIT(f.sp.to_x, f.sp.to_y);                       /* finish() :89-91 */
+#undef CF_EMIT
+  free(f.px); free(f.py);
+  if (rc < 0) { free(out); return rc; }
+  *pairs_out = out; *count_out = cnt;
+  return ORC_OK;
+}
+void orc_free(void* p) { free(p); }
+
+/* generate_cache_fix_code: codegen.rs:396-447 */
+static uint64_t emitted_bounded_lookup(const orc_trained_rmi* r, const uint64_t* sp, uint64_t num_spline_pts,
+                                       uint64_t line_size, uint64_t total_keys, uint64_t key, int* ub) {
+  uint64_t esearch; okey k; k.bits = key;
+  uint64_t start = emitted_lookup(r, ORC_KEY_U64, k, &esearch);
+  uint64_t upper = (start + esearch > num_spline_pts) ? num_spline_pts : start + esearch;
+  uint64_t lower = (esearch > start) ? 0 : start - esearch;
+  uint64_t lo = lower, hi = upper;                                           /* std::lower_bound on .key */
+  while (lo < hi) { uint64_t mid = lo + (hi - lo) / 2; if (sp[2 * mid] < key) lo = mid + 1; else hi = mid; }
+  uint64_t res = lo;
+  if (res == num_spline_pts) return total_keys - 1;
+  if (res == 0) { *ub = 1; return 0; }                                       /* *(res - 1) before begin: UB in the emitted code */
+  uint64_t k1 = sp[2 * (res - 1)], v1i = sp[2 * (res - 1) + 1], k2 = sp[2 * res], v2i = sp[2 * res + 1];
+  double v0 = (double)v1i, v1 = (double)v2i;
+  double t = ((double)(key - k1)) / (double)(k2 - k1);
+  return (sat_f64_to_u64(fma(1.0 - t, v0, t * v1)) / line_size) * line_size;
+}
+
+uint64_t orc_check_bounded_property(const orc_trained_rmi* rmi, const uint64_t* spline_pairs, uint64_t num_spline,
+                                    uint64_t line_size, const uint64_t* keys, uint64_t n, uint64_t* first_bad) {
+  uint64_t bad = 0; if (first_bad) *first_bad = n;
+  uint64_t lb = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    if (i > 0 && keys[i] != keys[i - 1]) lb = i;
+    int ub = 0;
+    uint64_t guess = emitted_bounded_lookup(rmi, spline_pairs, num_spline, line_size, n, keys[i], &ub);
+    uint64_t diff = guess > lb ? guess - lb : lb - guess;
+    if (ub || diff > line_size) { if (!bad && first_bad) *first_bad = i; bad++; }
+  }
+  return bad;
+}
+

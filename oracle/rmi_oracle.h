@@ -129,6 +129,21 @@ int orc_bucket_ids(const orc_model* root, int dtype, const void* keys, uint64_t 
 uint64_t orc_check_lookup_property(const orc_trained_rmi* rmi, int dtype, const void* keys,
                                    uint64_t n, uint64_t* first_bad);
 
+/* --- error-bounded mode (`--bounded line_size`): cache_fix.rs, train/mod.rs:156-184 --- */
+
+/* cache_fix(data, line_size) (cache_fix.rs:109-150): greedy spline over the unique keys (and their
+ * predecessors key-1) such that interpolating between consecutive spline points lands in the right
+ * `line_size`-aligned block.  *pairs_out = malloc'd [count][2] = (key, offset); orc_free() it.
+ * Returns ORC_ERR_BAD_ARG where the reference asserts. */
+int orc_cache_fix(const uint64_t* keys, uint64_t n, uint64_t line_size, uint64_t** pairs_out, uint64_t* count_out);
+void orc_free(void* p);
+
+/* The emitted lookup() of a bounded RMI (codegen.rs:396-447) -- `rmi` trained on the spline keys --
+ * and the reference tests' property |lookup(key) - lower_bound(key)| <= line_size
+ * (tests/cache_fix_wiki/main.cpp:26-44).  Returns the number of violating keys. */
+uint64_t orc_check_bounded_property(const orc_trained_rmi* rmi, const uint64_t* spline_pairs, uint64_t num_spline,
+                                    uint64_t line_size, const uint64_t* keys, uint64_t n, uint64_t* first_bad);
+
 const char* orc_version(void);
 
 #ifdef __cplusplus

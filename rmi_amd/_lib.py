@@ -52,6 +52,8 @@ SYMBOLS = [
     ("rmi_hip_generate_keys", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     ("rmi_hip_download_keys", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_device_keys", C.c_void_p, [C.c_void_p]),
+    ("rmi_hip_cache_fix", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("rmi_hip_download_cache_fix", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_root_table_entries", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("rmi_hip_download_root_table", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_set_root_table", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),

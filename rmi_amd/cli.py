@@ -6,8 +6,8 @@ Same positional arguments and the flags that concern the single-train and param-
 --no-code, --no-errors, -d/--data-path, -t/--threads (accepted, unused: the work runs on the GPU),
 --zero-build-time, --param-grid, --disable-parallel-training, --optimize <file> (Pareto search,
 src/main.rs:134-163) and --max-size <bytes> (train_for_size, :276-294).  The data type comes from a
-substring of the input path (uint64 / uint32 / f64, src/main.rs:122-132).  --bounded (cache-fix) is
-outside this build's scope and is rejected.
+substring of the input path (uint64 / uint32 / f64, src/main.rs:122-132).  --bounded <line_size>
+(cache-fix, u64 data only, src/main.rs:277-285) trains over the spline points.
 """
 from __future__ import annotations
 
@@ -36,7 +36,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--disable-parallel-training", action="store_true", help="accepted for compatibility")
     ap.add_argument("--optimize", metavar="file", help="Search for Pareto efficient RMI configurations. Specify the name of the output file.")
     ap.add_argument("--max-size", metavar="BYTES", type=int, help="uses the optimizer to find an RMI with a size less than specified")
-    ap.add_argument("--bounded", help="(not in this build)")
+    ap.add_argument("--bounded", metavar="line_size", type=int,
+                    help="construct an error-bounded RMI using the cachefix method for the given line size")
     ap.add_argument("--device", type=int, default=0)
     return ap
 
@@ -55,9 +56,6 @@ def _stats(rmi: train.TrainedRMI, n: int) -> dict:
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
-    if args.bounded:
-        print("--bounded is outside this build's scope (see DESIGN.md)", file=sys.stderr)
-        return 2
     if args.namespace and args.param_grid:
         print("Can only specify one of namespace or param-grid", file=sys.stderr)      # src/main.rs:116-118
         return 2
@@ -100,6 +98,11 @@ def main(argv=None) -> int:
         elif not args.models or args.branching_factor is None:
             print("models and branching factor are required", file=sys.stderr)
             return 2
+        elif args.bounded is not None:                                                 # src/main.rs:277-285
+            if keys.dtype != np.uint64:
+                print("Can only construct a bounded RMI on u64 data.", file=sys.stderr)
+                return 1
+            rmi = tr.train_bounded(args.models, args.branching_factor, args.bounded)
         else:
             rmi = tr.train(args.models, args.branching_factor)
         print(f"Model build time: {rmi.build_time // 1_000_000} ms (device {rmi.device_ns / 1e6:.3f} ms)")

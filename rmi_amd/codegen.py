@@ -77,11 +77,13 @@ def c_float(v: float) -> str:
     return s
 
 
-def rmi_size(root_kind: int, leaf_kind: int, num_leaves: int, with_errors: bool, root_table_entries: int = 0) -> int:
-    """codegen.rs:375-394 (two layers, no cache-fix).  A radix-table root is its hint table (4 B per entry)."""
+def rmi_size(root_kind: int, leaf_kind: int, num_leaves: int, with_errors: bool, root_table_entries: int = 0,
+             spline_points: int = 0) -> int:
+    """codegen.rs:375-394 (two layers).  A radix-table root is its hint table (4 B per entry); a
+    bounded RMI adds 16 B per spline point (:389-391)."""
     root_bytes = 4 * root_table_entries if root_kind in RADIX_TABLES else {CUBIC: 32, RADIX: 16}.get(root_kind, 16)
     leaf_bytes = 32 if leaf_kind == CUBIC else 16
-    return root_bytes + leaf_bytes * num_leaves + (8 * num_leaves if with_errors else 0)
+    return root_bytes + leaf_bytes * num_leaves + (8 * num_leaves if with_errors else 0) + 16 * spline_points
 
 
 def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", include_errors: bool = True,
@@ -186,15 +188,36 @@ def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", i
         free_code.append("    free(L1_PARAMETERS);")
     read_code += [f"    infile.read((char*)L1_PARAMETERS, {layer1_size});",
                   "    if (!infile.good()) return false;", "  }"]
+    # ---- cache-fix spline: one more layer of (key, offset) pairs, always an Array (codegen.rs:487-496) ----
+    cache_fix = getattr(rmi, "cache_fix", None)
+    if cache_fix is not None:
+        line_size, spline = int(cache_fix[0]), np.ascontiguousarray(cache_fix[1], dtype="<u8").reshape(-1, 2)
+        f2 = f"{namespace}_L2_PARAMETERS"
+        with open(os.path.join(data_dir, f2), "wb") as f:
+            f.write(spline.tobytes())
+        paths["L2_PARAMETERS"] = os.path.join(data_dir, f2)
+        nbytes = spline.size * 8
+        cf_malloc = nbytes >= 4 * 1024
+        data_h.append("uint64_t* L2_PARAMETERS;" if cf_malloc else f"uint64_t L2_PARAMETERS[{spline.size}];")
+        read_code += ["  {", f"    std::ifstream infile(std::filesystem::path(dataPath) / \"{f2}\", std::ios::in | std::ios::binary);",
+                      "    if (!infile.good()) return false;"]
+        if cf_malloc:
+            read_code += [f"    L2_PARAMETERS = (uint64_t*) malloc({nbytes});", "    if (L2_PARAMETERS == NULL) return false;"]
+            free_code.append("    free(L2_PARAMETERS);")
+        read_code += [f"    infile.read((char*)L2_PARAMETERS, {nbytes});", "    if (!infile.good()) return false;", "  }"]
     read_code += ["  return true;", "}"]
     free_code.append("}")
     data_h.append("} // namespace")
 
     # ---- code ----
     report_errors = include_errors
-    sig = f"uint64_t lookup({key_type} key, size_t* err)" if report_errors else f"uint64_t lookup({key_type} key)"
+    lookup_name = "lookup" if cache_fix is None else "_rmi_lookup_pre_cachefix"          # codegen.rs:621-625
+    sig = f"uint64_t {lookup_name}({key_type} key, size_t* err)" if report_errors else f"uint64_t {lookup_name}({key_type} key)"
     code = [f'#include "{namespace}.h"', f'#include "{namespace}_data.h"', "#include <math.h>", "#include <cmath>",
-            "#include <fstream>", "#include <filesystem>", "#include <iostream>", f"namespace {namespace} {{"]
+            "#include <fstream>", "#include <filesystem>", "#include <iostream>"]
+    if cache_fix is not None:
+        code.append("#include <algorithm>")
+    code.append(f"namespace {namespace} {{")
     code += read_code + free_code
     fns = []
     for k in (root.kind, leaf_kind):
@@ -229,13 +252,53 @@ inline size_t FCLAMP(double inp, double bound) {
     code.append(err_line)
     code.append(f"  return FCLAMP(fpred, {n}.0 - 1.0);")       # always bounds-checked (codegen.rs:713-717)
     code.append("}")
+    if cache_fix is not None:                                   # generate_cache_fix_code, codegen.rs:396-447
+        code.append(f"""
+struct __attribute__((packed)) SplinePoint {{
+  uint64_t key;
+  uint64_t value;
+}};
+
+uint64_t lookup(uint64_t key, size_t* err) {{
+  const uint64_t num_spline_pts = {len(spline)};
+  const uint64_t total_keys = {int(rmi.num_data_rows)};
+  size_t error_on_spline_search;
+
+  struct SplinePoint* begin = (struct SplinePoint*) L2_PARAMETERS;
+
+  *err = {line_size};
+  uint64_t start = _rmi_lookup_pre_cachefix(key, &error_on_spline_search);
+
+  size_t upper = (start + error_on_spline_search > num_spline_pts
+                  ? num_spline_pts : start + error_on_spline_search);
+  size_t lower = (error_on_spline_search > start
+                  ? 0 : start - error_on_spline_search);
+
+  struct SplinePoint* res = std::lower_bound(begin + lower,
+                                             begin + upper,
+                                             key,
+                                             [](const auto& lhs, const auto rhs) {{ return lhs.key < rhs; }});
+
+  if (res == begin + num_spline_pts)
+    // we've searched for something past the last point
+    return total_keys - 1;
+
+  auto pt1 = *(res - 1);
+  auto pt2 = *res;
+
+  auto v0 = (double)pt1.value;
+  auto v1 = (double)pt2.value;
+  auto t = ((double)(key - pt1.key)) / (double)(pt2.key - pt1.key);
+  return (((uint64_t) std::fma(1.0 - t, v0, t * v1)) / {line_size}) * {line_size};
+}}""")
     code.append("} // namespace")
 
     bt = int(getattr(rmi, "build_time", 0) if build_time_ns is None else build_time_ns)
     header = ["#include <cstddef>", "#include <cstdint>", f"namespace {namespace} {{",
               "bool load(char const* dataPath);", "void cleanup();",
-              f"const size_t RMI_SIZE = {rmi_size(root.kind, leaf_kind, L, include_errors, 0 if root.table is None else len(root.table))};",
-              f"const uint64_t BUILD_TIME_NS = {bt};", f'const char NAME[] = "{namespace}";', f"{sig};", "}"]
+              f"const size_t RMI_SIZE = {rmi_size(root.kind, leaf_kind, L, include_errors, 0 if root.table is None else len(root.table), 0 if cache_fix is None else len(spline))};",
+              f"const uint64_t BUILD_TIME_NS = {bt};", f'const char NAME[] = "{namespace}";',
+              (f"{sig};" if cache_fix is None else "uint64_t lookup(uint64_t key, size_t* err);"), "}"]
 
     for name, lines in ((f"{namespace}.cpp", code), (f"{namespace}_data.h", data_h), (f"{namespace}.h", header)):
         pth = os.path.join(out_dir, name)

@@ -44,6 +44,7 @@ struct rmi_hip_ctx {
   std::vector<uint32_t> h_table;
   uint32_t* d_table = nullptr;
   uint64_t d_table_cap = 0;
+  std::vector<uint64_t> h_spline;               // last rmi_hip_cache_fix result, (key, offset) pairs
   double* d_cube = nullptr;                     // cubic leaves: span, then pow(span, 3.0), per leaf
   uint64_t cube_cap = 0;
   std::vector<double> h_cube;
@@ -405,6 +406,17 @@ int rmi_hip_set_root_table(rmi_hip_ctx* c, const uint32_t* table, uint64_t entri
   HIPCHK(c, hipStreamSynchronize(c->stream));                  // a train call may still be reading the old table
   if (table != c->h_table.data()) c->h_table.assign(table, table + entries);
   HIPCHK(c, hipMemcpy(c->d_table, c->h_table.data(), entries * 4, hipMemcpyHostToDevice));
+  return RMI_OK;
+}
+int rmi_hip_cache_fix(rmi_hip_ctx* c, const uint64_t* host_keys, uint64_t n, uint64_t line_size, uint64_t* num_points) {
+  if (!c || !host_keys || !num_points) return RMI_ERR_BAD_ARG;
+  int rc = rmi_host::cache_fix(host_keys, n, line_size, c->h_spline);
+  *num_points = c->h_spline.size() / 2;
+  return rc;
+}
+int rmi_hip_download_cache_fix(const rmi_hip_ctx* c, uint64_t* out_pairs) {
+  if (!c || !out_pairs || c->h_spline.empty()) return RMI_ERR_BAD_ARG;
+  std::memcpy(out_pairs, c->h_spline.data(), c->h_spline.size() * 8);
   return RMI_OK;
 }
 int rmi_hip_root_table_entries(const rmi_hip_ctx* c, uint64_t* entries) {

@@ -314,4 +314,52 @@ inline uint64_t root_target(const rmi_hip_model_params& m, K k, uint64_t L, cons
   return p < L - 1 ? p : L - 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// cache_fix (cache_fix.rs:109-150), the host half of `--bounded`: a greedy spline over the unique
+// keys and their predecessors key-1 whose linear interpolation lands in the right line_size block
+// for every point it skips.  Sequential by construction (each decision depends on the last accepted
+// spline).  pairs = (key, offset) flattened.
+// ---------------------------------------------------------------------------------------------
+struct CfSpline { uint64_t from_x, from_y, to_x, to_y; };
+inline uint64_t cf_predict(const CfSpline& s, uint64_t inp) {                 // cache_fix.rs:37-43
+  const double v0 = (double)s.from_y, v1 = (double)s.to_y;
+  const double t = ((double)(inp - s.from_x)) / (double)(s.to_x - s.from_x);
+  return sat_u64(std::fma(1.0 - t, v0, t * v1));
+}
+inline int cache_fix(const uint64_t* keys, uint64_t n, uint64_t line_size, std::vector<uint64_t>& pairs) {
+  pairs.clear();
+  if (!keys || line_size == 0 || !(n > line_size)) return RMI_ERR_BAD_ARG;   // assert, cache_fix.rs:110
+  bool has = false;
+  CfSpline sp{0, 0, 0, 0};
+  std::vector<uint64_t> px, py;                                               // curr_pts
+  int rc = RMI_OK;
+  auto add_point = [&](uint64_t x, uint64_t y) {                              // SplineFit::add_point :60-86
+    if (!has) { has = true; sp = CfSpline{x, y, x, y}; pairs.push_back(x); pairs.push_back(y); return; }
+    const CfSpline last = sp;
+    if (!(x >= last.from_x) || !(y >= last.from_y)) { rc = RMI_ERR_BAD_ARG; return; }
+    const CfSpline prop{last.from_x, last.from_y, x, y};
+    px.push_back(last.to_x); py.push_back(last.to_y);
+    bool ok = true;
+    for (size_t i = 0; i < px.size(); i++)
+      if (cf_predict(prop, px[i]) / line_size != py[i] / line_size) { ok = false; break; }
+    if (ok) { sp = prop; return; }
+    if (!(x > last.to_x) || !(last.to_y <= y)) { rc = RMI_ERR_BAD_ARG; return; }
+    sp = CfSpline{last.to_x, last.to_y, x, y};
+    px.clear(); py.clear(); px.push_back(x); py.push_back(y);
+    pairs.push_back(last.to_x); pairs.push_back(last.to_y);
+  };
+  uint64_t last_key = 0;
+  for (uint64_t i = 0; i < n && rc == RMI_OK; i++) {                          // iter_unique(): first occurrences
+    if (i > 0 && keys[i] == keys[i - 1]) continue;
+    const uint64_t key = keys[i];
+    if (key == 0 || !(key - 1 >= last_key)) { rc = RMI_ERR_BAD_ARG; break; }   // minus_epsilon / assert :122
+    if (key - 1 != last_key) add_point(key - 1, i);
+    if (rc == RMI_OK) add_point(key, i);
+    last_key = key;
+  }
+  if (rc != RMI_OK) { pairs.clear(); return rc; }
+  if (has) { pairs.push_back(sp.to_x); pairs.push_back(sp.to_y); }            // finish()
+  return RMI_OK;
+}
+
 }  // namespace rmi_host

@@ -141,6 +141,7 @@ class Trainer:
 
     def __init__(self, keys=None, device: int = 0):
         self._lib = _lib.load()
+        self._device = device
         h = C.c_void_p()
         _check(self._lib.rmi_hip_create(device, C.byref(h)))
         self._h = h
@@ -279,6 +280,29 @@ class Trainer:
         out = self.train_leaves(root, leaf_kind, branch_factor)
         out.build_time = time.perf_counter_ns() - t0
         return out
+
+    def cache_fix(self, line_size: int) -> np.ndarray:
+        """cache_fix.rs:109-150 over the (u64) keys of this trainer -> [m, 2] uint64 (key, offset)."""
+        keys = self.download_keys()
+        if keys.dtype != np.uint64:
+            raise TypeError("Can only construct a bounded RMI on u64 data.")        # src/main.rs:281-282
+        cnt = C.c_uint64()
+        _check(self._lib.rmi_hip_cache_fix(self._h, keys.ctypes.data, keys.size, int(line_size), C.byref(cnt)), self._h)
+        out = np.empty((int(cnt.value), 2), dtype=np.uint64)
+        _check(self._lib.rmi_hip_download_cache_fix(self._h, out.ctypes.data), self._h)
+        return out
+
+    def train_bounded(self, model_spec: str, branch_factor: int, line_size: int, device: int | None = None) -> TrainedRMI:
+        """rmi_lib::train_bounded (train/mod.rs:156-184): spline on the host, RMI over the re-indexed
+        spline points on the device (a key set of its own; the returned object keeps its trainer)."""
+        t0 = time.perf_counter_ns()
+        spline = self.cache_fix(line_size)
+        sub = Trainer(np.ascontiguousarray(spline[:, 0]), device=self._device if device is None else device)
+        res = sub.train(model_spec, branch_factor)
+        res.cache_fix = (int(line_size), spline)
+        res.num_data_rows = self.n
+        res.build_time = time.perf_counter_ns() - t0
+        return res
 
     def _download(self, what: str, rmi: TrainedRMI):
         L, ppl = (rmi.shard_leaves or rmi.branching_factor), rmi.params_per_leaf

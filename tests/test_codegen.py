@@ -89,6 +89,92 @@ def test_emitted_code_compiles_and_is_sound(oracle, tmp_path, gen, root, leaf, L
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("gen,root,leaf,L,line", [("books_u64", "linear_spline", "linear", 4096, 8),   # tests/cache_fix_wiki
+                                                  ("dups_u64", "cubic", "linear", 768, 8),            # tests/cache_fix_osm
+                                                  ("uniform_u64", "linear", "linear", 64, 32)])
+def test_bounded_rmi_compiles_and_is_within_the_line(oracle, tmp_path, gen, root, leaf, L, line):
+    """`--bounded line_size` (cache_fix.rs, train_bounded, codegen.rs:396-447): the emitted lookup is
+    within line_size of lower_bound for every key -- the loop of tests/cache_fix_wiki/main.cpp:26-44."""
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    keys = dg.GENERATORS[gen](80_000)
+    o, spline = oracle.train_bounded(root, leaf, keys, L, line)
+    assert oracle.check_bounded_property(o, spline, line, keys) == (0, len(keys))
+    rmi = _as_rmi(o, len(spline))
+    rmi.cache_fix = (line, spline)
+    rmi.num_data_rows = len(keys)
+    kfile = str(tmp_path / "keys_uint64")
+    dg.write_keys(kfile, keys)
+    paths = codegen.output_rmi("rmi", rmi, str(tmp_path / "rmi_data"), key_type="uint64_t", out_dir=str(tmp_path))
+    assert np.array_equal(np.fromfile(paths["L2_PARAMETERS"], dtype="<u8").reshape(-1, 2), spline)
+    hdr = open(paths["rmi.h"]).read()
+    assert f"const size_t RMI_SIZE = {codegen.rmi_size(o.root.kind, o.leaf_kind, L, True, 0, len(spline))};" in hdr
+    assert "uint64_t lookup(uint64_t key, size_t* err);" in hdr
+    (tmp_path / "main.cpp").write_text(MAIN_CPP.replace("NS", "rmi").replace("LKEYT", "uint64_t").replace("KEYT", "uint64_t"))
+    exe = str(tmp_path / "a.out")
+    subprocess.check_call(["g++", "-std=c++17", "-O3", "-ffast-math", "-march=native", "-o", exe,
+                           str(tmp_path / "main.cpp"), paths["rmi.cpp"]], cwd=str(tmp_path))
+    out = subprocess.run([exe, kfile, str(tmp_path / "rmi_data")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_cache_fix_against_direct_restatement(oracle):
+    """cache_fix.rs has no unit test in the reference: pin the oracle against an independent
+    transcription of SplineFit / cache_fix on small inputs."""
+    rng = np.random.default_rng(11)
+
+    for trial in range(8):
+        n = int(rng.integers(40, 600))
+        keys = np.sort(rng.integers(2, 1 << int(rng.integers(12, 40)), size=n, dtype=np.uint64))
+        if trial % 2:
+            keys[5:9] = keys[5]
+            keys = np.sort(keys)
+        line = int(rng.choice([2, 4, 8]))
+        got = oracle.cache_fix(keys, line)
+        # --- direct restatement (Python floats are IEEE f64; fma emulated exactly with fractions) ---
+        from fractions import Fraction
+
+        def pred(sp, x):
+            fx, fy, tx, ty = sp
+            t = float(x - fx) / float(tx - fx)
+            one_minus_t = 1.0 - t
+            tv1 = t * float(ty)
+            exact = Fraction(one_minus_t) * Fraction(float(fy)) + Fraction(tv1)     # fma: one rounding of the exact sum
+            v = float(exact)
+            return int(v) if v > 0 else 0
+
+        spline, cur, pts, out = None, None, [], []
+        uniq = [(int(k), i) for i, k in enumerate(keys) if i == 0 or k != keys[i - 1]]
+        last_key = 0
+
+        def add(pt):
+            nonlocal spline, pts
+            if spline is None:
+                spline = (pt[0], pt[1], pt[0], pt[1])
+                return pt
+            last = spline
+            prop = (last[0], last[1], pt[0], pt[1])
+            pts.append((last[2], last[3]))
+            if all(pred(prop, x) // line == y // line for x, y in pts):
+                spline = prop
+                return None
+            spline = (last[2], last[3], pt[0], pt[1])
+            pts = [pt]
+            return (last[2], last[3])
+
+        for key, off in uniq:
+            if key - 1 != last_key:
+                r = add((key - 1, off))
+                if r:
+                    out.append(r)
+            r = add((key, off))
+            if r:
+                out.append(r)
+            last_key = key
+        out.append((spline[2], spline[3]))
+        assert got.tolist() == [list(p) for p in out]
+
+
 def test_c_float_formatting():
     # models/mod.rs:568-574: Rust Display (no exponent) + ".0" when there is no '.'
     assert codegen.c_float(1.0) == "1.0"

@@ -94,3 +94,39 @@ def test_optimizer_fast_profile(tmp_path, oracle, monkeypatch):
     r = subprocess.run([sys.executable, "-m", "rmi_amd.cli", kfile, "sized", "--max-size", "200000", "--no-code"], cwd=str(tmp_path),
                        env=dict(os.environ, PYTHONPATH=ROOT, RMI_OPTIMIZER_PROFILE="fast"), capture_output=True, text=True)
     assert r.returncode == 0 and "Found RMI config" in r.stdout, r.stdout + r.stderr
+
+
+def test_bounded_cli_end_to_end(tmp_path, oracle):
+    """`rmi <keys> rmi linear_spline,linear 4096 --bounded 8` (tests/cache_fix_wiki/Makefile:8): spline and
+    rows equal the oracle's, the emitted lookup stays within the line for every key."""
+    from tests.test_codegen import MAIN_CPP
+    from rmi_amd import train
+    keys = dg.books_u64(120_000)
+    tr = train.Trainer(keys)
+    sp = tr.cache_fix(8)
+    o, osp = oracle.train_bounded("linear_spline", "linear", keys, 4096, 8)
+    assert np.array_equal(sp, osp)
+    g = tr.train_bounded("linear_spline,linear", 4096, 8)
+    assert g.num_rmi_rows == len(osp) and g.num_data_rows == len(keys)
+    assert np.array_equal(g.leaf_params, o.leaf_params) and np.array_equal(g.last_layer_max_l1s, o.leaf_err)
+    tr.close()
+    kfile = str(tmp_path / "b_uint64")
+    dg.write_keys(kfile, keys)
+    r = subprocess.run([sys.executable, "-m", "rmi_amd.cli", kfile, "rmi", "linear_spline,linear", "4096", "--bounded", "8"],
+                       cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(str(tmp_path / "rmi_data" / "rmi_L2_PARAMETERS"), dtype="<u8").reshape(-1, 2), osp)
+    raw = np.fromfile(str(tmp_path / "rmi_data" / "rmi_L1_PARAMETERS"), dtype="<u8").reshape(4096, 3)
+    assert np.array_equal(raw[:, :2], o.leaf_params.view(np.uint64)) and np.array_equal(raw[:, 2], o.leaf_err)
+    if shutil.which("g++"):
+        (tmp_path / "main.cpp").write_text(MAIN_CPP.replace("NS", "rmi").replace("LKEYT", "uint64_t").replace("KEYT", "uint64_t"))
+        subprocess.check_call(["g++", "-std=c++17", "-O3", "-ffast-math", "-march=native", "-o", "a.out", "main.cpp", "rmi.cpp"],
+                              cwd=str(tmp_path))
+        out = subprocess.run(["./a.out", kfile, "rmi_data"], cwd=str(tmp_path), capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+    # u32 data is refused like the reference (src/main.rs:281-282)
+    k32 = str(tmp_path / "c_uint32")
+    dg.write_keys(k32, dg.uniform_u32(10_000))
+    r = subprocess.run([sys.executable, "-m", "rmi_amd.cli", k32, "rmi", "linear,linear", "64", "--bounded", "8"],
+                       cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True)
+    assert r.returncode != 0 and "u64" in (r.stdout + r.stderr)
