@@ -38,6 +38,10 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--max-size", metavar="BYTES", type=int, help="uses the optimizer to find an RMI with a size less than specified")
     ap.add_argument("--bounded", metavar="line_size", type=int,
                     help="construct an error-bounded RMI using the cachefix method for the given line size")
+    # declared by the reference's CLI and never read there either (src/main.rs:55-66): accepted, no effect
+    ap.add_argument("--dump-ll-model-data", metavar="model_index", help="accepted for compatibility (unused in the reference too)")
+    ap.add_argument("--dump-ll-errors", action="store_true", help="accepted for compatibility (unused in the reference too)")
+    ap.add_argument("-s", "--stats-file", metavar="file", help="accepted for compatibility (unused in the reference too)")
     ap.add_argument("--device", type=int, default=0)
     return ap
 
