@@ -64,7 +64,6 @@ struct rmi_hip_ctx {
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
   uint64_t err_threads = 262144;                // lanes of pass B (4 waves/SIMD)
   int fit_min_chunk = 64;
-  int err_kernel = 1;                           // pass B: 0 = k_err_wave, 1 = k_err_range (leaf_start-driven), 2 = k_err_stream
   bool robust_leaf = false;                     // this call's leaves are robust_linear (fitted by k_fit_leaf; predict like linear)
   int dbg = 0;                                  // ablation switches for profiling (0 = product behaviour)
   unsigned int long_min = 4096;                 // leaves with more points go to k_fit_long (>= FS_TMAX)
@@ -192,8 +191,6 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (ft && *ft) c->fit_threads = std::strtoull(ft, nullptr, 10);
   const char* et = std::getenv("RMI_HIP_ERR_THREADS");
   if (et && *et) c->err_threads = std::strtoull(et, nullptr, 10);
-  const char* ek = std::getenv("RMI_HIP_ERR_KERNEL");
-  if (ek && *ek) c->err_kernel = std::atoi(ek);
   const char* dbg = std::getenv("RMI_HIP_DBG");
   if (dbg && *dbg) c->dbg = std::atoi(dbg);
   const char* lm = std::getenv("RMI_HIP_LONG_MIN");
@@ -638,21 +635,13 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   } else if (c->pipeline == 1) {
     const uint64_t blocks = (n_it + 255) / 256;
     hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, params, maxerr, run);
-  } else if (c->err_kernel == 0) {
-    const uint64_t tiles = (n_it + 63) / 64;
-    const uint64_t waves = (tiles + EW_UNROLL - 1) / EW_UNROLL;
-    const uint64_t blocks = (waves + 3) / 4;
-    hipLaunchKernelGGL((k_err_wave<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, params, maxerr, run, c->dbg);
   } else {
     uint64_t C = (n_it + c->err_threads - 1) / c->err_threads;
     C = ((C + FS_ROW - 1) / FS_ROW) * FS_ROW;
     if (C < (uint64_t)c->fit_min_chunk) C = c->fit_min_chunk;
     const uint64_t chunks = (n_it + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
-    if (c->err_kernel == 2)
-      hipLaunchKernelGGL((k_err_stream<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, params, maxerr, run, c->dbg);
-    else
-      hipLaunchKernelGGL((k_err_range<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, leaf_start, params, maxerr, run);
+    hipLaunchKernelGGL((k_err_range<ROOT, LEAF, K>), dim3((unsigned)waves), dim3(64), 0, s, keys, sp, rp, C, leaf_start, params, maxerr, run);
   }
   mark();
   // --- finalize + stats ---

@@ -1,10 +1,11 @@
-// rmi_stream.hip.h -- the two streaming kernels of the leaf hot path (gfx950, wave64).
+// rmi_stream.hip.h -- the streaming kernels of the leaf hot path (gfx950, wave64).
 //
 //   k_fit_stream  ("pass A")  bucketing scan + exact per-leaf SLR (two_layer.rs:43-90, linear.rs:12-59)
-//   k_err_stream  ("pass B")  last-level error pass + run lengths (two_layer.rs:207-217,
-//                             lower_bound_correction.rs:104-119)
+//   k_err_range   ("pass B")  last-level error pass + run lengths (two_layer.rs:207-217,
+//                             lower_bound_correction.rs:104-119), boundaries from leaf_start
+//   k_fit_long                leaves too long for the lockstep pass, one wave each
 //
-// Both kernels share one skeleton.  A wave owns 64 consecutive chunks of C keys, one chunk per
+// Passes A and B share one skeleton.  A wave owns 64 consecutive chunks of C keys, one chunk per
 // lane, and all lanes advance one key per step in lockstep.  Per panel of 64 rows x 16 keys:
 //   load     coalesced HBM reads (each load instruction covers 4 rows = 4 full 128-B lines),
 //            transposed through a padded LDS image (row stride 17 slots: lane-per-row accesses are
@@ -489,136 +490,6 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
 }
 
 // =============================================================================================
-// Pass B: err = |min(pred, N) - min(y, N)| per key with its leaf's model, max per leaf; longest run of
-// equal keys per leaf (a run is recorded when the next different key arrives, so the globally last
-// run is never recorded: Q5).  A lane walks its chunk keeping the maxima of the current leaf in
-// registers and issues one atomicMax per (lane, leaf) segment: ~N/C + L atomics in total.
-// Runs of length 1 are not reported (k_finalize adds that floor).
-// =============================================================================================
-template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(64) k_err_stream(const K* __restrict__ keys, Span sp, RootP r, uint64_t C,
-                                                   const double* __restrict__ params,
-                                                   unsigned long long* __restrict__ leaf_maxerr,
-                                                   unsigned long long* __restrict__ leaf_run, int dbg) {
-  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
-  __shared__ unsigned long long panel[64 * FS_STRIDE];
-  __shared__ unsigned int leafp[64 * FS_STRIDE];
-
-  const int lane = threadIdx.x;
-  const uint64_t n = sp.n;
-  const uint64_t wave_base = sp.it_lo + (uint64_t)blockIdx.x * 64 * C;
-  const uint64_t p0 = wave_base + (uint64_t)lane * C;
-  const uint64_t chunk_end = (p0 + C < sp.it_hi) ? p0 + C : sp.it_hi;
-  const double Lm1f = (double)(r.L - 1);
-  const double midf = (double)(r.L / 2);
-  const double nf = (double)n;
-
-  K kprev = K();
-  double tprev = -1.0;
-  double yprev = 0.0;
-  unsigned int cur_leaf = 0;
-  bool have_leaf = false;
-  double pa[PPL], pn[PPL];                                   // current leaf, prefetched next leaf
-#pragma unroll
-  for (int q = 0; q < PPL; q++) { pa[q] = 0.0; pn[q] = 0.0; }
-  double maxerr = 0.0, maxrun = 0.0;
-  bool pn_ok = false;                                        // pn holds the parameters of leaf cur_leaf + 1
-  if (p0 < sp.it_hi && p0 > sp.rd_lo) {
-    bool oob;
-    kprev = keys[p0 - 1];
-    yprev = (double)first_occurrence(keys, p0 - 1, sp.rd_lo);
-    tprev = root_target_f<ROOT, K>(r, Lm1f, kprev, oob);
-    cur_leaf = (unsigned int)tprev;                          // owner of the run that ends at p0-1
-    have_leaf = true;
-    if (cur_leaf >= sp.leaf_lo && cur_leaf < sp.leaf_hi) {   // (the halo key before a shard belongs to another rank)
-#pragma unroll
-      for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)cur_leaf * PPL + q];
-      const unsigned int nx = cur_leaf + 1 < (unsigned int)sp.leaf_hi ? cur_leaf + 1 : cur_leaf;
-#pragma unroll
-      for (int q = 0; q < PPL; q++) pn[q] = params[(uint64_t)nx * PPL + q];
-      pn_ok = true;
-    }
-  }
-  unsigned int flags = 0;
-
-  auto flush = [&]() {
-    // the leaf of the halo key before a shard belongs to another rank: nothing to report for it
-    if (have_leaf && cur_leaf >= sp.leaf_lo && cur_leaf < sp.leaf_hi) {
-      if (maxerr > 0.0) atomicMax(&leaf_maxerr[cur_leaf], (unsigned long long)maxerr);
-      if (maxrun > 1.0) atomicMax(&leaf_run[cur_leaf], (unsigned long long)maxrun);
-    }
-  };
-
-  K stage[FS_ROW];
-  uint64_t row_i = p0;
-  double row_if = (double)p0;
-  bool lane_done = !(p0 < sp.it_hi);
-  uint64_t P = 0;
-  load_panel<K>(stage, keys, sp.rd_hi, wave_base, C, 0, lane);
-  while (__any(!lane_done)) {
-    stage_to_lds<K>(stage, panel, lane);
-    load_panel<K>(stage, keys, sp.rd_hi, wave_base, C, P + 1, lane);
-
-    unsigned int bmask = 0, dmask = 0;
-    int split_pos = -1;
-    const int end_pos = (row_i >= chunk_end) ? 0 : ((chunk_end - row_i < (uint64_t)FS_ROW) ? (int)(chunk_end - row_i) : FS_ROW);
-    const unsigned int vmask = lane_done ? 0u : ((1u << end_pos) - 1u);   // keys of this lane's chunk in the row
-    classify_row<ROOT, K, false, true>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, 0u,
-                                 kprev, tprev, bmask, dmask, split_pos, flags, nullptr, nullptr);
-
-    double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
-#pragma unroll 1
-    for (int s = 0; s < FS_ROW; s++) {
-      const double x = xn;
-      xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);
-      const bool valid = (vmask >> s) & 1u;
-      const bool dup = (dmask >> s) & 1u;
-      const double idxf = row_if + (double)s;
-      // a new key value ends the previous run: record its length for the leaf of the previous key
-      if (valid && !dup && have_leaf) maxrun = fmax(maxrun, idxf - yprev);
-      const double y = dup ? yprev : idxf;
-      const bool bit = (bmask >> s) & 1u;
-      if (__any(bit)) {
-        if (bit) {
-          flush();
-          const unsigned int nl = leafp[lane * FS_STRIDE + s];
-          if (have_leaf && pn_ok && nl == cur_leaf + 1) {
-#pragma unroll
-            for (int q = 0; q < PPL; q++) pa[q] = pn[q];
-          } else {
-#pragma unroll
-            for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)nl * PPL + q];
-          }
-          cur_leaf = nl; have_leaf = true; maxerr = 0.0; maxrun = 0.0;
-          const unsigned int nx = nl + 1 < (unsigned int)sp.leaf_hi ? nl + 1 : nl;   // stay inside this launch's leaf range
-#pragma unroll
-          for (int q = 0; q < PPL; q++) pn[q] = params[(uint64_t)nx * PPL + q];
-          pn_ok = (nx == nl + 1);
-        }
-      }
-      if (valid) {
-        double f;
-        if constexpr (LEAF == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(pa[0], x, pa[1]), x, pa[2]), x, pa[3]);
-        else f = __builtin_fma(pa[1], x, pa[0]);
-        // err in the f64 domain (all integers < 2^53): |min(pred, N) - y|, y < N
-        const double e = fabs(fmin(fmax(0.0, floor(f)), nf) - y);
-        maxerr = fmax(maxerr, e);
-        yprev = y;
-      }
-    }
-    row_i += FS_ROW;
-    row_if += (double)FS_ROW;
-    if (row_i >= chunk_end) lane_done = true;
-    P += 1;
-  }
-  // The key right after a shard starts another leaf (hence another key value): it ends the run of
-  // this shard's last key, but it is processed by the next rank, so account for it here.
-  if (p0 < sp.it_hi && chunk_end == sp.it_hi && sp.it_hi < sp.n && have_leaf) maxrun = fmax(maxrun, (double)sp.it_hi - yprev);
-  flush();
-}
-
-
-// =============================================================================================
 // Pass B driven by leaf_start ("k_err_range").  After pass A and the fill, every leaf boundary is
 // known, so pass B needs no root evaluation per key: a lane walks its chunk, compares the running
 // index with the end of its current leaf, and at a boundary switches to the next leaf whose
@@ -839,104 +710,6 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
   if (pending) drain();
 }
 
-// =============================================================================================
-// Pass B, wave-parallel form: one key per lane, coalesced loads straight into registers (no LDS),
-// leaf parameters gathered from L2 (a wave touches 1-2 leaves), wave-level DPP max reductions per
-// leaf segment and one atomicMax per (wave, leaf).  Keys of one leaf are contiguous, so a wave
-// of 64 consecutive keys holds one leaf (usual case), two, or -- for leaves shorter than a wave --
-// many; the latter falls back to one atomic per lane.
-// =============================================================================================
-__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
-  // inclusive max-scan inside rows of 16 (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31:
-  // lane 63 ends up with the maximum of all 64 lanes.  0 is the identity.
-  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
-  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
-  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
-  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
-  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
-  v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
-  return v;
-}
-
-constexpr int EW_UNROLL = 4;      // wave tiles (64 keys each) per wave
-
-template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(256) k_err_wave(const K* __restrict__ keys, Span sp, RootP r,
-                                                  const double* __restrict__ params,
-                                                  unsigned long long* __restrict__ leaf_maxerr,
-                                                  unsigned long long* __restrict__ leaf_run, int dbg) {
-  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
-  const int lane = threadIdx.x & 63;
-  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint64_t n = sp.n;
-  const double Lm1f = (double)(r.L - 1);
-  const double nf = (double)n;
-  const bool small = n <= 0xFFFFFFFFull;
-#pragma unroll
-  for (int u = 0; u < EW_UNROLL; u++) {
-    const uint64_t base = sp.it_lo + (wave_id * EW_UNROLL + u) * 64;
-    if (base >= sp.it_hi) break;                            // wave-uniform
-    const uint64_t i = base + lane;
-    const bool valid = i < sp.it_hi;
-    const uint64_t ic = valid ? i : sp.it_hi - 1;
-    const K k = keys[ic];
-    // neighbours: previous / next key (lane 0 / lane 63 fetch across the tile edge)
-    K kprev, knext;
-    {
-      unsigned long long kb = key_to_bits<K>(k);
-      unsigned int lo = (unsigned int)kb, hi = (unsigned int)(kb >> 32);
-      unsigned int plo = __shfl_up(lo, 1, 64), phi = __shfl_up(hi, 1, 64);
-      unsigned int nlo = __shfl_down(lo, 1, 64), nhi = __shfl_down(hi, 1, 64);
-      kprev = bits_to_key<K>(((unsigned long long)phi << 32) | plo);
-      knext = bits_to_key<K>(((unsigned long long)nhi << 32) | nlo);
-      if (lane == 0 && i > sp.rd_lo) kprev = keys[i - 1];
-      if (lane == 63 && i + 1 < sp.rd_hi) knext = keys[i + 1];
-    }
-    bool oob;
-    const double t = root_target_f<ROOT, K>(r, Lm1f, k, oob);
-    const unsigned int tj = (unsigned int)t;
-    double pa[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; q++) pa[q] = params[(uint64_t)tj * PPL + q];
-    if (dbg & 2) { pa[0] = t; pa[1] = 1e-9; }
-    uint64_t y = i;
-    if (valid && i > sp.rd_lo && k == kprev) y = first_occurrence(keys, i, sp.rd_lo);
-    const double x = KeyTraits<K>::as_float(k);
-    double f;
-    if constexpr (LEAF == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(pa[0], x, pa[1]), x, pa[2]), x, pa[3]);
-    else f = __builtin_fma(pa[1], x, pa[0]);
-    const double yf = (double)y;
-    double e = fabs(fmin(fmax(0.0, floor(f)), nf) - yf);     // |min(pred, N) - y|, integers < 2^53
-    double rl = (i + 1 < n && !(knext == k)) ? ((double)i - yf + 1.0) : 0.0;   // recorded when the next different key arrives
-    if (!valid) { e = 0.0; rl = 0.0; }
-    if (rl <= 1.0) rl = 0.0;                                 // runs of length 1 are added back by k_finalize
-    if (dbg & 1) { if (e + rl == -1.0) leaf_run[0] = 1; continue; }
-    const unsigned int t_first = __builtin_amdgcn_readfirstlane(tj);
-    const unsigned int t_last = __builtin_amdgcn_readlane(tj, 63);
-    const bool two = __ballot(tj != t_first && tj != t_last) == 0ull;
-    if (small && two) {
-      const unsigned int eu = (unsigned int)e, ru = (unsigned int)rl;
-      const bool inA = (tj == t_first);
-      const unsigned int ea = wave_max_u32(inA ? eu : 0u);
-      const unsigned int ra = wave_max_u32(inA ? ru : 0u);
-      if (lane == 63) {
-        if (ea) atomicMax(&leaf_maxerr[t_first], (unsigned long long)ea);
-        if (ra) atomicMax(&leaf_run[t_first], (unsigned long long)ra);
-      }
-      if (t_first != t_last) {                               // wave-uniform
-        const unsigned int eb = wave_max_u32(inA ? 0u : eu);
-        const unsigned int rb = wave_max_u32(inA ? 0u : ru);
-        if (lane == 63) {
-          if (eb) atomicMax(&leaf_maxerr[t_last], (unsigned long long)eb);
-          if (rb) atomicMax(&leaf_run[t_last], (unsigned long long)rb);
-        }
-      }
-    } else {
-      if (e > 0.0) atomicMax(&leaf_maxerr[tj], (unsigned long long)e);
-      if (rl > 0.0) atomicMax(&leaf_run[tj], (unsigned long long)rl);
-    }
-  }
-}
 
 
 // Read-only streaming kernel: the box's achievable HBM read bandwidth in this harness (the
