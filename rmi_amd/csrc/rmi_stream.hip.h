@@ -93,6 +93,18 @@ __device__ __forceinline__ void slr_push_r(SlrState& s, double x, double y, doub
   s.m2 += dx * dx2;
 }
 
+// OR of a 32-bit value over the 64 lanes of the wave, returned wave-uniform (an SGPR): DPP inside
+// rows of 16, then across rows.
+__device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8 -> lane 15 of each row holds the row's OR
+  const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 31);
+  const unsigned int r2 = (unsigned int)__builtin_amdgcn_readlane((int)v, 47), r3 = (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+  return r0 | r1 | r2 | r3;
+}
+
 template <typename K> struct UseRecipTable { static constexpr bool value = true; };
 template <> struct UseRecipTable<double> { static constexpr bool value = false; };   // f64 keys: plain IEEE division
 
@@ -392,6 +404,8 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
       }
       beyond = __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
     }
+    // steps at which some lane crosses a leaf boundary, wave-uniform: the step loop tests a scalar bit
+    const unsigned int any_mask = wave_or_u32(bmask);
     int my_closes = 0;
     {
       bool act = active;
@@ -428,7 +442,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         if constexpr (!NODUP) y = ((dmask >> s) & 1u) ? yprev : idxf;
         bool do_push = active;
         if (dbg & 1) do_push = false;
-        if (!(dbg & 2) && __any(bit)) {
+        if (!(dbg & 2) && ((any_mask >> s) & 1u)) {
           // close first (queue the running state of the leaf that ends here), then open
           const bool is_end = (s == end_pos);
           const bool is_split = (s == split_pos);
