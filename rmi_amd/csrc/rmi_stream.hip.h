@@ -651,6 +651,10 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
     // y is the running index and run lengths are all 1 (never reported), so the step is just
     // "predict, compare, max".
     const bool plain_ok = !__any(lane_done || end_pos < FS_ROW || dmask != 0u || (row_i > sp.rd_lo && yprev != row_if - 1.0));
+    // fast loop: a lane crosses at most once in this row, at a position known now -> the steps at
+    // which some lane crosses are a wave-uniform mask and the loop tests a scalar bit
+    const int cross_pos = crosses ? (int)(e_cur - row_if) : -1;           // e_cur in (row_if, row_endf): exact
+    const unsigned int cross_any = wave_or_u32((crosses && cross_pos >= 0 && cross_pos < FS_ROW) ? (1u << cross_pos) : 0u);
     auto steps = [&](auto fast_tag, auto plain_tag) {
       constexpr bool FAST = decltype(fast_tag)::value;
       constexpr bool PLAIN = decltype(plain_tag)::value;
@@ -668,8 +672,10 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
           if (valid && !dup && have_leaf) maxrun = fmax(maxrun, idxf - yprev);
         }
         const double y = dup ? yprev : idxf;
-        const bool bit = valid && (idxf >= e_cur);           // first key of another leaf
-        if (__any(bit)) {
+        bool bit, some;
+        if constexpr (FAST) { bit = (s == cross_pos); some = (cross_any >> s) & 1u; }
+        else { bit = valid && (idxf >= e_cur); some = __any(bit); }           // first key of another leaf
+        if (some) {
           flush(bit);
           if (bit) {
             bool use_prefetch = true;
