@@ -659,8 +659,7 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
       constexpr bool FAST = decltype(fast_tag)::value;
       constexpr bool PLAIN = decltype(plain_tag)::value;
       double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
-#pragma unroll 2
-      for (int s = 0; s < FS_ROW; s++) {
+      auto one = [&](int s) {
         const double x = xn;
         xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);
         const double idxf = row_if + (double)s;
@@ -711,6 +710,13 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
           maxerr = fmax(maxerr, e);
           if constexpr (!PLAIN) yprev = y;
         }
+      };
+      if constexpr (PLAIN) {
+#pragma unroll 8
+        for (int s = 0; s < FS_ROW; s++) one(s);
+      } else {
+#pragma unroll 2
+        for (int s = 0; s < FS_ROW; s++) one(s);
       }
       if constexpr (PLAIN) yprev = row_if + (double)(FS_ROW - 1);
     };
