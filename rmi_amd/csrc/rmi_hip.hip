@@ -65,7 +65,6 @@ struct rmi_hip_ctx {
   uint64_t err_threads = 262144;                // lanes of pass B (4 waves/SIMD)
   int fit_min_chunk = 64;
   bool robust_leaf = false;                     // this call's leaves are robust_linear (fitted by k_fit_leaf; predict like linear)
-  int dbg = 0;                                  // ablation switches for profiling (0 = product behaviour)
   unsigned int long_min = 4096;                 // leaves with more points go to k_fit_long (>= FS_TMAX)
   // last result
   uint64_t last_L = 0;
@@ -191,8 +190,6 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (ft && *ft) c->fit_threads = std::strtoull(ft, nullptr, 10);
   const char* et = std::getenv("RMI_HIP_ERR_THREADS");
   if (et && *et) c->err_threads = std::strtoull(et, nullptr, 10);
-  const char* dbg = std::getenv("RMI_HIP_DBG");
-  if (dbg && *dbg) c->dbg = std::atoi(dbg);
   const char* lm = std::getenv("RMI_HIP_LONG_MIN");
   if (lm && *lm) { long v = std::atol(lm); if (v >= FS_TMAX) c->long_min = (unsigned int)v; }
   const char* fc = std::getenv("RMI_HIP_FIT_MIN_CHUNK");
@@ -583,7 +580,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     const uint64_t chunks = (n_it + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
     const uint64_t fblocks = (waves + FA_WAVES - 1) / FA_WAVES;
-    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, sp, rp, C, leaf_start, params, c->d_state, c->d_long, c->long_min, c->dbg);
+    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, sp, rp, C, leaf_start, params, c->d_state, c->d_long, c->long_min);
     mark();
   }
   // --- fill empty leaves ---

@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
                                                              double* __restrict__ params,
                                                              DevState* __restrict__ st,
                                                              unsigned long long* __restrict__ long_idx,
-                                                             unsigned int long_min, int dbg) {
+                                                             unsigned int long_min) {
   __shared__ unsigned long long s_panel[FA_WAVES][64 * FS_STRIDE];   // raw key bits, then f64 x
   constexpr bool LEAFP = (ROOT == K_RADIX || ROOT == K_RADIX_TABLE);
   __shared__ unsigned int s_leafp[FA_WAVES][LEAFP ? 64 * FS_STRIDE : 1];   // leaf ids (radix roots only)
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     const int end_pos = (row_i >= rd_hi) ? 0 : ((rd_hi - row_i < (uint64_t)FS_ROW) ? (int)(rd_hi - row_i) : FS_ROW);
     const int own_cnt = (row_i >= chunk_end) ? 0 : ((chunk_end - row_i < (uint64_t)FS_ROW) ? (int)(chunk_end - row_i) : FS_ROW);
     const bool prev_split_in = carry_split;
-    if (!(dbg & 4)) {
+    {
       const unsigned int vmask = lane_done ? 0u : ((1u << end_pos) - 1u);
       const unsigned int ownmask = (1u << own_cnt) - 1u;
       classify_row<ROOT, K, true, LEAFP>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, ownmask,
@@ -441,8 +441,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         double y = idxf;                                     // FixDups first-occurrence offset
         if constexpr (!NODUP) y = ((dmask >> s) & 1u) ? yprev : idxf;
         bool do_push = active;
-        if (dbg & 1) do_push = false;
-        if (!(dbg & 2) && ((any_mask >> s) & 1u)) {
+        if ((any_mask >> s) & 1u) {
           // close first (queue the running state of the leaf that ends here), then open
           const bool is_end = (s == end_pos);
           const bool is_split = (s == split_pos);
@@ -496,7 +495,6 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
     if (!active && (row_i >= chunk_end || row_i >= rd_hi)) lane_done = true;
-    if ((dbg & 4) && row_i >= chunk_end) lane_done = true;
     P += 1;
   }
   if (pending) drain();
