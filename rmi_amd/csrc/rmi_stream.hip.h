@@ -304,7 +304,11 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   bool carry_split = false;                                  // the key just before the row was the split key
   // carries of the recurrence (phase 2)
   double xprev = 0.0, yprev = 0.0;
-  bool active = false;
+  // Which lanes have a leaf open: kept as an explicit lane mask in an SGPR pair and updated with
+  // scalar instructions at the (wave-uniform) boundary steps; predicates are formed from it with
+  // inverse_ballot, which costs nothing.  (A per-lane bool would be carried in a VGPR through the
+  // divergent boundary code and re-tested with vector compares at every step.)
+  unsigned long long active_m = 0;
   unsigned int roff = 8;                                     // byte offset of 1/(count+1) in the reciprocal table
   SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
   unsigned int flags = 0;
@@ -395,13 +399,16 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     // lockstep pass altogether (its lane would walk far beyond its chunk, alone, at the cost of a
     // whole wave): the lane hands it over to k_fit_long (by the index of its previous key) and goes
     // on looking for the next leaf start.
+    bool active = __builtin_amdgcn_inverse_ballot_w64(active_m);
     bool beyond = __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
     if (beyond) {
-      if (active && (roff >> 3) >= long_min) {
+      const bool hand_over = active && (roff >> 3) >= long_min;
+      active_m &= ~__ballot(hand_over);
+      if (hand_over) {
         const unsigned long long pos = atomicAdd(&st->long_count, 1ull);
         if (pos < st->long_cap) long_idx[pos] = row_i - 1;
-        active = false;
       }
+      active = __builtin_amdgcn_inverse_ballot_w64(active_m);
       beyond = __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
     }
     // steps at which some lane crosses a leaf boundary, wave-uniform: the step loop tests a scalar bit
@@ -440,16 +447,18 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         const double idxf = row_if + (double)s;
         double y = idxf;                                     // FixDups first-occurrence offset
         if constexpr (!NODUP) y = ((dmask >> s) & 1u) ? yprev : idxf;
-        bool do_push = active;
+        unsigned long long push_m = active_m;               // lanes that consume this key
         if ((any_mask >> s) & 1u) {
           // close first (queue the running state of the leaf that ends here), then open
           const bool is_end = (s == end_pos);
           const bool is_split = (s == split_pos);
           const uint64_t idx = row_i + s;
-          const bool do_close = bit && active;
+          const unsigned long long bit_m = __ballot(bit);
+          const unsigned long long close_m = bit_m & active_m;
+          const bool do_close = __builtin_amdgcn_inverse_ballot_w64(close_m);
           int slot = my_slot;
           if constexpr (!FAST) {
-            const unsigned long long cm = __ballot(do_close);
+            const unsigned long long cm = close_m;
             slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
             pending += __popcll(cm);
           }
@@ -463,20 +472,29 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
           const bool open = bit && !is_end && (s < own_cnt);
           const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
           const bool with_prev = !(is_split || idx == 0 || prev_split);
-          const double ini_n = with_prev ? 1.0 : 0.0;
-          sl.mx = open ? (with_prev ? xprev : 0.0) : sl.mx;
           double yp = yprev;                                   // y of the previous key
           if constexpr (NODUP) yp = (s == 0) ? yprev : idxf - 1.0;
-          sl.my = open ? (with_prev ? yp : 0.0) : sl.my;
-          sl.c = open ? 0.0 : sl.c;
-          sl.m2 = open ? 0.0 : sl.m2;
-          sl.nf = open ? ini_n : sl.nf;
-          roff = open ? (with_prev ? 16u : 8u) : roff;
-          rr = open ? (with_prev ? 0.5 : 1.0) : rr;          // 1/(cnt+1)
-          active = bit ? open : active;                      // end of data / the next lane takes over: inactive
-          do_push = bit ? (open && !is_split) : do_push;
+          if (open) {
+            // Re-initialise the running state in place, under the execution mask of the opening
+            // lanes (the state of the others is not touched, so nothing is selected or copied):
+            // w = 1 with a prev-last point (count 1, means = that point), else 0 (all zero).
+            // The asm operands are tied ("+v") so that the values stay in their registers.
+            const double w = with_prev ? 1.0 : 0.0;
+            const unsigned int ro = with_prev ? 16u : 8u;
+            asm("v_mul_f64 %0, %1, %2" : "+v"(sl.mx) : "v"(xprev), "v"(w));          // (keys are >= 0 or w == 1 / +-0 alike)
+            asm("v_mul_f64 %0, %1, %2" : "+v"(sl.my) : "v"(yp), "v"(w));
+            asm("v_mov_b64 %0, 0" : "+v"(sl.c));
+            asm("v_mov_b64 %0, 0" : "+v"(sl.m2));
+            asm("v_mov_b64 %0, %1" : "+v"(sl.nf) : "v"(w));
+            asm("v_mov_b32 %0, %1" : "+v"(roff) : "v"(ro));
+            asm("v_fma_f64 %0, %1, -0.5, 1.0" : "+v"(rr) : "v"(w));               // 1/(cnt+1): 0.5 or 1.0
+          }
+          // end of data / the next lane takes over: inactive.  Q2: the key at split_idx is not consumed.
+          const unsigned long long open_m = __ballot(open);
+          active_m = (active_m & ~bit_m) | open_m;
+          push_m = (push_m & ~bit_m) | (open_m & ~__ballot(is_split));
         }
-        if (do_push) {
+        if (__builtin_amdgcn_inverse_ballot_w64(push_m)) {
           roff += 8;
           if constexpr (FAST) slr_push_r(sl, x, y, rr);
           else slr_push(sl, x, y);
@@ -494,7 +512,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     if (pending >= FS_QDRAIN) drain();
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
-    if (!active && (row_i >= chunk_end || row_i >= rd_hi)) lane_done = true;
+    if (!__builtin_amdgcn_inverse_ballot_w64(active_m) && (row_i >= chunk_end || row_i >= rd_hi)) lane_done = true;
     P += 1;
   }
   if (pending) drain();
