@@ -449,36 +449,40 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         if constexpr (!NODUP) y = ((dmask >> s) & 1u) ? yprev : idxf;
         unsigned long long push_m = active_m;               // lanes that consume this key
         if ((any_mask >> s) & 1u) {
-          // close first (queue the running state of the leaf that ends here), then open
-          const bool is_end = (s == end_pos);
-          const bool is_split = (s == split_pos);
-          const uint64_t idx = row_i + s;
+          // close first (queue the running state of the leaf that ends here), then open.  All the
+          // conditions are lane masks built from one vector compare each and combined with scalar
+          // instructions; `sb` pins the index arithmetic inside this (rare) block.
+          int sb = s;
+          asm volatile("" : "+s"(sb));
+          const uint64_t idx = row_i + (uint64_t)sb;
           const unsigned long long bit_m = __ballot(bit);
+          const unsigned long long end_m = __ballot(sb == end_pos);
+          const unsigned long long split_m = __ballot(sb == split_pos);
           const unsigned long long close_m = bit_m & active_m;
           const bool do_close = __builtin_amdgcn_inverse_ballot_w64(close_m);
           int slot = my_slot;
           if constexpr (!FAST) {
-            const unsigned long long cm = close_m;
-            slot = pending + __popcll(cm & ((1ull << lane) - 1ull));
-            pending += __popcll(cm);
+            slot = pending + __popcll(close_m & ((1ull << lane) - 1ull));
+            pending += __popcll(close_m);
           }
           if (do_close) {
             q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
-            q_idx[slot] = (is_end || is_split) ? (idx | FS_NO_NEXT) : idx;   // Q3: no next-first across the halves / at the end
+            // Q3: no next-first across the halves / at the end
+            q_idx[slot] = __builtin_amdgcn_inverse_ballot_w64(end_m | split_m) ? (idx | FS_NO_NEXT) : idx;
           }
-          // open the leaf that starts here (selects, so that the running state stays in place):
-          // prev-last point (two_layer.rs:74-78) unless at the start of a half / after Q4 (Q3/Q4);
-          // Q2: the key at split_idx is in neither half.
-          const bool open = bit && !is_end && (s < own_cnt);
-          const bool prev_split = (s == 0) ? prev_split_in : (split_pos == s - 1);
-          const bool with_prev = !(is_split || idx == 0 || prev_split);
+          // open the leaf that starts here: prev-last point (two_layer.rs:74-78) unless at the start
+          // of a half / after Q4 (Q3/Q4); Q2: the key at split_idx is in neither half.
+          const unsigned long long open_m = bit_m & ~end_m & __ballot(sb < own_cnt);
+          const unsigned long long psplit_m = (sb == 0) ? __ballot(prev_split_in) : __ballot(split_pos == sb - 1);
+          const unsigned long long wp_m = ~(split_m | __ballot(idx == 0) | psplit_m);
           double yp = yprev;                                   // y of the previous key
-          if constexpr (NODUP) yp = (s == 0) ? yprev : idxf - 1.0;
-          if (open) {
+          if constexpr (NODUP) { if (sb != 0) yp = idxf - 1.0; }
+          if (__builtin_amdgcn_inverse_ballot_w64(open_m)) {
             // Re-initialise the running state in place, under the execution mask of the opening
             // lanes (the state of the others is not touched, so nothing is selected or copied):
             // w = 1 with a prev-last point (count 1, means = that point), else 0 (all zero).
             // The asm operands are tied ("+v") so that the values stay in their registers.
+            const bool with_prev = __builtin_amdgcn_inverse_ballot_w64(wp_m);
             const double w = with_prev ? 1.0 : 0.0;
             const unsigned int ro = with_prev ? 16u : 8u;
             asm("v_mul_f64 %0, %1, %2" : "+v"(sl.mx) : "v"(xprev), "v"(w));          // (keys are >= 0 or w == 1 / +-0 alike)
@@ -490,9 +494,8 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
             asm("v_fma_f64 %0, %1, -0.5, 1.0" : "+v"(rr) : "v"(w));               // 1/(cnt+1): 0.5 or 1.0
           }
           // end of data / the next lane takes over: inactive.  Q2: the key at split_idx is not consumed.
-          const unsigned long long open_m = __ballot(open);
           active_m = (active_m & ~bit_m) | open_m;
-          push_m = (push_m & ~bit_m) | (open_m & ~__ballot(is_split));
+          push_m = (push_m & ~bit_m) | (open_m & ~split_m);
         }
         if (__builtin_amdgcn_inverse_ballot_w64(push_m)) {
           roff += 8;
