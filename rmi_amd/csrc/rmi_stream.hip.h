@@ -436,12 +436,12 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         pending += __popcll(cmask);
       }
       double xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE]);
-#pragma unroll 2
-      for (int s = 0; s < FS_ROW; s++) {
+      auto one = [&](int s) {
         const double x = xn;
         xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);   // next step's x
         double rr = 0.0;
-        if constexpr (FAST && TAB) rr = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rtab) + (roff & (FS_TMAX * 8 - 1)));
+        // (TAB: the counts of this row stay inside the table, see `beyond`: no wrap-around mask needed)
+        if constexpr (FAST && TAB) rr = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rtab) + roff);
         if constexpr (FAST && !TAB) rr = recip_exact(sl.nf + 1.0);
         const bool bit = (bmask >> s) & 1u;
         const double idxf = row_if + (double)s;
@@ -505,6 +505,13 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         xprev = x;
         if constexpr (!NODUP) yprev = y;
         if constexpr (!FAST) { if (pending >= FS_QDRAIN) drain(); }
+      };
+      if constexpr (FAST && NODUP && TAB) {                  // the usual instance: fully unrolled (constant LDS offsets, no loop state)
+#pragma unroll
+        for (int s = 0; s < FS_ROW; s++) one(s);
+      } else {
+#pragma unroll 2
+        for (int s = 0; s < FS_ROW; s++) one(s);
       }
       if constexpr (NODUP) yprev = row_if + (double)(FS_ROW - 1);
     };
