@@ -130,14 +130,15 @@ __device__ __forceinline__ K bits_to_key(unsigned long long b) {
   else return __builtin_bit_cast(K, (unsigned int)b);
 }
 
-// Coalesced load of panel P of this wave (64 rows x 16 keys) into registers with 16-byte loads:
-// a lane fetches V = 16/sizeof(K) consecutive keys of one row, LPR = 16/V lanes cover a row (one
-// full 128-B line for 8-byte keys), an instruction covers 64/LPR rows, LPR instructions cover the
-// panel.  Near the end of the readable keys the panel is fetched key by key instead, indices past
+// Coalesced load of panel P of this wave (64 rows x 16 keys) into registers: a lane fetches V = 2
+// consecutive keys of one row (16 bytes for 8-byte keys), LPR = 8 lanes cover a row (one full 128-B
+// line for 8-byte keys), an instruction covers 8 rows, 8 instructions cover the panel.  Near the end of the readable keys the panel is fetched key by key instead, indices past
 // the end clamped to n-1 (no branches around the loads); the duplicated key is masked out by the
 // validity masks downstream.
 template <typename K> struct PanelGeom {
-  static constexpr int V = 16 / (int)sizeof(K);      // keys per lane per load
+  static constexpr int V = 2;                         // keys per lane per load: 16-byte loads for 8-byte keys, 8-byte
+                                                      // loads for u32 (4 keys per lane spread an instruction over 16
+                                                      // rows and cost the u32 configuration 30 % in pass B)
   static constexpr int LPR = FS_ROW / V;              // lanes per row == loads per panel
   static constexpr int RPI = 64 / LPR;                // rows per load instruction
 };
@@ -145,7 +146,7 @@ template <typename K>
 __device__ __forceinline__ void load_panel(K (&stage)[FS_ROW], const K* __restrict__ keys, uint64_t n,
                                            uint64_t wave_base, uint64_t C, uint64_t P, int lane) {
   using G = PanelGeom<K>;
-  struct alignas(8) Vec { K v[G::V]; };                 // 16 bytes; the address is only key-aligned in a shard
+  struct alignas(sizeof(K)) Vec { K v[G::V]; };         // the address is only key-aligned in a shard
   // wave-uniform base (SGPRs) + one 32-bit lane offset: no per-load 64-bit VGPR address math
   const uint64_t ubase = wave_base + P * FS_ROW;
   const unsigned int loff = (unsigned int)(lane / G::LPR) * (unsigned int)C + (unsigned int)(lane % G::LPR) * G::V;
@@ -578,8 +579,11 @@ __device__ __forceinline__ void convert_row(unsigned long long* __restrict__ pan
   kprev = kp;
 }
 
-constexpr int ER_QDRAIN = 8;      // drain the result queue once this many (lane, leaf) maxima are pending
-constexpr int ER_QCAP = ER_QDRAIN + 64;   // at most 64 more arrive per panel in the fast loop; 4 waves/SIMD need <= 10 KB LDS per wave
+// Result queue of a wave: (leaf, max error, longest run) per (lane, leaf) segment.  4 waves/SIMD
+// leave 1536 B of LDS per wave for it.  Below 2^32 keys the two maxima fit 32 bits: 128 entries,
+// drained in bursts of >= 64; otherwise 72 entries of f64 maxima (bursts of >= 8).  At most 64
+// entries arrive per panel in the fast loop.
+constexpr int ER_QWORDS = 384;
       // result queue per wave (drained in bursts of >= 64)
 
 template <int ROOT, int LEAF, typename K>
@@ -590,8 +594,12 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
                                                   unsigned long long* __restrict__ leaf_run) {
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   __shared__ unsigned long long panel[64 * FS_STRIDE];
-  __shared__ unsigned int q_leaf[ER_QCAP];
-  __shared__ double q_err[ER_QCAP], q_run[ER_QCAP];
+  __shared__ alignas(8) unsigned int qraw[ER_QWORDS];
+  const bool q32 = sp.n < (1ull << 32);
+  const int q_cap = q32 ? 128 : 72, q_drain = q_cap - 64;
+  unsigned int* q_leaf = qraw;
+  unsigned int* q_err32 = qraw + 128; unsigned int* q_run32 = qraw + 256;
+  double* q_err64 = reinterpret_cast<double*>(qraw + 72); double* q_run64 = reinterpret_cast<double*>(qraw + 72 + 144);
 
   const int lane = threadIdx.x;
   const uint64_t n = sp.n;
@@ -636,9 +644,10 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
       const int slot = b + lane;
       if (slot < pending) {
         const unsigned int lj = q_leaf[slot];
-        const double e = q_err[slot], rn = q_run[slot];
-        if (e > 0.0) atomicMax(&leaf_maxerr[lj], (unsigned long long)e);
-        if (rn > 1.0) atomicMax(&leaf_run[lj], (unsigned long long)rn);
+        const unsigned long long e = q32 ? (unsigned long long)q_err32[slot] : (unsigned long long)q_err64[slot];
+        const unsigned long long rn = q32 ? (unsigned long long)q_run32[slot] : (unsigned long long)q_run64[slot];
+        if (e > 0) atomicMax(&leaf_maxerr[lj], e);
+        if (rn > 1) atomicMax(&leaf_run[lj], rn);
       }
     }
     pending = 0;
@@ -650,7 +659,9 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
     if (pm) {
       if (push) {
         const int slot = pending + __popcll(pm & ((1ull << lane) - 1ull));
-        q_leaf[slot] = cur_leaf; q_err[slot] = maxerr; q_run[slot] = maxrun;
+        q_leaf[slot] = cur_leaf;
+        if (q32) { q_err32[slot] = (unsigned int)maxerr; q_run32[slot] = (unsigned int)maxrun; }
+        else { q_err64[slot] = maxerr; q_run64[slot] = maxrun; }
       }
       pending += __popcll(pm);
     }
@@ -744,7 +755,7 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
             pn_ok = false; pn_inflight = false;
             pn_need = cur_leaf < leaf_last;
           }
-          if constexpr (!FAST) { if (pending >= ER_QDRAIN) drain(); }
+          if constexpr (!FAST) { if (pending >= q_drain) drain(); }
         }
         if (valid) {
           double f;
@@ -768,7 +779,7 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
     if (__any(general)) steps(std::false_type{}, std::false_type{});
     else if (plain_ok) steps(std::true_type{}, std::true_type{});
     else steps(std::true_type{}, std::false_type{});
-    if (pending >= ER_QDRAIN) drain();                       // (at most 64 more can arrive per panel in the fast loop)
+    if (pending >= q_drain) drain();                         // (at most 64 more can arrive per panel in the fast loop)
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
     if (row_i >= chunk_end) lane_done = true;

@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B of the u32 / radix root / linear_spline configuration (BASELINE config 5 on one GPU)
+A="--spec radix,linear_spline --leaves 4194304 --keys 400000000 --dtype uint32"
+P='import sys,json; d=json.loads(sys.stdin.read()); print("   ms/step %.4f" % d["ms_per_step"], {k: round(v) for k, v in d["roofline"]["kernel_us"].items()})'
+for rep in 1 2; do
+  echo "old"; RMI_HIP_LIB=$PWD/build_ab/old.so python bench.py --steps 10 --warmup 2 --no-cpu-baseline $A 2>&1 | tail -1 | python -c "$P"
+  echo "new"; python bench.py --steps 10 --warmup 2 --no-cpu-baseline $A 2>&1 | tail -1 | python -c "$P"
+  for e in "$@"; do echo "new $e"; env $e python bench.py --steps 10 --warmup 2 --no-cpu-baseline $A 2>&1 | tail -1 | python -c "$P"; done
+done
