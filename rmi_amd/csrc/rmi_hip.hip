@@ -568,7 +568,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
     } else {
       constexpr uint64_t V = 16 / sizeof(K);
-      const uint64_t blocks = ((n_it + V - 1) / V + 255) / 256;
+      const uint64_t blocks = ((n_it + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
       hipLaunchKernelGGL((k_bounds_vec<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
     }
     mark();

@@ -75,58 +75,81 @@ __global__ void __launch_bounds__(256) k_init(unsigned long long* __restrict__ l
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_bounds_vec: the same bucketing scan with 16 bytes per lane (2 x 8-byte or 4 x 4-byte keys),
-// fully coalesced; the key before a lane's first key comes from the previous lane (shuffle) or,
-// for lane 0, from memory.  One root evaluation per key (+1 per lane for the predecessor).
+// k_bounds_vec: the same bucketing scan with 16 bytes per lane and load (2 x 8-byte or 4 x 4-byte
+// keys), fully coalesced, BV_UNROLL independent loads in flight per lane.  The target of the key
+// before a lane's first key comes from the previous lane (DPP-free wave shuffle of its last
+// target) or, for lane 0 of a wave, from one extra load.  One root evaluation per key.
 // ---------------------------------------------------------------------------------------------
+constexpr int BV_UNROLL = 4;
+
 template <int ROOT, typename K>
 __global__ void __launch_bounds__(256) k_bounds_vec(const K* __restrict__ keys, Span sp, RootP r,
                                                     unsigned long long* __restrict__ leaf_start,
                                                     DevState* __restrict__ st) {
   constexpr int V = 16 / sizeof(K);
-  const uint64_t base = sp.it_lo + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-  if (base >= sp.it_hi) return;
   const uint64_t n = sp.n;
   const uint64_t Lm1 = r.L - 1;
   const uint64_t mid = r.L / 2;                                   // two_layer.rs:131
-  K kk[V];
-  if (base + V <= sp.it_hi && (((uintptr_t)(keys + base)) & 15) == 0) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(keys + base);
-    __builtin_memcpy(kk, &raw, 16);
-  } else {
+  const int lane = threadIdx.x & 63;
+  const uint64_t first = sp.it_lo + ((uint64_t)blockIdx.x * BV_UNROLL * blockDim.x + threadIdx.x) * V;
+  const bool aligned = (((uintptr_t)(keys + sp.it_lo)) & 15) == 0;
+  K kk[BV_UNROLL][V];
 #pragma unroll
-    for (int q = 0; q < V; q++) kk[q] = keys[(base + q < sp.it_hi) ? base + q : sp.it_hi - 1];
+  for (int u = 0; u < BV_UNROLL; u++) {                           // all loads first
+    const uint64_t base = first + (uint64_t)u * blockDim.x * V;
+    if (base + V <= sp.it_hi && aligned) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(keys + base);
+      __builtin_memcpy(kk[u], &raw, 16);
+    } else {
+#pragma unroll
+      for (int q = 0; q < V; q++) kk[u][q] = (base < sp.it_hi) ? keys[(base + q < sp.it_hi) ? base + q : sp.it_hi - 1] : K();
+    }
   }
   unsigned int flags = 0;
-  uint64_t tp = ~0ull;                                            // target of the previous key (none yet)
-  if (base > sp.rd_lo) {
-    const uint64_t pp = root_predict<ROOT, K>(r, keys[base - 1]);
-    tp = pp < Lm1 ? pp : Lm1;
-  }
 #pragma unroll
-  for (int q = 0; q < V; q++) {
-    const uint64_t i = base + q;
-    if (i < sp.it_hi) {
-      const uint64_t p = root_predict<ROOT, K>(r, kk[q]);
-      if constexpr (!root_needs_bounds_check<ROOT>()) { if (p > Lm1) flags |= EF_ROOT_OOB; }    // two_layer.rs:45-48
-      const uint64_t t = p < Lm1 ? p : Lm1;                      // two_layer.rs:49
-      const bool mine = t >= sp.leaf_lo && t < sp.leaf_hi;
-      if (i == 0) {
-        if (mine) leaf_start[t] = 0;
-        if (t >= mid) flags |= EF_DEGENERATE_SPLIT;              // split_idx == 0 -> :27
-      } else if (tp != ~0ull) {
-        if (t < tp) flags |= EF_NON_MONOTONE;                    // two_layer.rs:50 / :144
-        else if (t > tp) {
-          if (mine) leaf_start[t] = i;
-          if (tp < mid && t >= mid) {                            // two_layer.rs:132-136,152-156
-            st->split_idx = i;
-            st->split_target = t;
-            if (i + 1 >= n) flags |= EF_DEGENERATE_SPLIT;        // second half empty -> :27
+  for (int u = 0; u < BV_UNROLL; u++) {
+    const uint64_t base = first + (uint64_t)u * blockDim.x * V;
+    const bool live = base < sp.it_hi;                            // (wave-uniform except in the last wave)
+    uint64_t t[V];
+#pragma unroll
+    for (int q = 0; q < V; q++) {
+      const uint64_t p = root_predict<ROOT, K>(r, kk[u][q]);
+      if constexpr (!root_needs_bounds_check<ROOT>()) { if (live && base + q < sp.it_hi && p > Lm1) flags |= EF_ROOT_OOB; }   // two_layer.rs:45-48
+      t[q] = p < Lm1 ? p : Lm1;                                   // two_layer.rs:49
+    }
+    // target of the key before this lane's first key: the previous lane's last target; lane 0 loads it
+    uint64_t tp = __shfl_up(t[V - 1], 1);
+    if (lane == 0 || !live) {
+      tp = ~0ull;
+      if (live && base > sp.rd_lo) {
+        const uint64_t pp = root_predict<ROOT, K>(r, keys[base - 1]);
+        tp = pp < Lm1 ? pp : Lm1;
+      }
+    }
+    if (!live) continue;
+#pragma unroll
+    for (int q = 0; q < V; q++) {
+      const uint64_t i = base + q;
+      if (i < sp.it_hi) {
+        const uint64_t tq = t[q];
+        const bool mine = tq >= sp.leaf_lo && tq < sp.leaf_hi;
+        if (i == 0) {
+          if (mine) leaf_start[tq] = 0;
+          if (tq >= mid) flags |= EF_DEGENERATE_SPLIT;            // split_idx == 0 -> :27
+        } else if (tp != ~0ull) {
+          if (tq < tp) flags |= EF_NON_MONOTONE;                  // two_layer.rs:50 / :144
+          else if (tq > tp) {
+            if (mine) leaf_start[tq] = i;
+            if (tp < mid && tq >= mid) {                          // two_layer.rs:132-136,152-156
+              st->split_idx = i;
+              st->split_target = tq;
+              if (i + 1 >= n) flags |= EF_DEGENERATE_SPLIT;       // second half empty -> :27
+            }
           }
         }
+        if (i == n - 1) st->last_target = tq;
+        tp = tq;
       }
-      if (i == n - 1) st->last_target = t;
-      tp = t;
     }
   }
   if (flags) atomicOr(&st->err_flags, flags);
