@@ -91,3 +91,47 @@ def test_sharded_matches_oracle(oracle):
     o = oracle.train_two_layer("linear", "linear", keys, 1024)
     assert np.array_equal(full.leaf_params, o.leaf_params)
     assert np.array_equal(full.last_layer_max_l1s, o.leaf_err)
+
+
+def _sharded_trainer_worker(rank, world, port, n_global, L, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    from rmi_amd import sharded, train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                                      # both ranks share the one GPU of the box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = train.Trainer(device=0)
+    sh = sharded.ShardedTrainer(tr, dist, rank, world, "uniform", np.uint64, n_global, L, "linear,linear", chunk=700_000)
+    sh.step()
+    sh.step()                                                     # (a second step re-uses every buffer)
+    rows = sh.full_rows.cpu().numpy().copy()
+    ok = True
+    if rank == 0:                                                 # against the unsharded result on the same keys
+        t1 = train.Trainer(device=0)
+        t1.generate_keys("uniform", np.uint64, n_global)
+        ref = t1.train("linear,linear", L)
+        ok = bool(np.array_equal(rows, ref.rows)) and ref.root.p == sh.root.p
+        t1.close()
+    q.put((rank, ok))
+    tr.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_trainer_two_ranks_one_gpu():
+    """bench.py's N>1 driver (ShardedTrainer: streamed exact root on rank 0, broadcast, plan, device-side
+    key generation per shard, per-step exchange) with two gloo ranks on one GPU: every rank ends with
+    the byte-identical table of the unsharded run."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_trainer_worker, args=(r, 2, port, 2_000_000, 8192, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
