@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         if constexpr (!NODUP) yprev = y;
         if constexpr (!FAST) { if (pending >= FS_QDRAIN) drain(); }
       };
-      if constexpr (FAST && NODUP && TAB) {                  // the usual instance: fully unrolled (constant LDS offsets, no loop state)
+      if constexpr (FAST && TAB) {                           // the usual instances: fully unrolled (constant LDS offsets, no loop state)
 #pragma unroll
         for (int s = 0; s < FS_ROW; s++) one(s);
       } else {
