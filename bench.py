@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=200_000_000,
                     help="keys of the workload the CPU baseline is timed on (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N>1: finish the row exchange of a step before the next step starts (default: it overlaps the next step's kernels)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo for functional tests)")
     return ap.parse_args()
 
@@ -101,6 +103,7 @@ def main():
     key_bytes = np.dtype(np_dtype).itemsize
 
     tr = T.Trainer(device=local_rank)
+    sh = None
     if world == 1:
         if args.dataset == "books":
             from rmi_amd import datagen
@@ -115,12 +118,15 @@ def main():
         run_step = lambda: tr.train_leaves(root, leaf_kind, L_local)
     else:
         from rmi_amd import sharded
-        sh = sharded.ShardedTrainer(tr, dist, rank, world, args.dataset, np_dtype, n_global, L_global, args.spec)
+        sh = sharded.ShardedTrainer(tr, dist, rank, world, args.dataset, np_dtype, n_global, L_global, args.spec,
+                                    pipeline=not args.no_pipeline)
         root_s = sh.root_seconds
         run_step = sh.step
         keys_np = None
 
     def sync():
+        if sh is not None:
+            sh.finish()                 # the exchange of the last step (pipelined mode) belongs to the timed region
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -163,6 +169,8 @@ def main():
                 "workload": f"{args.spec} {L_global} leaves on {n_global} synthetic sorted {args.dtype} keys "
                             f"({args.dataset}), {n_local} keys + {L_local} leaves per GPU",
                 "keys_per_gpu": n_local, "leaves_per_gpu": L_local, "mode": "exact (reference-order SLR)",
+                "exchange": (None if world == 1 else ("all-gather of rows, overlapped with the next step's kernels (double-buffered)"
+                                                      if (sh is not None and sh.pipeline) else "all-gather of rows at the end of every step")),
                 "root_fit_seconds_untimed": root_s,
             },
             "roofline": {

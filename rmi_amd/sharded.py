@@ -180,7 +180,7 @@ class ShardedTrainer:
     synthetic key array in HBM, rank 0 fits the root exactly (streamed) and broadcasts it."""
 
     def __init__(self, tr: T.Trainer, dist, rank: int, world: int, dataset: str, np_dtype,
-                 n_global: int, num_leaves: int, spec: str, chunk: int = 50_000_000):
+                 n_global: int, num_leaves: int, spec: str, chunk: int = 50_000_000, pipeline: bool = False):
         import torch
         from . import datagen
         self.tr, self.dist, self.rank, self.world = tr, dist, rank, world
@@ -225,22 +225,50 @@ class ShardedTrainer:
         self.plan = Planner(key_at, n_global, np_dtype, self.root, num_leaves).plan(world)[rank]
         tr.generate_keys(dataset, np_dtype, n_global, self.plan.read_lo, self.plan.read_hi - self.plan.read_lo)
         self.row_bytes = 24
-        self.full_rows = torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda")
         per = (self.plan.leaf_hi - self.plan.leaf_lo) * self.row_bytes
-        self.my_rows = torch.empty(per, dtype=torch.uint8, device="cuda")     # the kernels write this rank's rows here
-        self.rows_ptr = self.my_rows.data_ptr()
+        # Two sets of buffers: with `pipeline` the all-gather of one training runs (on RCCL's stream)
+        # while the kernels of the next one write the other set -- trainings are independent jobs
+        # (the optimizer runs ~100 of them over one key set), so the exchange need not sit on the
+        # critical path of the next one.  finish() completes the last exchange.
+        self.pipeline = bool(pipeline) and on_gpu
+        nbuf = 2 if self.pipeline else 1
+        self._full = [torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+        self._mine = [torch.empty(per, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]   # the kernels write this rank's rows here
+        self._cur = 0
+        self._pending = None
+        self.full_rows = self._full[0]
+        self.my_rows = self._mine[0]
         self._host = None if on_gpu else (torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8),
                                           torch.empty(per, dtype=torch.uint8))
         self._torch = torch
 
     def step(self):
-        res = run_shard(self.tr, self.plan, self.root, self.leaf_kind, self.rows_ptr)   # (synchronises its stream)
-        if self._host is None:
-            exchange_rows(self.dist, self.full_rows, self.my_rows, self.rank, self.world)   # RCCL all-gather, device to device
-            self._torch.cuda.current_stream().synchronize()    # the step ends when every rank holds the full table
-        else:                                                                    # gloo functional path: host bounce
+        b = self._cur
+        res = run_shard(self.tr, self.plan, self.root, self.leaf_kind, self._mine[b].data_ptr())   # (synchronises its stream)
+        if self._host is not None:                                               # gloo functional path: host bounce
             full_h, mine_h = self._host
-            mine_h.copy_(self.my_rows)
+            mine_h.copy_(self._mine[b])
             exchange_rows(self.dist, full_h, mine_h, self.rank, self.world)
-            self.full_rows.copy_(full_h)
+            self._full[b].copy_(full_h)
+        elif self.pipeline:
+            if self._pending is not None:
+                # the exchange of the previous training ran beside this one's kernels; it must be
+                # complete on the HOST's timeline before its buffers are written again (the kernels
+                # run on the library's stream, which knows nothing of torch's stream waits)
+                self._pending.wait()
+                self._torch.cuda.current_stream().synchronize()
+            self._pending = self.dist.all_gather_into_tensor(self._full[b], self._mine[b], async_op=True)
+            self._cur = b ^ 1
+        else:
+            exchange_rows(self.dist, self._full[b], self._mine[b], self.rank, self.world)   # RCCL all-gather, device to device
+            self._torch.cuda.current_stream().synchronize()    # the step ends when every rank holds the full table
+        self.full_rows, self.my_rows = self._full[b], self._mine[b]
         return res
+
+    def finish(self):
+        """Complete the exchange that is still in flight (pipelined mode); the table of the last
+        training is then in `full_rows` on every rank."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+        self._torch.cuda.synchronize()

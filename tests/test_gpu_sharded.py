@@ -135,3 +135,47 @@ def test_sharded_trainer_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _nccl_pipelined_worker(port, n_global, L, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    from rmi_amd import sharded, train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    tr = train.Trainer(device=0)
+    sh = sharded.ShardedTrainer(tr, dist, 0, 1, "uniform", np.uint64, n_global, L, "linear,linear", chunk=700_000, pipeline=True)
+    assert sh.pipeline
+    tables = []
+    for _ in range(5):                                            # exchanges overlap the next step; buffers alternate
+        sh.step()
+    sh.finish()
+    tables.append(sh.full_rows.cpu().numpy().copy())
+    sh.step()
+    sh.finish()
+    tables.append(sh.full_rows.cpu().numpy().copy())
+    t1 = train.Trainer(device=0)
+    t1.generate_keys("uniform", np.uint64, n_global)
+    ref = t1.train("linear,linear", L)
+    ok = all(np.array_equal(t, ref.rows) for t in tables)
+    q.put(bool(ok))
+    t1.close(); tr.close()
+    dist.destroy_process_group()
+
+
+def test_sharded_trainer_rccl_pipelined_single_rank():
+    """The RCCL code path of the N>1 driver (async all_gather_into_tensor on RCCL's stream, double
+    buffers, finish()) with the one rank a 1-GPU box allows."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_pipelined_worker, args=(port, 3_000_000, 4096, q))
+    p.start()
+    ok = q.get(timeout=300)
+    p.join(timeout=60)
+    assert ok
