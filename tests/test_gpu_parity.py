@@ -166,6 +166,29 @@ def test_parity_long_leaves(trainer_mod, oracle, gen):
     _compare(trainer_mod, oracle, keys, "cubic", "linear", 64)
 
 
+@pytest.mark.parametrize("name", ["all_equal", "two_keys", "one_key", "two_values", "max_key", "run_over_split"])
+def test_parity_degenerate_inputs(trainer_mod, oracle, name):
+    """Inputs on which the reference mostly panics (one leaf swallows everything, the 2-way split
+    degenerates, num_bits asserts): the same results or the matching error code."""
+    keys = {
+        "all_equal": np.full(1000, 77, dtype=np.uint64),
+        "two_keys": np.array([5, 9], dtype=np.uint64),
+        "one_key": np.array([5], dtype=np.uint64),
+        "two_values": np.array([3] * 500 + [900] * 500, dtype=np.uint64),
+        "max_key": np.array([1, 2, 3, (1 << 64) - 2], dtype=np.uint64),
+        "run_over_split": np.sort(np.concatenate([np.arange(1, 400, dtype=np.uint64), np.full(300, 400, dtype=np.uint64),
+                                                  np.arange(401, 800, dtype=np.uint64)])),
+    }[name]
+    for root, leaf in [("linear", "linear"), ("radix", "linear"), ("cubic", "linear_spline"), ("linear", "cubic"),
+                       ("radix8", "linear")]:
+        for L in (2, 8, 64):
+            try:
+                oracle.fit_root(root, keys, L)
+            except oracle.OracleError:
+                continue                                   # the root itself is undefined here (e.g. num_bits); covered by test_error_codes
+            _compare(trainer_mod, oracle, keys, root, leaf, L)
+
+
 def test_parity_tiny(trainer_mod, oracle):
     keys = np.array([10, 11, 12, 20, 21, 30, 30, 31, 40, 41, 42, 50], dtype=np.uint64)
     for L in (2, 3, 4, 7):
