@@ -93,17 +93,6 @@ __device__ __forceinline__ void slr_push_r(SlrState& s, double x, double y, doub
   s.m2 += dx * dx2;
 }
 
-// The same step with the count n (and its reciprocal) handed in from the (1/n, n) table: the
-// running count is then not part of the loop-carried state at all (it is the table offset).
-__device__ __forceinline__ void slr_push_rn(SlrState& s, double x, double y, double r, double n) {
-  const double dx = x - s.mx;
-  s.mx += div_by_count(dx, n, r);
-  s.my += div_by_count(y - s.my, n, r);
-  s.c += dx * (y - s.my);
-  const double dx2 = x - s.mx;
-  s.m2 += dx * dx2;
-}
-
 // OR of a 32-bit value over the 64 lanes of the wave, returned wave-uniform (an SGPR): DPP inside
 // rows of 16, then across rows.
 __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
@@ -287,7 +276,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   __shared__ unsigned long long s_panel[FA_WAVES][64 * FS_STRIDE];   // raw key bits, then f64 x
   constexpr bool LEAFP = (ROOT == K_RADIX || ROOT == K_RADIX_TABLE);
   __shared__ unsigned int s_leafp[FA_WAVES][LEAFP ? 64 * FS_STRIDE : 1];   // leaf ids (radix roots only)
-  __shared__ double2 rtab[FS_TMAX];                        // (1/q, q): one 16-byte read per step
+  __shared__ double rtab[FS_TMAX];
   __shared__ double s_q[FA_WAVES][5][FS_QCAP2];
   __shared__ unsigned long long s_qidx[FA_WAVES][FS_QCAP2];
 
@@ -307,7 +296,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   const double Lm1f = (double)(r.L - 1);
   const double midf = (double)(r.L / 2);                     // two_layer.rs:131
 
-  for (int q = threadIdx.x; q < FS_TMAX; q += 64 * FA_WAVES) rtab[q] = make_double2(1.0 / (double)(q > 0 ? q : 1), (double)q);
+  for (int q = threadIdx.x; q < FS_TMAX; q += 64 * FA_WAVES) rtab[q] = 1.0 / (double)(q > 0 ? q : 1);
   __syncthreads();
 
   // carries of the classification (phase 1)
@@ -321,7 +310,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   // inverse_ballot, which costs nothing.  (A per-lane bool would be carried in a VGPR through the
   // divergent boundary code and re-tested with vector compares at every step.)
   unsigned long long active_m = 0;
-  unsigned int roff = 16;                                    // byte offset of (1/(count+1), count+1) in the reciprocal table
+  unsigned int roff = 8;                                     // byte offset of 1/(count+1) in the reciprocal table
   SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};
   unsigned int flags = 0;
   if (p0 < sp.it_hi && p0 > sp.rd_lo) {
@@ -412,16 +401,16 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     // whole wave): the lane hands it over to k_fit_long (by the index of its previous key) and goes
     // on looking for the next leaf start.
     bool active = __builtin_amdgcn_inverse_ballot_w64(active_m);
-    bool beyond = __any(active && (roff >> 4) + FS_ROW + 2 >= (unsigned)FS_TMAX);
+    bool beyond = __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
     if (beyond) {
-      const bool hand_over = active && (roff >> 4) >= long_min;
+      const bool hand_over = active && (roff >> 3) >= long_min;
       active_m &= ~__ballot(hand_over);
       if (hand_over) {
         const unsigned long long pos = atomicAdd(&st->long_count, 1ull);
         if (pos < st->long_cap) long_idx[pos] = row_i - 1;
       }
       active = __builtin_amdgcn_inverse_ballot_w64(active_m);
-      beyond = __any(active && (roff >> 4) + FS_ROW + 2 >= (unsigned)FS_TMAX);
+      beyond = __any(active && (roff >> 3) + FS_ROW + 2 >= (unsigned)FS_TMAX);
     }
     // steps at which some lane crosses a leaf boundary, wave-uniform: the step loop tests a scalar bit
     const unsigned int any_mask = wave_or_u32(bmask);
@@ -451,12 +440,9 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
       auto one = [&](int s) {
         const double x = xn;
         xn = __builtin_bit_cast(double, panel[lane * FS_STRIDE + ((s + 1) & (FS_ROW - 1))]);   // next step's x
-        double rr = 0.0, rn = 0.0;
+        double rr = 0.0;
         // (TAB: the counts of this row stay inside the table, see `beyond`: no wrap-around mask needed)
-        if constexpr (FAST && TAB) {
-          const double2 t2 = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(rtab) + roff);
-          rr = t2.x; rn = t2.y;
-        }
+        if constexpr (FAST && TAB) rr = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(rtab) + roff);
         if constexpr (FAST && !TAB) rr = recip_exact(sl.nf + 1.0);
         const bool bit = (bmask >> s) & 1u;
         const double idxf = row_if + (double)s;
@@ -481,9 +467,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
             pending += __popcll(close_m);
           }
           if (do_close) {
-            q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2;
-            if constexpr (FAST && TAB) q_nf[slot] = (double)((roff >> 4) - 1u);      // the count is the table offset
-            else q_nf[slot] = sl.nf;
+            q_mx[slot] = sl.mx; q_my[slot] = sl.my; q_c[slot] = sl.c; q_m2[slot] = sl.m2; q_nf[slot] = sl.nf;
             // Q3: no next-first across the halves / at the end
             q_idx[slot] = __builtin_amdgcn_inverse_ballot_w64(end_m | split_m) ? (idx | FS_NO_NEXT) : idx;
           }
@@ -501,7 +485,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
             // The asm operands are tied ("+v") so that the values stay in their registers.
             const bool with_prev = __builtin_amdgcn_inverse_ballot_w64(wp_m);
             const double w = with_prev ? 1.0 : 0.0;
-            const unsigned int ro = with_prev ? 32u : 16u;
+            const unsigned int ro = with_prev ? 16u : 8u;
             asm("v_mul_f64 %0, %1, %2" : "+v"(sl.mx) : "v"(xprev), "v"(w));          // (keys are >= 0 or w == 1 / +-0 alike)
             asm("v_mul_f64 %0, %1, %2" : "+v"(sl.my) : "v"(yp), "v"(w));
             asm("v_mov_b64 %0, 0" : "+v"(sl.c));
@@ -509,16 +493,14 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
             asm("v_mov_b64 %0, %1" : "+v"(sl.nf) : "v"(w));
             asm("v_mov_b32 %0, %1" : "+v"(roff) : "v"(ro));
             asm("v_fma_f64 %0, %1, -0.5, 1.0" : "+v"(rr) : "v"(w));               // 1/(cnt+1): 0.5 or 1.0
-            if constexpr (FAST && TAB) asm("v_add_f64 %0, %1, 1.0" : "+v"(rn) : "v"(w));   // cnt+1: 2 or 1
           }
           // end of data / the next lane takes over: inactive.  Q2: the key at split_idx is not consumed.
           active_m = (active_m & ~bit_m) | open_m;
           push_m = (push_m & ~bit_m) | (open_m & ~split_m);
         }
         if (__builtin_amdgcn_inverse_ballot_w64(push_m)) {
-          roff += 16;
-          if constexpr (FAST && TAB) slr_push_rn(sl, x, y, rr, rn);
-          else if constexpr (FAST) slr_push_r(sl, x, y, rr);
+          roff += 8;
+          if constexpr (FAST) slr_push_r(sl, x, y, rr);
           else slr_push(sl, x, y);
         }
         xprev = x;
@@ -533,7 +515,6 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         for (int s = 0; s < FS_ROW; s++) one(s);
       }
       if constexpr (NODUP) yprev = row_if + (double)(FS_ROW - 1);
-      if constexpr (FAST && TAB) sl.nf = (double)((roff >> 4) - 1u);    // back into the state the other instances carry
     };
     if (general) steps(std::false_type{}, std::false_type{}, std::false_type{});
     else if (beyond) steps(std::true_type{}, std::false_type{}, std::false_type{});
