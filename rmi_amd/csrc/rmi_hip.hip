@@ -236,6 +236,7 @@ static size_t key_size(int dtype) { return dtype == RMI_KEY_U32 ? 4 : 8; }
 int rmi_hip_upload_keys(rmi_hip_ctx* c, const void* host_keys, uint64_t n, int dtype) {
   if (!c || !host_keys || n == 0 || dtype < 0 || dtype > 2) return RMI_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  c->d_keys = nullptr; c->n = 0;                               // (no stale pointer if anything below fails)
   if (c->d_keys_owned) { HIPCHK(c, hipFree(c->d_keys_owned)); c->d_keys_owned = nullptr; }
   HIPCHK(c, hipMalloc(&c->d_keys_owned, n * key_size(dtype)));
   HIPCHK(c, hipMemcpyAsync(c->d_keys_owned, host_keys, n * key_size(dtype), hipMemcpyHostToDevice, c->stream));
@@ -247,6 +248,7 @@ int rmi_hip_upload_keys(rmi_hip_ctx* c, const void* host_keys, uint64_t n, int d
 int rmi_hip_attach_device_keys(rmi_hip_ctx* c, const void* device_keys, uint64_t n, int dtype) {
   if (!c || !device_keys || n == 0 || dtype < 0 || dtype > 2) return RMI_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  c->d_keys = nullptr; c->n = 0;
   if (c->d_keys_owned) { HIPCHK(c, hipFree(c->d_keys_owned)); c->d_keys_owned = nullptr; }
   c->d_keys = device_keys; c->n = n; c->dtype = dtype;
   return RMI_OK;
@@ -279,12 +281,13 @@ int rmi_hip_generate_keys(rmi_hip_ctx* c, int generator, int dtype, uint64_t n_g
                           uint64_t count, uint64_t seed) {
   if (!c || n_global == 0 || count == 0 || start + count > n_global) return RMI_ERR_BAD_ARG;
   if (generator < 0 || generator > 1 || (dtype != RMI_KEY_U64 && dtype != RMI_KEY_U32)) return RMI_ERR_BAD_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
-  if (c->d_keys_owned) { HIPCHK(c, hipFree(c->d_keys_owned)); c->d_keys_owned = nullptr; }
-  HIPCHK(c, hipMalloc(&c->d_keys_owned, count * key_size(dtype)));
   const unsigned long long span = dtype == RMI_KEY_U64 ? 0xFFFFFFFFFFFFFFFEull : 0xFFFFFFFDull;  // 2^64-2 / 2^32-3
   const unsigned long long stride = span / n_global;
   if (stride == 0) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->d_keys = nullptr; c->n = 0;
+  if (c->d_keys_owned) { HIPCHK(c, hipFree(c->d_keys_owned)); c->d_keys_owned = nullptr; }
+  HIPCHK(c, hipMalloc(&c->d_keys_owned, count * key_size(dtype)));
   const unsigned long long base_seed = seed ? seed : (dtype == RMI_KEY_U64 ? 42ull : 46ull);
   const unsigned long long dup_seed = dtype == RMI_KEY_U64 ? 45ull : 47ull;
   const unsigned blocks = (unsigned)((count + 255) / 256);
