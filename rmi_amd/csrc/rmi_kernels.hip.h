@@ -666,27 +666,19 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_stats: aggregates of two_layer.rs:267-287 (parallel reduction; the f64 sums are not
-// bit-identical to the reference's sequential sums -- rmi_hip_stats_exact recomputes on host).
+// k_stats / k_stats_reduce: aggregates of two_layer.rs:267-287.  Every block reduces its leaves to one
+// partial record; a single block then combines the records in a fixed order (deterministic sums,
+// no same-address atomics: those serialise at ~26 ns each).  The f64 sums are a tree reduction, not
+// the reference's sequential sum: equal within 1e-12 relative, which is what the tests ask.
+// (max_error, max_error_idx) is the lexicographic maximum: `max_by_key` keeps the LAST maximum.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_stats(uint64_t leaf_lo, uint64_t L, uint64_t n,
-                                               const unsigned long long* __restrict__ leaf_err,
-                                               const unsigned long long* __restrict__ leaf_count,
-                                               DevState* __restrict__ st) {
+constexpr int STATS_BLOCKS = 1024;
+struct StatsPartial { unsigned long long mx, mi, sum; double l2, lg; };
+
+__device__ __forceinline__ void stats_block_reduce(unsigned long long& mx, unsigned long long& mi, unsigned long long& sm,
+                                                   double& l2, double& lg) {
   __shared__ unsigned long long s_max[256], s_idx[256], s_sum[256];
   __shared__ double s_l2[256], s_lg[256];
-  unsigned long long mx = 0, mi = 0, sm = 0;
-  double l2 = 0.0, lg = 0.0;
-  const double nf = (double)n;
-  for (uint64_t j = leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
-    const unsigned long long e = leaf_err[j], c = leaf_count[j];
-    if (e >= mx) { mx = e; mi = j; }                 // max_by_key keeps the last maximum
-    const unsigned long long ne = c * e;
-    sm += ne;
-    const double v = (double)ne;
-    l2 += (v * v) / nf;
-    lg += (double)c * log2((double)(2 * e + 2));
-  }
   s_max[threadIdx.x] = mx; s_idx[threadIdx.x] = mi; s_sum[threadIdx.x] = sm; s_l2[threadIdx.x] = l2; s_lg[threadIdx.x] = lg;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -699,22 +691,40 @@ __global__ void __launch_bounds__(256) k_stats(uint64_t leaf_lo, uint64_t L, uin
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    // combine across blocks with atomics: max/idx packed compare via CAS loop on max_err then idx
-    atomicAdd(&st->sum_n_err, s_sum[0]);
-    atomicAdd(&st->sum_l2, s_l2[0]);
-    atomicAdd(&st->sum_log2, s_lg[0]);
-    // (max_err, max_err_idx): lexicographic max; single-word CAS on max_err, idx fixed up after
-    unsigned long long old = atomicMax(&st->max_err, s_max[0]);
-    (void)old;
-  }
+  mx = s_max[0]; mi = s_idx[0]; sm = s_sum[0]; l2 = s_l2[0]; lg = s_lg[0];
 }
-// second tiny pass: the last index attaining max_err
-__global__ void __launch_bounds__(256) k_stats_argmax(uint64_t leaf_lo, uint64_t L, const unsigned long long* __restrict__ leaf_err,
-                                                      DevState* __restrict__ st) {
-  const unsigned long long mx = st->max_err;
+
+__global__ void __launch_bounds__(256) k_stats(uint64_t leaf_lo, uint64_t L, uint64_t n,
+                                               const unsigned long long* __restrict__ leaf_err,
+                                               const unsigned long long* __restrict__ leaf_count,
+                                               StatsPartial* __restrict__ partials) {
+  unsigned long long mx = 0, mi = 0, sm = 0;
+  double l2 = 0.0, lg = 0.0;
+  const double nf = (double)n;
   for (uint64_t j = leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
-    if (leaf_err[j] == mx) atomicMax(&st->max_err_idx, (unsigned long long)j);
+    const unsigned long long e = leaf_err[j], c = leaf_count[j];
+    if (e >= mx) { mx = e; mi = j; }                 // max_by_key keeps the last maximum
+    const unsigned long long ne = c * e;
+    sm += ne;
+    const double v = (double)ne;
+    l2 += (v * v) / nf;
+    lg += (double)c * log2((double)(2 * e + 2));
+  }
+  stats_block_reduce(mx, mi, sm, l2, lg);
+  if (threadIdx.x == 0) partials[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
+}
+
+__global__ void __launch_bounds__(256) k_stats_reduce(const StatsPartial* __restrict__ partials, int count, DevState* __restrict__ st) {
+  unsigned long long mx = 0, mi = 0, sm = 0;
+  double l2 = 0.0, lg = 0.0;
+  for (int q = threadIdx.x; q < count; q += 256) {           // (leaf ranges of the blocks interleave: any order combines)
+    const StatsPartial p = partials[q];
+    if (p.mx > mx || (p.mx == mx && p.mi > mi)) { mx = p.mx; mi = p.mi; }
+    sm += p.sum; l2 += p.l2; lg += p.lg;
+  }
+  stats_block_reduce(mx, mi, sm, l2, lg);
+  if (threadIdx.x == 0) {
+    st->max_err = mx; st->max_err_idx = mi; st->sum_n_err = sm; st->sum_l2 = l2; st->sum_log2 = lg;
   }
 }
 
