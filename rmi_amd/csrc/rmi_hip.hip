@@ -374,8 +374,24 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
   std::vector<unsigned char> tmp;
   const void* hk = host_keys;
+  if (!hk && (root_kind == RMI_MODEL_RADIX || root_kind == RMI_MODEL_LINEAR_SPLINE)) {
+    // these two need a handful of keys only: fetch them from HBM one by one
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t ks = key_size(c->dtype);
+    const unsigned char* base = (const unsigned char*)c->d_keys;
+    bool failed = false;
+    auto fetch = [&](uint64_t i, void* dst) { if (hipMemcpy(dst, base + i * ks, ks, hipMemcpyDeviceToHost) != hipSuccess) failed = true; };
+    int rc = RMI_ERR_BAD_ARG;
+    switch (c->dtype) {
+      case RMI_KEY_U64: rc = rmi_host::fit_root_sparse<uint64_t>(root_kind, [&](uint64_t i) { uint64_t k = 0; fetch(i, &k); return k; }, c->n, num_leaves, out); break;
+      case RMI_KEY_U32: rc = rmi_host::fit_root_sparse<uint32_t>(root_kind, [&](uint64_t i) { uint32_t k = 0; fetch(i, &k); return k; }, c->n, num_leaves, out); break;
+      case RMI_KEY_F64: rc = rmi_host::fit_root_sparse<double>(root_kind, [&](uint64_t i) { double k = 0; fetch(i, &k); return k; }, c->n, num_leaves, out); break;
+    }
+    if (failed) { c->err = "hipMemcpy of a key failed"; return RMI_ERR_HIP; }
+    return rc;
+  }
   if (!hk) {
-    // TODO(next): radix / linear_spline need O(1) keys only; linear needs the full pass.
+    // (linear, robust_linear, cubic and the radix tables are passes over all keys)
     HIPCHK(c, hipSetDevice(c->device));
     tmp.resize(c->n * key_size(c->dtype));
     HIPCHK(c, hipMemcpy(tmp.data(), c->d_keys, tmp.size(), hipMemcpyDeviceToHost));

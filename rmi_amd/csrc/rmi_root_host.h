@@ -61,6 +61,18 @@ inline void for_each_fixdups(const Data<K>& d, uint64_t skip, uint64_t take, F&&
   }
 }
 
+// common_prefix_size (utils.rs:23-36) is an OR / AND fold over all keys: the number of leading bits
+// on which every key agrees.  The keys are sorted (as unsigned integers; `as_uint` of an f64 key is
+// monotone), so every key lies between the first and the last one and shares their common leading
+// bits, and the first bit on which those two differ is a bit on which not all keys agree: the fold
+// equals the number of leading zeros of first XOR last.  O(1) instead of a pass over the data.
+template <typename K>
+inline int common_prefix_sorted(const Data<K>& d) {
+  if (d.n == 0) return 64;
+  const uint64_t x = as_uint(d.keys[0]) ^ as_uint(d.keys[d.n - 1]);
+  return x == 0 ? 64 : __builtin_clzll(x);
+}
+
 struct Slr {                                          // linear.rs:12-59
   double mean_x = 0.0, mean_y = 0.0, c = 0.0, m2 = 0.0;
   uint64_t n = 0;
@@ -200,16 +212,41 @@ inline int fit_radix(const Data<K>& d, rmi_hip_model_params* m) {          // ra
   while (first > 0 && d.keys[first - 1] == d.keys[d.n - 1]) first--;
   const int bits = num_bits(d.scale_y(first));
   if (bits < 0) return RMI_ERR_NUM_BITS;
-  // common_prefix_size (utils.rs:23-36): OR/AND fold over sorted keys.  For unsigned integer
-  // keys the fold over a sorted array equals the fold over {first, last} only in its leading
-  // bits; do the full fold to stay literal.
-  uint64_t any_ones = 0, no_ones = ~0ull;
-  for (uint64_t i = 0; i < d.n; i++) { const uint64_t v = as_uint(d.keys[i]); any_ones |= v; no_ones &= v; }
-  const uint64_t inv = ~((~no_ones) ^ any_ones);
-  const int prefix = inv == 0 ? 64 : __builtin_clzll(inv);
+  const int prefix = common_prefix_sorted(d);
   m->ip[0] = (uint64_t)(uint8_t)prefix;
   m->ip[1] = (uint64_t)(uint8_t)bits;
   return RMI_OK;
+}
+
+// The roots that need O(1) keys (`radix`: first key, last key, start of the last run; `linear_spline`:
+// first and last key), fitted through an accessor -- for key sets that live in HBM only.
+template <typename K, typename Get>
+inline int fit_root_sparse(int kind, Get get, uint64_t n, uint64_t num_leaves, rmi_hip_model_params* m) {
+  std::memset(m, 0, sizeof *m);
+  m->kind = kind;
+  if (n == 0) return RMI_OK;
+  const Data<K> d{nullptr, n, (double)num_leaves / (double)n};
+  const K k0 = get(0), kl = get(n - 1);
+  if (kind == RMI_MODEL_LINEAR_SPLINE) {                                     // linear_spline.rs:13-35
+    const double y0 = (double)d.scale_y(0);
+    if (n == 1 || k0 == kl) { m->p[0] = y0; m->p[1] = 0.0; return RMI_OK; }
+    const double y1 = (double)d.scale_y(n - 1);
+    const double slope = (y0 - y1) / (as_float(k0) - as_float(kl));
+    m->p[0] = y0 - slope * as_float(k0);
+    m->p[1] = slope;
+    return RMI_OK;
+  }
+  if (kind == RMI_MODEL_RADIX) {                                             // radix.rs:18-39
+    uint64_t lo = 0, hi = n - 1;                                             // first occurrence of the last key
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (get(mid) < kl) lo = mid + 1; else hi = mid; }
+    const int bits = num_bits(d.scale_y(lo));
+    if (bits < 0) return RMI_ERR_NUM_BITS;
+    const uint64_t x = as_uint(k0) ^ as_uint(kl);
+    m->ip[0] = (uint64_t)(uint8_t)(x == 0 ? 64 : __builtin_clzll(x));
+    m->ip[1] = (uint64_t)(uint8_t)bits;
+    return RMI_OK;
+  }
+  return RMI_ERR_UNSUPPORTED_MODEL;
 }
 
 // RadixTable::new (radix.rs:90-121): hint_table[radix] = scaled first-occurrence offset of the first
@@ -231,10 +268,7 @@ inline uint64_t radix_table_slot(uint64_t prefix, uint64_t bits, uint64_t x) {  
 template <typename K>
 inline int fit_radix_table(const Data<K>& d, int kind, rmi_hip_model_params* m, std::vector<uint32_t>& table) {
   const uint64_t bits = (uint64_t)radix_table_bits(kind);
-  uint64_t any_ones = 0, no_ones = ~0ull;                                      // common_prefix_size, utils.rs:23-36
-  for (uint64_t i = 0; i < d.n; i++) { const uint64_t v = as_uint(d.keys[i]); any_ones |= v; no_ones &= v; }
-  const uint64_t inv = ~((~no_ones) ^ any_ones);
-  const uint64_t prefix = inv == 0 ? 64 : (uint64_t)__builtin_clzll(inv);
+  const uint64_t prefix = (uint64_t)common_prefix_sorted(d);
   const uint64_t len = 1ull << bits;
   table.assign(len, 0u);
   uint64_t last_radix = 0;

@@ -219,6 +219,24 @@ def test_computed_reciprocal_is_ieee(trainer_mod):
     tr.close()
 
 
+def test_root_fit_from_device_resident_keys(trainer_mod, oracle):
+    """Keys that exist in HBM only: `radix` and `linear_spline` roots are fitted from the handful of
+    keys they depend on (no download), the others after one download; all equal the oracle's."""
+    for gen, dt in [("uniform", np.uint64), ("dups", np.uint64), ("dups", np.uint32)]:
+        tr = trainer_mod.Trainer()
+        tr.generate_keys(gen, dt, 300_000)
+        assert tr._host_keys is None
+        roots = {name: tr.fit_root(name, 4096) for name in ("radix", "linear_spline")}
+        assert tr._host_keys is None                       # still no host copy
+        keys = tr.download_keys().copy()
+        tr._host_keys = None
+        roots["linear"] = tr.fit_root("linear", 4096)
+        for name, g in roots.items():
+            o = oracle.fit_root(name, keys, 4096)
+            assert g.p == o.p and g.ip == o.ip, (gen, name, g, o)
+        tr.close()
+
+
 def test_device_generators_match_numpy(trainer_mod):
     for gen, dt, ref in [("uniform", np.uint64, dg.uniform_u64), ("dups", np.uint64, dg.dups_u64),
                          ("uniform", np.uint32, dg.uniform_u32), ("dups", np.uint32, dg.dups_u32)]:
