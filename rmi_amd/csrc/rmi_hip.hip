@@ -365,6 +365,73 @@ int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* c, int iters, double* gb_per_s) 
   return RMI_OK;
 }
 
+}  // extern "C"
+
+// Radix-table root fitted where the keys are: bucketing scan over the table's slots, fill, scale.
+template <typename K>
+static int fit_radix_table_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves, rmi_hip_model_params* out) {
+  const uint64_t bits = (uint64_t)rmi_host::radix_table_bits(kind);
+  const uint64_t slots = 1ull << bits;
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipSetDevice(c->device));
+  K k0{}, kl{};
+  HIPCHK(c, hipMemcpy(&k0, c->d_keys, sizeof(K), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(&kl, (const K*)c->d_keys + (c->n - 1), sizeof(K), hipMemcpyDeviceToHost));
+  const uint64_t x = rmi_host::as_uint(k0) ^ rmi_host::as_uint(kl);
+  const uint64_t prefix = x == 0 ? 64 : (uint64_t)__builtin_clzll(x);          // common_prefix_size of sorted keys
+  std::memset(out, 0, sizeof *out);
+  out->kind = kind; out->ip[0] = prefix; out->ip[1] = bits;
+  unsigned long long* d_first = nullptr;
+  unsigned long long* d_tmin = nullptr;
+  const uint64_t ntiles = (slots + 1 + FILL_TILE - 1) / FILL_TILE;
+  HIPCHK(c, hipMalloc(&d_first, (slots + 1) * 8));
+  if (hipMalloc(&d_tmin, (ntiles + 1) * 8) != hipSuccess) { (void)hipFree(d_first); return RMI_ERR_HIP; }
+  if (c->d_table_cap < slots) {
+    if (c->d_table) (void)hipFree(c->d_table);
+    c->d_table = nullptr; c->d_table_cap = 0;
+    if (hipMalloc(&c->d_table, slots * 4) != hipSuccess) { (void)hipFree(d_first); (void)hipFree(d_tmin); return RMI_ERR_HIP; }
+    c->d_table_cap = slots;
+  }
+  int rc = RMI_OK;
+  if (prefix == 64) {
+    // every key is the same value x: the masked shifts of radix.rs:98-99 leave slot = x
+    const uint64_t xv = rmi_host::as_uint(k0);
+    if (xv >= slots) rc = RMI_ERR_BAD_ARG;                                     // assert!, radix.rs:101
+    else {
+      c->h_table.assign(slots, (uint32_t)slots);
+      for (uint64_t i = 0; i <= xv; i++) c->h_table[i] = 0;
+      if (hipMemcpy(c->d_table, c->h_table.data(), slots * 4, hipMemcpyHostToDevice) != hipSuccess) rc = RMI_ERR_HIP;
+    }
+  } else {
+    Span sp; sp.it_lo = 0; sp.it_hi = c->n; sp.rd_lo = 0; sp.rd_hi = c->n; sp.n = c->n; sp.leaf_lo = 0; sp.leaf_hi = slots;
+    RootP rp; rp.p0 = rp.p1 = rp.p2 = rp.p3 = 0.0; rp.prefix = (uint32_t)prefix; rp.L = slots; rp.table = nullptr;
+    // slot = ((x << p) >> p) >> max(0, 64 - p - bits)  ==  the `radix` function with min(bits, 64 - p) bits
+    rp.bits = (uint32_t)(bits < 64 - prefix ? bits : 64 - prefix);
+    DevState init; std::memset(&init, 0, sizeof init);
+    init.split_idx = c->n; init.last_target = ~0ull;
+    (void)hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, s);
+    hipLaunchKernelGGL(k_table_init, dim3(1024), dim3(256), 0, s, d_first, slots);
+    constexpr uint64_t V = 16 / sizeof(K);
+    const uint64_t blocks = ((c->n + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
+    hipLaunchKernelGGL((k_bounds_vec<K_RADIX, K>), dim3((unsigned)blocks), dim3(256), 0, s, (const K*)c->d_keys, sp, rp, d_first, c->d_state);
+    hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, d_first, slots + 1, d_tmin);
+    hipLaunchKernelGGL(k_fill_scan_tiles, dim3(1), dim3(1024), 0, s, d_tmin, ntiles);
+    hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, d_first, slots + 1, d_tmin);
+    const double scale = (double)num_leaves / (double)c->n;                    // two_layer.rs:109
+    const int scaled = std::fabs(scale - 1.0) > DBL_EPSILON ? 1 : 0;           // map_scale!, models/mod.rs:238-250
+    hipLaunchKernelGGL(k_table_from_starts, dim3(1024), dim3(256), 0, s, d_first, slots, scale, scaled, c->d_table);
+    c->h_table.resize(slots);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(c->h_table.data(), c->d_table, slots * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) rc = RMI_ERR_HIP;
+  }
+  (void)hipFree(d_first); (void)hipFree(d_tmin);
+  if (rc == RMI_ERR_HIP) c->err = "radix table fit on the device failed";
+  if (rc != RMI_OK) c->h_table.clear();
+  return rc;
+}
+
+extern "C" {
+
 int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const void* host_keys,
                      rmi_hip_model_params* out) {
   if (!c || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
@@ -372,6 +439,14 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
   const bool is_table = rmi_host::radix_table_bits(root_kind) > 0;
   if (root_kind > RMI_MODEL_ROBUST_LINEAR && !is_table) return RMI_ERR_UNSUPPORTED_MODEL;
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  if (is_table) {                                              // integer work on the resident keys: exact on the device
+    switch (c->dtype) {
+      case RMI_KEY_U64: return fit_radix_table_device<uint64_t>(c, root_kind, num_leaves, out);
+      case RMI_KEY_U32: return fit_radix_table_device<uint32_t>(c, root_kind, num_leaves, out);
+      case RMI_KEY_F64: return fit_radix_table_device<double>(c, root_kind, num_leaves, out);
+    }
+    return RMI_ERR_BAD_ARG;
+  }
   std::vector<unsigned char> tmp;
   const void* hk = host_keys;
   if (!hk && (root_kind == RMI_MODEL_RADIX || root_kind == RMI_MODEL_LINEAR_SPLINE)) {
@@ -397,15 +472,12 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
     HIPCHK(c, hipMemcpy(tmp.data(), c->d_keys, tmp.size(), hipMemcpyDeviceToHost));
     hk = tmp.data();
   }
-  std::vector<uint32_t> table;
-  int rc = RMI_ERR_BAD_ARG;
   switch (c->dtype) {
-    case RMI_KEY_U64: rc = rmi_host::fit_root<uint64_t>(root_kind, (const uint64_t*)hk, c->n, num_leaves, out, &table); break;
-    case RMI_KEY_U32: rc = rmi_host::fit_root<uint32_t>(root_kind, (const uint32_t*)hk, c->n, num_leaves, out, &table); break;
-    case RMI_KEY_F64: rc = rmi_host::fit_root<double>(root_kind, (const double*)hk, c->n, num_leaves, out, &table); break;
+    case RMI_KEY_U64: return rmi_host::fit_root<uint64_t>(root_kind, (const uint64_t*)hk, c->n, num_leaves, out);
+    case RMI_KEY_U32: return rmi_host::fit_root<uint32_t>(root_kind, (const uint32_t*)hk, c->n, num_leaves, out);
+    case RMI_KEY_F64: return rmi_host::fit_root<double>(root_kind, (const double*)hk, c->n, num_leaves, out);
   }
-  if (rc == RMI_OK && is_table) rc = rmi_hip_set_root_table(c, table.data(), table.size());
-  return rc;
+  return RMI_ERR_BAD_ARG;
 }
 
 // The hint table of a radix-table root lives in the context (host copy + HBM copy): it is set by

@@ -59,6 +59,29 @@ __global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Radix-table root on the device (RadixTable::new, radix.rs:90-121), integer work, exact: the table
+// slot of a key is the `radix` bucketing function with bits = table_bits, so "first key index of
+// every slot" is the bucketing scan over 2^bits slots followed by the suffix-min fill (a gap takes
+// the next present slot's value, radix.rs:104-107); the hint is that index scaled like every y
+// (map_scale!, models/mod.rs:238-250); slots after the last present one hold table.len() (:112-114).
+// The first key of a slot differs from its predecessor, so its FixDups offset is its own index.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_table_init(unsigned long long* __restrict__ first_idx, uint64_t slots) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= slots; j += stride) first_idx[j] = NO_START;
+}
+__global__ void __launch_bounds__(256) k_table_from_starts(const unsigned long long* __restrict__ first_idx, uint64_t slots,
+                                                           double scale, int scaled, unsigned int* __restrict__ table) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < slots; j += stride) {
+    const unsigned long long i = first_idx[j];
+    unsigned long long y = (unsigned long long)slots;                      // tail: hint_table.len()
+    if (i != NO_START) y = scaled ? sat_f64_to_u64((double)i * scale) : i;
+    table[j] = (unsigned int)y;                                            // `y as u32`
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_init: one launch instead of four memsets and two small copies: leaf_start := "no start" with
 // the sentinel entry leaf_start[L_own] = it_hi, maxerr := run := 0, device state := initial state.
 // ---------------------------------------------------------------------------------------------

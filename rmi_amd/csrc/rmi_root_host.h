@@ -249,8 +249,7 @@ inline int fit_root_sparse(int kind, Get get, uint64_t n, uint64_t num_leaves, r
   return RMI_ERR_UNSUPPORTED_MODEL;
 }
 
-// RadixTable::new (radix.rs:90-121): hint_table[radix] = scaled first-occurrence offset of the first
-// key with that radix; gaps take the value of the next present radix, the tail takes table.len().
+// RadixTable (radix.rs:83-170): table size by registry name (train/mod.rs:46-50) and the slot function.
 inline int radix_table_bits(int kind) {
   switch (kind) {
     case RMI_MODEL_RADIX8: return 8;
@@ -266,29 +265,7 @@ inline uint64_t radix_table_slot(uint64_t prefix, uint64_t bits, uint64_t x) {  
   return ((x << (prefix & 63)) >> (prefix & 63)) >> (num_bits & 63);           // release-mode masked shifts
 }
 template <typename K>
-inline int fit_radix_table(const Data<K>& d, int kind, rmi_hip_model_params* m, std::vector<uint32_t>& table) {
-  const uint64_t bits = (uint64_t)radix_table_bits(kind);
-  const uint64_t prefix = (uint64_t)common_prefix_sorted(d);
-  const uint64_t len = 1ull << bits;
-  table.assign(len, 0u);
-  uint64_t last_radix = 0;
-  int rc = RMI_OK;
-  for_each_fixdups(d, 0, UINT64_MAX, [&](K k, uint64_t y) {
-    const uint64_t cur = radix_table_slot(prefix, bits, as_uint(k));
-    if (cur == last_radix) return;
-    if (cur >= len) { rc = RMI_ERR_BAD_ARG; return; }                         // assert!, radix.rs:101
-    table[cur] = (uint32_t)y;
-    for (uint64_t i = last_radix + 1; i < cur; i++) table[i] = (uint32_t)y;
-    last_radix = cur;
-  });
-  for (uint64_t i = last_radix + 1; i < len; i++) table[i] = (uint32_t)len;
-  m->ip[0] = prefix; m->ip[1] = bits;
-  return rc;
-}
-
-template <typename K>
-inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rmi_hip_model_params* m,
-                    std::vector<uint32_t>* table = nullptr) {
+inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rmi_hip_model_params* m) {
   std::memset(m, 0, sizeof *m);
   m->kind = kind;
   Data<K> d{keys, n, (double)num_leaves / (double)n};                       // two_layer.rs:109
@@ -298,10 +275,7 @@ inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rm
     case RMI_MODEL_LINEAR_SPLINE: linear_splines(d, &m->p[0], &m->p[1]); return RMI_OK;
     case RMI_MODEL_CUBIC: return fit_cubic(d, m);
     case RMI_MODEL_RADIX: return fit_radix(d, m);
-    case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22: case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28:
-      if (!table) return RMI_ERR_BAD_ARG;
-      return fit_radix_table(d, kind, m, *table);
-    default: return RMI_ERR_UNSUPPORTED_MODEL;
+    default: return RMI_ERR_UNSUPPORTED_MODEL;      // (the radix tables are fitted on the device: rmi_hip.hip)
   }
 }
 

@@ -219,6 +219,15 @@ def test_computed_reciprocal_is_ieee(trainer_mod):
     tr.close()
 
 
+def test_radix_table_wider_than_the_key_range(trainer_mod, oracle):
+    """prefix + table_bits > 64: the slot shift of radix.rs:98-99 bottoms out at 0 and the slot is the
+    key's low bits; and a table fitted for more leaves than keys (scale > 1)."""
+    rng = np.random.default_rng(3)
+    keys = np.unique(rng.integers(1, 1 << 20, size=60_000, dtype=np.uint64))          # 44 common leading bits
+    _compare(trainer_mod, oracle, keys, "radix22", "linear", 512)
+    _compare(trainer_mod, oracle, keys, "radix18", "linear_spline", 1 << 17)
+
+
 def test_root_fit_from_device_resident_keys(trainer_mod, oracle):
     """Keys that exist in HBM only: `radix` and `linear_spline` roots are fitted from the handful of
     keys they depend on (no download), the others after one download; all equal the oracle's."""
