@@ -197,6 +197,13 @@ int rmi_hip_set_rows_output(rmi_hip_ctx* ctx, void* device_rows);
 int rmi_hip_fit_root(rmi_hip_ctx* ctx, int root_kind, uint64_t num_leaves, const void* host_keys,
                      rmi_hip_model_params* out);
 
+/* FAST root fit, opt-in: `linear` / `robust_linear` from parallel sums on the device
+ * instead of the reference's sequential recurrence -- same points, coefficients within ~1e-12
+ * relative, NOT bit-identical (a handful of keys next to leaf boundaries may change bucket; the leaf
+ * path then trains, exactly, the RMI of THAT root, and the emitted index is as sound as any).  Other
+ * root kinds fall through to rmi_hip_fit_root.  Milliseconds instead of ~6 ns per key on one core. */
+int rmi_hip_fit_root_fast(rmi_hip_ctx* ctx, int root_kind, uint64_t num_leaves, rmi_hip_model_params* out);
+
 /* min(L-1, root.predict_to_int(key)) evaluated on the host (two_layer.rs:49): lets a caller plan
  * leaf-aligned shard cuts with exactly the bucketing the kernels use.  key_bits: the key's bits. */
 int rmi_hip_root_target(const rmi_hip_model_params* root, int dtype, uint64_t key_bits,

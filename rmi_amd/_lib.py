@@ -63,6 +63,7 @@ SYMBOLS = [
     ("rmi_hip_set_shard", C.c_int, [C.c_void_p, C.POINTER(Shard)]),
     ("rmi_hip_set_rows_output", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_fit_root", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(ModelParams)]),
+    ("rmi_hip_fit_root_fast", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(ModelParams)]),
     ("rmi_hip_root_target", C.c_int, [C.POINTER(ModelParams), C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rmi_hip_root_stream_begin", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
     ("rmi_hip_root_stream_push", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),

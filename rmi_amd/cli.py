@@ -42,6 +42,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--dump-ll-model-data", metavar="model_index", help="accepted for compatibility (unused in the reference too)")
     ap.add_argument("--dump-ll-errors", action="store_true", help="accepted for compatibility (unused in the reference too)")
     ap.add_argument("-s", "--stats-file", metavar="file", help="accepted for compatibility (unused in the reference too)")
+    ap.add_argument("--fast-root", action="store_true",
+                    help="(extension) fit linear / robust_linear roots from parallel sums on the GPU: not bit-identical to the reference")
     ap.add_argument("--device", type=int, default=0)
     return ap
 
@@ -71,7 +73,8 @@ def main(argv=None) -> int:
         if args.optimize:                                                              # src/main.rs:134-163
             if optimizer.skipped_models():
                 print("not on the device path, left out of the search: " + ", ".join(optimizer.skipped_models()), file=sys.stderr)
-            results = optimizer.find_pareto_efficient_configs(tr, 10, threads=args.threads)
+            results = optimizer.find_pareto_efficient_configs(tr, 10, threads=args.threads,
+                                                              root_mode="fast" if args.fast_root else "exact")
             optimizer.display_table(results)
             prefix = args.namespace or os.path.basename(args.input) or "rmi"
             specs = [r.to_grid_spec(f"{prefix}_{i}") for i, r in enumerate(results)]
@@ -97,7 +100,7 @@ def main(argv=None) -> int:
             return 2
         if args.max_size is not None:                                                  # src/main.rs:286-292
             print(f"Constructing RMI with size less than {args.max_size}")
-            rmi = optimizer.train_for_size(tr, args.max_size, threads=args.threads)
+            rmi = optimizer.train_for_size(tr, args.max_size, threads=args.threads, root_mode="fast" if args.fast_root else "exact")
             print(f"Found RMI config {rmi.models} {rmi.branching_factor}")
         elif not args.models or args.branching_factor is None:
             print("models and branching factor are required", file=sys.stderr)
@@ -108,7 +111,7 @@ def main(argv=None) -> int:
                 return 1
             rmi = tr.train_bounded(args.models, args.branching_factor, args.bounded)
         else:
-            rmi = tr.train(args.models, args.branching_factor)
+            rmi = tr.train(args.models, args.branching_factor, root_mode="fast" if args.fast_root else "exact")
         print(f"Model build time: {rmi.build_time // 1_000_000} ms (device {rmi.device_ns / 1e6:.3f} ms)")
         print(f"Average model error: {rmi.model_avg_error} ({rmi.model_avg_error / n * 100.0}%)")
         print(f"Average model L2 error: {rmi.model_avg_l2_error}")

@@ -430,7 +430,60 @@ static int fit_radix_table_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves,
   return rc;
 }
 
+// linear / robust_linear from parallel sums (opt-in fast mode)
+template <typename K>
+static int fit_linear_fast_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves, rmi_hip_model_params* out) {
+  const uint64_t n = c->n;
+  std::memset(out, 0, sizeof *out);
+  out->kind = kind;
+  uint64_t lo = 0, hi = n;
+  int tail = 1;
+  if (kind == RMI_MODEL_ROBUST_LINEAR) {                       // linear.rs:239-260
+    uint64_t bnd = rmi_host::sat_u64((double)n * 0.0001);
+    if (bnd < 1) bnd = 1;
+    if (!(bnd * 2 + 1 < n)) return RMI_ERR_ROBUST_TOO_SMALL;
+    lo = bnd; hi = n - bnd; tail = 0;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  RootPartial* d_p = nullptr;
+  HIPCHK(c, hipMalloc(&d_p, sizeof(RootPartial) * RF_BLOCKS));
+  const double scale = (double)num_leaves / (double)n;
+  const int scaled = std::fabs(scale - 1.0) > DBL_EPSILON ? 1 : 0;
+  hipLaunchKernelGGL((k_root_sums<K>), dim3(RF_BLOCKS), dim3(256), 0, c->stream, (const K*)c->d_keys, n, lo, hi, scale, scaled, tail, d_p);
+  std::vector<RootPartial> h(RF_BLOCKS);
+  K k0{};
+  int rc = RMI_OK;
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h.data(), d_p, sizeof(RootPartial) * RF_BLOCKS, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&k0, c->d_keys, sizeof(K), hipMemcpyDeviceToHost) != hipSuccess) rc = RMI_ERR_HIP;
+  (void)hipFree(d_p);
+  if (rc != RMI_OK) { c->err = "fast root fit failed"; return rc; }
+  long double cn = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;       // 1024 partials: combine in extended precision
+  for (const RootPartial& p : h) { cn += p.n; sx += p.sx; sy += p.sy; sxx += p.sxx; sxy += p.sxy; }
+  if (cn < 1.5L) { out->p[0] = (double)(cn > 0 ? sy : 0); out->p[1] = 0.0; return RMI_OK; }
+  const long double mx = sx / cn, my = sy / cn;
+  const long double m2 = sxx - sx * mx, cxy = sxy - sx * my;
+  if (!(m2 > 0)) { out->p[0] = (double)my; out->p[1] = 0.0; return RMI_OK; }          // linear.rs:50-53
+  const long double beta = cxy / m2;
+  const long double x0 = (long double)rmi_host::as_float(k0);
+  out->p[1] = (double)beta;
+  out->p[0] = (double)(my - beta * (mx + x0));                                           // undo the shift by the first key
+  return RMI_OK;
+}
+
 extern "C" {
+
+int rmi_hip_fit_root_fast(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, rmi_hip_model_params* out) {
+  if (!c || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  if (root_kind != RMI_MODEL_LINEAR && root_kind != RMI_MODEL_ROBUST_LINEAR)
+    return rmi_hip_fit_root(c, root_kind, num_leaves, nullptr, out);          // the other roots are exact and cheap, or (cubic) host work
+  switch (c->dtype) {
+    case RMI_KEY_U64: return fit_linear_fast_device<uint64_t>(c, root_kind, num_leaves, out);
+    case RMI_KEY_U32: return fit_linear_fast_device<uint32_t>(c, root_kind, num_leaves, out);
+    case RMI_KEY_F64: return fit_linear_fast_device<double>(c, root_kind, num_leaves, out);
+  }
+  return RMI_ERR_BAD_ARG;
+}
 
 int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const void* host_keys,
                      rmi_hip_model_params* out) {

@@ -59,6 +59,43 @@ __global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// FAST (not bit-identical) root fit of `linear` / `robust_linear`: the same least-squares line over
+// the same points (x = f64(key), y = scaled FixDups offset, items [lo, hi) of iter() plus, for the
+// full range, the Q1 tail duplicate), from parallel sums instead of the reference's sequential
+// recurrence -- the coefficients agree to ~1e-12 relative, a handful of keys next to leaf
+// boundaries may change bucket.  Opt-in (rmi_hip_fit_root_fast); the exact host fit
+// stays the default.  x is taken relative to the first key to keep the squares well conditioned.
+// ---------------------------------------------------------------------------------------------
+constexpr int RF_BLOCKS = 1024;
+struct RootPartial { double n, sx, sy, sxx, sxy; };
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_root_sums(const K* __restrict__ keys, uint64_t n, uint64_t lo, uint64_t hi,
+                                                   double scale, int scaled, int tail_dup, RootPartial* __restrict__ partials) {
+  __shared__ double sm[5][256];
+  const double x0 = KeyTraits<K>::as_float(keys[0]);
+  double c = 0.0, sx = 0.0, sy = 0.0, sxx = 0.0, sxy = 0.0;
+  auto add = [&](uint64_t i) {
+    const uint64_t f = first_occurrence(keys, i);
+    const double y = (double)(scaled ? sat_f64_to_u64((double)f * scale) : f);
+    const double x = KeyTraits<K>::as_float(keys[i]) - x0;
+    c += 1.0; sx += x; sy += y; sxx += x * x; sxy += x * y;
+  };
+  for (uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * blockDim.x) add(i);
+  if (tail_dup && blockIdx.x == 0 && threadIdx.x == 0) add(n - 1);          // models/mod.rs:180
+  sm[0][threadIdx.x] = c; sm[1][threadIdx.x] = sx; sm[2][threadIdx.x] = sy; sm[3][threadIdx.x] = sxx; sm[4][threadIdx.x] = sxy;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+#pragma unroll
+      for (int q = 0; q < 5; q++) sm[q][threadIdx.x] += sm[q][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = RootPartial{sm[0][0], sm[1][0], sm[2][0], sm[3][0], sm[4][0]};
+}
+
+// ---------------------------------------------------------------------------------------------
 // Radix-table root on the device (RadixTable::new, radix.rs:90-121), integer work, exact: the table
 // slot of a key is the `radix` bucketing function with bits = table_bits, so "first key index of
 // every slot" is the bucketing scan over 2^bits slots followed by the suffix-min fill (a gap takes

@@ -146,7 +146,7 @@ def second_phase_configs(first_phase: list[RMIStatistics]) -> list[tuple[str, in
 
 
 def measure_rmis(tr: train.Trainer, configs: list[tuple[str, int]], threads: int = 4,
-                 root_cache: dict | None = None, progress=None) -> list[RMIStatistics]:
+                 root_cache: dict | None = None, progress=None, root_mode: str = "exact") -> list[RMIStatistics]:
     """optimizer.rs:220-231.  Root fits (host, exact, sequential each) run `threads` at a time and are
     shared between the configurations that have the same (root, branching factor); the leaf passes
     run one after the other on the device over the resident keys."""
@@ -158,7 +158,7 @@ def measure_rmis(tr: train.Trainer, configs: list[tuple[str, int]], threads: int
         if (rk, bf) not in root_cache and (rk, bf) not in need:
             need.append((rk, bf))
     with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
-        futs = {key: pool.submit(tr.fit_root, key[0], key[1]) for key in need}
+        futs = {key: pool.submit(tr.fit_root, key[0], key[1], root_mode) for key in need}
         out = []
         for (rk, lk), _m, bf in parsed:
             if (rk, bf) not in root_cache:
@@ -171,10 +171,10 @@ def measure_rmis(tr: train.Trainer, configs: list[tuple[str, int]], threads: int
 
 
 def find_pareto_efficient_configs(tr: train.Trainer, restrict: int, threads: int = 4,
-                                  progress=None) -> list[RMIStatistics]:     # optimizer.rs:233-249
+                                  progress=None, root_mode: str = "exact") -> list[RMIStatistics]:     # optimizer.rs:233-249
     cache: dict = {}
-    first = measure_rmis(tr, first_phase_configs(), threads, cache, progress)
-    second = measure_rmis(tr, second_phase_configs(first), threads, cache, progress)
+    first = measure_rmis(tr, first_phase_configs(), threads, cache, progress, root_mode)
+    second = measure_rmis(tr, second_phase_configs(first), threads, cache, progress, root_mode)
     front = pareto_front(second)                 # the reference takes the front of the second phase only
     front = narrow_front(front, restrict)
     front.sort(key=lambda r: r.average_log2_error)
@@ -192,13 +192,13 @@ def display_table(items: list[RMIStatistics], file=None) -> None:            # o
         print(" ".join([r[0].ljust(w[0])] + [r[c].rjust(w[c]) for c in range(1, 5)]), file=file)
 
 
-def train_for_size(tr: train.Trainer, max_size: int, threads: int = 4) -> train.TrainedRMI:   # train/mod.rs:128-154
+def train_for_size(tr: train.Trainer, max_size: int, threads: int = 4, root_mode: str = "exact") -> train.TrainedRMI:   # train/mod.rs:128-154
     t0 = time.perf_counter_ns()
-    pareto = find_pareto_efficient_configs(tr, 1000, threads)
+    pareto = find_pareto_efficient_configs(tr, 1000, threads, root_mode=root_mode)
     fits = [c for c in pareto if c.size < max_size]
     if not fits:
         raise ValueError(f"Could not find any configurations smaller than {max_size}")
     cfg = fits[0]
-    res = tr.train(cfg.models, cfg.branching_factor)
+    res = tr.train(cfg.models, cfg.branching_factor, root_mode=root_mode)
     res.build_time = time.perf_counter_ns() - t0
     return res

@@ -222,11 +222,19 @@ class Trainer:
     def set_stream(self, stream_ptr: int | None):
         _check(self._lib.rmi_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
-    def fit_root(self, root: str | int, num_leaves: int) -> Model:
+    def fit_root(self, root: str | int, num_leaves: int, mode: str = "exact") -> Model:
+        """mode="exact" (default): the reference's fit, bit for bit.  mode="fast": `linear` /
+        `robust_linear` from parallel sums on the device (rmi_hip_fit_root_fast) -- the same line to
+        ~1e-12, not bit-identical; the other kinds are exact either way."""
         kind = root if isinstance(root, int) else self._lib.rmi_hip_model_from_name(root.encode())
         if kind < 0:
             raise RMIError(kind)
         m = _lib.ModelParams()
+        if mode == "fast" and kind in (0, 4):
+            _check(self._lib.rmi_hip_fit_root_fast(self._h, kind, num_leaves, C.byref(m)), self._h)
+            return Model._from_c(m)
+        if mode not in ("exact", "fast"):
+            raise ValueError("mode must be 'exact' or 'fast'")
         hk = C.c_void_p(self._host_keys.ctypes.data) if self._host_keys is not None else None
         if not (8 <= kind <= 12):
             _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
@@ -272,11 +280,11 @@ class Trainer:
                      "sum_n_err": int(res.sum_n_err), "sum_l2": float(res.sum_l2), "sum_log2": float(res.sum_log2)},
             _trainer=self)
 
-    def train(self, model_spec: str, branch_factor: int) -> TrainedRMI:
+    def train(self, model_spec: str, branch_factor: int, root_mode: str = "exact") -> TrainedRMI:
         """rmi_lib::train (train/mod.rs:100-126)."""
         t0 = time.perf_counter_ns()
         root_kind, leaf_kind = parse_spec(model_spec)
-        root = self.fit_root(root_kind, branch_factor)
+        root = self.fit_root(root_kind, branch_factor, mode=root_mode)
         out = self.train_leaves(root, leaf_kind, branch_factor)
         out.build_time = time.perf_counter_ns() - t0
         return out

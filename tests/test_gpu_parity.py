@@ -228,6 +228,37 @@ def test_radix_table_wider_than_the_key_range(trainer_mod, oracle):
     _compare(trainer_mod, oracle, keys, "radix18", "linear_spline", 1 << 17)
 
 
+@pytest.mark.parametrize("gen", ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "dups_u32", "uniform_f64"])
+def test_fast_root_mode(trainer_mod, oracle, gen):
+    """Opt-in fast root (parallel sums): the same line as the exact fit to 1e-10, and the
+    leaf path trains exactly the RMI of THAT root -- equal to the oracle given the same root, sound
+    for every key."""
+    keys = dg.GENERATORS[gen](300_000)
+    tr = trainer_mod.Trainer(keys)
+    for root_name in ("linear", "robust_linear"):
+        L = 2048
+        exact = tr.fit_root(root_name, L)
+        fast = tr.fit_root(root_name, L, mode="fast")
+        # compare predictions over the key range (the intercept of a line far from the origin is ill-conditioned by itself)
+        x = np.array([float(keys[0]), float(keys[len(keys) // 2]), float(keys[-1])])
+        pe = exact.p[0] + exact.p[1] * x
+        pf = fast.p[0] + fast.p[1] * x
+        if gen != "clustered_u64":
+            assert np.all(np.abs(pe - pf) <= 1e-6 * L), (gen, root_name, exact, fast)
+            assert abs(fast.p[1] - exact.p[1]) <= 1e-9 * abs(exact.p[1])
+        else:
+            # keys near 2^62 with gaps < 2^12: f64(key) has a resolution of 1024 there and the
+            # reference's running mean is quantised to it -- its own line is off by ~0.2 %; the
+            # fast fit works on x - x0 and is the better conditioned of the two.  Same shape only.
+            assert np.all(np.abs(pe - pf) <= 0.01 * L) and abs(fast.p[1] - exact.p[1]) <= 0.01 * abs(exact.p[1])
+        g = tr.train_leaves(fast, "linear", L)
+        o_root = oracle.Model(fast.kind, fast.p, fast.ip)
+        o = oracle.train_two_layer(root_name, "linear", keys, L, root=o_root)
+        assert np.array_equal(g.leaf_params, o.leaf_params) and np.array_equal(g.last_layer_max_l1s, o.leaf_err)
+        assert oracle.check_lookup_property(o, keys) == (0, len(keys))
+    tr.close()
+
+
 def test_root_fit_from_device_resident_keys(trainer_mod, oracle):
     """Keys that exist in HBM only: `radix` and `linear_spline` roots are fitted from the handful of
     keys they depend on (no download), the others after one download; all equal the oracle's."""
