@@ -430,6 +430,49 @@ static int fit_radix_table_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves,
   return rc;
 }
 
+// Cubic root of HBM-resident keys: coefficients from O(log n) fetched keys (exact), the model choice
+// from a device reduction when it is clear-cut (see k_cubic_root_sums), else *decided = false and the
+// caller runs the reference's sequential pass.
+template <typename K>
+static int fit_cubic_device(rmi_hip_ctx* c, uint64_t num_leaves, rmi_hip_model_params* out, bool* decided) {
+  *decided = false;
+  const uint64_t n = c->n;
+  HIPCHK(c, hipSetDevice(c->device));
+  bool failed = false;
+  auto get = [&](uint64_t i) { K k{}; if (hipMemcpy(&k, (const K*)c->d_keys + i, sizeof(K), hipMemcpyDeviceToHost) != hipSuccess) failed = true; return k; };
+  const rmi_host::Data<K> d{nullptr, n, (double)num_leaves / (double)n};
+  double cp[4];
+  int rc = rmi_host::cubic_coeffs_get<K>(get, d, cp);
+  if (failed) { c->err = "hipMemcpy of a key failed"; return RMI_ERR_HIP; }
+  if (rc) return rc;
+  rmi_hip_model_params lin;
+  rc = rmi_host::fit_root_sparse<K>(RMI_MODEL_LINEAR_SPLINE, get, n, num_leaves, &lin);
+  if (failed) { c->err = "hipMemcpy of a key failed"; return RMI_ERR_HIP; }
+  if (rc) return rc;
+  const double la = lin.p[0], lb = lin.p[1];
+  CubicPartial* d_p = nullptr;
+  HIPCHK(c, hipMalloc(&d_p, sizeof(CubicPartial) * RF_BLOCKS));
+  const int scaled = std::fabs(d.scale - 1.0) > DBL_EPSILON ? 1 : 0;
+  hipLaunchKernelGGL((k_cubic_root_sums<K>), dim3(RF_BLOCKS), dim3(256), 0, c->stream, (const K*)c->d_keys, n, d.scale, scaled,
+                     cp[0], cp[1], cp[2], cp[3], la, lb, d_p);
+  std::vector<CubicPartial> h(RF_BLOCKS);
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h.data(), d_p, sizeof(CubicPartial) * RF_BLOCKS, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipFree(d_p); c->err = "cubic root reduction failed"; return RMI_ERR_HIP; }
+  (void)hipFree(d_p);
+  long double eo = 0, el = 0;
+  for (const CubicPartial& p : h) { eo += p.our_err; el += p.lin_err; }
+  // Any summation order of n <= 2^32 non-negative f64 terms is within n * 2^-53 < 1e-6 relative of
+  // the exact sum; decide only when the two sums are further apart than that, both ways.
+  const long double gap = eo > el ? eo - el : el - eo;
+  if (!(eo == eo) || !(el == el) || !(gap > 4e-6L * (eo + el))) return RMI_OK;   // (NaN / too close: undecided)
+  std::memset(out, 0, sizeof *out);
+  out->kind = RMI_MODEL_CUBIC;
+  if (el < eo) { out->p[0] = 0.0; out->p[1] = 0.0; out->p[2] = lb; out->p[3] = la; }
+  else std::memcpy(out->p, cp, sizeof cp);
+  *decided = true;
+  return RMI_OK;
+}
+
 // linear / robust_linear from parallel sums (opt-in fast mode)
 template <typename K>
 static int fit_linear_fast_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves, rmi_hip_model_params* out) {
@@ -499,6 +542,17 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
       case RMI_KEY_F64: return fit_radix_table_device<double>(c, root_kind, num_leaves, out);
     }
     return RMI_ERR_BAD_ARG;
+  }
+  if (root_kind == RMI_MODEL_CUBIC && c->n < (1ull << 32)) {    // exact and usually O(log n) host work + one device reduction
+    bool decided = false;
+    int rc = RMI_ERR_BAD_ARG;
+    switch (c->dtype) {
+      case RMI_KEY_U64: rc = fit_cubic_device<uint64_t>(c, num_leaves, out, &decided); break;
+      case RMI_KEY_U32: rc = fit_cubic_device<uint32_t>(c, num_leaves, out, &decided); break;
+      case RMI_KEY_F64: rc = fit_cubic_device<double>(c, num_leaves, out, &decided); break;
+    }
+    if (rc != RMI_OK || decided) return rc;
+    // (too close to call from a parallel sum: the reference's sequential pass below)
   }
   std::vector<unsigned char> tmp;
   const void* hk = host_keys;

@@ -95,6 +95,36 @@ __global__ void __launch_bounds__(256) k_root_sums(const K* __restrict__ keys, u
   if (threadIdx.x == 0) partials[blockIdx.x] = RootPartial{sm[0][0], sm[1][0], sm[2][0], sm[3][0], sm[4][0]};
 }
 
+// Cubic root: the comparison pass of CubicSplineModel::new (cubic_spline.rs:117-131), sum |cubic - y|
+// and sum |line - y| over iter(), as a parallel reduction.  The sums only DECIDE between the two
+// candidate models (whose coefficients come from O(1) keys, exactly); the host accepts the decision
+// when the sums differ by far more than any summation order can move them, and otherwise repeats the
+// reference's sequential pass -- so the fitted root is always the reference's, bit for bit.
+struct CubicPartial { double our_err, lin_err; };
+template <typename K>
+__global__ void __launch_bounds__(256) k_cubic_root_sums(const K* __restrict__ keys, uint64_t n, double scale, int scaled,
+                                                         double a, double b, double c, double d, double la, double lb,
+                                                         CubicPartial* __restrict__ partials) {
+  __shared__ double sm[2][256];
+  double eo = 0.0, el = 0.0;
+  auto add = [&](uint64_t i) {
+    const uint64_t f = first_occurrence(keys, i);
+    const double y = (double)(scaled ? sat_f64_to_u64((double)f * scale) : f);
+    const double x = KeyTraits<K>::as_float(keys[i]);
+    eo += fabs(__builtin_fma(__builtin_fma(__builtin_fma(a, x, b), x, c), x, d) - y);
+    el += fabs(__builtin_fma(lb, x, la) - y);
+  };
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) add(i);
+  if (blockIdx.x == 0 && threadIdx.x == 0) add(n - 1);                       // Q1 tail duplicate
+  sm[0][threadIdx.x] = eo; sm[1][threadIdx.x] = el;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sm[0][threadIdx.x] += sm[0][threadIdx.x + s]; sm[1][threadIdx.x] += sm[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = CubicPartial{sm[0][0], sm[1][0]};
+}
+
 // ---------------------------------------------------------------------------------------------
 // Radix-table root on the device (RadixTable::new, radix.rs:90-121), integer work, exact: the table
 // slot of a key is the `radix` bucketing function with bits = table_bits, so "first key index of

@@ -134,36 +134,35 @@ inline double cubic_eval(const double p[4], double x) {                     // c
   return std::fma(std::fma(std::fma(p[0], x, p[1]), x, p[2]), x, p[3]);
 }
 
-template <typename K>
-inline int cubic_coeffs(const Data<K>& d, double out[4]) {                  // cubic_spline.rs:18-101
+// cubic() (cubic_spline.rs:18-101) through a key accessor.  The two searches of the reference --
+// the first item of iter() whose scaled x is > 0 and the last index whose scaled x is < 1 -- are
+// monotone predicates over sorted keys, so they are binary searches here (the same predicate, the
+// same answer, O(log n) keys instead of a scan that is long exactly on degenerate data).
+template <typename K, typename Get>
+inline int cubic_coeffs_get(Get get, const Data<K>& d, double out[4]) {
   if (d.n == 0) { out[0] = 0.0; out[1] = 0.0; out[2] = 1.0; out[3] = 0.0; return RMI_OK; }
   const double y_first = (double)d.scale_y(0);
   if (d.n == 1) { out[0] = out[1] = out[2] = 0.0; out[3] = y_first; return RMI_OK; }
-  const K k0 = d.keys[0], kl = d.keys[d.n - 1];
+  const K k0 = get(0), kl = get(d.n - 1);
   if (k0 == kl) { out[0] = out[1] = out[2] = 0.0; out[3] = y_first; return RMI_OK; }  // sorted: all equal
   const double xmin = as_float(k0), ymin = y_first;
   const double xmax = as_float(kl), ymax = (double)d.scale_y(d.n - 1);
   auto sc = [](double v, double mn, double mx) { return (v - mn) / (mx - mn); };
-  // m1: first item of iter() whose scaled x > 0 (FixDups offsets)
   double m1;
-  {
-    bool found = false; K xn = k0; uint64_t yn = 0; uint64_t first = 0;
-    for (uint64_t i = 0; i < d.n; i++) {
-      if (i == 0 || !(d.keys[i] == d.keys[i - 1])) first = i;
-      if (sc(as_float(d.keys[i]), xmin, xmax) > 0.0) { xn = d.keys[i]; yn = d.scale_y(first); found = true; break; }
-    }
-    if (!found) return RMI_ERR_CUBIC_DEGENERATE;
-    const double sxn = sc(as_float(xn), xmin, xmax), syn = sc((double)yn, ymin, ymax);
+  {  // :46-54.  The found key differs from its predecessor, so its FixDups offset is its own index.
+    uint64_t lo = 0, hi = d.n;
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (sc(as_float(get(mid)), xmin, xmax) > 0.0) hi = mid; else lo = mid + 1; }
+    if (lo >= d.n) return RMI_ERR_CUBIC_DEGENERATE;                           // .unwrap() on None
+    const double sxn = sc(as_float(get(lo)), xmin, xmax), syn = sc((double)d.scale_y(lo), ymin, ymax);
     m1 = (syn - 0.0) / (sxn - 0.0);
   }
   double m2;
-  {
-    bool found = false; K xp = k0; uint64_t yp = 0;
-    for (uint64_t i = d.n; i-- > 0;) {
-      if (sc(as_float(d.keys[i]), xmin, xmax) < 1.0) { xp = d.keys[i]; yp = d.scale_y(i); found = true; break; }
-    }
-    if (!found) return RMI_ERR_CUBIC_DEGENERATE;
-    const double sxp = sc(as_float(xp), xmin, xmax), syp = sc((double)yp, ymin, ymax);
+  {  // :56-65 (get(): raw index)
+    uint64_t lo = 0, hi = d.n;                                                // first index whose scaled x is NOT < 1
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (sc(as_float(get(mid)), xmin, xmax) < 1.0) lo = mid + 1; else hi = mid; }
+    if (lo == 0) return RMI_ERR_CUBIC_DEGENERATE;
+    const uint64_t ip = lo - 1;
+    const double sxp = sc(as_float(get(ip)), xmin, xmax), syp = sc((double)d.scale_y(ip), ymin, ymax);
     m2 = (1.0 - syp) / (1.0 - sxp);
   }
   if (m1 * m1 + m2 * m2 > 9.0) {
@@ -178,6 +177,10 @@ inline int cubic_coeffs(const Data<K>& d, double out[4]) {                  // c
   a *= ymax - ymin; b *= ymax - ymin; c *= ymax - ymin; dd *= ymax - ymin; dd += ymin;
   out[0] = a; out[1] = b; out[2] = c; out[3] = dd;
   return RMI_OK;
+}
+template <typename K>
+inline int cubic_coeffs(const Data<K>& d, double out[4]) {
+  return cubic_coeffs_get<K>([&](uint64_t i) { return d.keys[i]; }, d, out);
 }
 
 template <typename K>

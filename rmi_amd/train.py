@@ -231,11 +231,16 @@ class Trainer:
             raise RMIError(kind)
         m = _lib.ModelParams()
         if mode == "fast" and kind in (0, 4):
-            _check(self._lib.rmi_hip_fit_root_fast(self._h, kind, num_leaves, C.byref(m)), self._h)
+            with self._ctx_lock:                    # device work on the context's stream
+                _check(self._lib.rmi_hip_fit_root_fast(self._h, kind, num_leaves, C.byref(m)), self._h)
             return Model._from_c(m)
         if mode not in ("exact", "fast"):
             raise ValueError("mode must be 'exact' or 'fast'")
         hk = C.c_void_p(self._host_keys.ctypes.data) if self._host_keys is not None else None
+        if kind == 2:                               # cubic: a device reduction on the context's stream
+            with self._ctx_lock:
+                _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
+            return Model._from_c(m)
         if not (8 <= kind <= 12):
             _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
             return Model._from_c(m)
