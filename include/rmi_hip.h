@@ -163,6 +163,8 @@ const void* rmi_hip_device_keys(const rmi_hip_ctx* ctx);
 /* Device self-test: the reciprocal-table division used inside the SLR recurrence against IEEE
  * division, on `trials` pseudo-random and near-midpoint operands; *mismatches must come back 0. */
 int rmi_hip_selftest_div(rmi_hip_ctx* ctx, uint64_t trials, uint64_t seed, uint64_t* mismatches);
+/* Host twin: the reciprocal form of the host root recurrence (no context, no GPU). */
+int rmi_hip_selftest_host_div(uint64_t trials, uint64_t seed, uint64_t* mismatches);
 /* The computed reciprocal used for counts beyond the table: checks RN(1/n) == 1.0/n for every
  * integer n in [n_lo, n_hi), 1 <= n_lo < n_hi <= 2^40. */
 int rmi_hip_selftest_recip(rmi_hip_ctx* ctx, uint64_t n_lo, uint64_t n_hi, uint64_t* mismatches);

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("rmi_hip_download_root_table", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_set_root_table", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("rmi_hip_selftest_div", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("rmi_hip_selftest_host_div", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rmi_hip_selftest_recip", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rmi_hip_measure_read_bandwidth", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     ("rmi_hip_set_shard", C.c_int, [C.c_void_p, C.POINTER(Shard)]),

@@ -331,6 +331,40 @@ int rmi_hip_selftest_div(rmi_hip_ctx* c, uint64_t trials, uint64_t seed, uint64_
   return RMI_OK;
 }
 
+// Host twin of rmi_hip_selftest_div for the reciprocal form of the root recurrence (rmi_root_host.h):
+// fma(a, r, a*rl) against a / n on random and near-midpoint numerators, counts up to 2^40.
+RMI_HOST_FMA static uint64_t host_div_mismatches(uint64_t trials, uint64_t seed) {
+  uint64_t bad = 0, state = seed * 0x9E3779B97F4A7C15ull + 12345;
+  for (uint64_t it = 0; it < trials; it++) {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    uint64_t z = state ^ (state >> 29);
+    z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    const uint64_t n = ((z >> 6) & 1ull) ? 1ull + ((state >> 11) % ((1ull << 40) - 1ull)) : 1ull + (z % 4096ull);
+    const double nf = (double)n;
+    const int ex = (int)((z >> 40) % 150ull) - 84;                     // 2^-84 .. 2^65, the operands of the recurrence
+    const double frac = 1.0 + (double)((z >> 8) & 0xFFFFFFFFFFFFFull) * 0x1p-52;
+    double a;
+    const unsigned mode = (unsigned)(z >> 60) & 3u;
+    if (mode == 0) a = std::ldexp(frac, ex);
+    else {
+      const double q = std::ldexp(frac, ex), half = std::ldexp(1.0, ex - 53);
+      a = ((mode & 1u) ? q + half : q - half) * nf;                    // quotient next to a rounding midpoint
+      if (mode == 3) a = std::nextafter(a, (z & 1ull) ? 1e300 : -1e300);
+    }
+    if ((z >> 7) & 1ull) a = -a;
+    const double r = 1.0 / nf, rl = __builtin_fma(-nf, r, 1.0) * r;
+    const double got = __builtin_fma(a, r, a * rl), want = a / nf;
+    uint64_t gb, wb; std::memcpy(&gb, &got, 8); std::memcpy(&wb, &want, 8);
+    if (gb != wb) bad++;
+  }
+  return bad;
+}
+int rmi_hip_selftest_host_div(uint64_t trials, uint64_t seed, uint64_t* mismatches) {
+  if (!mismatches || trials == 0) return RMI_ERR_BAD_ARG;
+  *mismatches = rmi_host::host_has_fma() ? host_div_mismatches(trials, seed) : 0;
+  return RMI_OK;
+}
+
 int rmi_hip_selftest_recip(rmi_hip_ctx* c, uint64_t n_lo, uint64_t n_hi, uint64_t* mismatches) {
   if (!c || !mismatches || n_lo == 0 || n_hi <= n_lo || n_hi > (1ull << 40)) return RMI_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));

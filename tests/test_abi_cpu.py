@@ -76,3 +76,26 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "from oracle" not in src and "import oracle" not in src and "rmi_oracle" not in src, f
+
+
+def test_host_root_recurrence_is_the_reference_recurrence(lib, oracle):
+    """The host root fit runs the recurrence with fma(a, r, a*rl) in place of a / n (one division off
+    the dependent chain): bit for bit the same quotients (self-test on random and near-midpoint
+    operands), and the streamed `linear` root equals the oracle's on every key set -- no GPU needed."""
+    import ctypes as C
+    import numpy as np
+    from rmi_amd import _lib, datagen as dg
+    bad = C.c_uint64(99)
+    assert lib.rmi_hip_selftest_host_div(20_000_000, 5, C.byref(bad)) == 0 and bad.value == 0
+    for gen, dt in [("uniform_u64", 0), ("books_u64", 0), ("dups_u64", 0), ("clustered_u64", 0), ("dups_u32", 1), ("uniform_f64", 2)]:
+        keys = dg.GENERATORS[gen](300_000)
+        for L in (64, 1 << 16, 300_000):
+            rs = C.c_void_p()
+            assert lib.rmi_hip_root_stream_begin(0, dt, len(keys), L, C.byref(rs)) == 0
+            for lo in range(0, len(keys), 70_001):                       # uneven chunks
+                part = np.ascontiguousarray(keys[lo:lo + 70_001])
+                assert lib.rmi_hip_root_stream_push(rs, part.ctypes.data, len(part)) == 0
+            m = _lib.ModelParams()
+            assert lib.rmi_hip_root_stream_finish(rs, C.byref(m)) == 0
+            o = oracle.fit_root("linear", keys, L)
+            assert (m.p[0], m.p[1]) == (o.p[0], o.p[1]), (gen, L)
