@@ -43,13 +43,13 @@
 extern "C" {
 #endif
 
-#define RMI_HIP_ABI_VERSION 1
+#define RMI_HIP_ABI_VERSION 2
 
 /* src/load.rs:15-19 */
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
 
 /* model registry, train/mod.rs:37-54.  On the device path: roots linear, linear_spline, cubic,
- * radix, robust_linear and the radix tables (ids 8-12); leaves linear, linear_spline, cubic,
+ * radix, robust_linear, the radix tables (ids 8-12) and bradix; leaves linear, linear_spline, cubic,
  * robust_linear (radix is top-only in the reference; radix tables as leaves are rejected).
  * The rest of the registry is recognised by name and rejected with RMI_ERR_UNSUPPORTED_MODEL. */
 enum rmi_hip_model_kind {
@@ -93,12 +93,14 @@ typedef struct rmi_hip_ctx rmi_hip_ctx;
 
 /* Model parameters in `params()` order of each plugin: linear / linear_spline / robust_linear:
  * p = (alpha, beta) (linear.rs:99-101); cubic: p = (a, b, c, d) (cubic_spline.rs:160-167);
- * radix: ip = (prefix_len, bits) (radix.rs:60-62). */
+ * radix: ip = (prefix_len, bits) (radix.rs:60-62); bradix: ip = (prefix_len, bits, clamp)
+ * (balanced_radix.rs:124-130) and ip[3] = 1 for the clamp-high function, 0 for clamp-low
+ * (the `high` member, :17, which selects the emitted function, :132-164). */
 typedef struct {
   int32_t kind;
   int32_t _pad;
   double p[4];
-  uint64_t ip[2];
+  uint64_t ip[4];
 } rmi_hip_model_params;
 
 /* Aggregates of two_layer.rs:267-287 + timings.  Per-leaf arrays stay in HBM until downloaded. */

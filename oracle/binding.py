@@ -25,6 +25,7 @@ MODEL_IDS = {
     "radix": MODEL_RADIX,
     "robust_linear": MODEL_ROBUST_LINEAR,
     "radix8": 8, "radix18": 9, "radix22": 10, "radix26": 11, "radix28": 12,      # RadixTable (train/mod.rs:46-50)
+    "bradix": 13,                                                                 # BalancedRadixModel
 }
 ERRORS = {
     -1: "unknown model (train/mod.rs:53)",
@@ -47,7 +48,7 @@ class OracleError(RuntimeError):
 
 
 class _Model(C.Structure):
-    _fields_ = [("kind", C.c_int), ("p", C.c_double * 4), ("ip", C.c_uint64 * 2),
+    _fields_ = [("kind", C.c_int), ("p", C.c_double * 4), ("ip", C.c_uint64 * 4),
                 ("table", C.POINTER(C.c_uint32)), ("table_len", C.c_uint64)]
 
 
@@ -150,12 +151,15 @@ class Model:
     ip: tuple
     table: np.ndarray | None = None       # radix tables: hint_table (u32), radix.rs:83-88
 
+    def __post_init__(self):
+        self.ip = tuple(int(v) for v in self.ip) + (0,) * (4 - len(self.ip))
+
     def _c(self) -> _Model:
         m = _Model()
         m.kind = self.kind
         for i in range(4):
             m.p[i] = self.p[i]
-        for i in range(2):
+        for i in range(4):
             m.ip[i] = self.ip[i]
         if self.table is not None:
             m.table = self.table.ctypes.data_as(C.POINTER(C.c_uint32))     # borrowed: self keeps it alive

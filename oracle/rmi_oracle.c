@@ -366,6 +366,65 @@ static int fit_radix(const otd* d, orc_model* m) {
   return ORC_OK;
 }
 
+/* BalancedRadixModel: balanced_radix.rs.  predict_to_int :104-116 */
+static inline uint64_t bradix_predict(const orc_model* m, uint64_t as_int) {
+  const uint64_t res = (as_int << (m->ip[0] & 63)) >> ((64 - m->ip[1]) & 63);   /* release-mode masked shifts */
+  const uint64_t clamp = m->ip[2];
+  if (m->ip[3]) return res < clamp ? res : clamp;                               /* u64::min(res, clamp) */
+  return res < clamp ? 0 : res - clamp;
+}
+/* chi2: :20-38.  counts are i32 there (integer literal default); the sum starts from 0.0 in bin order */
+static int bradix_chi2(const otd* d, uint64_t max_bin, const orc_model* m, double* score) {
+  int32_t* counts = (int32_t*)calloc(max_bin ? max_bin : 1, sizeof(int32_t));
+  if (!counts) return ORC_ERR_BAD_ARG;
+  fixdups_it it; fd_init(&it, d); okey k; size_t y;
+  while (fd_next(&it, &k, &y)) {                                                /* iter_model_input(): N+1 items */
+    const uint64_t b = bradix_predict(m, key_as_uint(d->dtype, k));
+    if (b >= max_bin) { free(counts); return ORC_ERR_BAD_ARG; }                 /* index out of bounds: panic */
+    counts[b] = (int32_t)((uint32_t)counts[b] + 1u);
+  }
+  const double expected = (double)d->len / (double)max_bin;
+  double sum = 0.0;
+  for (uint64_t b = 0; b < max_bin; b++) {
+    const double df = (double)counts[b] - expected;
+    sum += (df * df) / expected;                                                /* powf(2.0) */
+  }
+  free(counts);
+  *score = sum;
+  return ORC_OK;
+}
+/* bradix: :40-87; BalancedRadixModel::new: :90-101 */
+static int fit_bradix(const otd* d, orc_model* m) {
+  m->kind = ORC_MODEL_BRADIX;
+  m->ip[0] = 0; m->ip[1] = 0; m->ip[2] = 0; m->ip[3] = 1;
+  if (d->len == 0) return ORC_OK;
+  uint64_t max_output = 0;
+  { fixdups_it it; fd_init(&it, d); okey k; size_t y;
+    while (fd_next(&it, &k, &y)) { if ((uint64_t)y > max_output) max_output = y; } }
+  const int bits = orc_num_bits(max_output);
+  if (bits < 0) return ORC_ERR_NUM_BITS;
+  const int prefix = common_prefix_size_td(d);
+  double best = INFINITY;
+  int have = 0;
+  const int end = bits + 2 < 64 ? bits + 2 : 64;
+  for (int tb = bits; tb < end; tb++) {
+    const uint64_t bits_max = (1ull << ((tb + 1) & 63)) - 1;
+    orc_model cand; memset(&cand, 0, sizeof cand);
+    cand.kind = ORC_MODEL_BRADIX;
+    cand.ip[0] = (uint64_t)(uint8_t)prefix; cand.ip[1] = (uint64_t)tb;
+    double score;
+    cand.ip[2] = max_output - 1; cand.ip[3] = 1;                                /* high */
+    int rc = bradix_chi2(d, max_output, &cand, &score);
+    if (rc) return rc;
+    if (score < best) { best = score; *m = cand; have = 1; }
+    cand.ip[2] = max_output - bits_max; cand.ip[3] = 0;                         /* low; wrapping sub (release build) */
+    rc = bradix_chi2(d, max_output, &cand, &score);
+    if (rc) return rc;
+    if (score < best) { best = score; *m = cand; have = 1; }
+  }
+  return have ? ORC_OK : ORC_ERR_BAD_ARG;                                       /* best_result.unwrap() */
+}
+
 /* RadixTable::new: radix.rs:90-121 */
 static inline int is_radix_table(int kind) { return kind >= ORC_MODEL_RADIX8 && kind <= ORC_MODEL_RADIX28; }
 static inline int radix_table_bits(int kind) {
@@ -409,6 +468,7 @@ static int train_model(int kind, const otd* d, orc_model* m) {
     case ORC_MODEL_LINEAR_SPLINE: return fit_linear_spline(d, m);
     case ORC_MODEL_CUBIC: return fit_cubic(d, m);
     case ORC_MODEL_RADIX: return fit_radix(d, m);
+    case ORC_MODEL_BRADIX: return fit_bradix(d, m);
     case ORC_MODEL_RADIX8: case ORC_MODEL_RADIX18: case ORC_MODEL_RADIX22: case ORC_MODEL_RADIX26:
     case ORC_MODEL_RADIX28: return fit_radix_table(d, kind, m);
     default: return ORC_ERR_UNKNOWN_MODEL;
@@ -417,7 +477,7 @@ static int train_model(int kind, const otd* d, orc_model* m) {
 
 static inline int model_needs_bounds_check(int kind) {
   /* default true (mod.rs:751-753); cubic false (cubic_spline.rs:184-186); radix false (radix.rs:72-74) */
-  return !(kind == ORC_MODEL_CUBIC || kind == ORC_MODEL_RADIX || is_radix_table(kind));   /* radix.rs:160-162 */
+  return !(kind == ORC_MODEL_CUBIC || kind == ORC_MODEL_RADIX || kind == ORC_MODEL_BRADIX || is_radix_table(kind));   /* radix.rs:160-162, balanced_radix.rs:164-166 */
 }
 static inline int model_params_per(int kind) { return kind == ORC_MODEL_CUBIC ? 4 : 2; }
 
@@ -434,6 +494,7 @@ static inline double model_predict_float_k(const orc_model* m, int dtype, okey k
       uint64_t r = (v << (m->ip[0] & 63)) >> ((64 - m->ip[1]) & 63);
       return (double)r;
     }
+    case ORC_MODEL_BRADIX: return (double)bradix_predict(m, key_as_uint(dtype, k));
     case ORC_MODEL_RADIX8: case ORC_MODEL_RADIX18: case ORC_MODEL_RADIX22: case ORC_MODEL_RADIX26:
     case ORC_MODEL_RADIX28:
       return (double)m->table[radix_table_slot(m->ip[0], m->ip[1], key_as_uint(dtype, k))];
@@ -446,6 +507,7 @@ static inline uint64_t model_predict_int_k(const orc_model* m, int dtype, okey k
     uint64_t v = key_as_uint(dtype, k);
     return (v << (m->ip[0] & 63)) >> ((64 - m->ip[1]) & 63);  /* release-mode masked shifts */
   }
+  if (m->kind == ORC_MODEL_BRADIX) return bradix_predict(m, key_as_uint(dtype, k));
   if (is_radix_table(m->kind))                                /* radix.rs:124-134 */
     return (uint64_t)m->table[radix_table_slot(m->ip[0], m->ip[1], key_as_uint(dtype, k))];
   double f = floor(model_predict_float_k(m, dtype, k));
@@ -487,7 +549,9 @@ static int validate(int root_kind, int leaf_kind) {
     switch (kinds[idx]) {
       case ORC_MODEL_LINEAR: case ORC_MODEL_ROBUST_LINEAR: case ORC_MODEL_LINEAR_SPLINE:
       case ORC_MODEL_CUBIC: break;
-      case ORC_MODEL_RADIX: if (idx != 0) return ORC_ERR_RESTRICTION; break;
+      case ORC_MODEL_RADIX: case ORC_MODEL_BRADIX:             /* MustBeTop: radix.rs:75-80, balanced_radix.rs:167-169 */
+        if (idx != 0) return ORC_ERR_RESTRICTION;
+        break;
       case ORC_MODEL_RADIX8: case ORC_MODEL_RADIX18: case ORC_MODEL_RADIX22: case ORC_MODEL_RADIX26:
       case ORC_MODEL_RADIX28:
         /* ModelRestriction::None (radix.rs:163-165); as a leaf its parameters are a table per leaf,
@@ -834,7 +898,7 @@ static uint64_t emitted_lookup(const orc_trained_rmi* r, int dtype, okey key, ui
   size_t model_index;
   const orc_model* top = &r->root;
   /* key C type: uint64_t for u64/u32 files, double for f64 (main.rs:122-132) */
-  if (top->kind == ORC_MODEL_RADIX || is_radix_table(top->kind)) {
+  if (top->kind == ORC_MODEL_RADIX || top->kind == ORC_MODEL_BRADIX || is_radix_table(top->kind)) {
     uint64_t ipred = model_predict_int_k(top, dtype, key);
     model_index = (size_t)ipred;                                   /* no bounds check: radix.rs:72-74 */
   } else {

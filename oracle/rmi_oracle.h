@@ -38,7 +38,8 @@ enum {
   ORC_MODEL_RADIX18 = 9,
   ORC_MODEL_RADIX22 = 10,
   ORC_MODEL_RADIX26 = 11,
-  ORC_MODEL_RADIX28 = 12
+  ORC_MODEL_RADIX28 = 12,
+  ORC_MODEL_BRADIX = 13            /* BalancedRadixModel, balanced_radix.rs */
 };
 
 /* return codes: 0 ok; negative = the reference would have panicked at the cited line */
@@ -61,7 +62,7 @@ enum {
 typedef struct {
   int kind;
   double p[4];
-  uint64_t ip[2];
+  uint64_t ip[4];   /* bradix: (prefix, bits, clamp) = params() (balanced_radix.rs:124-130), ip[3] = `high` (:17) */
   /* radix tables (radix.rs:83-121): ip = (prefix_bits, table_bits), hint_table of 2^table_bits u32.
    * malloc'd by the fit (release with orc_model_free) or borrowed from the caller. */
   uint32_t* table;

@@ -10,7 +10,7 @@ SO = os.path.join(HERE, "librmi_hip.so")
 
 
 class ModelParams(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("p", C.c_double * 4), ("ip", C.c_uint64 * 2)]
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("p", C.c_double * 4), ("ip", C.c_uint64 * 4)]
 
 
 class Shard(C.Structure):

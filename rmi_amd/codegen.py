@@ -19,6 +19,7 @@ import numpy as np
 
 LINEAR, LINEAR_SPLINE, CUBIC, RADIX, ROBUST_LINEAR = 0, 1, 2, 3, 4
 RADIX_TABLES = (8, 9, 10, 11, 12)            # radix8/18/22/26/28 (RadixTable, radix.rs:83-170)
+BRADIX = 13                                  # BalancedRadixModel (balanced_radix.rs)
 
 _MODEL_CODE = {
     "linear": """
@@ -36,21 +37,37 @@ inline double cubic(double a, double b, double c, double d, double x) {
 inline uint64_t radix(uint64_t prefix_length, uint64_t bits, uint64_t inp) {
     return (inp << prefix_length) >> (64 - bits);
 }""",
+    # balanced_radix.rs:132-152
+    "bradix_clamp_high": """
+inline uint64_t bradix_clamp_high(uint64_t prefix_length,
+                                  uint64_t bits, uint64_t clamp, uint64_t inp) {
+    uint64_t tmp = (inp << prefix_length) >> (64 - bits);
+    return (tmp > clamp ? clamp : tmp);
+}""",
+    "bradix_clamp_low": """
+inline uint64_t bradix_clamp_low(uint64_t prefix_length,
+                                 uint64_t bits, uint64_t clamp, uint64_t inp) {
+    uint64_t tmp = (inp << prefix_length) >> (64 - bits);
+    return (tmp < clamp ? 0 : tmp - clamp);
+}""",
 }
 
 
-def _fn_name(kind: int) -> str:
+def _fn_name(kind: int, model=None) -> str:
     if kind in RADIX_TABLES:
         return "radix_table"
+    if kind == BRADIX:                                                   # balanced_radix.rs:155-161
+        return "bradix_clamp_high" if int(model.ip[3]) else "bradix_clamp_low"
     return {LINEAR: "linear", LINEAR_SPLINE: "linear", ROBUST_LINEAR: "linear", CUBIC: "cubic", RADIX: "radix"}[kind]
 
 
 def _output_is_float(kind: int) -> bool:
-    return kind != RADIX and kind not in RADIX_TABLES
+    return kind not in (RADIX, BRADIX) and kind not in RADIX_TABLES
 
 
 def _needs_bounds_check(kind: int) -> bool:
-    return kind not in (CUBIC, RADIX) and kind not in RADIX_TABLES     # cubic_spline.rs:184-186, radix.rs:72-74, :160-162
+    # cubic_spline.rs:184-186, radix.rs:72-74, :160-162, balanced_radix.rs:164-166
+    return kind not in (CUBIC, RADIX, BRADIX) and kind not in RADIX_TABLES
 
 
 def _radix_table_code(prefix: int, table_bits: int) -> str:              # radix.rs:140-153
@@ -81,7 +98,7 @@ def rmi_size(root_kind: int, leaf_kind: int, num_leaves: int, with_errors: bool,
              spline_points: int = 0) -> int:
     """codegen.rs:375-394 (two layers).  A radix-table root is its hint table (4 B per entry); a
     bounded RMI adds 16 B per spline point (:389-391)."""
-    root_bytes = 4 * root_table_entries if root_kind in RADIX_TABLES else {CUBIC: 32, RADIX: 16}.get(root_kind, 16)
+    root_bytes = 4 * root_table_entries if root_kind in RADIX_TABLES else {CUBIC: 32, RADIX: 16, BRADIX: 24}.get(root_kind, 16)
     leaf_bytes = 32 if leaf_kind == CUBIC else 16
     return root_bytes + leaf_bytes * num_leaves + (8 * num_leaves if with_errors else 0) + 16 * spline_points
 
@@ -130,6 +147,9 @@ def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", i
         root_vals, root_ctype = [], "uint32_t"
     elif root.kind == RADIX:
         root_vals = [f"{int(root.ip[0])}UL", f"{int(root.ip[1])}UL"]
+        root_ctype = "uint64_t"
+    elif root.kind == BRADIX:                                # params(): (prefix, bits, clamp), balanced_radix.rs:124-130
+        root_vals = [f"{int(root.ip[i])}UL" for i in range(3)]
         root_ctype = "uint64_t"
     else:
         nroot = 4 if root.kind == CUBIC else 2
@@ -221,7 +241,7 @@ def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", i
     code += read_code + free_code
     fns = []
     for k in (root.kind, leaf_kind):
-        c = _radix_table_code(int(root.ip[0]), int(root.ip[1])) if k in RADIX_TABLES else _MODEL_CODE[_fn_name(k)]
+        c = _radix_table_code(int(root.ip[0]), int(root.ip[1])) if k in RADIX_TABLES else _MODEL_CODE[_fn_name(k, root)]
         if c not in fns:
             fns.append(c)
     code += fns
@@ -240,7 +260,7 @@ inline size_t FCLAMP(double inp, double bound) {
     root_in = "double" if _output_is_float(root.kind) else "uint64_t"
     root_var = "fpred" if _output_is_float(root.kind) else "ipred"
     args = root_table_args or ", ".join(f"L0_PARAMETER{i}" for i in range(len(root_vals)))
-    code.append(f"  {root_var} = {_fn_name(root.kind)}({args}, ({root_in})key);")
+    code.append(f"  {root_var} = {_fn_name(root.kind, root)}({args}, ({root_in})key);")
     # model_index_from_output! (codegen.rs:346-373)
     if _output_is_float(root.kind):
         mi = f"FCLAMP(fpred, {L}.0 - 1.0)" if _needs_bounds_check(root.kind) else "(uint64_t) fpred"

@@ -29,7 +29,19 @@ struct RootP {
   uint32_t prefix, bits;   // radix: (prefix, bits); radix table: (prefix, shift = 64 - prefix - table_bits or 0)
   uint64_t L;              // number of leaves
   const uint32_t* table;   // radix table: hint_table in HBM (2^table_bits entries), else null
+  // radix family: largest leaf id a key can get, and the raw prediction above which the root is
+  // out of bounds (two_layer.rs:45-48).  radix: (L-1, L-1).  bradix (balanced_radix.rs:104-116) is
+  // the radix function with its own clamp: (min(clamp, L-1), never).
+  uint64_t cap, oob_cap;
 };
+
+// largest leaf id / out-of-bounds threshold of the raw root prediction
+template <int ROOT> __device__ __forceinline__ uint64_t root_cap(const RootP& r) {
+  if constexpr (ROOT == K_RADIX) return r.cap; else return r.L - 1;
+}
+template <int ROOT> __device__ __forceinline__ uint64_t root_oob_above(const RootP& r) {
+  if constexpr (ROOT == K_RADIX) return r.oob_cap; else return r.L - 1;
+}
 
 // radix.rs:125-131 (release-mode masked shifts)
 __device__ __forceinline__ uint64_t radix_table_slot(const RootP& r, uint64_t v) {
@@ -180,8 +192,8 @@ __device__ __forceinline__ double root_target_f(const RootP& r, double Lm1f, K k
   if constexpr (ROOT == K_RADIX) {
     uint64_t v = KeyTraits<K>::as_uint(k);
     uint64_t p = (v << (r.prefix & 63u)) >> ((64u - r.bits) & 63u);
-    oob = p > (uint64_t)Lm1f;
-    p = p < r.L - 1 ? p : r.L - 1;
+    oob = p > r.oob_cap;
+    p = p < r.cap ? p : r.cap;
     return (double)p;
   } else if constexpr (ROOT == K_RADIX_TABLE) {
     uint64_t p = (uint64_t)r.table[radix_table_slot(r, KeyTraits<K>::as_uint(k))];

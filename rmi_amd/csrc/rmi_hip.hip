@@ -401,6 +401,27 @@ int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* c, int iters, double* gb_per_s) 
 
 }  // extern "C"
 
+// Bucketing scan of the resident keys with a radix-family root over `bins` bins:
+// d_first[j] = index of the first key whose bin is >= j (j in [0, bins]; d_first[bins] = n), on
+// the stream of the context.  d_first: bins + 1 entries; d_tmin: bin_starts_tiles(bins) + 1.
+static uint64_t bin_starts_tiles(uint64_t bins) { return (bins + 1 + FILL_TILE - 1) / FILL_TILE; }
+template <typename K>
+static void launch_bin_starts(rmi_hip_ctx* c, const RootP& rp, uint64_t bins, unsigned long long* d_first, unsigned long long* d_tmin) {
+  hipStream_t s = c->stream;
+  const uint64_t ntiles = bin_starts_tiles(bins);
+  Span sp; sp.it_lo = 0; sp.it_hi = c->n; sp.rd_lo = 0; sp.rd_hi = c->n; sp.n = c->n; sp.leaf_lo = 0; sp.leaf_hi = bins;
+  DevState init; std::memset(&init, 0, sizeof init);
+  init.split_idx = c->n; init.last_target = ~0ull;
+  (void)hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, s);
+  hipLaunchKernelGGL(k_table_init, dim3(1024), dim3(256), 0, s, d_first, bins);
+  constexpr uint64_t V = 16 / sizeof(K);
+  const uint64_t blocks = ((c->n + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
+  hipLaunchKernelGGL((k_bounds_vec<K_RADIX, K>), dim3((unsigned)blocks), dim3(256), 0, s, (const K*)c->d_keys, sp, rp, d_first, c->d_state);
+  hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, d_first, bins + 1, d_tmin);
+  hipLaunchKernelGGL(k_fill_scan_tiles, dim3(1), dim3(1024), 0, s, d_tmin, ntiles);
+  hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, d_first, bins + 1, d_tmin);
+}
+
 // Radix-table root fitted where the keys are: bucketing scan over the table's slots, fill, scale.
 template <typename K>
 static int fit_radix_table_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves, rmi_hip_model_params* out) {
@@ -417,9 +438,8 @@ static int fit_radix_table_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves,
   out->kind = kind; out->ip[0] = prefix; out->ip[1] = bits;
   unsigned long long* d_first = nullptr;
   unsigned long long* d_tmin = nullptr;
-  const uint64_t ntiles = (slots + 1 + FILL_TILE - 1) / FILL_TILE;
   HIPCHK(c, hipMalloc(&d_first, (slots + 1) * 8));
-  if (hipMalloc(&d_tmin, (ntiles + 1) * 8) != hipSuccess) { (void)hipFree(d_first); return RMI_ERR_HIP; }
+  if (hipMalloc(&d_tmin, (bin_starts_tiles(slots) + 1) * 8) != hipSuccess) { (void)hipFree(d_first); return RMI_ERR_HIP; }
   if (c->d_table_cap < slots) {
     if (c->d_table) (void)hipFree(c->d_table);
     c->d_table = nullptr; c->d_table_cap = 0;
@@ -437,20 +457,11 @@ static int fit_radix_table_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves,
       if (hipMemcpy(c->d_table, c->h_table.data(), slots * 4, hipMemcpyHostToDevice) != hipSuccess) rc = RMI_ERR_HIP;
     }
   } else {
-    Span sp; sp.it_lo = 0; sp.it_hi = c->n; sp.rd_lo = 0; sp.rd_hi = c->n; sp.n = c->n; sp.leaf_lo = 0; sp.leaf_hi = slots;
     RootP rp; rp.p0 = rp.p1 = rp.p2 = rp.p3 = 0.0; rp.prefix = (uint32_t)prefix; rp.L = slots; rp.table = nullptr;
+    rp.cap = slots - 1; rp.oob_cap = slots - 1;
     // slot = ((x << p) >> p) >> max(0, 64 - p - bits)  ==  the `radix` function with min(bits, 64 - p) bits
     rp.bits = (uint32_t)(bits < 64 - prefix ? bits : 64 - prefix);
-    DevState init; std::memset(&init, 0, sizeof init);
-    init.split_idx = c->n; init.last_target = ~0ull;
-    (void)hipMemcpyAsync(c->d_state, &init, sizeof init, hipMemcpyHostToDevice, s);
-    hipLaunchKernelGGL(k_table_init, dim3(1024), dim3(256), 0, s, d_first, slots);
-    constexpr uint64_t V = 16 / sizeof(K);
-    const uint64_t blocks = ((c->n + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
-    hipLaunchKernelGGL((k_bounds_vec<K_RADIX, K>), dim3((unsigned)blocks), dim3(256), 0, s, (const K*)c->d_keys, sp, rp, d_first, c->d_state);
-    hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, d_first, slots + 1, d_tmin);
-    hipLaunchKernelGGL(k_fill_scan_tiles, dim3(1), dim3(1024), 0, s, d_tmin, ntiles);
-    hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, d_first, slots + 1, d_tmin);
+    launch_bin_starts<K>(c, rp, slots, d_first, d_tmin);
     const double scale = (double)num_leaves / (double)c->n;                    // two_layer.rs:109
     const int scaled = std::fabs(scale - 1.0) > DBL_EPSILON ? 1 : 0;           // map_scale!, models/mod.rs:238-250
     hipLaunchKernelGGL(k_table_from_starts, dim3(1024), dim3(256), 0, s, d_first, slots, scale, scaled, c->d_table);
@@ -462,6 +473,51 @@ static int fit_radix_table_device(rmi_hip_ctx* c, int kind, uint64_t num_leaves,
   if (rc == RMI_ERR_HIP) c->err = "radix table fit on the device failed";
   if (rc != RMI_OK) c->h_table.clear();
   return rc;
+}
+
+// bradix root (balanced_radix.rs:40-101): the chi-square scores of its candidates come from bin
+// counts; the bins of a monotone function over sorted keys are index ranges, so one bucketing scan
+// per `high` candidate gives the counts exactly; the sums run on the host in the reference's order.
+template <typename K>
+static int fit_bradix_device(rmi_hip_ctx* c, uint64_t num_leaves, rmi_hip_model_params* out) {
+  const uint64_t n = c->n;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::memset(out, 0, sizeof *out);
+  out->kind = RMI_MODEL_BRADIX;
+  bool failed = false;
+  auto get = [&](uint64_t i) { K k{}; if (hipMemcpy(&k, (const K*)c->d_keys + i, sizeof(K), hipMemcpyDeviceToHost) != hipSuccess) failed = true; return k; };
+  const K k0 = get(0), kl = get(n - 1);
+  uint64_t lo = 0, hi = n - 1;                                                 // first occurrence of the last key
+  while (lo < hi && !failed) { const uint64_t mid = lo + (hi - lo) / 2; if (get(mid) < kl) lo = mid + 1; else hi = mid; }
+  if (failed) { c->err = "hipMemcpy of a key failed"; return RMI_ERR_HIP; }
+  const rmi_host::Data<K> d{nullptr, n, (double)num_leaves / (double)n};
+  const uint64_t max_output = d.scale_y(lo);                                   // largest y over iter(), balanced_radix.rs:98
+  if (rmi_host::num_bits(max_output) < 0) return RMI_ERR_NUM_BITS;
+  const uint64_t x = rmi_host::as_uint(k0) ^ rmi_host::as_uint(kl);
+  const int prefix = x == 0 ? 64 : __builtin_clzll(x);
+  const uint64_t bins = max_output;
+  unsigned long long* d_first = nullptr;
+  unsigned long long* d_tmin = nullptr;
+  HIPCHK(c, hipMalloc(&d_first, (bins + 1) * 8));
+  if (hipMalloc(&d_tmin, (bin_starts_tiles(bins) + 1) * 8) != hipSuccess) { (void)hipFree(d_first); return RMI_ERR_HIP; }
+  std::vector<unsigned long long> first(bins + 1);
+  int rc = RMI_OK;
+  auto high_counts = [&](int test_bits) {
+    RootP rp; rp.p0 = rp.p1 = rp.p2 = rp.p3 = 0.0; rp.prefix = (uint32_t)prefix; rp.bits = (uint32_t)test_bits; rp.L = bins; rp.table = nullptr;
+    rp.cap = max_output - 1; rp.oob_cap = ~0ull;
+    launch_bin_starts<K>(c, rp, bins, d_first, d_tmin);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(first.data(), d_first, (bins + 1) * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) rc = RMI_ERR_HIP;
+    for (auto& v : first) if (v > n) v = n;                                   // bins after the last key: no start
+    // the tail duplicate of iter_model_input() (Q1) lands in the last key's bin: the last non-empty one
+    uint64_t last_bin = bins - 1;
+    while (last_bin > 0 && first[last_bin] >= n) last_bin--;
+    return [&first, last_bin](uint64_t b) { return (uint64_t)(first[b + 1] - first[b]) + (b == last_bin ? 1 : 0); };
+  };
+  const int rc2 = rmi_host::bradix_choose(n, max_output, prefix, high_counts, out);
+  (void)hipFree(d_first); (void)hipFree(d_tmin);
+  if (rc == RMI_ERR_HIP) c->err = "bradix fit on the device failed";
+  return rc != RMI_OK ? rc : rc2;
 }
 
 // Cubic root of HBM-resident keys: coefficients from O(log n) fetched keys (exact), the model choice
@@ -567,8 +623,16 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
   if (!c || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
   if (root_kind < 0 || root_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
   const bool is_table = rmi_host::radix_table_bits(root_kind) > 0;
-  if (root_kind > RMI_MODEL_ROBUST_LINEAR && !is_table) return RMI_ERR_UNSUPPORTED_MODEL;
+  if (root_kind > RMI_MODEL_ROBUST_LINEAR && !is_table && root_kind != RMI_MODEL_BRADIX) return RMI_ERR_UNSUPPORTED_MODEL;
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  if (root_kind == RMI_MODEL_BRADIX) {                         // bin counts of the resident keys: exact on the device
+    switch (c->dtype) {
+      case RMI_KEY_U64: return fit_bradix_device<uint64_t>(c, num_leaves, out);
+      case RMI_KEY_U32: return fit_bradix_device<uint32_t>(c, num_leaves, out);
+      case RMI_KEY_F64: return fit_bradix_device<double>(c, num_leaves, out);
+    }
+    return RMI_ERR_BAD_ARG;
+  }
   if (is_table) {                                              // integer work on the resident keys: exact on the device
     switch (c->dtype) {
       case RMI_KEY_U64: return fit_radix_table_device<uint64_t>(c, root_kind, num_leaves, out);
@@ -908,7 +972,7 @@ static int dispatch_root(rmi_hip_ctx* c, int root_kind, const RootP& rp, int lea
     case RMI_MODEL_LINEAR: case RMI_MODEL_ROBUST_LINEAR: case RMI_MODEL_LINEAR_SPLINE:
       return dispatch_leaf<K_LINEAR, K>(c, rp, leaf_kind, L);     // all three predict with fma(beta, x, alpha)
     case RMI_MODEL_CUBIC: return dispatch_leaf<K_CUBIC, K>(c, rp, leaf_kind, L);
-    case RMI_MODEL_RADIX: return dispatch_leaf<K_RADIX, K>(c, rp, leaf_kind, L);
+    case RMI_MODEL_RADIX: case RMI_MODEL_BRADIX: return dispatch_leaf<K_RADIX, K>(c, rp, leaf_kind, L);
     case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22: case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28:
       return dispatch_leaf<K_RADIX_TABLE, K>(c, rp, leaf_kind, L);
     default: return RMI_ERR_UNSUPPORTED_MODEL;
@@ -924,7 +988,8 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (root->kind < 0 || root->kind >= kNumModels || leaf_kind < 0 || leaf_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
   if (must_be_top(leaf_kind)) return RMI_ERR_RESTRICTION;
   const int table_bits = rmi_host::radix_table_bits(root->kind);
-  if ((root->kind > RMI_MODEL_ROBUST_LINEAR && table_bits < 0) || leaf_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
+  if ((root->kind > RMI_MODEL_ROBUST_LINEAR && table_bits < 0 && root->kind != RMI_MODEL_BRADIX) || leaf_kind > RMI_MODEL_ROBUST_LINEAR)
+    return RMI_ERR_UNSUPPORTED_MODEL;
   if (table_bits > 0 && (c->h_table.size() != (1ull << table_bits) || root->ip[1] != (uint64_t)table_bits || !c->d_table))
     return RMI_ERR_BAD_ARG;                                    // no (matching) table in this context: rmi_hip_set_root_table
   // robust_linear as a leaf trims 0.01 % tails of each container (linear.rs:247-252): its own fit, then a linear leaf
@@ -944,6 +1009,17 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   rp.prefix = (uint32_t)root->ip[0]; rp.bits = (uint32_t)root->ip[1];
   rp.L = num_leaves;
   rp.table = nullptr;
+  rp.cap = num_leaves - 1; rp.oob_cap = num_leaves - 1;        // two_layer.rs:45-49
+  if (root->kind == RMI_MODEL_BRADIX) {
+    // balanced_radix.rs:104-116 on the radix kernels: clamp-high is the radix function with a lower
+    // cap and no bounds error; clamp-low with a clamp no prediction reaches (every fit of
+    // balanced_radix.rs:63 in a release build, see rmi_root_host.h) sends every key to leaf 0.
+    const uint64_t clamp = root->ip[2];
+    rp.oob_cap = ~0ull;
+    if (root->ip[3]) rp.cap = clamp < num_leaves - 1 ? clamp : num_leaves - 1;
+    else if (root->ip[1] < 64 && (clamp >> root->ip[1]) != 0) rp.cap = 0;
+    else return RMI_ERR_UNSUPPORTED_MODEL;
+  }
   if (table_bits > 0) {                                        // radix.rs:125-131: slot = ((x << p) >> p) >> shift
     rp.table = c->d_table;
     rp.bits = (root->ip[0] + root->ip[1] > 64) ? 0u : (uint32_t)(64 - (root->ip[0] + root->ip[1]));

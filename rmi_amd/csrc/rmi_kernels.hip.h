@@ -31,11 +31,11 @@ __global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, 
   const uint64_t i = sp.it_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sp.it_hi) return;
   const uint64_t n = sp.n;
-  const uint64_t Lm1 = r.L - 1;
+  const uint64_t Lm1 = root_cap<ROOT>(r);
   const uint64_t mid = r.L / 2;                                   // two_layer.rs:131
   const uint64_t p = root_predict<ROOT, K>(r, keys[i]);
   if constexpr (!root_needs_bounds_check<ROOT>()) {
-    if (p > Lm1) atomicOr(&st->err_flags, EF_ROOT_OOB);           // two_layer.rs:45-48
+    if (p > root_oob_above<ROOT>(r)) atomicOr(&st->err_flags, EF_ROOT_OOB);           // two_layer.rs:45-48
   }
   const uint64_t t = p < Lm1 ? p : Lm1;                           // two_layer.rs:49
   const bool mine = t >= sp.leaf_lo && t < sp.leaf_hi;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_bounds_vec(const K* __restrict__ keys, 
                                                     DevState* __restrict__ st) {
   constexpr int V = 16 / sizeof(K);
   const uint64_t n = sp.n;
-  const uint64_t Lm1 = r.L - 1;
+  const uint64_t Lm1 = root_cap<ROOT>(r);
   const uint64_t mid = r.L / 2;                                   // two_layer.rs:131
   const int lane = threadIdx.x & 63;
   const uint64_t first = sp.it_lo + ((uint64_t)blockIdx.x * BV_UNROLL * blockDim.x + threadIdx.x) * V;
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) k_bounds_vec(const K* __restrict__ keys, 
 #pragma unroll
     for (int q = 0; q < V; q++) {
       const uint64_t p = root_predict<ROOT, K>(r, kk[u][q]);
-      if constexpr (!root_needs_bounds_check<ROOT>()) { if (live && base + q < sp.it_hi && p > Lm1) flags |= EF_ROOT_OOB; }   // two_layer.rs:45-48
+      if constexpr (!root_needs_bounds_check<ROOT>()) { if (live && base + q < sp.it_hi && p > root_oob_above<ROOT>(r)) flags |= EF_ROOT_OOB; }   // two_layer.rs:45-48
       t[q] = p < Lm1 ? p : Lm1;                                   // two_layer.rs:49
     }
     // target of the key before this lane's first key: the previous lane's last target; lane 0 loads it
@@ -666,7 +666,7 @@ __global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, Span sp
   const int lane = threadIdx.x & (WAVE - 1);
   const uint64_t n = sp.n;
   const bool active = i < sp.it_hi;
-  const uint64_t Lm1 = r.L - 1;
+  const uint64_t Lm1 = root_cap<ROOT>(r);
   unsigned long long t = ~0ull, err = 0, run = 0;
   if (active) {
     const K k = keys[i];

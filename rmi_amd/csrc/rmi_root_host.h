@@ -304,6 +304,57 @@ inline int fit_root_sparse(int kind, Get get, uint64_t n, uint64_t num_leaves, r
   return RMI_ERR_UNSUPPORTED_MODEL;
 }
 
+// BalancedRadixModel (balanced_radix.rs).  predict_to_int (:104-116) is the radix function followed
+// by a clamp: high = min(res, clamp); low = res < clamp ? 0 : res - clamp.
+inline uint64_t bradix_predict(uint64_t prefix, uint64_t bits, uint64_t clamp, bool high, uint64_t x) {
+  const uint64_t res = (x << (prefix & 63)) >> ((64 - bits) & 63);             // release-mode masked shifts
+  if (high) return res < clamp ? res : clamp;
+  return res < clamp ? 0 : res - clamp;
+}
+// chi2 (:20-38): sum over the bins, in bin order, of (count - expected)^2 / expected, where the
+// counts come from the N+1 items of iter_model_input() (Q1).  `count_of(bin)`: exact bin counts;
+// the reference counts in the default integer type (i32), so the value converted is the wrapped one.
+template <typename CountOf>
+inline double bradix_chi2(uint64_t n, uint64_t max_bin, CountOf count_of) {
+  const double expected = (double)n / (double)max_bin;
+  double sum = 0.0;                                                            // Iterator::sum::<f64>() starts from 0.0
+  for (uint64_t b = 0; b < max_bin; b++) {
+    const double c = (double)(int32_t)(uint32_t)count_of(b);
+    const double d = c - expected;
+    sum += (d * d) / expected;                                                 // powf(2.0) == x * x
+  }
+  return sum;
+}
+// bradix (:40-87): candidates in the reference's order -- for test_bits in {bits, bits + 1}: high
+// (clamp = max_output - 1), then low (clamp = max_output - bits_max) -- the first strictly smaller
+// score wins.  bits_max = 2^(test_bits+1) - 1 always exceeds max_output (num_bits: 2^(bits+1) - 1 >
+// max_output), so the low clamp wraps around (release build: no overflow checks) to 2^64 - d and
+// the low function sends every key to bin 0.  `high_counts(test_bits)` returns an accessor for the
+// bin counts of the high candidate; the low candidates' counts are (n + 1, 0, 0, ...).
+template <typename HighCounts>
+inline int bradix_choose(uint64_t n, uint64_t max_output, int prefix, HighCounts high_counts, rmi_hip_model_params* m) {
+  const int bits = num_bits(max_output);
+  if (bits < 0) return RMI_ERR_NUM_BITS;
+  double best = INFINITY;
+  bool have = false;
+  const int hi_bits = bits + 2 < 64 ? bits + 2 : 64;
+  for (int tb = bits; tb < hi_bits; tb++) {
+    const uint64_t bits_max = (1ull << ((tb + 1) & 63)) - 1;
+    {
+      auto cnt = high_counts(tb);
+      const double score = bradix_chi2(n, max_output, cnt);
+      if (score < best) { best = score; have = true; m->ip[0] = (uint64_t)(uint8_t)prefix; m->ip[1] = (uint64_t)tb; m->ip[2] = max_output - 1; m->ip[3] = 1; }
+    }
+    {
+      const uint64_t clamp = max_output - bits_max;                            // wraps
+      if (!(clamp >> 63)) return RMI_ERR_UNSUPPORTED_MODEL;                    // (cannot happen, see above)
+      const double score = bradix_chi2(n, max_output, [&](uint64_t b) { return b == 0 ? n + 1 : 0ull; });
+      if (score < best) { best = score; have = true; m->ip[0] = (uint64_t)(uint8_t)prefix; m->ip[1] = (uint64_t)tb; m->ip[2] = clamp; m->ip[3] = 0; }
+    }
+  }
+  return have ? RMI_OK : RMI_ERR_BAD_ARG;                                      // best_result.unwrap(): every score NaN
+}
+
 // RadixTable (radix.rs:83-170): table size by registry name (train/mod.rs:46-50) and the slot function.
 inline int radix_table_bits(int kind) {
   switch (kind) {
@@ -377,6 +428,7 @@ inline uint64_t root_target(const rmi_hip_model_params& m, K k, uint64_t L, cons
     case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22: case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28:
       p = table[radix_table_slot(m.ip[0], m.ip[1], as_uint(k))]; break;
     case RMI_MODEL_RADIX: p = (as_uint(k) << (m.ip[0] & 63)) >> ((64 - m.ip[1]) & 63); break;
+    case RMI_MODEL_BRADIX: p = bradix_predict(m.ip[0], m.ip[1], m.ip[2], m.ip[3] != 0, as_uint(k)); break;
     case RMI_MODEL_CUBIC: p = sat_u64(std::fmax(0.0, std::floor(cubic_eval(m.p, as_float(k))))); break;
     default: p = sat_u64(std::fmax(0.0, std::floor(std::fma(m.p[1], as_float(k), m.p[0])))); break;
   }

@@ -24,7 +24,7 @@ from . import codegen, train
 
 EPSILON = sys.float_info.epsilon
 
-SUPPORTED_TOP = ("linear", "robust_linear", "linear_spline", "cubic", "radix", "radix8", "radix18", "radix22", "radix26", "radix28")
+SUPPORTED_TOP = ("linear", "robust_linear", "linear_spline", "cubic", "radix", "radix8", "radix18", "radix22", "radix26", "radix28", "bradix")
 SUPPORTED_LEAF = ("linear", "linear_spline", "cubic")
 
 

@@ -54,8 +54,11 @@ class Model:
     """Parameters of one model in `params()` order (models/mod.rs:742)."""
     kind: int
     p: tuple = (0.0, 0.0, 0.0, 0.0)
-    ip: tuple = (0, 0)
+    ip: tuple = (0, 0, 0, 0)       # radix: (prefix, bits); bradix: (prefix, bits, clamp, high)
     table: object = field(default=None, repr=False, compare=False)   # radix tables: hint_table, np.uint32 (radix.rs:83-88)
+
+    def __post_init__(self):
+        self.ip = tuple(int(v) for v in self.ip) + (0,) * (4 - len(self.ip))
 
     @property
     def name(self) -> str:
@@ -70,7 +73,7 @@ class Model:
         m.kind = self.kind
         for i in range(4):
             m.p[i] = self.p[i]
-        for i in range(2):
+        for i in range(4):
             m.ip[i] = self.ip[i]
         return m
 

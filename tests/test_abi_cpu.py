@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.rmi_hip_abi_version() == 1
+    assert lib.rmi_hip_abi_version() == 2
 
 
 def test_registry_names(lib):
@@ -99,3 +99,25 @@ def test_host_root_recurrence_is_the_reference_recurrence(lib, oracle):
             assert lib.rmi_hip_root_stream_finish(rs, C.byref(m)) == 0
             o = oracle.fit_root("linear", keys, L)
             assert (m.p[0], m.p[1]) == (o.p[0], o.p[1]), (gen, L)
+
+
+def test_host_root_target_of_radix_family(lib, oracle):
+    """rmi_hip_root_target (the bucketing a multi-GPU caller plans its cuts with) for radix and both
+    bradix functions (balanced_radix.rs:104-116) equals min(L-1, predict_to_int) of the oracle."""
+    import ctypes as C
+    import numpy as np
+    from rmi_amd import _lib
+    rng = np.random.default_rng(9)
+    keys = rng.integers(0, 1 << 63, size=300, dtype=np.uint64) * 2 + 1
+    L = 1000
+    for kind, ip in [(3, (0, 10, 0, 0)), (13, (0, 10, 998, 1)), (13, (3, 12, 500, 1)), (13, (0, 10, 300, 0)),
+                     (13, (0, 10, (1 << 64) - 1048, 0))]:
+        m = _lib.ModelParams()
+        m.kind = kind
+        for i in range(4):
+            m.ip[i] = ip[i]
+        om = oracle.Model(kind, (0.0,) * 4, ip)
+        for k in keys:
+            out = C.c_uint64()
+            assert lib.rmi_hip_root_target(C.byref(m), 0, int(k), L, C.byref(out)) == 0
+            assert out.value == min(L - 1, om.predict_to_int(int(k))), (kind, ip, int(k))

@@ -56,6 +56,8 @@ def _as_rmi(o, n):
     ("books_u64", "radix18", "linear", 2048, True),       # hint table in <ns>_L0_PARAMETERS (radix.rs:83-170)
     ("dups_u32", "radix8", "linear_spline", 256, True),   # 1 KiB table: literal array in <ns>_data.h
     ("uniform_u64", "radix22", "cubic", 512, True),
+    ("uniform_u64", "bradix", "linear", 1024, True),      # bradix_clamp_high, three integer literals (balanced_radix.rs:124-152)
+    ("dups_u32", "bradix", "linear_spline", 300, True),
 ])
 def test_emitted_code_compiles_and_is_sound(oracle, tmp_path, gen, root, leaf, L, with_err):
     if shutil.which("g++") is None:

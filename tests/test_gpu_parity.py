@@ -87,6 +87,8 @@ GENS = ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "uniform_u32", 
     ("radix18", "linear", 4096),
     ("radix8", "linear_spline", 200),
     ("radix22", "cubic", 32768),
+    ("bradix", "linear", 4096),
+    ("bradix", "linear_spline", 1000),
 ])
 def test_parity_small(trainer_mod, oracle, gen, root, leaf, L):
     keys = dg.GENERATORS[gen](300_000)
@@ -180,7 +182,7 @@ def test_parity_degenerate_inputs(trainer_mod, oracle, name):
                                                   np.arange(401, 800, dtype=np.uint64)])),
     }[name]
     for root, leaf in [("linear", "linear"), ("radix", "linear"), ("cubic", "linear_spline"), ("linear", "cubic"),
-                       ("radix8", "linear")]:
+                       ("radix8", "linear"), ("bradix", "linear")]:
         for L in (2, 8, 64):
             try:
                 oracle.fit_root(root, keys, L)

@@ -72,7 +72,9 @@ def test_empty(oracle, kind, expect):
 
 def test_radix_empty(oracle):
     m = oracle.fit_pairs("radix", u64(), [])
-    assert m.ip == (0, 0)
+    assert m.ip[:2] == (0, 0)
+    m = oracle.fit_pairs("bradix", u64(), [])                 # balanced_radix.rs:91-96, :176-179 (test_empty)
+    assert m.ip == (0, 0, 0, 1)
 
 
 def test_common_prefix_size(oracle):
@@ -183,5 +185,77 @@ def test_radix_table_against_direct_restatement(oracle):
             last = cur
         for j in range(last + 1, len(table)):
             table[j] = len(table)
-        assert m.ip == (prefix, bits)
+        assert m.ip[:2] == (prefix, bits)
         assert [int(v) for v in m.table] == table
+
+
+def test_bradix_against_direct_restatement(oracle):
+    """BalancedRadixModel (balanced_radix.rs:20-101) has no numeric unit test in the reference; pin the
+    oracle against an independent transcription on small inputs (release-build arithmetic: the
+    `max_output - bits_max` of :63 wraps)."""
+    import numpy as np
+    M64 = (1 << 64) - 1
+
+    def predict(prefix, bits, clamp, high, x):                # :104-116
+        res = ((x << (prefix & 63)) & M64) >> ((64 - bits) & 63)
+        if high:
+            return min(res, clamp)
+        return 0 if res < clamp else res - clamp
+
+    def fit(ks, L):
+        n = len(ks)
+        scale = L / n
+        items = []
+        for i, k in enumerate(ks):                            # FixDups + Q1
+            if i == 0 or k != ks[i - 1]:
+                first = i
+            items.append((k, int(float(first) * scale) if abs(scale - 1.0) > 2.220446049250313e-16 else first))
+        items.append(items[-1])
+        max_output = max(y for _, y in items)
+        bits = 0
+        while ((1 << (bits + 1)) - 1) <= max_output:
+            bits += 1
+        assert bits >= 1
+        any_ones, no_ones = 0, M64
+        for k in ks:
+            any_ones |= k
+            no_ones &= k
+        agree = ((~no_ones) ^ any_ones) & M64
+        prefix = 64
+        for b in range(64):
+            if not (agree >> (63 - b)) & 1:
+                prefix = b
+                break
+        best, best_score = None, float("inf")
+        for tb in range(bits, min(bits + 2, 64)):
+            bits_max = (1 << (tb + 1)) - 1
+            for high, clamp in ((1, max_output - 1), (0, (max_output - bits_max) & M64)):
+                counts = [0] * max_output
+                for k, _ in items:
+                    counts[predict(prefix, tb, clamp, high, k)] += 1
+                expected = n / max_output
+                score = 0.0
+                for c in counts:
+                    score += ((c - expected) * (c - expected)) / expected
+                if score < best_score:
+                    best_score, best = score, (prefix, tb, clamp, high)
+        return best
+
+    # worked example: 16 keys i << 4, L = 8 -> max_output 7, bits 3, prefix 56; high/3 bits wins
+    keys = np.array([i << 4 for i in range(16)], dtype=np.uint64)
+    assert oracle.fit_root("bradix", keys, 8).ip == (56, 3, 6, 1) == fit([int(k) for k in keys], 8)
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        n = int(rng.integers(20, 600))
+        keys = np.sort(rng.integers(1, 1 << int(rng.integers(10, 64)), size=n, dtype=np.uint64))
+        if trial % 3 == 1:
+            keys[n // 2:n // 2 + 5] = keys[n // 2]
+            keys = np.sort(keys)
+        if trial % 3 == 2:                                    # skewed: most keys share their leading bits
+            keys[: n - 3] = np.sort(rng.integers(1, 1 << 12, size=n - 3, dtype=np.uint64))
+            keys = np.sort(keys)
+        L = int(rng.integers(4, 200))
+        m = oracle.fit_root("bradix", keys, L)
+        assert m.ip == fit([int(k) for k in keys], L), (trial, m)
+        for k in (int(keys[0]), int(keys[n // 3]), int(keys[-1])):
+            assert m.predict_to_int(k) == predict(*m.ip, k)
