@@ -49,7 +49,7 @@ extern "C" {
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
 
 /* model registry, train/mod.rs:37-54.  On the device path: roots linear, linear_spline, cubic,
- * radix, robust_linear, the radix tables (ids 8-12) and bradix; leaves linear, linear_spline, cubic,
+ * radix, robust_linear, loglinear, normal, the radix tables (ids 8-12) and bradix; leaves linear, linear_spline, cubic,
  * robust_linear (radix is top-only in the reference; radix tables as leaves are rejected).
  * The rest of the registry is recognised by name and rejected with RMI_ERR_UNSUPPORTED_MODEL. */
 enum rmi_hip_model_kind {
@@ -93,6 +93,7 @@ typedef struct rmi_hip_ctx rmi_hip_ctx;
 
 /* Model parameters in `params()` order of each plugin: linear / linear_spline / robust_linear:
  * p = (alpha, beta) (linear.rs:99-101); cubic: p = (a, b, c, d) (cubic_spline.rs:160-167);
+ * loglinear: p = (alpha, beta) (linear.rs:189-191); normal: p = (mean, stdev, scale) (normal.rs:94-100);
  * radix: ip = (prefix_len, bits) (radix.rs:60-62); bradix: ip = (prefix_len, bits, clamp)
  * (balanced_radix.rs:124-130) and ip[3] = 1 for the clamp-high function, 0 for clamp-low
  * (the `high` member, :17, which selects the emitted function, :132-164). */

@@ -24,6 +24,7 @@ MODEL_IDS = {
     "cubic": MODEL_CUBIC,
     "radix": MODEL_RADIX,
     "robust_linear": MODEL_ROBUST_LINEAR,
+    "loglinear": 5, "normal": 6,
     "radix8": 8, "radix18": 9, "radix22": 10, "radix26": 11, "radix28": 12,      # RadixTable (train/mod.rs:46-50)
     "bradix": 13,                                                                 # BalancedRadixModel
 }

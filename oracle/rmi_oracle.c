@@ -202,6 +202,74 @@ static int fit_linear(const otd* d, orc_model* m) {
   return slr_over_iter(d, 0, SIZE_MAX, &m->p[0], &m->p[1]);
 }
 
+/* loglinear_slr + LogLinearModel::new: linear.rs:60-72, :168-174.  The pairs (x, ln y) with a finite
+ * ln y are collected and handed to slr; ln is libm's. */
+static int fit_loglinear(const otd* d, orc_model* m) {
+  m->kind = ORC_MODEL_LOGLINEAR;
+  size_t cap = d->len + 1, cnt = 0;
+  okey* pk = (okey*)malloc(cap * sizeof(okey));
+  double* ly = (double*)malloc(cap * sizeof(double));
+  if (!pk || !ly) { free(pk); free(ly); return ORC_ERR_BAD_ARG; }
+  fixdups_it it; fd_init(&it, d); okey k; size_t y;
+  while (fd_next(&it, &k, &y)) {
+    double v = log((double)y);
+    if (isfinite(v)) { pk[cnt] = k; ly[cnt] = v; cnt++; }
+  }
+  double mean_x = 0.0, mean_y = 0.0, c = 0.0, m2 = 0.0;
+  uint64_t n = 0;
+  for (size_t i = 0; i < cnt; i++) {                                       /* slr: linear.rs:24-34 */
+    double x = key_as_float(d->dtype, pk[i]);
+    n += 1;
+    double dx = x - mean_x;
+    mean_x += dx / (double)n;
+    mean_y += (ly[i] - mean_y) / (double)n;
+    c += dx * (ly[i] - mean_y);
+    double dx2 = x - mean_x;
+    m2 += dx * dx2;
+  }
+  free(pk); free(ly);
+  if (cnt == 0) { m->p[0] = 0.0; m->p[1] = 0.0; return ORC_OK; }
+  if (cnt == 1) { m->p[0] = mean_y; m->p[1] = 0.0; return ORC_OK; }
+  double cov = c / (double)(n - 1), var = m2 / (double)(n - 1);
+  if (!(var >= 0.0)) return ORC_ERR_NEGATIVE_VARIANCE;
+  if (var == 0.0) { m->p[0] = mean_y; m->p[1] = 0.0; return ORC_OK; }
+  double b = cov / var;
+  m->p[0] = mean_y - b * mean_x; m->p[1] = b;
+  return ORC_OK;
+}
+
+/* exp1, phi: normal.rs:12-27 (and linear.rs:156-166, stdlib.rs:29-45) */
+static inline double exp1(double inp) {
+  double x = inp;
+  x = 1.0 + x / 64.0;
+  x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
+  return x;
+}
+static inline double phi(double x) { return 1.0 / (1.0 + exp1(-1.65451 * x)); }
+
+/* ncdf + NormalModel::new: normal.rs:29-50, :74-78 */
+static int fit_normal(const otd* d, orc_model* m) {
+  m->kind = ORC_MODEL_NORMAL;
+  double scale = -INFINITY, mean = 0.0, stdev = 0.0;
+  const double n = (double)d->len;
+  fixdups_it it; okey k; size_t y;
+  fd_init(&it, d);
+  while (fd_next(&it, &k, &y)) {
+    double x = key_as_float(d->dtype, k);
+    mean += x / n;
+    scale = fmax(scale, (double)y);
+  }
+  fd_init(&it, d);
+  while (fd_next(&it, &k, &y)) {
+    double x = key_as_float(d->dtype, k);
+    stdev += (x - mean) * (x - mean);                                      /* powf(2.0) */
+  }
+  stdev /= n;
+  stdev = sqrt(stdev);
+  m->p[0] = mean; m->p[1] = stdev; m->p[2] = scale;
+  return ORC_OK;
+}
+
 /* RobustLinearModel::new: linear.rs:239-260 */
 static int fit_robust_linear(const otd* d, orc_model* m) {
   m->kind = ORC_MODEL_ROBUST_LINEAR;
@@ -465,6 +533,8 @@ static int train_model(int kind, const otd* d, orc_model* m) {
   switch (kind) {
     case ORC_MODEL_LINEAR: return fit_linear(d, m);
     case ORC_MODEL_ROBUST_LINEAR: return fit_robust_linear(d, m);
+    case ORC_MODEL_LOGLINEAR: return fit_loglinear(d, m);
+    case ORC_MODEL_NORMAL: return fit_normal(d, m);
     case ORC_MODEL_LINEAR_SPLINE: return fit_linear_spline(d, m);
     case ORC_MODEL_CUBIC: return fit_cubic(d, m);
     case ORC_MODEL_RADIX: return fit_radix(d, m);
@@ -488,6 +558,10 @@ static inline double model_predict_float_k(const orc_model* m, int dtype, okey k
       return fma(m->p[1], key_as_float(dtype, k), m->p[0]);       /* linear.rs:87-90 */
     case ORC_MODEL_CUBIC:
       return cubic_predict(m->p, key_as_float(dtype, k));
+    case ORC_MODEL_LOGLINEAR:
+      return exp1(fma(m->p[1], key_as_float(dtype, k), m->p[0]));  /* linear.rs:177-180 */
+    case ORC_MODEL_NORMAL:
+      return phi((key_as_float(dtype, k) - m->p[0]) / m->p[1]) * m->p[2];   /* normal.rs:81-84 */
     case ORC_MODEL_RADIX: {
       /* default predict_to_float = predict_to_int as f64 (mod.rs:731-733) */
       uint64_t v = key_as_uint(dtype, k);
@@ -549,6 +623,10 @@ static int validate(int root_kind, int leaf_kind) {
     switch (kinds[idx]) {
       case ORC_MODEL_LINEAR: case ORC_MODEL_ROBUST_LINEAR: case ORC_MODEL_LINEAR_SPLINE:
       case ORC_MODEL_CUBIC: break;
+      case ORC_MODEL_LOGLINEAR: case ORC_MODEL_NORMAL:
+        /* no restriction in the reference; as leaves their fits are not restated here */
+        if (idx != 0) return ORC_ERR_BAD_ARG;
+        break;
       case ORC_MODEL_RADIX: case ORC_MODEL_BRADIX:             /* MustBeTop: radix.rs:75-80, balanced_radix.rs:167-169 */
         if (idx != 0) return ORC_ERR_RESTRICTION;
         break;

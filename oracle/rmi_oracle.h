@@ -33,6 +33,8 @@ enum {
   ORC_MODEL_CUBIC = 2,
   ORC_MODEL_RADIX = 3,
   ORC_MODEL_ROBUST_LINEAR = 4,
+  ORC_MODEL_LOGLINEAR = 5,         /* LogLinearModel, linear.rs:152-210 (as a root) */
+  ORC_MODEL_NORMAL = 6,            /* NormalModel, normal.rs:70-126 (as a root): p = (mean, stdev, scale) */
   /* RadixTable::new(data, bits), train/mod.rs:46-50: same ids as include/rmi_hip.h */
   ORC_MODEL_RADIX8 = 8,
   ORC_MODEL_RADIX18 = 9,

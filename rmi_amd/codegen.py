@@ -20,6 +20,23 @@ import numpy as np
 LINEAR, LINEAR_SPLINE, CUBIC, RADIX, ROBUST_LINEAR = 0, 1, 2, 3, 4
 RADIX_TABLES = (8, 9, 10, 11, 12)            # radix8/18/22/26/28 (RadixTable, radix.rs:83-170)
 BRADIX = 13                                  # BalancedRadixModel (balanced_radix.rs)
+LOGLINEAR, NORMAL = 5, 6                     # linear.rs:152-210, normal.rs:70-126 (roots)
+
+# StdFunctions (models/stdlib.rs:29-45), emitted before the model functions that use them
+_STD_CODE = {
+    "exp1": """
+inline double exp1(double x) {
+  x = 1.0 + x / 64.0;
+  x *= x; x *= x; x *= x; x *= x;
+  x *= x; x *= x;
+  return x;
+}""",
+    "phi": """
+inline double phi(double x) {
+  return 1.0 / (1.0 + exp1(- 1.65451 * x));
+}""",
+}
+_STD_NEEDED = {LOGLINEAR: ("exp1",), NORMAL: ("exp1", "phi")}     # linear.rs:205-209, normal.rs:112-117
 
 _MODEL_CODE = {
     "linear": """
@@ -36,6 +53,14 @@ inline double cubic(double a, double b, double c, double d, double x) {
     "radix": """
 inline uint64_t radix(uint64_t prefix_length, uint64_t bits, uint64_t inp) {
     return (inp << prefix_length) >> (64 - bits);
+}""",
+    "loglinear": """
+inline double loglinear(double alpha, double beta, double inp) {
+    return exp1(std::fma(beta, inp, alpha));
+}""",
+    "ncdf": """
+inline double ncdf(double mean, double stdev, double scale, double inp) {
+    return phi((inp - mean) / stdev) * scale;
 }""",
     # balanced_radix.rs:132-152
     "bradix_clamp_high": """
@@ -58,7 +83,8 @@ def _fn_name(kind: int, model=None) -> str:
         return "radix_table"
     if kind == BRADIX:                                                   # balanced_radix.rs:155-161
         return "bradix_clamp_high" if int(model.ip[3]) else "bradix_clamp_low"
-    return {LINEAR: "linear", LINEAR_SPLINE: "linear", ROBUST_LINEAR: "linear", CUBIC: "cubic", RADIX: "radix"}[kind]
+    return {LINEAR: "linear", LINEAR_SPLINE: "linear", ROBUST_LINEAR: "linear", CUBIC: "cubic", RADIX: "radix",
+            LOGLINEAR: "loglinear", NORMAL: "ncdf"}[kind]
 
 
 def _output_is_float(kind: int) -> bool:
@@ -98,7 +124,7 @@ def rmi_size(root_kind: int, leaf_kind: int, num_leaves: int, with_errors: bool,
              spline_points: int = 0) -> int:
     """codegen.rs:375-394 (two layers).  A radix-table root is its hint table (4 B per entry); a
     bounded RMI adds 16 B per spline point (:389-391)."""
-    root_bytes = 4 * root_table_entries if root_kind in RADIX_TABLES else {CUBIC: 32, RADIX: 16, BRADIX: 24}.get(root_kind, 16)
+    root_bytes = 4 * root_table_entries if root_kind in RADIX_TABLES else {CUBIC: 32, RADIX: 16, BRADIX: 24, NORMAL: 24}.get(root_kind, 16)
     leaf_bytes = 32 if leaf_kind == CUBIC else 16
     return root_bytes + leaf_bytes * num_leaves + (8 * num_leaves if with_errors else 0) + 16 * spline_points
 
@@ -152,7 +178,7 @@ def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", i
         root_vals = [f"{int(root.ip[i])}UL" for i in range(3)]
         root_ctype = "uint64_t"
     else:
-        nroot = 4 if root.kind == CUBIC else 2
+        nroot = {CUBIC: 4, NORMAL: 3}.get(root.kind, 2)
         root_vals = [c_float(root.p[i]) for i in range(nroot)]
         root_ctype = "double"
     for i, v in enumerate(root_vals):
@@ -239,7 +265,7 @@ def output_rmi(namespace: str, rmi, data_dir: str, key_type: str = "uint64_t", i
         code.append("#include <algorithm>")
     code.append(f"namespace {namespace} {{")
     code += read_code + free_code
-    fns = []
+    fns = [_STD_CODE[f] for f in _STD_NEEDED.get(root.kind, ())]
     for k in (root.kind, leaf_kind):
         c = _radix_table_code(int(root.ip[0]), int(root.ip[1])) if k in RADIX_TABLES else _MODEL_CODE[_fn_name(k, root)]
         if c not in fns:

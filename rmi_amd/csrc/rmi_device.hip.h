@@ -11,7 +11,9 @@
 namespace rmi {
 
 enum : int { K_LINEAR = 0, K_LINEAR_SPLINE = 1, K_CUBIC = 2, K_RADIX = 3, K_ROBUST_LINEAR = 4,
-             K_RADIX_TABLE = 5 };    // RadixTable (radix8/18/22/26/28): roots only
+             K_RADIX_TABLE = 5,      // RadixTable (radix8/18/22/26/28): roots only
+             K_LOGLINEAR = 6,        // exp1(fma(beta, x, alpha)), linear.rs:176-180: roots only
+             K_NORMAL = 7 };         // phi((x - mean) / stdev) * scale, normal.rs:80-84: roots only
 
 // error bits raised by kernels (host maps them to rmi_hip_error codes)
 enum : uint32_t {
@@ -25,7 +27,7 @@ enum : uint32_t {
 
 // Root model parameters + branching factor, passed by value to kernels.
 struct RootP {
-  double p0, p1, p2, p3;   // linear-like: (alpha, beta); cubic: (a, b, c, d)
+  double p0, p1, p2, p3;   // linear-like, loglinear: (alpha, beta); cubic: (a, b, c, d); normal: (mean, stdev, scale)
   uint32_t prefix, bits;   // radix: (prefix, bits); radix table: (prefix, shift = 64 - prefix - table_bits or 0)
   uint64_t L;              // number of leaves
   const uint32_t* table;   // radix table: hint_table in HBM (2^table_bits entries), else null
@@ -121,6 +123,29 @@ __device__ __forceinline__ uint64_t float_pred_to_int(double f) {
   return sat_f64_to_u64(fmax(0.0, floor(f)));
 }
 
+// exp1 / phi of the reference's standard functions (normal.rs:12-27, linear.rs:156-166,
+// stdlib.rs:29-45): plain IEEE operations, so the device value is the host value.
+__device__ __forceinline__ double exp1_ref(double x) {
+  x = 1.0 + x / 64.0;
+  x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
+  return x;
+}
+__device__ __forceinline__ double phi_ref(double x) { return 1.0 / (1.0 + exp1_ref(-1.65451 * x)); }
+
+// predict_to_float of a float root at x = key as f64
+template <int ROOT>
+__device__ __forceinline__ double root_eval_f(const RootP& r, double x) {
+  if constexpr (ROOT == K_CUBIC) {
+    return __builtin_fma(__builtin_fma(__builtin_fma(r.p0, x, r.p1), x, r.p2), x, r.p3);   // cubic_spline.rs:146-148
+  } else if constexpr (ROOT == K_LOGLINEAR) {
+    return exp1_ref(__builtin_fma(r.p1, x, r.p0));           // linear.rs:177-180
+  } else if constexpr (ROOT == K_NORMAL) {
+    return phi_ref((x - r.p0) / r.p1) * r.p2;                // normal.rs:81-84
+  } else {
+    return __builtin_fma(r.p1, x, r.p0);                     // linear.rs:87-90
+  }
+}
+
 // Root prediction, NOT yet clamped to L-1.
 template <int ROOT, typename K>
 __device__ __forceinline__ uint64_t root_predict(const RootP& r, K k) {
@@ -130,15 +155,8 @@ __device__ __forceinline__ uint64_t root_predict(const RootP& r, K k) {
     return (v << (r.prefix & 63u)) >> ((64u - r.bits) & 63u);
   } else if constexpr (ROOT == K_RADIX_TABLE) {
     return (uint64_t)r.table[radix_table_slot(r, KeyTraits<K>::as_uint(k))];   // radix.rs:124-134
-  } else if constexpr (ROOT == K_CUBIC) {
-    double x = KeyTraits<K>::as_float(k);
-    double v1 = __builtin_fma(r.p0, x, r.p1);     // cubic_spline.rs:146-148
-    double v2 = __builtin_fma(v1, x, r.p2);
-    double v3 = __builtin_fma(v2, x, r.p3);
-    return float_pred_to_int(v3);
   } else {
-    double x = KeyTraits<K>::as_float(k);
-    return float_pred_to_int(__builtin_fma(r.p1, x, r.p0));   // linear.rs:87-90
+    return float_pred_to_int(root_eval_f<ROOT>(r, KeyTraits<K>::as_float(k)));
   }
 }
 
@@ -201,13 +219,7 @@ __device__ __forceinline__ double root_target_f(const RootP& r, double Lm1f, K k
     p = p < r.L - 1 ? p : r.L - 1;
     return (double)p;
   } else {
-    double x = KeyTraits<K>::as_float(k);
-    double f;
-    if constexpr (ROOT == K_CUBIC) {
-      f = __builtin_fma(__builtin_fma(__builtin_fma(r.p0, x, r.p1), x, r.p2), x, r.p3);
-    } else {
-      f = __builtin_fma(r.p1, x, r.p0);
-    }
+    double f = root_eval_f<ROOT>(r, KeyTraits<K>::as_float(k));
     f = fmax(0.0, floor(f));          // f64::max(0.0, NaN) == 0.0, as in models/mod.rs:736
     oob = f > Lm1f;
     return fmin(f, Lm1f);

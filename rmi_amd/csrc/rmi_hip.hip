@@ -137,6 +137,15 @@ const char* rmi_hip_model_name(int kind) {
   return kModelNames[kind];
 }
 
+// Roots the device path evaluates.  Not: lognormal (libm's ln per key, normal.rs:189-193: no device
+// routine reproduces it bit for bit) and histogram (a binary search over L pivots per key).
+static bool root_on_device_path(int kind) {
+  switch (kind) {
+    case RMI_MODEL_LOGNORMAL: case RMI_MODEL_HISTOGRAM: return false;
+    default: return kind >= 0 && kind <= RMI_MODEL_HISTOGRAM;
+  }
+}
+
 static bool must_be_top(int kind) {
   // radix.rs:75-80, balanced_radix.rs:167-169, histogram.rs:102 (MustBeTop).  RadixTable has no
   // restriction (radix.rs:163-165).
@@ -623,7 +632,7 @@ int rmi_hip_fit_root(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, const v
   if (!c || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
   if (root_kind < 0 || root_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
   const bool is_table = rmi_host::radix_table_bits(root_kind) > 0;
-  if (root_kind > RMI_MODEL_ROBUST_LINEAR && !is_table && root_kind != RMI_MODEL_BRADIX) return RMI_ERR_UNSUPPORTED_MODEL;
+  if (!root_on_device_path(root_kind)) return RMI_ERR_UNSUPPORTED_MODEL;
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
   if (root_kind == RMI_MODEL_BRADIX) {                         // bin counts of the resident keys: exact on the device
     switch (c->dtype) {
@@ -729,7 +738,8 @@ extern "C" {
 
 int rmi_hip_root_target(const rmi_hip_model_params* root, int dtype, uint64_t key_bits, uint64_t num_leaves, uint64_t* out) {
   if (!root || !out || num_leaves == 0) return RMI_ERR_BAD_ARG;
-  if (rmi_host::radix_table_bits(root->kind) > 0) return RMI_ERR_UNSUPPORTED_MODEL;   // needs the table: plan on the caller's side
+  if (rmi_host::radix_table_bits(root->kind) > 0 || !root_on_device_path(root->kind))
+    return RMI_ERR_UNSUPPORTED_MODEL;                          // (the radix tables need the table: plan on the caller's side)
   switch (dtype) {
     case RMI_KEY_U64: *out = rmi_host::root_target<uint64_t>(*root, (uint64_t)key_bits, num_leaves); return RMI_OK;
     case RMI_KEY_U32: *out = rmi_host::root_target<uint32_t>(*root, (uint32_t)key_bits, num_leaves); return RMI_OK;
@@ -972,6 +982,8 @@ static int dispatch_root(rmi_hip_ctx* c, int root_kind, const RootP& rp, int lea
     case RMI_MODEL_LINEAR: case RMI_MODEL_ROBUST_LINEAR: case RMI_MODEL_LINEAR_SPLINE:
       return dispatch_leaf<K_LINEAR, K>(c, rp, leaf_kind, L);     // all three predict with fma(beta, x, alpha)
     case RMI_MODEL_CUBIC: return dispatch_leaf<K_CUBIC, K>(c, rp, leaf_kind, L);
+    case RMI_MODEL_LOGLINEAR: return dispatch_leaf<K_LOGLINEAR, K>(c, rp, leaf_kind, L);
+    case RMI_MODEL_NORMAL: return dispatch_leaf<K_NORMAL, K>(c, rp, leaf_kind, L);
     case RMI_MODEL_RADIX: case RMI_MODEL_BRADIX: return dispatch_leaf<K_RADIX, K>(c, rp, leaf_kind, L);
     case RMI_MODEL_RADIX8: case RMI_MODEL_RADIX18: case RMI_MODEL_RADIX22: case RMI_MODEL_RADIX26: case RMI_MODEL_RADIX28:
       return dispatch_leaf<K_RADIX_TABLE, K>(c, rp, leaf_kind, L);
@@ -988,8 +1000,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (root->kind < 0 || root->kind >= kNumModels || leaf_kind < 0 || leaf_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
   if (must_be_top(leaf_kind)) return RMI_ERR_RESTRICTION;
   const int table_bits = rmi_host::radix_table_bits(root->kind);
-  if ((root->kind > RMI_MODEL_ROBUST_LINEAR && table_bits < 0 && root->kind != RMI_MODEL_BRADIX) || leaf_kind > RMI_MODEL_ROBUST_LINEAR)
-    return RMI_ERR_UNSUPPORTED_MODEL;
+  if (!root_on_device_path(root->kind) || leaf_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
   if (table_bits > 0 && (c->h_table.size() != (1ull << table_bits) || root->ip[1] != (uint64_t)table_bits || !c->d_table))
     return RMI_ERR_BAD_ARG;                                    // no (matching) table in this context: rmi_hip_set_root_table
   // robust_linear as a leaf trims 0.01 % tails of each container (linear.rs:247-252): its own fit, then a linear leaf

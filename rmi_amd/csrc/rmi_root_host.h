@@ -158,6 +158,45 @@ inline int fit_linear(const Data<K>& d, rmi_hip_model_params* m) {        // lin
   return s.finish(&m->p[0], &m->p[1]);
 }
 
+// loglinear_slr (linear.rs:60-72): slr over (x, ln(y)) of the items whose ln(y) is finite (y >= 1).
+// `ln` is the platform libm's, as in the reference.
+template <typename K>
+inline int fit_loglinear(const Data<K>& d, rmi_hip_model_params* m) {
+  Slr s;
+  for_each_fixdups(d, 0, UINT64_MAX, [&](K k, uint64_t y) {
+    const double ly = std::log((double)y);
+    if (std::isfinite(ly)) s.push(as_float(k), ly);
+  });
+  return s.finish(&m->p[0], &m->p[1]);
+}
+
+// ncdf (normal.rs:29-50): params (mean, stdev, scale); sequential sums over the N+1 items of iter().
+template <typename K>
+inline int fit_normal(const Data<K>& d, rmi_hip_model_params* m) {
+  double scale = -INFINITY, mean = 0.0, stdev = 0.0;
+  const double n = (double)d.n;
+  for_each_fixdups(d, 0, UINT64_MAX, [&](K k, uint64_t y) {
+    mean += as_float(k) / n;
+    scale = std::fmax(scale, (double)y);
+  });
+  for_each_fixdups(d, 0, UINT64_MAX, [&](K k, uint64_t) {
+    const double dx = as_float(k) - mean;
+    stdev += dx * dx;                                                        // powf(2.0)
+  });
+  stdev /= n;
+  stdev = std::sqrt(stdev);
+  m->p[0] = mean; m->p[1] = stdev; m->p[2] = scale;
+  return RMI_OK;
+}
+
+// exp1 / phi: normal.rs:12-27, linear.rs:156-166
+inline double exp1_ref(double x) {
+  x = 1.0 + x / 64.0;
+  x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
+  return x;
+}
+inline double phi_ref(double x) { return 1.0 / (1.0 + exp1_ref(-1.65451 * x)); }
+
 template <typename K>
 inline int fit_robust_linear(const Data<K>& d, rmi_hip_model_params* m) { // linear.rs:239-260
   if (d.n == 0) { m->p[0] = 0.0; m->p[1] = 0.0; return RMI_OK; }
@@ -381,7 +420,9 @@ inline int fit_root(int kind, const K* keys, uint64_t n, uint64_t num_leaves, rm
     case RMI_MODEL_LINEAR_SPLINE: linear_splines(d, &m->p[0], &m->p[1]); return RMI_OK;
     case RMI_MODEL_CUBIC: return fit_cubic(d, m);
     case RMI_MODEL_RADIX: return fit_radix(d, m);
-    default: return RMI_ERR_UNSUPPORTED_MODEL;      // (the radix tables are fitted on the device: rmi_hip.hip)
+    case RMI_MODEL_LOGLINEAR: return fit_loglinear(d, m);
+    case RMI_MODEL_NORMAL: return fit_normal(d, m);
+    default: return RMI_ERR_UNSUPPORTED_MODEL;      // (the radix tables and bradix are fitted on the device: rmi_hip.hip)
   }
 }
 
@@ -430,6 +471,9 @@ inline uint64_t root_target(const rmi_hip_model_params& m, K k, uint64_t L, cons
     case RMI_MODEL_RADIX: p = (as_uint(k) << (m.ip[0] & 63)) >> ((64 - m.ip[1]) & 63); break;
     case RMI_MODEL_BRADIX: p = bradix_predict(m.ip[0], m.ip[1], m.ip[2], m.ip[3] != 0, as_uint(k)); break;
     case RMI_MODEL_CUBIC: p = sat_u64(std::fmax(0.0, std::floor(cubic_eval(m.p, as_float(k))))); break;
+    case RMI_MODEL_LOGLINEAR: p = sat_u64(std::fmax(0.0, std::floor(exp1_ref(std::fma(m.p[1], as_float(k), m.p[0]))))); break;
+    case RMI_MODEL_NORMAL: p = sat_u64(std::fmax(0.0, std::floor(phi_ref((as_float(k) - m.p[0]) / m.p[1]) * m.p[2]))); break;
+    case RMI_MODEL_LOGNORMAL: case RMI_MODEL_HISTOGRAM: p = 0; break;          // (not on the device path; callers reject them first)
     default: p = sat_u64(std::fmax(0.0, std::floor(std::fma(m.p[1], as_float(k), m.p[0])))); break;
   }
   return p < L - 1 ? p : L - 1;

@@ -183,10 +183,7 @@ __device__ __forceinline__ unsigned int leaf_id_at(const unsigned long long* __r
   if constexpr (LEAFP) return leafp[lane * FS_STRIDE + s];
   else {
     const double x = __builtin_bit_cast(double, panel[lane * FS_STRIDE + s]);
-    double f;
-    if constexpr (ROOT == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(r.p0, x, r.p1), x, r.p2), x, r.p3);
-    else f = __builtin_fma(r.p1, x, r.p0);
-    return (unsigned int)fmin(fmax(0.0, floor(f)), Lm1f);
+    return (unsigned int)fmin(fmax(0.0, floor(root_eval_f<ROOT>(r, x))), Lm1f);
   }
 }
 

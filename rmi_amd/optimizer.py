@@ -9,8 +9,8 @@ work left is the exact, sequential root fit (rmi_hip_fit_root) -- computed once 
 (root, branching factor), shared by all leaf types, and overlapped across configurations on a few
 host threads (the reference's `par_iter` over whole trainings, optimizer.rs:220-231).
 
-Models the device path does not implement (normal, lognormal, loglinear: the `disk` profile's extra
-tops) are left out of the lists; `skipped_models()` names them.
+The one model of the lists the device path does not implement (lognormal, one of the `disk` profile's
+extra tops: it needs libm's `ln` per key) is left out; `skipped_models()` names it.
 """
 from __future__ import annotations
 
@@ -24,7 +24,7 @@ from . import codegen, train
 
 EPSILON = sys.float_info.epsilon
 
-SUPPORTED_TOP = ("linear", "robust_linear", "linear_spline", "cubic", "radix", "radix8", "radix18", "radix22", "radix26", "radix28", "bradix")
+SUPPORTED_TOP = ("linear", "robust_linear", "linear_spline", "cubic", "radix", "radix8", "radix18", "radix22", "radix26", "radix28", "bradix", "normal", "loglinear")
 SUPPORTED_LEAF = ("linear", "linear_spline", "cubic")
 
 

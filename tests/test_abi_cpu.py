@@ -121,3 +121,27 @@ def test_host_root_target_of_radix_family(lib, oracle):
             out = C.c_uint64()
             assert lib.rmi_hip_root_target(C.byref(m), 0, int(k), L, C.byref(out)) == 0
             assert out.value == min(L - 1, om.predict_to_int(int(k))), (kind, ip, int(k))
+
+
+def test_host_root_target_of_float_roots(lib, oracle):
+    """rmi_hip_root_target for loglinear (linear.rs:177-180) and normal (normal.rs:81-84) roots equals
+    min(L-1, predict_to_int) of the oracle: exp1 / phi are plain IEEE arithmetic on both sides."""
+    import ctypes as C
+    import numpy as np
+    from rmi_amd import _lib, datagen as dg
+    keys = dg.uniform_u64(50_000)
+    L = 4096
+    for name, kind in [("loglinear", 5), ("normal", 6)]:
+        om = oracle.fit_root(name, keys, L)
+        m = _lib.ModelParams()
+        m.kind = kind
+        for i in range(4):
+            m.p[i] = om.p[i]
+        for k in keys[::97]:
+            out = C.c_uint64()
+            assert lib.rmi_hip_root_target(C.byref(m), 0, int(k), L, C.byref(out)) == 0
+            assert out.value == min(L - 1, om.predict_to_int(int(k))), (name, int(k))
+    for kind in (7, 14):                                             # lognormal, histogram: not on the device path
+        m = _lib.ModelParams()
+        m.kind = kind
+        assert lib.rmi_hip_root_target(C.byref(m), 0, 5, L, C.byref(C.c_uint64())) < 0

@@ -58,6 +58,8 @@ def _as_rmi(o, n):
     ("uniform_u64", "radix22", "cubic", 512, True),
     ("uniform_u64", "bradix", "linear", 1024, True),      # bradix_clamp_high, three integer literals (balanced_radix.rs:124-152)
     ("dups_u32", "bradix", "linear_spline", 300, True),
+    ("uniform_u64", "normal", "linear", 1024, True),      # ncdf + phi + exp1 (normal.rs:94-117)
+    ("books_u64", "loglinear", "linear", 512, True),      # loglinear + exp1 (linear.rs:193-209)
 ])
 def test_emitted_code_compiles_and_is_sound(oracle, tmp_path, gen, root, leaf, L, with_err):
     if shutil.which("g++") is None:

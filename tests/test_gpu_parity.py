@@ -89,6 +89,9 @@ GENS = ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "uniform_u32", 
     ("radix22", "cubic", 32768),
     ("bradix", "linear", 4096),
     ("bradix", "linear_spline", 1000),
+    ("normal", "linear", 4096),
+    ("normal", "linear_spline", 512),
+    ("loglinear", "linear", 2048),
 ])
 def test_parity_small(trainer_mod, oracle, gen, root, leaf, L):
     keys = dg.GENERATORS[gen](300_000)
@@ -96,7 +99,8 @@ def test_parity_small(trainer_mod, oracle, gen, root, leaf, L):
 
 
 @pytest.mark.parametrize("root,leaf,L", [("linear", "linear", 2048), ("linear", "linear_spline", 2048),
-                                         ("cubic", "linear", 1024), ("linear_spline", "linear", 512)])
+                                         ("cubic", "linear", 1024), ("linear_spline", "linear", 512),
+                                         ("normal", "linear", 1024), ("loglinear", "linear", 256), ("bradix", "linear", 512)])
 def test_parity_f64_keys(trainer_mod, oracle, root, leaf, L):
     """f64 key files (src/load.rs:71-95): as_float is the identity, +-epsilon widening (models/mod.rs:101-111)."""
     keys = dg.uniform_f64(200_000)

@@ -23,7 +23,7 @@ def test_branching_factors_and_lists(monkeypatch):
     assert len(opt.first_phase_configs()) == 3 * 2 * 2 and opt.skipped_models() == []
     monkeypatch.setenv("RMI_OPTIMIZER_PROFILE", "disk")
     assert opt.get_branching_factors()[-1] == 2 ** 27
-    assert opt.skipped_models() == ["normal", "lognormal", "loglinear"]
+    assert opt.skipped_models() == ["lognormal"]
     monkeypatch.setenv("RMI_OPTIMIZER_PROFILE", "bogus")
     with pytest.raises(ValueError):
         opt.get_branching_factors()

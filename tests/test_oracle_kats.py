@@ -259,3 +259,27 @@ def test_bradix_against_direct_restatement(oracle):
         assert m.ip == fit([int(k) for k in keys], L), (trial, m)
         for k in (int(keys[0]), int(keys[n // 3]), int(keys[-1])):
             assert m.predict_to_int(k) == predict(*m.ip, k)
+
+
+def test_normal_and_loglinear_reference_kats(oracle):
+    """normal.rs:131-139 (test_ncdf1) and linear.rs:216-224 (loglin test).  Both tests predate FixDupsIter's
+    tail duplicate (Q1): their expected values hold for parameters fitted WITHOUT the repeated last
+    item, which pins exp1 / phi / predict_to_int; the fits themselves include the repeated item, like
+    every model fitted through data.iter() today (models/mod.rs:180)."""
+    import math
+    # ncdf over (1,1),(2,3),(3,5) without Q1: mean 2, stdev sqrt(2/3), scale 5
+    m = oracle.Model(6, (2.0, math.sqrt(2.0 / 3.0), 5.0, 0.0), (0, 0))
+    assert m.predict_to_int(2) == 2 and m.predict_to_int(1) == 0
+    # loglinear over (2,2),(3,4),(4,16) without Q1: slr of (x, ln y)
+    xs, ys = [2.0, 3.0, 4.0], [math.log(2.0), math.log(4.0), math.log(16.0)]
+    mx, my = sum(xs) / 3, sum(ys) / 3
+    beta = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
+    m = oracle.Model(5, (my - beta * mx, beta, 0.0, 0.0), (0, 0))
+    assert m.predict_to_int(2) == 1 and m.predict_to_int(4) == 13
+    # the fits with Q1: four items (the last twice), n = len = 3 in ncdf (normal.rs:34)
+    f = oracle.fit_pairs("normal", u64(1, 2, 3), [1, 3, 5])
+    assert f.p[0] == 1 / 3 + 2 / 3 + 3 / 3 + 3 / 3 and f.p[2] == 5.0
+    assert f.p[1] == math.sqrt(((1 - f.p[0]) ** 2 + (2 - f.p[0]) ** 2 + (3 - f.p[0]) ** 2 + (3 - f.p[0]) ** 2) / 3)
+    g = oracle.fit_pairs("loglinear", u64(2, 3, 4), [0, 4, 16])           # ln 0 = -inf: the item is dropped (linear.rs:65)
+    h = oracle.fit_pairs("loglinear", u64(3, 4), [4, 16])
+    assert g.p == h.p
