@@ -51,7 +51,7 @@ struct rmi_hip_ctx {
   unsigned long long* d_long = nullptr;         // long-leaf hand-over list (pass A -> k_fit_long)
   uint64_t long_cap = 0;
   DevState* d_state = nullptr;
-  StatsPartial* d_partials = nullptr;           // per-block records of k_stats
+  StatsPartial* d_partials = nullptr;           // per-block aggregate records of k_finalize
   DevState* h_state = nullptr;                  // pinned
   unsigned long long* h_sentinel = nullptr;     // pinned
   // shard of a multi-GPU run (rmi_hip_set_shard); keys resident = global [rd_lo, rd_hi)
@@ -189,7 +189,6 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   c->stream = c->own_stream;
   if (hipMalloc(&c->d_state, sizeof(DevState)) != hipSuccess) { delete c; return RMI_ERR_HIP; }
-  if (hipMalloc(&c->d_partials, sizeof(StatsPartial) * STATS_BLOCKS) != hipSuccess) { (void)hipFree(c->d_state); delete c; return RMI_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_sentinel, 64, hipHostMallocDefault) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return RMI_ERR_HIP; }
@@ -212,6 +211,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
 static void free_outputs(rmi_hip_ctx* c) {
   (void)hipFree(c->d_leaf_start); (void)hipFree(c->d_params); (void)hipFree(c->d_maxerr); (void)hipFree(c->d_run);
   (void)hipFree(c->d_err); (void)hipFree(c->d_count); (void)hipFree(c->d_rows); (void)hipFree(c->d_tilemin);
+  (void)hipFree(c->d_partials); c->d_partials = nullptr;
   if (c->d_long) { (void)hipFree(c->d_long); c->d_long = nullptr; c->long_cap = 0; }
   if (c->d_cube) { (void)hipFree(c->d_cube); c->d_cube = nullptr; c->cube_cap = 0; }
   c->d_leaf_start = nullptr; c->d_params = nullptr; c->d_maxerr = nullptr; c->d_run = nullptr;
@@ -227,7 +227,6 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->d_table) (void)hipFree(c->d_table);       // the root table is an input, not an output: it outlives re-sizing
   if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
   if (c->d_state) (void)hipFree(c->d_state);
-  if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_sentinel) (void)hipHostFree(c->h_sentinel);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -800,6 +799,7 @@ static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   HIPCHK(c, hipMalloc(&c->d_count, L * 8));
   HIPCHK(c, hipMalloc(&c->d_rows, L * (ppl * 8 + 8)));
   HIPCHK(c, hipMalloc(&c->d_tilemin, ((L + 1 + FILL_TILE - 1) / FILL_TILE + 1) * 8));
+  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 255) / 256)));
   c->cap_leaves = L; c->cap_ppl = ppl;
   return RMI_OK;
 }
@@ -954,10 +954,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   {
     const uint64_t blocks = (L_own + 255) / 256;
     hipLaunchKernelGGL((k_finalize<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state,
-                       params, maxerr, run, err, count, rows);
-    const unsigned sb = (unsigned)(blocks < STATS_BLOCKS ? blocks : STATS_BLOCKS);
-    hipLaunchKernelGGL(k_stats, dim3(sb), dim3(256), 0, s, sp.leaf_lo, sp.leaf_hi, sp.n, err, count, c->d_partials);
-    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, s, c->d_partials, (int)sb, c->d_state);
+                       params, maxerr, run, err, count, rows, c->d_partials);
+    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, s, c->d_partials, (int)blocks, c->d_state);
   }
   mark();
   HIPCHK(c, hipEventRecord(c->ev[9], s));

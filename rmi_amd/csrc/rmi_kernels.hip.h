@@ -11,7 +11,7 @@
 //                  lower_bound_correction.rs:104-125)
 //   k_finalize     empty-leaf fix, lower-bound widening, row packing
 //                  (two_layer.rs:185-197, 226-259; codegen.rs:288-315)
-//   k_stats        aggregates                              (two_layer.rs:267-287)
+//   k_stats_reduce aggregates from k_finalize's block records (two_layer.rs:267-287)
 #pragma once
 #include "rmi_device.hip.h"
 
@@ -694,6 +694,34 @@ __global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, Span sp
 }
 
 // ---------------------------------------------------------------------------------------------
+// Aggregates of two_layer.rs:267-287.  Every block of k_finalize reduces its leaves to one partial
+// record; k_stats_reduce (a single block) then combines the records in a fixed order (deterministic sums,
+// no same-address atomics: those serialise at ~26 ns each).  The f64 sums are a tree reduction, not
+// the reference's sequential sum: equal within 1e-12 relative, which is what the tests ask.
+// (max_error, max_error_idx) is the lexicographic maximum: `max_by_key` keeps the LAST maximum.
+// ---------------------------------------------------------------------------------------------
+struct StatsPartial { unsigned long long mx, mi, sum; double l2, lg; };
+
+__device__ __forceinline__ void stats_block_reduce(unsigned long long& mx, unsigned long long& mi, unsigned long long& sm,
+                                                   double& l2, double& lg) {
+  __shared__ unsigned long long s_max[256], s_idx[256], s_sum[256];
+  __shared__ double s_l2[256], s_lg[256];
+  s_max[threadIdx.x] = mx; s_idx[threadIdx.x] = mi; s_sum[threadIdx.x] = sm; s_l2[threadIdx.x] = l2; s_lg[threadIdx.x] = lg;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const int o = threadIdx.x + s;
+      if (s_max[o] > s_max[threadIdx.x] || (s_max[o] == s_max[threadIdx.x] && s_idx[o] > s_idx[threadIdx.x])) {
+        s_max[threadIdx.x] = s_max[o]; s_idx[threadIdx.x] = s_idx[o];
+      }
+      s_sum[threadIdx.x] += s_sum[o]; s_l2[threadIdx.x] += s_l2[o]; s_lg[threadIdx.x] += s_lg[o];
+    }
+    __syncthreads();
+  }
+  mx = s_max[0]; mi = s_idx[0]; sm = s_sum[0]; l2 = s_l2[0]; lg = s_lg[0];
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_finalize: one thread per leaf (O(L)).
 // ---------------------------------------------------------------------------------------------
 template <int LEAF, typename K>
@@ -705,12 +733,15 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
                                                   const unsigned long long* __restrict__ leaf_run,
                                                   unsigned long long* __restrict__ leaf_err,
                                                   unsigned long long* __restrict__ leaf_count,
-                                                  unsigned char* __restrict__ rows) {
+                                                  unsigned char* __restrict__ rows,
+                                                  StatsPartial* __restrict__ partials) {
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   constexpr int ROWB = PPL * 8 + 8;
   const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = j < sp.leaf_hi;
   const uint64_t n = sp.n;
+  unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;      // this leaf's terms of the aggregates
+  double st_l2 = 0.0, st_lg = 0.0;
   if (in_range) {
   const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
   double p[PPL];
@@ -752,62 +783,21 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
 #pragma unroll
   for (int q = 0; q < PPL; q++) rp[q] = p[q];
   *reinterpret_cast<unsigned long long*>(rows + j * ROWB + PPL * 8) = final_err;
+  // two_layer.rs:267-287
+  st_mx = final_err; st_mi = j;
+  st_sum = cnt_j * final_err;                                              // wrapping u64, like the reference's sum
+  const double v = (double)st_sum;
+  st_l2 = (v * v) / (double)n;
+  st_lg = (double)cnt_j * log2((double)(2 * final_err + 2));
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_stats / k_stats_reduce: aggregates of two_layer.rs:267-287.  Every block reduces its leaves to one
-// partial record; a single block then combines the records in a fixed order (deterministic sums,
-// no same-address atomics: those serialise at ~26 ns each).  The f64 sums are a tree reduction, not
-// the reference's sequential sum: equal within 1e-12 relative, which is what the tests ask.
-// (max_error, max_error_idx) is the lexicographic maximum: `max_by_key` keeps the LAST maximum.
-// ---------------------------------------------------------------------------------------------
-constexpr int STATS_BLOCKS = 1024;
-struct StatsPartial { unsigned long long mx, mi, sum; double l2, lg; };
-
-__device__ __forceinline__ void stats_block_reduce(unsigned long long& mx, unsigned long long& mi, unsigned long long& sm,
-                                                   double& l2, double& lg) {
-  __shared__ unsigned long long s_max[256], s_idx[256], s_sum[256];
-  __shared__ double s_l2[256], s_lg[256];
-  s_max[threadIdx.x] = mx; s_idx[threadIdx.x] = mi; s_sum[threadIdx.x] = sm; s_l2[threadIdx.x] = l2; s_lg[threadIdx.x] = lg;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      const int o = threadIdx.x + s;
-      if (s_max[o] > s_max[threadIdx.x] || (s_max[o] == s_max[threadIdx.x] && s_idx[o] > s_idx[threadIdx.x])) {
-        s_max[threadIdx.x] = s_max[o]; s_idx[threadIdx.x] = s_idx[o];
-      }
-      s_sum[threadIdx.x] += s_sum[o]; s_l2[threadIdx.x] += s_l2[o]; s_lg[threadIdx.x] += s_lg[o];
-    }
-    __syncthreads();
-  }
-  mx = s_max[0]; mi = s_idx[0]; sm = s_sum[0]; l2 = s_l2[0]; lg = s_lg[0];
-}
-
-__global__ void __launch_bounds__(256) k_stats(uint64_t leaf_lo, uint64_t L, uint64_t n,
-                                               const unsigned long long* __restrict__ leaf_err,
-                                               const unsigned long long* __restrict__ leaf_count,
-                                               StatsPartial* __restrict__ partials) {
-  unsigned long long mx = 0, mi = 0, sm = 0;
-  double l2 = 0.0, lg = 0.0;
-  const double nf = (double)n;
-  for (uint64_t j = leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += (uint64_t)gridDim.x * blockDim.x) {
-    const unsigned long long e = leaf_err[j], c = leaf_count[j];
-    if (e >= mx) { mx = e; mi = j; }                 // max_by_key keeps the last maximum
-    const unsigned long long ne = c * e;
-    sm += ne;
-    const double v = (double)ne;
-    l2 += (v * v) / nf;
-    lg += (double)c * log2((double)(2 * e + 2));
-  }
-  stats_block_reduce(mx, mi, sm, l2, lg);
-  if (threadIdx.x == 0) partials[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
+  stats_block_reduce(st_mx, st_mi, st_sum, st_l2, st_lg);
+  if (threadIdx.x == 0) partials[blockIdx.x] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
 }
 
 __global__ void __launch_bounds__(256) k_stats_reduce(const StatsPartial* __restrict__ partials, int count, DevState* __restrict__ st) {
   unsigned long long mx = 0, mi = 0, sm = 0;
   double l2 = 0.0, lg = 0.0;
-  for (int q = threadIdx.x; q < count; q += 256) {           // (leaf ranges of the blocks interleave: any order combines)
+  for (int q = threadIdx.x; q < count; q += 256) {           // (lexicographic maximum and sums: any order combines)
     const StatsPartial p = partials[q];
     if (p.mx > mx || (p.mx == mx && p.mi > mi)) { mx = p.mx; mi = p.mi; }
     sm += p.sum; l2 += p.l2; lg += p.lg;
