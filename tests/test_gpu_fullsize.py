@@ -75,3 +75,44 @@ def test_large_configs_properties(n, dtype, spec, L, gen):
     g2 = tr.train_leaves(root, spec.split(",")[1], L)
     assert np.array_equal(g2.rows, g.rows)
     tr.close()
+
+
+def test_more_than_2_pow_32_keys(oracle):
+    """Indices beyond 32 bits (34 GB of u64 keys on one GPU): bucket table, counts, and -- on sampled
+    leaves -- the coefficients against the oracle's slr over the same container (y values above 2^32)
+    and the reference's soundness property, with the keys regenerated on the host from their closed form."""
+    from rmi_amd import train, datagen as dg
+    n, L = (1 << 32) + 1_000_003, 1 << 22
+    tr = train.Trainer()
+    tr.generate_keys("uniform", np.uint64, n)
+    root = tr.fit_root("linear_spline", L)                                  # O(1) keys: exact without a host pass
+    g = tr.train_leaves(root, "linear", L)
+    starts = g.leaf_starts.astype(np.int64)
+    assert starts[0] == 0 and starts[-1] == n and (np.diff(starts) >= 0).all()
+    counts = g.leaf_counts.astype(np.int64)
+    assert int(counts.sum()) == n + 1
+    sizes = np.diff(starts)
+    last_leaf = int(np.nonzero(sizes > 0)[0][-1])
+    expect = sizes.copy(); expect[last_leaf] += 1
+    assert np.array_equal(counts, expect)
+    params, errs = g.leaf_params, g.last_layer_max_l1s
+    assert errs.max() == g.model_max_error
+    rng = np.random.default_rng(1)
+    picked = 0
+    for j in [1, 2, L // 4, L // 2 - 5, L // 2 + 5, L - 3] + [int(v) for v in rng.integers(3, L - 3, size=40)]:
+        s, e = int(starts[j]), int(starts[j + 1])
+        if abs(j - int(g.split_target)) <= 2 or e <= s or s == 0 or e >= n or sizes[j - 1] == 0 or sizes[j + 1] == 0:
+            continue                                                        # (Q2/Q3 neighbourhoods and empty neighbours: covered at small sizes)
+        keys = dg.uniform_u64(n, start=s - 1, count=e - s + 2)              # prev-last, own keys, next-first
+        ys = np.arange(s - 1, e + 1, dtype=np.uint64)
+        m = oracle.fit_pairs("linear", keys, ys)
+        assert (m.p[0], m.p[1]) == (float(params[j, 0]), float(params[j, 1])), (j, s, e)
+        # soundness of the error bound on the leaf's own keys (tests/simple_model_wiki/main.cpp:26-41)
+        x = keys[1:-1].astype(np.float64)
+        pred = np.floor(np.clip([float(np.float64(params[j, 1]) * xi + params[j, 0]) for xi in x], 0, n - 1))
+        assert np.all(np.abs(pred - ys[1:-1].astype(np.float64)) <= float(errs[j]) + 1), j   # (+1: fma vs mul+add in this check)
+        picked += 1
+    assert picked >= 20
+    g2 = tr.train_leaves(root, "linear", L)
+    assert np.array_equal(g2.rows, g.rows)
+    tr.close()
