@@ -301,7 +301,8 @@ int rmi_hip_generate_keys(rmi_hip_ctx* c, int generator, int dtype, uint64_t n_g
   HIPCHK(c, hipMalloc(&c->d_keys_owned, count * key_size(dtype)));
   const unsigned long long base_seed = seed ? seed : (dtype == RMI_KEY_U64 ? 42ull : 46ull);
   const unsigned long long dup_seed = dtype == RMI_KEY_U64 ? 45ull : 47ull;
-  const unsigned blocks = (unsigned)((count + 255) / 256);
+  const uint64_t want = (count + 255) / 256;
+  const unsigned blocks = (unsigned)(want < (1u << 20) ? want : (1u << 20));   // grid-stride beyond 2^28 keys
   if (dtype == RMI_KEY_U64)
     hipLaunchKernelGGL((k_generate<uint64_t>), dim3(blocks), dim3(256), 0, c->stream, (uint64_t*)c->d_keys_owned, start, count, stride, base_seed, generator, dup_seed);
   else
@@ -867,12 +868,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   }
 
   HIPCHK(c, hipEventRecord(c->ev[0], s));
-  const bool stream_fit = (c->pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
+  // pipeline 1 launches one thread per key: a grid dimension holds fewer than 2^32 threads
+  const int pipeline = (c->pipeline == 1 && n_it < (1ull << 32) - 1024) ? 1 : 2;
+  const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
   if (n_it == 0) {
     mark();                                              // a shard without keys: every leaf is empty
   } else if (!stream_fit) {
     // --- bucketing scan ---
-    if (c->pipeline == 1) {
+    if (pipeline == 1) {
       const uint64_t blocks = (n_it + 255) / 256;
       hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
     } else {
@@ -938,7 +941,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   mark();
   // --- error pass ---
   if (n_it == 0) {
-  } else if (c->pipeline == 1) {
+  } else if (pipeline == 1) {
     const uint64_t blocks = (n_it + 255) / 256;
     hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, params, maxerr, run);
   } else {

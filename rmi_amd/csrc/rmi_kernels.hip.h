@@ -825,16 +825,16 @@ template <typename K>
 __global__ void __launch_bounds__(256) k_generate(K* __restrict__ out, uint64_t start, uint64_t count,
                                                   unsigned long long stride, unsigned long long seed,
                                                   int gen, unsigned long long dup_seed) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= count) return;
-  unsigned long long i = start + t;
-  if (gen == 1) {
-    const unsigned long long c = splitmix64((i >> 3) + dup_seed) % 5ull;
-    const unsigned long long r = c < 3 ? 1ull : (c == 3 ? 2ull : 8ull);
-    i = i - (i % r);
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x) {
+    unsigned long long i = start + t;
+    if (gen == 1) {
+      const unsigned long long c = splitmix64((i >> 3) + dup_seed) % 5ull;
+      const unsigned long long r = c < 3 ? 1ull : (c == 3 ? 2ull : 8ull);
+      i = i - (i % r);
+    }
+    const unsigned long long k = 1ull + i * stride + (splitmix64(i + seed) % stride);
+    out[t] = (K)k;
   }
-  const unsigned long long k = 1ull + i * stride + (splitmix64(i + seed) % stride);
-  out[t] = (K)k;
 }
 
 }  // namespace rmi
