@@ -144,7 +144,11 @@ __device__ __forceinline__ void load_panel(K (&stage)[FS_ROW], const K* __restri
 #pragma unroll
     for (int k = 0; k < G::LPR; k++) {
       const K* __restrict__ pk = keys + (ubase + (uint64_t)k * step);
-      const Vec t = *reinterpret_cast<const Vec*>(pk + loff);
+      // streamed once per kernel: non-temporal (`nt`) loads -- the keys do not displace leaf_start /
+      // params in the L2 (pass B -3 %, pass A -1 %, measured)
+      typedef unsigned int raw_t __attribute__((ext_vector_type(sizeof(Vec) / 4), aligned(sizeof(K))));
+      const raw_t rw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(pk + loff));
+      const Vec t = __builtin_bit_cast(Vec, rw);
 #pragma unroll
       for (int q = 0; q < G::V; q++) stage[k * G::V + q] = t.v[q];
     }
@@ -382,6 +386,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
       const unsigned int ownmask = (1u << own_cnt) - 1u;
       classify_row<ROOT, K, true, LEAFP>(panel, leafp, lane, r, Lm1f, midf, row_i, n, vmask, ownmask,
                                   kprev, tprev, bmask, dmask, split_pos, flags, leaf_start, st);
+
       if (!lane_done && end_pos < FS_ROW) bmask |= 1u << end_pos;   // end of data acts as a final boundary
       carry_split = (split_pos == FS_ROW - 1);
     }
@@ -513,10 +518,15 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
       }
       if constexpr (NODUP) yprev = row_if + (double)(FS_ROW - 1);
     };
+    // The step loop is the dependent chain of the recurrence; the other wave of the SIMD is usually
+    // in another phase (loads, staging, classification: independent instructions).  Raised issue
+    // priority for the chain shortens it and lets the other wave fill the gaps: pass A -4.5 %.
+    __builtin_amdgcn_s_setprio(2);
     if (general) steps(std::false_type{}, std::false_type{}, std::false_type{});
     else if (beyond) steps(std::true_type{}, std::false_type{}, std::false_type{});
     else if (!__any(dmask != 0u)) steps(std::true_type{}, std::true_type{}, std::true_type{});
     else steps(std::true_type{}, std::false_type{}, std::true_type{});
+    __builtin_amdgcn_s_setprio(0);
     if (pending >= FS_QDRAIN) drain();
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
@@ -754,9 +764,11 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
       }
       if constexpr (PLAIN) yprev = row_if + (double)(FS_ROW - 1);
     };
+    __builtin_amdgcn_s_setprio(2);                           // as in pass A: -2.5 % (with the nt loads -5.6 %)
     if (__any(general)) steps(std::false_type{}, std::false_type{});
     else if (plain_ok) steps(std::true_type{}, std::true_type{});
     else steps(std::true_type{}, std::false_type{});
+    __builtin_amdgcn_s_setprio(0);
     if (pending >= q_drain) drain();                         // (at most 64 more can arrive per panel in the fast loop)
     row_i += FS_ROW;
     row_if += (double)FS_ROW;
