@@ -28,7 +28,6 @@ namespace rmi {
 
 constexpr int FS_ROW = 16;        // keys per panel row
 constexpr int FS_STRIDE = 17;     // padded row stride (slots)
-constexpr int FS_QCAP = 128;      // close-record queue capacity per wave (drain at >= 64, <= 64 pushed per step)
 constexpr int FS_TMAX = 1024;     // reciprocal table size (leaves with more points divide with `/`)
 constexpr unsigned long long FS_NO_NEXT = 1ull << 63;
 
@@ -264,7 +263,7 @@ __device__ __forceinline__ void classify_row(unsigned long long* __restrict__ pa
 // Pass A.  Block = 4 independent waves (they only share the reciprocal table).
 // =============================================================================================
 constexpr int FA_WAVES = 4;
-constexpr int FS_QDRAIN = 32;     // drain the close queue once this many leaves are pending
+constexpr int FS_QDRAIN = 64;     // drain the close queue in full batches of 64 leaves (every lane busy)
 constexpr int FS_QCAP2 = FS_QDRAIN + 64;
 
 template <int ROOT, typename K>
@@ -328,10 +327,12 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
   int pending = 0;                                           // wave-uniform
 
   // drain: every lane finishes one queued leaf (extra points + final divisions)
-  auto drain = [&]() {
-    for (int b = 0; b < pending; b += 64) {
+  // (full batches of 64 only, so that every lane has a leaf to finish; `all`: the last call)
+  auto drain = [&](bool all = false) {
+    const int todo = all ? pending : (pending & ~63);
+    for (int b = 0; b < todo; b += 64) {
       const int slot = b + lane;
-      if (slot < pending) {
+      if (slot < todo) {
         SlrState s2 = {q_mx[slot], q_my[slot], q_c[slot], q_m2[slot], q_nf[slot]};
         const unsigned long long qi = q_idx[slot];
         const uint64_t bi = qi & ~FS_NO_NEXT;                // the boundary index; the leaf is that of key[bi-1]
@@ -362,7 +363,15 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
         params[lj * 2 + 1] = be;
       }
     }
-    pending = 0;
+    // the incomplete batch stays queued, moved to the front
+    const int rem = pending - todo;
+    if (rem > 0 && todo > 0) {
+      const bool mv = lane < rem;
+      double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0; unsigned long long ti = 0;
+      if (mv) { t0 = q_mx[todo + lane]; t1 = q_my[todo + lane]; t2 = q_c[todo + lane]; t3 = q_m2[todo + lane]; t4 = q_nf[todo + lane]; ti = q_idx[todo + lane]; }
+      if (mv) { q_mx[lane] = t0; q_my[lane] = t1; q_c[lane] = t2; q_m2[lane] = t3; q_nf[lane] = t4; q_idx[lane] = ti; }
+    }
+    pending = rem;
   };
 
   K stage[FS_ROW];
@@ -533,7 +542,7 @@ __global__ void __launch_bounds__(64 * FA_WAVES) k_fit_stream(const K* __restric
     if (!__builtin_amdgcn_inverse_ballot_w64(active_m) && (row_i >= chunk_end || row_i >= rd_hi)) lane_done = true;
     P += 1;
   }
-  if (pending) drain();
+  if (pending) drain(true);
   if (flags) atomicOr(&st->err_flags, flags);
 }
 
