@@ -104,6 +104,14 @@ __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
   return r0 | r1 | r2 | r3;
 }
 
+// v_max_f64 / v_min_f64 as such.  Through fmax() / fmin() the compiler first canonicalises every
+// operand it cannot prove quiet (`v_max_f64 x, x, x`: loop-carried maxima, kernel arguments) -- two
+// extra f64 operations in a nine-operation step of pass B.  No signalling NaN can reach these
+// operands; for quiet NaNs the instructions already are maxNum / minNum.
+__device__ __forceinline__ double fmin_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double fmax_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double fmax_abs_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 template <typename K> struct UseRecipTable { static constexpr bool value = true; };
 template <> struct UseRecipTable<double> { static constexpr bool value = false; };   // f64 keys: plain IEEE division
 
@@ -721,7 +729,7 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
           valid = (vmask >> s) & 1u;
           dup = (dmask >> s) & 1u;
           // a new key value ends the previous run: record its length for the leaf of the previous key
-          if (valid && !dup && have_leaf) maxrun = fmax(maxrun, idxf - yprev);
+          if (valid && !dup && have_leaf) maxrun = fmax_raw(maxrun, idxf - yprev);
         }
         const double y = dup ? yprev : idxf;
         bool bit, some;
@@ -759,8 +767,7 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
           if constexpr (LEAF == K_CUBIC) f = __builtin_fma(__builtin_fma(__builtin_fma(pa[0], x, pa[1]), x, pa[2]), x, pa[3]);
           else f = __builtin_fma(pa[1], x, pa[0]);
           // err in the f64 domain (all integers < 2^53): |min(pred, N) - y|, y < N
-          const double e = fabs(fmin(fmax(0.0, floor(f)), nf) - y);
-          maxerr = fmax(maxerr, e);
+          maxerr = fmax_abs_raw(maxerr, fmin_raw(fmax(0.0, floor(f)), nf) - y);
           if constexpr (!PLAIN) yprev = y;
         }
       };
