@@ -958,7 +958,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     const uint64_t blocks = (L_own + 255) / 256;
     hipLaunchKernelGGL((k_finalize<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state,
                        params, maxerr, run, err, count, rows, c->d_partials);
-    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(256), 0, s, c->d_partials, (int)blocks, c->d_state);
+    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials, (int)blocks, c->d_state);
   }
   mark();
   HIPCHK(c, hipEventRecord(c->ev[9], s));

@@ -297,8 +297,8 @@ __global__ void __launch_bounds__(1024) k_fill_scan_tiles(unsigned long long* __
 
 __global__ void __launch_bounds__(256) k_fill_apply(unsigned long long* __restrict__ ls, uint64_t count,
                                                     const unsigned long long* __restrict__ tile_carry) {
-  // one wave-serial pass per tile is enough: tile is 2048 entries; thread t owns 8 consecutive
-  // entries, block-level exclusive suffix-min across threads via LDS.
+  // tile of 2048 entries; thread t owns 8 consecutive entries, block-level exclusive suffix-min
+  // across threads via LDS.
   __shared__ unsigned long long sm[256];
   const uint64_t base = (uint64_t)blockIdx.x * FILL_TILE + (uint64_t)threadIdx.x * 8;
   unsigned long long v[8];
@@ -311,12 +311,16 @@ __global__ void __launch_bounds__(256) k_fill_apply(unsigned long long* __restri
   }
   sm[threadIdx.x] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long run = tile_carry[blockIdx.x];
-    for (int k = 255; k >= 0; k--) { unsigned long long x = sm[k]; sm[k] = run; run = x < run ? x : run; }
+  // inclusive suffix-min over the 256 thread minima by doubling, then shifted by one thread and
+  // combined with the carry of the tiles to the right
+  for (int d = 1; d < 256; d <<= 1) {
+    const unsigned long long o = ((int)threadIdx.x + d < 256) ? sm[threadIdx.x + d] : NO_START;
+    __syncthreads();
+    if (o < sm[threadIdx.x]) sm[threadIdx.x] = o;
+    __syncthreads();
   }
-  __syncthreads();
-  unsigned long long carry = sm[threadIdx.x];
+  unsigned long long carry = tile_carry[blockIdx.x];
+  if (threadIdx.x + 1 < 256) { const unsigned long long o = sm[threadIdx.x + 1]; carry = o < carry ? o : carry; }
 #pragma unroll
   for (int k = 7; k >= 0; k--) {
     uint64_t idx = base + k;
@@ -702,13 +706,14 @@ __global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, Span sp
 // ---------------------------------------------------------------------------------------------
 struct StatsPartial { unsigned long long mx, mi, sum; double l2, lg; };
 
+template <int THREADS = 256>
 __device__ __forceinline__ void stats_block_reduce(unsigned long long& mx, unsigned long long& mi, unsigned long long& sm,
                                                    double& l2, double& lg) {
-  __shared__ unsigned long long s_max[256], s_idx[256], s_sum[256];
-  __shared__ double s_l2[256], s_lg[256];
+  __shared__ unsigned long long s_max[THREADS], s_idx[THREADS], s_sum[THREADS];
+  __shared__ double s_l2[THREADS], s_lg[THREADS];
   s_max[threadIdx.x] = mx; s_idx[threadIdx.x] = mi; s_sum[threadIdx.x] = sm; s_l2[threadIdx.x] = l2; s_lg[threadIdx.x] = lg;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = THREADS / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
       const int o = threadIdx.x + s;
       if (s_max[o] > s_max[threadIdx.x] || (s_max[o] == s_max[threadIdx.x] && s_idx[o] > s_idx[threadIdx.x])) {
@@ -794,15 +799,15 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
   if (threadIdx.x == 0) partials[blockIdx.x] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
 }
 
-__global__ void __launch_bounds__(256) k_stats_reduce(const StatsPartial* __restrict__ partials, int count, DevState* __restrict__ st) {
+__global__ void __launch_bounds__(1024) k_stats_reduce(const StatsPartial* __restrict__ partials, int count, DevState* __restrict__ st) {
   unsigned long long mx = 0, mi = 0, sm = 0;
   double l2 = 0.0, lg = 0.0;
-  for (int q = threadIdx.x; q < count; q += 256) {           // (lexicographic maximum and sums: any order combines)
+  for (int q = threadIdx.x; q < count; q += 1024) {           // (lexicographic maximum and sums: any order combines)
     const StatsPartial p = partials[q];
     if (p.mx > mx || (p.mx == mx && p.mi > mi)) { mx = p.mx; mi = p.mi; }
     sm += p.sum; l2 += p.l2; lg += p.lg;
   }
-  stats_block_reduce(mx, mi, sm, l2, lg);
+  stats_block_reduce<1024>(mx, mi, sm, l2, lg);
   if (threadIdx.x == 0) {
     st->max_err = mx; st->max_err_idx = mi; st->sum_n_err = sm; st->sum_l2 = l2; st->sum_log2 = lg;
   }
