@@ -32,8 +32,9 @@ KERNEL_NAMES = ["k_fit_stream", "k_fill", "k_fit_long", "k_err_range", "k_finali
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (a step is ~1 ms: 200 steps let the clocks settle, the first ~20 run 5-10 %% slower)")
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--keys", type=int, default=200_000_000, help="keys per GPU")
     ap.add_argument("--leaves", type=int, default=1 << 20, help="leaves per GPU")
     ap.add_argument("--spec", default="linear,linear")

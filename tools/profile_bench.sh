@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 B="python bench.py --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats -T -d $OUT/kt -o kt -f csv -- $B --steps 20 --warmup 3 > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -T -d $OUT/kt -o kt -f csv -- $B --steps 200 --warmup 50 > $OUT/kt.log 2>&1
 INC='k_fit_stream|k_fit_long|k_err_range|k_finalize|k_fill|k_stats'
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
    --kernel-include-regex "$INC" -d $OUT/pmc1 -o p -f csv -- $B --steps 2 --warmup 0 > $OUT/pmc1.log 2>&1
