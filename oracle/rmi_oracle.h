@@ -9,7 +9,10 @@
  * for this path and cannot be compiled in this image (no cargo/rustc).  The oracle is
  * a line-by-line restatement of the cited Rust sources and is pinned only by the
  * reference's stale in-file KATs and its end-to-end soundness property
- * (see tests/test_oracle_kats.py, tests/test_oracle_property.py).
+ * (see tests/test_oracle_kats.py, tests/test_oracle_property.py), by independent
+ * transcriptions of single functions in those tests, and by a second, independent
+ * restatement of the whole trainer in Python (tests/pyref.py, tests/test_pyref.py).
+ * None of that is an execution of the reference itself.
  *
  * Every function cites the reference file:line (relative to /root/reference) it follows.
  */
