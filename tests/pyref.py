@@ -4,7 +4,7 @@ another side.  TEST INFRASTRUCTURE: imported by tests/test_pyref.py only.
 
 It follows the reference literally (vectors of (key, y) pairs, iterators, Option as None) rather
 than the closed forms the oracle and the kernels use, so a slip in one is unlikely to be repeated in
-the other.  u64 keys.  Python floats are IEEE doubles and nothing is contracted; `mul_add` is
+the other.  u64, u32 and f64 keys.  Python floats are IEEE doubles and nothing is contracted; `mul_add` is
 computed exactly in rationals and rounded once; `powf(3.0)` is libm's pow like the reference's,
 `powf(2.0)` is x*x (what LLVM makes of it).  Where the reference asserts or unwraps None this code
 raises ReferencePanic.
@@ -29,7 +29,11 @@ def _assert(cond, what=""):
 def fma(a, b, c):                                   # f64::mul_add: one rounding
     if any(math.isinf(v) or math.isnan(v) for v in (a, b, c)):
         return a * b + c
-    return float(Fraction(a) * Fraction(b) + Fraction(c))
+    exact = Fraction(a) * Fraction(b) + Fraction(c)
+    try:
+        return float(exact)
+    except OverflowError:                           # beyond the largest double: rounds to infinity
+        return math.inf if exact > 0 else -math.inf
 
 
 def sat_u64(f):                                     # Rust `f64 as u64`
@@ -38,6 +42,28 @@ def sat_u64(f):                                     # Rust `f64 as u64`
     if f >= 18446744073709551616.0:
         return U64
     return int(f)
+
+
+# ---- TrainingKey (models/mod.rs:65-111) for the three key types of src/load.rs ----
+class KeyType:
+    def __init__(self, kind):
+        self.kind = kind
+        self.max_value = {"u64": U64, "u32": (1 << 32) - 1, "f64": 1.7976931348623157e308}[kind]
+        self.zero_value = 0.0 if kind == "f64" else 0
+
+    def minus_epsilon(self, k):                     # unchecked -1 (release build: wraps)
+        if self.kind == "f64":
+            return k - 2.220446049250313e-16
+        return (k - 1) & (U64 if self.kind == "u64" else (1 << 32) - 1)
+
+    def plus_epsilon(self, k):
+        if self.kind == "f64":
+            return k + 2.220446049250313e-16
+        return (k + 1) & (U64 if self.kind == "u64" else (1 << 32) - 1)
+
+
+def as_int(key):                                    # ModelInput::as_int, models/mod.rs:428-433
+    return sat_u64(key) if isinstance(key, float) else key
 
 
 # ---- models/mod.rs: RMITrainingData over a vector of (key, offset) pairs ----
@@ -250,8 +276,8 @@ def num_bits(largest):                              # utils.rs:13-21
 def common_prefix_size(data):                       # utils.rs:23-36
     any_ones, no_ones = 0, U64
     for x, _ in data.iter():
-        any_ones |= x
-        no_ones &= x
+        any_ones |= as_int(x)
+        no_ones &= as_int(x)
     any_zeros = ~no_ones & U64
     prefix_bits = any_zeros ^ any_ones
     inv = ~prefix_bits & U64
@@ -270,7 +296,7 @@ class Radix:                                        # radix.rs:13-81
 
     def predict_to_int(self, key):
         prefix, bits = self.ip
-        return ((key << (prefix & 63)) & U64) >> ((64 - bits) & 63)
+        return ((as_int(key) << (prefix & 63)) & U64) >> ((64 - bits) & 63)
 
 
 def predict_to_int(model, key):                     # models/mod.rs:735-737: f64::max(0.0, pred.floor()) as u64
@@ -293,7 +319,7 @@ def train_model(name, data):                        # train/mod.rs:35-57
 
 # ---- train/lower_bound_correction.rs ----
 class LowerBoundCorrection:                         # :92-137
-    def __init__(self, pred, num_leaves, data):
+    def __init__(self, pred, num_leaves, data, kt):
         L = num_leaves
         first, last, runs = [None] * L, [None] * L, [0] * L
         last_target, run_len, run_key = 0, 0, data.get_key(0)
@@ -308,7 +334,7 @@ class LowerBoundCorrection:                         # :92-137
                 first[target] = (y, x)
             last[target] = (y, x)
         n = len(data)
-        nxt = [(0, 0)] * L                          # compute_next_for_leaf :30-56
+        nxt = [(0, kt.zero_value)] * L              # compute_next_for_leaf :30-56
         idx = 0
         while idx < L:
             above = None
@@ -323,9 +349,9 @@ class LowerBoundCorrection:                         # :92-137
                 idx = above[0]
             else:
                 for i in range(idx, L):
-                    nxt[i] = (n, U64)
+                    nxt[i] = (n, kt.max_value)
                 break
-        prv = [(0, 0)] * L                          # compute_prev_for_leaf :58-80
+        prv = [(0, kt.zero_value)] * L              # compute_prev_for_leaf :58-80
         idx = L - 1
         while idx > 0:
             below = None
@@ -378,9 +404,10 @@ def build_models_from(data, top, model_type, start_idx, end_idx, first_model_idx
     return leaf_models
 
 
-def train_two_layer(keys, layer1, layer2, num_leaves):   # :101-306
+def train_two_layer(keys, layer1, layer2, num_leaves, kind="u64"):   # :101-306
     L = num_leaves
-    md = Data([(int(k), i) for i, k in enumerate(keys)])
+    kt = KeyType(kind)
+    md = Data([((float(k) if kind == "f64" else int(k)), i) for i, k in enumerate(keys)])
     n = len(md)
     md.scale = float(L) / float(n)
     top = train_model(layer1, md)
@@ -399,7 +426,7 @@ def train_two_layer(keys, layer1, layer2, num_leaves):   # :101-306
         st = min(L - 1, predict_to_int(top, md.get_key(split_idx)))
         leaves = build_models_from(md, top, layer2, 0, split_idx, 0, st) + \
             build_models_from(md, top, layer2, split_idx + 1, n, st, L - st)
-    lb = LowerBoundCorrection(lambda x: predict_to_int(top, x), L, md)
+    lb = LowerBoundCorrection(lambda x: predict_to_int(top, x), L, md, kt)
     for idx in range(L - 1):
         _assert((lb.first[idx] is None) == (lb.last[idx] is None))
         if lb.last[idx] is None:
@@ -412,10 +439,10 @@ def train_two_layer(keys, layer1, layer2, num_leaves):   # :101-306
     for leaf in range(L):
         curr = l1[leaf][1]
         idx_next, key_next = lb.next[leaf]
-        upper = error_between(predict_to_int(leaves[leaf], (key_next - 1) & U64), idx_next + 1, n)
+        upper = error_between(predict_to_int(leaves[leaf], kt.minus_epsilon(key_next)), idx_next + 1, n)
         prev_idx = 0 if leaf == 0 else leaf - 1
         first_idx = lb.next[prev_idx][0]
-        lower = error_between(predict_to_int(leaves[leaf], (lb.prev[leaf][1] + 1) & U64), first_idx, n)
+        lower = error_between(predict_to_int(leaves[leaf], kt.plus_epsilon(lb.prev[leaf][1])), first_idx, n)
         l1[leaf] = (l1[leaf][0], max(curr, upper, lower) + lb.runs[leaf])
     m_idx, m_err = 0, l1[0][1]
     for i, (_, e) in enumerate(l1):                 # max_by_key: the last maximum

@@ -78,3 +78,35 @@ def test_panics_and_edge_cases_agree(oracle, root, leaf, keys, L):
     ppl = o.params_per_leaf
     assert [[float(v) for v in o.leaf_params[j, :ppl]] for j in range(L)] == [m.params() for m in ref["leaves"]]
     assert [int(v) for v in o.leaf_err] == ref["errs"] and [int(v) for v in o.leaf_count] == ref["counts"]
+
+
+@pytest.mark.parametrize("kind", ["u32", "f64"])
+@pytest.mark.parametrize("root,leaf", [("linear", "linear"), ("radix", "linear_spline"), ("cubic", "linear"), ("linear", "cubic")])
+def test_other_key_types_agree(oracle, kind, root, leaf):
+    """u32 keys (T::MAX = 2^32-1 in the widening of the last leaf, widened to u64 for radix) and f64 keys
+    (as_float is the identity, +-EPSILON, `as u64` saturating for radix): models/mod.rs:89-111."""
+    rng = np.random.default_rng(7 + len(root) + 3 * len(leaf) + (0 if kind == "u32" else 100))
+    for trial in range(16):
+        n = int(rng.integers(12, 300))
+        if kind == "u32":
+            hi = [1 << 32, 5000, 1 << 20, 300][trial % 4]
+            keys = np.sort(rng.integers(1, hi - 1, size=n, dtype=np.uint64)).astype(np.uint32)
+        else:
+            keys = np.sort(rng.random(n) * [1e6, 3.0, 1e15, 50.0][trial % 4] + 1.0)
+            if trial % 3 == 0:
+                keys[n // 2:n // 2 + 4] = keys[n // 2]
+                keys = np.sort(keys)
+        L = int(rng.integers(2, 40))
+        try:
+            ref = pyref.train_two_layer(list(keys.tolist()), root, leaf, L, kind=kind)
+        except pyref.ReferencePanic:
+            with pytest.raises(oracle.OracleError):
+                oracle.train_two_layer(root, leaf, keys, L)
+            continue
+        o = oracle.train_two_layer(root, leaf, keys, L)
+        ppl = o.params_per_leaf
+        got = [[float(v) for v in o.leaf_params[j, :ppl]] for j in range(L)]
+        assert got == [m.params() for m in ref["leaves"]], (kind, trial, L)
+        assert [int(v) for v in o.leaf_err] == ref["errs"], (kind, trial, L)
+        assert [int(v) for v in o.leaf_count] == ref["counts"]
+        assert o.model_max_error == ref["max_error"] and o.model_max_error_idx == ref["max_error_idx"]
