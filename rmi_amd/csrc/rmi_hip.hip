@@ -60,7 +60,8 @@ struct rmi_hip_ctx {
   unsigned long long shard_split_idx = ~0ull, shard_split_target = 0;
   void* d_rows_ext = nullptr;                   // caller-provided row buffer (e.g. the all-gather buffer)
   hipEvent_t ev[10] = {};
-  bool profile_kernels = false;
+  int profile_level = 0;                        // 0: whole call only; 1: + the first (dominant) kernel; 2: every kernel group
+  DevState* h_state_dev = nullptr;              // device address of the pinned h_state (written by the last kernel)
   int pipeline = 2;                             // 1 = one kernel per reference pass; 2 = tiled/streaming kernels
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
   uint64_t err_threads = 262144;                // lanes of pass B (4 waves/SIMD)
@@ -189,11 +190,12 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   c->stream = c->own_stream;
   if (hipMalloc(&c->d_state, sizeof(DevState)) != hipSuccess) { delete c; return RMI_ERR_HIP; }
-  if (hipHostMalloc((void**)&c->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  if (hipHostMalloc((void**)&c->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->h_state_dev, c->h_state, 0) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_sentinel, 64, hipHostMallocDefault) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return RMI_ERR_HIP; }
   const char* pk = std::getenv("RMI_HIP_PROFILE_KERNELS");
-  c->profile_kernels = pk && *pk && *pk != '0';
+  c->profile_level = (pk && *pk && *pk != '0') ? 2 : 0;
   const char* pl = std::getenv("RMI_HIP_PIPELINE");
   if (pl && *pl) c->pipeline = std::atoi(pl);
   const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
@@ -235,6 +237,12 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
 }
 
 const char* rmi_hip_last_error(const rmi_hip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rmi_hip_set_profile_level(rmi_hip_ctx* c, int level) {
+  if (!c || level < 0 || level > 2) return RMI_ERR_BAD_ARG;
+  c->profile_level = level;
+  return RMI_OK;
+}
 
 int rmi_hip_set_stream(rmi_hip_ctx* c, void* s) {
   if (!c) return RMI_ERR_BAD_ARG;
@@ -826,9 +834,12 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   hipStream_t s = c->stream;
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   constexpr int ROWB = PPL * 8 + 8;
-  const bool pk = c->profile_kernels;
+  // An event between two kernels costs ~5.5 us of idle device time (measured in the kernel trace):
+  // level 0 records the start and the end of the call only, level 1 also brackets the first,
+  // dominant kernel, level 2 every kernel group.
+  const int pl = c->profile_level;
   int evi = 0;
-  auto mark = [&]() { if (pk) (void)hipEventRecord(c->ev[1 + evi], s); evi++; };
+  auto mark = [&]() { if (pl >= 2 || (pl == 1 && evi == 0)) (void)hipEventRecord(c->ev[1 + evi], s); evi++; };
 
   // ---- index space of this launch (global indices; see Span) ----
   Span sp;
@@ -861,13 +872,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
+  HIPCHK(c, hipEventRecord(c->ev[8], s));                      // start of the device work of this call
   {
     const uint64_t ib = (L_own + 1 + 255) / 256;
     hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, c->d_leaf_start, c->d_maxerr, c->d_run,
                        L_own, (unsigned long long)sp.it_hi, c->d_state, init);
   }
 
-  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));
   // pipeline 1 launches one thread per key: a grid dimension holds fewer than 2^32 threads
   const int pipeline = (c->pipeline == 1 && n_it < (1ull << 32) - 1024) ? 1 : 2;
   const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
@@ -958,11 +970,12 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     const uint64_t blocks = (L_own + 255) / 256;
     hipLaunchKernelGGL((k_finalize<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state,
                        params, maxerr, run, err, count, rows, c->d_partials);
-    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials, (int)blocks, c->d_state);
+    // (the last kernel also copies the device state into the pinned host copy: a separate 100-byte
+    // copy command would cost ~15 us of the call)
+    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials, (int)blocks, c->d_state, c->h_state_dev);
   }
   mark();
   HIPCHK(c, hipEventRecord(c->ev[9], s));
-  HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipGetLastError());
   return RMI_OK;
 }
@@ -1071,14 +1084,11 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   out->split_idx = st.split_idx; out->split_target = st.split_target;
   out->long_leaves = st.long_count;
   float ms = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[9]));
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[8], c->ev[9]));
   out->device_ns = (uint64_t)((double)ms * 1e6);
-  if (c->profile_kernels) {
-    for (int k = 0; k < 5; k++) {
-      float m2 = 0.f;
-      hipEvent_t a = k == 0 ? c->ev[0] : c->ev[k];
-      if (hipEventElapsedTime(&m2, a, c->ev[k + 1]) == hipSuccess) out->kernel_ns[k] = (uint64_t)((double)m2 * 1e6);
-    }
+  for (int k = 0; k < (c->profile_level >= 2 ? 5 : c->profile_level); k++) {
+    float m2 = 0.f;
+    if (hipEventElapsedTime(&m2, c->ev[k], c->ev[k + 1]) == hipSuccess) out->kernel_ns[k] = (uint64_t)((double)m2 * 1e6);
   }
   return RMI_OK;
 }

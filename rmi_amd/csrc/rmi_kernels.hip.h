@@ -799,7 +799,8 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
   if (threadIdx.x == 0) partials[blockIdx.x] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
 }
 
-__global__ void __launch_bounds__(1024) k_stats_reduce(const StatsPartial* __restrict__ partials, int count, DevState* __restrict__ st) {
+__global__ void __launch_bounds__(1024) k_stats_reduce(const StatsPartial* __restrict__ partials, int count, DevState* __restrict__ st,
+                                                       DevState* __restrict__ host_copy) {
   unsigned long long mx = 0, mi = 0, sm = 0;
   double l2 = 0.0, lg = 0.0;
   for (int q = threadIdx.x; q < count; q += 1024) {           // (lexicographic maximum and sums: any order combines)
@@ -810,6 +811,7 @@ __global__ void __launch_bounds__(1024) k_stats_reduce(const StatsPartial* __res
   stats_block_reduce<1024>(mx, mi, sm, l2, lg);
   if (threadIdx.x == 0) {
     st->max_err = mx; st->max_err_idx = mi; st->sum_n_err = sm; st->sum_l2 = l2; st->sum_log2 = lg;
+    if (host_copy) *host_copy = *st;                       // pinned host memory: visible to the host once the stream is synchronised
   }
 }
 

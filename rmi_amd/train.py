@@ -222,6 +222,10 @@ class Trainer:
         _check(self._lib.rmi_hip_measure_read_bandwidth(self._h, iters, C.byref(v)), self._h)
         return float(v.value)
 
+    def set_profile_level(self, level: int):
+        """0: device_ns only; 1: + kernel_ns[0] (the first, dominant kernel); 2: every kernel group."""
+        _check(self._lib.rmi_hip_set_profile_level(self._h, int(level)), self._h)
+
     def set_stream(self, stream_ptr: int | None):
         _check(self._lib.rmi_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
