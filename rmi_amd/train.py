@@ -69,12 +69,17 @@ class Model:
         return 8 <= self.kind <= 12
 
     def _c(self) -> _lib.ModelParams:
+        key = (self.kind, self.p, self.ip)
+        cached = self.__dict__.get("_cstruct")
+        if cached is not None and cached[0] == key:            # (train_leaves is called ~1000x per second)
+            return cached[1]
         m = _lib.ModelParams()
         m.kind = self.kind
         for i in range(4):
             m.p[i] = self.p[i]
         for i in range(4):
             m.ip[i] = self.ip[i]
+        self.__dict__["_cstruct"] = (key, m)
         return m
 
     @staticmethod
@@ -285,7 +290,7 @@ class Trainer:
             model_max_error_idx=int(res.model_max_error_idx), model_max_log2_error=res.model_max_log2_error,
             models=f"{root.name},{MODEL_NAMES[leaf_kind]}", branching_factor=int(num_leaves), root=root,
             leaf_kind=leaf_kind, params_per_leaf=int(res.params_per_leaf),
-            device_ns=int(res.device_ns), kernel_ns=tuple(int(x) for x in res.kernel_ns), long_leaves=int(res.long_leaves),
+            device_ns=int(res.device_ns), kernel_ns=tuple(res.kernel_ns), long_leaves=int(res.long_leaves),
             split_idx=int(res.split_idx), split_target=int(res.split_target),
             shard_leaf_lo=int(res.shard_leaf_lo), shard_leaves=int(res.shard_leaves),
             partial={"max_error": int(res.model_max_error), "max_error_idx": int(res.model_max_error_idx),
