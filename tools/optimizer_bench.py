@@ -9,7 +9,11 @@ import numpy as np
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000_000
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-os.environ["RMI_OPTIMIZER_PROFILE"] = sys.argv[3] if len(sys.argv) > 3 else "fast"
+prof = sys.argv[3] if len(sys.argv) > 3 else "fast"
+if prof in ("", "default"):
+    os.environ.pop("RMI_OPTIMIZER_PROFILE", None)          # the reference's default lists
+else:
+    os.environ["RMI_OPTIMIZER_PROFILE"] = prof
 from rmi_amd import optimizer, train
 
 tr = train.Trainer()
@@ -23,7 +27,7 @@ front = optimizer.find_pareto_efficient_configs(tr, 10, threads=threads, root_mo
 wall = time.perf_counter() - t0
 optimizer.display_table(front)
 roots = len({(m.split(",")[0], bf) for m, bf in cfgs})
-print(f"keys {n}  profile {os.environ['RMI_OPTIMIZER_PROFILE']}  configurations trained {len(cfgs)}  distinct root fits {roots}  host threads {threads}")
+print(f"keys {n}  profile {os.environ.get('RMI_OPTIMIZER_PROFILE', 'default')}  configurations trained {len(cfgs)}  distinct root fits {roots}  host threads {threads}")
 print(f"wall {wall:.2f} s   device time of all leaf passes {sum(dev_ns) / 1e9:.3f} s   "
       f"(mean {sum(dev_ns) / len(dev_ns) / 1e6:.2f} ms, max {max(dev_ns) / 1e6:.2f} ms per configuration)")
 slow = sorted(zip(dev_ns, cfgs), reverse=True)[:8]
