@@ -310,7 +310,54 @@ def predict_to_int(model, key):                     # models/mod.rs:735-737: f64
     return sat_u64(max(0.0, f))
 
 
-MODELS = {"linear": Linear, "robust_linear": RobustLinear, "linear_spline": LinearSpline, "cubic": Cubic, "radix": Radix}
+# ---- models/normal.rs, LogLinearModel in models/linear.rs (used as roots) ----
+def exp1(x):                                        # normal.rs:12-23, linear.rs:156-166
+    x = 1.0 + x / 64.0
+    for _ in range(6):
+        x *= x
+    return x
+
+
+def phi(x):                                         # normal.rs:25-27
+    return 1.0 / (1.0 + exp1(-1.65451 * x))
+
+
+class Normal:                                       # normal.rs:29-50, :70-126
+    needs_bounds_check = True
+
+    def __init__(self, data):
+        scale, mean, stdev = -math.inf, 0.0, 0.0
+        n = float(len(data))
+        for x, y in data.iter():
+            mean += float(x) / n
+            scale = max(scale, float(y))
+        for x, _ in data.iter():
+            stdev += (float(x) - mean) * (float(x) - mean)
+        stdev /= n
+        self.p = (mean, math.sqrt(stdev), scale)
+
+    def predict_to_float(self, key):
+        mean, stdev, scale = self.p
+        try:
+            return phi((float(key) - mean) / stdev) * scale
+        except ZeroDivisionError:
+            return math.nan
+
+    def params(self):
+        return list(self.p)
+
+
+class LogLinear(Linear):                            # linear.rs:60-72, :152-210
+    def __init__(self, data):
+        pts = [(float(x), math.log(float(y))) for x, y in data.iter() if y > 0]     # ln 0 = -inf is filtered out
+        self.p = slr(pts)
+
+    def predict_to_float(self, key):
+        return exp1(fma(self.p[1], float(key), self.p[0]))
+
+
+MODELS = {"linear": Linear, "robust_linear": RobustLinear, "linear_spline": LinearSpline, "cubic": Cubic, "radix": Radix,
+          "normal": Normal, "loglinear": LogLinear}
 
 
 def train_model(name, data):                        # train/mod.rs:35-57

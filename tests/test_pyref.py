@@ -8,7 +8,8 @@ import pytest
 from tests import pyref
 
 CASES = [("linear", "linear"), ("linear", "linear_spline"), ("linear", "cubic"), ("cubic", "linear"), ("radix", "linear"),
-         ("linear_spline", "linear"), ("robust_linear", "linear"), ("radix", "linear_spline"), ("cubic", "cubic")]
+         ("linear_spline", "linear"), ("robust_linear", "linear"), ("radix", "linear_spline"), ("cubic", "cubic"),
+         ("normal", "linear"), ("loglinear", "linear")]
 
 
 def _keys(rng, trial):
