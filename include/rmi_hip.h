@@ -159,6 +159,10 @@ int rmi_hip_upload_keys(rmi_hip_ctx* ctx, const void* host_keys, uint64_t n, int
 /* Borrow a device buffer that already holds the sorted keys (stays owned by the caller). */
 int rmi_hip_attach_device_keys(rmi_hip_ctx* ctx, const void* device_keys, uint64_t n, int dtype);
 uint64_t rmi_hip_num_keys(const rmi_hip_ctx* ctx);
+/* The resident key buffer of a context (owned or borrowed), e.g. to attach it to further contexts:
+ * independent trainings on one key set can then be in flight together, one context per caller thread
+ * (optimizer.rs:220-231 trains its configurations with par_iter).  The buffer stays owned by `ctx`. */
+int rmi_hip_key_buffer(const rmi_hip_ctx* ctx, const void** device_keys, uint64_t* n, int* dtype);
 /* Synthetic sorted keys generated in HBM (bit-identical to rmi_amd/datagen.py):
  * generator 0 = uniform, 1 = uniform with duplicate runs.  Produces indices
  * [start, start+count) of the n_global-key array (so ranks can generate their own shard).

@@ -42,6 +42,7 @@ SYMBOLS = [
     ("rmi_hip_destroy", None, [C.c_void_p]),
     ("rmi_hip_last_error", C.c_char_p, [C.c_void_p]),
     ("rmi_hip_strerror", C.c_char_p, [C.c_int]),
+    ("rmi_hip_key_buffer", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     ("rmi_hip_set_profile_level", C.c_int, [C.c_void_p, C.c_int]),
     ("rmi_hip_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_model_from_name", C.c_int, [C.c_char_p]),

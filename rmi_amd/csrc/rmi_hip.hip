@@ -275,6 +275,13 @@ int rmi_hip_attach_device_keys(rmi_hip_ctx* c, const void* device_keys, uint64_t
 
 uint64_t rmi_hip_num_keys(const rmi_hip_ctx* c) { return c ? c->n : 0; }
 
+int rmi_hip_key_buffer(const rmi_hip_ctx* c, const void** device_keys, uint64_t* n, int* dtype) {
+  if (!c || !device_keys || !n || !dtype) return RMI_ERR_BAD_ARG;
+  if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  *device_keys = c->d_keys; *n = c->n; *dtype = c->dtype;
+  return RMI_OK;
+}
+
 int rmi_hip_set_shard(rmi_hip_ctx* c, const rmi_hip_shard* sh) {
   if (!c) return RMI_ERR_BAD_ARG;
   if (!sh) { c->have_shard = false; return RMI_OK; }

@@ -161,6 +161,20 @@ class Trainer:
         if keys is not None:
             self.set_keys(keys)
 
+    def view(self) -> "Trainer":
+        """A second context on the same resident keys (borrowed, not copied): trainings issued through
+        different views can be in flight together, one host thread each."""
+        ptr, n, dt = C.c_void_p(), C.c_uint64(), C.c_int()
+        _check(self._lib.rmi_hip_key_buffer(self._h, C.byref(ptr), C.byref(n), C.byref(dt)), self._h)
+        v = Trainer(device=self._device)
+        _check(self._lib.rmi_hip_attach_device_keys(v._h, ptr, n.value, dt.value), v._h)
+        v._keepalive = self                       # the keys belong to this trainer
+        v._host_keys = self._host_keys
+        v.n = int(n.value)
+        if hasattr(self, "_np_dtype"):
+            v._np_dtype = self._np_dtype
+        return v
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.rmi_hip_destroy(self._h)
@@ -249,7 +263,7 @@ class Trainer:
         if mode not in ("exact", "fast"):
             raise ValueError("mode must be 'exact' or 'fast'")
         hk = C.c_void_p(self._host_keys.ctypes.data) if self._host_keys is not None else None
-        if kind == 2:                               # cubic: a device reduction on the context's stream
+        if kind in (2, 13):                         # cubic, bradix: device reductions / scans on the context's stream
             with self._ctx_lock:
                 _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
             return Model._from_c(m)

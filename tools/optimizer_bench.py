@@ -1,5 +1,5 @@
 """Wall time of the Pareto search (rmi_amd/optimizer.py) over a resident synthetic key set.
-usage: python tools/optimizer_bench.py [n_keys] [threads] [profile] [exact|fast]"""
+usage: python tools/optimizer_bench.py [n_keys] [threads] [profile] [exact|fast] [leaf passes in flight]"""
 import os
 import sys
 import time
@@ -22,7 +22,8 @@ tr.download_keys()
 dev_ns, cfgs = [], []
 t0 = time.perf_counter()
 root_mode = sys.argv[4] if len(sys.argv) > 4 else "exact"
-front = optimizer.find_pareto_efficient_configs(tr, 10, threads=threads, root_mode=root_mode,
+in_flight = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+front = optimizer.find_pareto_efficient_configs(tr, 10, threads=threads, root_mode=root_mode, in_flight=in_flight,
                                                 progress=lambda s, r: (dev_ns.append(r.device_ns), cfgs.append((s.models, s.branching_factor))))
 wall = time.perf_counter() - t0
 optimizer.display_table(front)
