@@ -96,6 +96,28 @@ def test_optimizer_fast_profile(tmp_path, oracle, monkeypatch):
     assert r.returncode == 0 and "Found RMI config" in r.stdout, r.stdout + r.stderr
 
 
+def test_views_and_leaf_passes_in_flight(oracle):
+    """Trainer.view: further contexts on the same resident keys.  Leaf passes issued through them
+    concurrently (optimizer.measure_rmis, in_flight > 1) return exactly what one-at-a-time returns,
+    and a view trains what its parent trains, bit for bit."""
+    from rmi_amd import optimizer, train
+    keys = dg.dups_u64(250_000)
+    tr = train.Trainer(keys)
+    configs = [(f"{r},{l}", bf) for r in ("linear", "radix", "radix18", "cubic") for l in ("linear", "cubic", "linear_spline")
+               for bf in (64, 4096)]
+    one = optimizer.measure_rmis(tr, configs, threads=4, in_flight=1)
+    four = optimizer.measure_rmis(tr, configs, threads=4, in_flight=4)
+    assert one == four and len(one) == len(configs)
+    v = tr.view()
+    root = tr.fit_root("linear", 2048)
+    a, b = tr.train_leaves(root, "linear", 2048), v.train_leaves(root, "linear", 2048)
+    assert np.array_equal(a.rows, b.rows) and a.model_max_error == b.model_max_error
+    o = oracle.train_two_layer("linear", "linear", keys, 2048)
+    assert np.array_equal(b.leaf_params, o.leaf_params) and np.array_equal(b.last_layer_max_l1s, o.leaf_err)
+    v.close()
+    tr.close()
+
+
 def test_bounded_cli_end_to_end(tmp_path, oracle):
     """`rmi <keys> rmi linear_spline,linear 4096 --bounded 8` (tests/cache_fix_wiki/Makefile:8): spline and
     rows equal the oracle's, the emitted lookup stays within the line for every key."""
