@@ -7,14 +7,16 @@
 //
 // Passes A and B share one skeleton.  A wave owns 64 consecutive chunks of C keys, one chunk per
 // lane, and all lanes advance one key per step in lockstep.  Per panel of 64 rows x 16 keys:
-//   load     coalesced HBM reads (each load instruction covers 4 rows = 4 full 128-B lines),
-//            transposed through a padded LDS image (row stride 17 slots: lane-per-row accesses are
-//            bank-conflict free); the next panel is prefetched into registers meanwhile.
+//   load     coalesced, non-temporal HBM reads (16 bytes per lane for 8-byte keys: an instruction
+//            covers 8 rows = 8 full 128-B lines), transposed through a padded LDS image (row stride
+//            17 slots: lane-per-row accesses are bank-conflict free); the next panel is prefetched
+//            into registers meanwhile.
 //   phase 1  every lane classifies the 16 keys of its own row (root target, leaf-boundary and
 //            duplicate-key bit masks, split point), converts them to f64 in place and leaves the
 //            leaf ids in a second LDS panel.  This is the bucketing scan.
-//   phase 2  16 lockstep steps.  The common step is straight-line code; steps in which some lane
-//            crosses a leaf boundary take a wave-uniform slow path.
+//   phase 2  16 lockstep steps at raised issue priority (s_setprio).  The common step is
+//            straight-line code; steps in which some lane crosses a leaf boundary take a
+//            wave-uniform slow path.
 //
 // Why lane-per-chunk: the SLR recurrence (linear.rs:24-34) is order dependent, so bit-identical
 // coefficients need the reference order inside a leaf; the parallelism is across leaves, and
@@ -28,7 +30,7 @@ namespace rmi {
 
 constexpr int FS_ROW = 16;        // keys per panel row
 constexpr int FS_STRIDE = 17;     // padded row stride (slots)
-constexpr int FS_TMAX = 1024;     // reciprocal table size (leaves with more points divide with `/`)
+constexpr int FS_TMAX = 1024;     // reciprocal table size (beyond it the reciprocal is computed, see recip_exact)
 constexpr unsigned long long FS_NO_NEXT = 1ull << 63;
 
 struct SlrState { double mx, my, c, m2, nf; };
