@@ -213,6 +213,23 @@ def main():
             out["pcie_inclusive"] = {"value": n_local / (t2 - t0), "unit": "keys/s", "upload_ms": (t1 - t0) * 1e3,
                                      "upload_GBps": n_local * key_bytes / (t1 - t0) / 1e9, "step_ms": (t2 - t1) * 1e3,
                                      "note": "pageable host buffer, hipMemcpy, then one step; not the headline value"}
+        if world == 1 and root_kind in (0, 4):
+            # B_leaf + B_root over t_root + t_leaf when the root is fitted on the GPU -- the
+            # opt-in fast root (parallel sums, not bit-identical to the reference's sequential fit)
+            tr.fit_root(root_kind, L_global, mode="fast")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fr = tr.fit_root(root_kind, L_global, mode="fast")
+            root_fast_s = (time.perf_counter() - t0) / 10
+            t0 = time.perf_counter()
+            for _ in range(10):
+                tr.train_leaves(fr, leaf_kind, L_local)
+            leaf_s = (time.perf_counter() - t0) / 10
+            out["fast_root_inclusive"] = {"value": n_local / (root_fast_s + leaf_s), "unit": "keys/s", "root_ms": root_fast_s * 1e3,
+                                          "leaf_ms": leaf_s * 1e3, "bytes": 2 * n_local * key_bytes + 24 * L_local,
+                                          "note": "root fitted on the GPU from parallel sums (opt-in, coefficients within ~1e-12 of the "
+                                                  "exact fit, not bit-identical) + the leaf path of THAT root; not the headline value"}
         if not args.no_cpu_baseline and args.cpu_sample > 0 and world == 1:
             sample = keys_np[: min(args.cpu_sample, len(keys_np))]
             out["cpu_baseline"] = cpu_baseline(sample, args.spec, L_global, n_global)
