@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RMI_HIP_ABI_VERSION 2
+#define RMI_HIP_ABI_VERSION 3
 
 /* src/load.rs:15-19 */
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
@@ -128,6 +128,13 @@ typedef struct {
   uint64_t kernel_ns[8];          /* per-kernel hipEvent times, see RMI_K_* */
   uint64_t long_leaves;           /* leaves too long for the lockstep fit pass, fitted one lane each
                                    * (skew diagnostic: each is a sequential chain of its own length) */
+  /* one-pass mode (rmi_hip_set_fit_mode): did this call run it, how many leaves it handed to the exact
+   * kernels (irregular leaves + guard), and how many leaves the guard flagged */
+  int32_t fit_mode_used;
+  int32_t _pad2;
+  uint64_t exact_leaves;
+  uint64_t guard_leaves;
+  uint64_t generation;            /* number of this train call on the context, for rmi_hip_download_checked */
 } rmi_hip_result;
 
 enum { RMI_K_BOUNDARIES = 0, RMI_K_FILL = 1, RMI_K_FIT = 2, RMI_K_ERR = 3, RMI_K_FINALIZE = 4 };
@@ -143,6 +150,23 @@ const char* rmi_hip_strerror(int code);
  * dominant kernel of the call, 2 = every kernel group (RMI_K_*).  An event between two kernels costs
  * ~5 us of idle device time, so the detail is not free.  RMI_HIP_PROFILE_KERNELS=1 selects 2 at creation. */
 int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
+/* How linear leaves (linear.rs:12-59) are fitted:
+ *   RMI_FIT_EXACT (default): the reference's recurrence in the reference's order; coefficients, error
+ *     integers and counts bit-identical to the reference; two streaming passes over the keys.
+ *   RMI_FIT_ONEPASS_GUARDED: ONE pass over the keys; a leaf's line from shifted sums (n, S dx, S dx^2,
+ *     S dx dy) reduced in parallel, the error pass from LDS.  Bucket ids, per-leaf error integers and
+ *     counts stay bit-identical: a leaf with any prediction closer to an integer than a bound on the
+ *     distance between the two lines (guard_k times a first-order rounding bound, see rmi_sigma.hip.h),
+ *     or that the sums do not describe (duplicate keys, the leaves at the split of two_layer.rs:130-175,
+ *     first / last leaf, leaves longer than a tile), is re-fitted by the exact kernels.  Coefficients of
+ *     the other leaves agree with the reference's to its own rounding noise (~1e-9 relative on 200M u64
+ *     keys), not bit for bit.
+ *   RMI_FIT_ONEPASS: the same without the re-fit of guard-flagged leaves (they are counted in
+ *     rmi_hip_result.guard_leaves): error bounds are those of the emitted coefficients (the index is
+ *     sound), a few may differ by one from the reference's.
+ * guard_k <= 0 keeps the current factor (default 4).  Leaf kinds other than `linear` ignore the mode. */
+enum rmi_hip_fit_mode { RMI_FIT_EXACT = 0, RMI_FIT_ONEPASS_GUARDED = 1, RMI_FIT_ONEPASS = 2 };
+int rmi_hip_set_fit_mode(rmi_hip_ctx* ctx, int mode, double guard_k);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = context's own. */
 int rmi_hip_set_stream(rmi_hip_ctx* ctx, void* hip_stream);
 
@@ -256,6 +280,12 @@ int rmi_hip_download_leaf_errors(rmi_hip_ctx* ctx, uint64_t* host_out /* L */);
 int rmi_hip_download_leaf_counts(rmi_hip_ctx* ctx, uint64_t* host_out /* L */);
 int rmi_hip_download_leaf_starts(rmi_hip_ctx* ctx, uint64_t* host_out /* L+1 */);
 int rmi_hip_download_rows(rmi_hip_ctx* ctx, void* host_out /* L*row_bytes */);
+/* The same downloads for callers that hold on to a result while the context trains on: `what` is one of
+ * RMI_DL_*, `generation` the rmi_hip_result.generation of the call whose arrays are wanted, `capacity_bytes`
+ * the size of host_out.  RMI_ERR_BAD_ARG if the context has trained again since (the arrays are gone) or
+ * if the buffer is too small -- nothing is written then. */
+enum { RMI_DL_PARAMS = 0, RMI_DL_ERRORS = 1, RMI_DL_COUNTS = 2, RMI_DL_STARTS = 3, RMI_DL_ROWS = 4 };
+int rmi_hip_download_checked(rmi_hip_ctx* ctx, int what, uint64_t generation, void* host_out, uint64_t capacity_bytes);
 /* Device pointer of the packed rows (for an all-gather over RCCL without a host bounce). */
 void* rmi_hip_device_rows(rmi_hip_ctx* ctx);
 

@@ -31,6 +31,9 @@ class Result(C.Structure):
         ("sum_n_err", C.c_uint64), ("sum_l2", C.c_double), ("sum_log2", C.c_double),
         ("device_ns", C.c_uint64), ("kernel_ns", C.c_uint64 * 8),
         ("long_leaves", C.c_uint64),
+        ("fit_mode_used", C.c_int32), ("_pad2", C.c_int32),
+        ("exact_leaves", C.c_uint64), ("guard_leaves", C.c_uint64),
+        ("generation", C.c_uint64),
     ]
 
 
@@ -45,6 +48,7 @@ SYMBOLS = [
     ("rmi_hip_key_buffer", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     ("rmi_hip_set_profile_level", C.c_int, [C.c_void_p, C.c_int]),
     ("rmi_hip_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rmi_hip_set_fit_mode", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     ("rmi_hip_model_from_name", C.c_int, [C.c_char_p]),
     ("rmi_hip_model_name", C.c_char_p, [C.c_int]),
     ("rmi_hip_parse_spec", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -77,6 +81,7 @@ SYMBOLS = [
     ("rmi_hip_download_leaf_counts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_download_leaf_starts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_download_rows", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("rmi_hip_download_checked", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64]),
     ("rmi_hip_device_rows", C.c_void_p, [C.c_void_p]),
 ]
 

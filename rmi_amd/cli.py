@@ -49,15 +49,14 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def _stats(rmi: train.TrainedRMI, n: int) -> dict:
-    # src/main.rs:207-221
+    # src/main.rs:207-221, key for key ("average error %" is the MAX error over the row count there, :211-212)
     return {"layers": rmi.models, "branching factor": rmi.branching_factor,
-            "average error": rmi.model_avg_error, "average error %": rmi.model_avg_error / n * 100.0,
+            "average error": rmi.model_avg_error, "average error %": rmi.model_max_error / n * 100.0,
             "average l2 error": rmi.model_avg_l2_error, "average log2 error": rmi.model_avg_log2_error,
             "max error": rmi.model_max_error, "max error %": rmi.model_max_error / n * 100.0,
             "max log2 error": rmi.model_max_log2_error,
             "size binary search": codegen.rmi_size(rmi.root.kind, rmi.leaf_kind, rmi.branching_factor, True,
-                                                      0 if rmi.root.table is None else len(rmi.root.table)),
-            "build time": rmi.build_time}
+                                                      0 if rmi.root.table is None else len(rmi.root.table))}
 
 
 def main(argv=None) -> int:
@@ -87,13 +86,14 @@ def main(argv=None) -> int:
             for cfg in grid["configs"]:
                 rmi = tr.train(cfg["layers"], int(cfg["branching factor"]))
                 res = _stats(rmi, n)
+                res["namespace"] = cfg.get("namespace")                                # src/main.rs:207-221: null when absent
                 if "namespace" in cfg:
-                    res["namespace"] = cfg["namespace"]
-                    codegen.output_rmi(cfg["namespace"], rmi, args.data_path, key_type=key_c, include_errors=not args.no_errors,
+                    # (grid mode always emits with errors, src/main.rs:232-238)
+                    codegen.output_rmi(cfg["namespace"], rmi, args.data_path, key_type=key_c, include_errors=True,
                                        build_time_ns=0 if args.zero_build_time else None)
                 results.append(res)
             with open(f"{args.param_grid}_results", "w") as f:
-                json.dump(results, f)
+                json.dump({"results": results}, f)                                     # src/main.rs:254-257
             return 0
         if not args.namespace:
             print("Must specify either a name space or a parameter grid.", file=sys.stderr)

@@ -78,6 +78,10 @@ struct DevState {
   // leaves too long for the lockstep pass (see k_fit_long): number of entries in the long list
   unsigned long long long_count;
   unsigned long long long_cap;
+  // one-pass mode (rmi_sigma.hip.h): leaves handed to the exact kernels, and how many of them by the guard
+  unsigned long long flag_count;
+  unsigned long long flag_cap;
+  unsigned long long guard_count;
 };
 
 template <typename K> struct KeyTraits;

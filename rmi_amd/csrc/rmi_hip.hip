@@ -16,6 +16,7 @@
 #include "../../include/rmi_hip.h"
 #include "rmi_kernels.hip.h"
 #include "rmi_stream.hip.h"
+#include "rmi_sigma.hip.h"
 #include "rmi_root_host.h"
 
 using namespace rmi;
@@ -68,9 +69,19 @@ struct rmi_hip_ctx {
   int fit_min_chunk = 64;
   bool robust_leaf = false;                     // this call's leaves are robust_linear (fitted by k_fit_leaf; predict like linear)
   unsigned int long_min = 4096;                 // leaves with more points go to k_fit_long (>= FS_TMAX)
+  // fit mode of linear leaves: 0 = exact (two streaming passes), 1 = one pass from sufficient statistics with the
+  // guard (error integers bit-identical, flagged leaves re-fitted exactly), 2 = one pass, guard only counted
+  int fit_mode = 0;
+  double guard_k = 4.0;
+  uint64_t sigma_blocks = 512;                  // blocks of k_sigma (2 per CU)
+  unsigned int sigma_min_leaf = 32;             // average keys per leaf below which the exact kernels are used
+  unsigned int* d_flist = nullptr;              // leaves handed to the exact kernels
+  uint64_t flist_cap = 0;
+  bool last_sigma = false;
   // last result
   uint64_t last_L = 0;
   int last_ppl = 2;
+  uint64_t generation = 0;                      // train calls so far on this context
   std::string err;
 };
 
@@ -187,13 +198,14 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   rmi_hip_ctx* c = new rmi_hip_ctx();
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess) { delete c; return RMI_ERR_HIP; }
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  // (rmi_hip_destroy releases whatever has been created so far)
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   c->stream = c->own_stream;
-  if (hipMalloc(&c->d_state, sizeof(DevState)) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+  if (hipMalloc(&c->d_state, sizeof(DevState)) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
-      hipHostGetDevicePointer((void**)&c->h_state_dev, c->h_state, 0) != hipSuccess) { delete c; return RMI_ERR_HIP; }
-  if (hipHostMalloc((void**)&c->h_sentinel, 64, hipHostMallocDefault) != hipSuccess) { delete c; return RMI_ERR_HIP; }
-  for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return RMI_ERR_HIP; }
+      hipHostGetDevicePointer((void**)&c->h_state_dev, c->h_state, 0) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
+  if (hipHostMalloc((void**)&c->h_sentinel, 64, hipHostMallocDefault) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
+  for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   const char* pk = std::getenv("RMI_HIP_PROFILE_KERNELS");
   c->profile_level = (pk && *pk && *pk != '0') ? 2 : 0;
   const char* pl = std::getenv("RMI_HIP_PIPELINE");
@@ -206,6 +218,12 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (lm && *lm) { long v = std::atol(lm); if (v >= FS_TMAX) c->long_min = (unsigned int)v; }
   const char* fc = std::getenv("RMI_HIP_FIT_MIN_CHUNK");
   if (fc && *fc) c->fit_min_chunk = std::atoi(fc);
+  const char* fm = std::getenv("RMI_HIP_FIT_MODE");
+  if (fm && *fm) { const int v = std::atoi(fm); if (v >= 0 && v <= 2) c->fit_mode = v; }
+  const char* gk = std::getenv("RMI_HIP_GUARD_K");
+  if (gk && *gk) { const double v = std::atof(gk); if (v > 0.0) c->guard_k = v; }
+  const char* sb = std::getenv("RMI_HIP_SIGMA_BLOCKS");
+  if (sb && *sb) { const long v = std::atol(sb); if (v > 0) c->sigma_blocks = (uint64_t)v; }
   *out = c;
   return RMI_OK;
 }
@@ -216,6 +234,7 @@ static void free_outputs(rmi_hip_ctx* c) {
   (void)hipFree(c->d_partials); c->d_partials = nullptr;
   if (c->d_long) { (void)hipFree(c->d_long); c->d_long = nullptr; c->long_cap = 0; }
   if (c->d_cube) { (void)hipFree(c->d_cube); c->d_cube = nullptr; c->cube_cap = 0; }
+  if (c->d_flist) { (void)hipFree(c->d_flist); c->d_flist = nullptr; c->flist_cap = 0; }
   c->d_leaf_start = nullptr; c->d_params = nullptr; c->d_maxerr = nullptr; c->d_run = nullptr;
   c->d_err = nullptr; c->d_count = nullptr; c->d_rows = nullptr; c->d_tilemin = nullptr;
   c->cap_leaves = 0; c->cap_ppl = 0;
@@ -224,7 +243,7 @@ static void free_outputs(rmi_hip_ctx* c) {
 void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_outputs(c);
   if (c->d_table) (void)hipFree(c->d_table);       // the root table is an input, not an output: it outlives re-sizing
   if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
@@ -241,6 +260,13 @@ const char* rmi_hip_last_error(const rmi_hip_ctx* c) { return c ? c->err.c_str()
 int rmi_hip_set_profile_level(rmi_hip_ctx* c, int level) {
   if (!c || level < 0 || level > 2) return RMI_ERR_BAD_ARG;
   c->profile_level = level;
+  return RMI_OK;
+}
+
+int rmi_hip_set_fit_mode(rmi_hip_ctx* c, int mode, double guard_k) {
+  if (!c || mode < 0 || mode > 2) return RMI_ERR_BAD_ARG;
+  c->fit_mode = mode;
+  if (guard_k > 0.0) c->guard_k = guard_k;
   return RMI_OK;
 }
 
@@ -876,6 +902,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   }
   DevState init; std::memset(&init, 0, sizeof init);
   init.long_cap = c->long_cap;
+  init.flag_cap = (uint64_t)L_own + 64;
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
@@ -890,7 +917,34 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   // pipeline 1 launches one thread per key: a grid dimension holds fewer than 2^32 threads
   const int pipeline = (c->pipeline == 1 && n_it < (1ull << 32) - 1024) ? 1 : 2;
   const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
-  if (n_it == 0) {
+  // one pass from sufficient statistics: leaves of at least a few dozen keys on average (the rows of a tile hold
+  // 16 keys; shorter leaves are cheap chains for the exact kernels anyway), indices below 2^32
+  const bool sigma = stream_fit && c->fit_mode != 0 && sp.n < (1ull << 32) && n_it >= (uint64_t)c->sigma_min_leaf * L_own;
+  c->last_sigma = sigma;
+  if (sigma) {
+    if constexpr (LEAF == K_LINEAR) {
+      if (c->flist_cap < L_own + 64) {
+        if (c->d_flist) (void)hipFree(c->d_flist);
+        c->d_flist = nullptr; c->flist_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_flist, (L_own + 64) * 4));
+        c->flist_cap = L_own + 64;
+      }
+      constexpr int ROWS = 256;
+      uint64_t chunk = (n_it + c->sigma_blocks - 1) / c->sigma_blocks;
+      chunk = ((chunk + 15) / 16) * 16;
+      if (chunk < (uint64_t)ROWS * 16) chunk = (uint64_t)ROWS * 16;
+      const uint64_t sblocks = (n_it + chunk - 1) / chunk;
+      SgParams sgp; sgp.chunk = chunk; sgp.guard_k = c->guard_k; sgp.mode = c->fit_mode; sgp.flist = c->d_flist;
+      constexpr size_t smem = sg_smem_bytes<K, ROWS>();
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<ROOT, K, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((k_sigma<ROOT, K, ROWS>), dim3((unsigned)sblocks), dim3(ROWS), smem, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state);
+      mark();
+    }
+  } else if (n_it == 0) {
     mark();                                              // a shard without keys: every leaf is empty
   } else if (!stream_fit) {
     // --- bucketing scan ---
@@ -923,7 +977,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count_e, c->d_tilemin);
   }
   mark();
-  if (n_it == 0) {
+  if (sigma) {
+    if constexpr (LEAF == K_LINEAR) {
+      // --- exact kernels for the leaves the one-pass kernel handed over ---
+      hipLaunchKernelGGL((k_fit_list<K>), dim3(256), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_flist, c->d_long, c->long_min);
+      const uint64_t lblocks = c->long_cap < 2048 ? c->long_cap : 2048;
+      hipLaunchKernelGGL((k_fit_long<ROOT, K>), dim3((unsigned)lblocks), dim3(64), 0, s, keys, sp, rp, leaf_start, c->d_state, params, c->d_long);
+      mark();
+      hipLaunchKernelGGL((k_err_list<K>), dim3(4096), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_flist, maxerr, run);
+    }
+  } else if (n_it == 0) {
   } else if (!stream_fit) {
     // --- per-leaf fit ---
     const uint64_t blocks = (L_own + 255) / 256;
@@ -957,9 +1020,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     const uint64_t blocks = c->long_cap < 2048 ? c->long_cap : 2048;   // ~2 waves per SIMD saturate its f64 issue
     hipLaunchKernelGGL((k_fit_long<ROOT, K>), dim3((unsigned)blocks), dim3(64), 0, s, keys, sp, rp, leaf_start, c->d_state, params, c->d_long);
   }
-  mark();
+  if (!sigma) mark();
   // --- error pass ---
-  if (n_it == 0) {
+  if (n_it == 0 || sigma) {
   } else if (pipeline == 1) {
     const uint64_t blocks = (n_it + 255) / 256;
     hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, params, maxerr, run);
@@ -1024,6 +1087,8 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (!root_on_device_path(root->kind) || leaf_kind > RMI_MODEL_ROBUST_LINEAR) return RMI_ERR_UNSUPPORTED_MODEL;
   if (table_bits > 0 && (c->h_table.size() != (1ull << table_bits) || root->ip[1] != (uint64_t)table_bits || !c->d_table))
     return RMI_ERR_BAD_ARG;                                    // no (matching) table in this context: rmi_hip_set_root_table
+  c->last_L = 0;                                               // the arrays of the previous call are gone from here on
+  c->generation++;
   // robust_linear as a leaf trims 0.01 % tails of each container (linear.rs:247-252): its own fit, then a linear leaf
   c->robust_leaf = (leaf_kind == RMI_MODEL_ROBUST_LINEAR);
   HIPCHK(c, hipSetDevice(c->device));
@@ -1064,7 +1129,6 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   }
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->last_L = L_own; c->last_ppl = ppl;
 
   const DevState& st = *c->h_state;
   if (st.err_flags) {
@@ -1077,7 +1141,9 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
     set_err(c, "%s", rmi_hip_strerror(rc));
     return rc;
   }
+  c->last_L = L_own; c->last_ppl = ppl;
   std::memset(out, 0, sizeof *out);
+  out->generation = c->generation;
   const uint64_t n_glob = c->have_shard ? c->shard.n : c->n;
   out->num_rows = n_glob; out->num_leaves = num_leaves; out->leaf_kind = leaf_kind;
   out->shard_leaf_lo = c->have_shard ? c->shard.leaf_lo : 0; out->shard_leaves = L_own;
@@ -1090,6 +1156,9 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   out->model_max_log2_error = std::log2((double)st.max_err);
   out->split_idx = st.split_idx; out->split_target = st.split_target;
   out->long_leaves = st.long_count;
+  out->fit_mode_used = c->last_sigma ? c->fit_mode : 0;
+  out->exact_leaves = c->last_sigma ? st.flag_count : 0;
+  out->guard_leaves = c->last_sigma ? st.guard_count : 0;
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev[8], c->ev[9]));
   out->device_ns = (uint64_t)((double)ms * 1e6);
@@ -1113,6 +1182,21 @@ int rmi_hip_download_leaf_errors(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, 
 int rmi_hip_download_leaf_counts(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_count : nullptr, c ? c->last_L * 8 : 0); }
 int rmi_hip_download_leaf_starts(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_leaf_start : nullptr, c ? (c->last_L + 1) * 8 : 0); }
 int rmi_hip_download_rows(rmi_hip_ctx* c, void* o) { return dl(c, o, c ? (c->d_rows_ext ? (unsigned char*)c->d_rows_ext : c->d_rows) : nullptr, c ? c->last_L * (c->last_ppl * 8 + 8) : 0); }
+int rmi_hip_download_checked(rmi_hip_ctx* c, int what, uint64_t generation, void* o, uint64_t capacity) {
+  if (!c || !o || !c->last_L || generation != c->generation) return RMI_ERR_BAD_ARG;
+  const void* src = nullptr;
+  uint64_t bytes = 0;
+  switch (what) {
+    case RMI_DL_PARAMS: src = c->d_params; bytes = c->last_L * c->last_ppl * 8; break;
+    case RMI_DL_ERRORS: src = c->d_err; bytes = c->last_L * 8; break;
+    case RMI_DL_COUNTS: src = c->d_count; bytes = c->last_L * 8; break;
+    case RMI_DL_STARTS: src = c->d_leaf_start; bytes = (c->last_L + 1) * 8; break;
+    case RMI_DL_ROWS: src = c->d_rows_ext ? (const unsigned char*)c->d_rows_ext : c->d_rows; bytes = c->last_L * (c->last_ppl * 8 + 8); break;
+    default: return RMI_ERR_BAD_ARG;
+  }
+  if (capacity < bytes) return RMI_ERR_BAD_ARG;
+  return dl(c, o, src, bytes);
+}
 void* rmi_hip_device_rows(rmi_hip_ctx* c) { return c ? (c->d_rows_ext ? c->d_rows_ext : (void*)c->d_rows) : nullptr; }
 
 }  // extern "C"

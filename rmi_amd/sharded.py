@@ -143,6 +143,7 @@ def run_shard(tr: T.Trainer, plan: ShardPlan, root: T.Model, leaf, rows_ptr: int
         return tr.train_leaves(root, leaf, plan.num_leaves)
     finally:
         lib.rmi_hip_set_shard(tr._h, None)
+        lib.rmi_hip_set_rows_output(tr._h, None)      # (a later unsharded training must not write into the caller's slot)
 
 
 def combine_stats(parts, n_global: int) -> dict:

@@ -113,13 +113,24 @@ class TrainedRMI:
     shard_leaves: int = 0
     partial: dict = field(default_factory=dict)   # per-shard partial sums of the aggregates
     cache_fix: object = None
+    fit_mode_used: int = 0          # 0 exact, 1 one pass + guard, 2 one pass (rmi_hip_set_fit_mode)
+    exact_leaves: int = 0           # one-pass modes: leaves re-fitted by the exact kernels
+    guard_leaves: int = 0           # ... of which flagged by the guard (mode 2: counted only)
+    generation: int = 0             # which train call of the trainer's context produced the per-leaf arrays
     _trainer: object = field(default=None, repr=False)
     _cache: dict = field(default_factory=dict, repr=False)
 
     def _get(self, what: str):
+        """Per-leaf arrays live in the trainer's context until its next train call: fetch them before
+        (``materialize()``), or get a ``RuntimeError`` instead of another training's arrays."""
         if what not in self._cache:
             self._cache[what] = self._trainer._download(what, self)
         return self._cache[what]
+
+    def materialize(self) -> "TrainedRMI":
+        """Download every per-leaf array now (the object then no longer depends on the trainer)."""
+        _ = self.leaf_params, self.last_layer_max_l1s, self.leaf_counts, self.leaf_starts, self.rows
+        return self
 
     @property
     def leaf_params(self) -> np.ndarray:        # rmi[1][j].params()
@@ -245,6 +256,12 @@ class Trainer:
         """0: device_ns only; 1: + kernel_ns[0] (the first, dominant kernel); 2: every kernel group."""
         _check(self._lib.rmi_hip_set_profile_level(self._h, int(level)), self._h)
 
+    def set_fit_mode(self, mode: int | str, guard_k: float = 0.0):
+        """How linear leaves are fitted (include/rmi_hip.h, rmi_hip_set_fit_mode): "exact" (0, default),
+        "onepass_guarded" (1: one pass over the keys, error integers still bit-identical), "onepass" (2)."""
+        m = {"exact": 0, "onepass_guarded": 1, "onepass": 2}.get(mode, mode)
+        _check(self._lib.rmi_hip_set_fit_mode(self._h, int(m), float(guard_k)), self._h)
+
     def set_stream(self, stream_ptr: int | None):
         _check(self._lib.rmi_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
@@ -309,7 +326,8 @@ class Trainer:
             shard_leaf_lo=int(res.shard_leaf_lo), shard_leaves=int(res.shard_leaves),
             partial={"max_error": int(res.model_max_error), "max_error_idx": int(res.model_max_error_idx),
                      "sum_n_err": int(res.sum_n_err), "sum_l2": float(res.sum_l2), "sum_log2": float(res.sum_log2)},
-            _trainer=self)
+            fit_mode_used=int(res.fit_mode_used), exact_leaves=int(res.exact_leaves), guard_leaves=int(res.guard_leaves),
+            generation=int(res.generation), _trainer=self)
 
     def train(self, model_spec: str, branch_factor: int, root_mode: str = "exact") -> TrainedRMI:
         """rmi_lib::train (train/mod.rs:100-126)."""
@@ -345,23 +363,22 @@ class Trainer:
 
     def _download(self, what: str, rmi: TrainedRMI):
         L, ppl = (rmi.shard_leaves or rmi.branching_factor), rmi.params_per_leaf
-        if what == "params":
-            a = np.empty((L, ppl), dtype=np.float64)
-            _check(self._lib.rmi_hip_download_leaf_params(self._h, a.ctypes.data), self._h)
-        elif what == "errors":
-            a = np.empty(L, dtype=np.uint64)
-            _check(self._lib.rmi_hip_download_leaf_errors(self._h, a.ctypes.data), self._h)
-        elif what == "counts":
-            a = np.empty(L, dtype=np.uint64)
-            _check(self._lib.rmi_hip_download_leaf_counts(self._h, a.ctypes.data), self._h)
-        elif what == "starts":
-            a = np.empty(L + 1, dtype=np.uint64)
-            _check(self._lib.rmi_hip_download_leaf_starts(self._h, a.ctypes.data), self._h)
-        elif what == "rows":
-            a = np.empty(L * (ppl * 8 + 8), dtype=np.uint8)
-            _check(self._lib.rmi_hip_download_rows(self._h, a.ctypes.data), self._h)
-        else:
-            raise KeyError(what)
+        code, a = {
+            "params": (0, lambda: np.empty((L, ppl), dtype=np.float64)),
+            "errors": (1, lambda: np.empty(L, dtype=np.uint64)),
+            "counts": (2, lambda: np.empty(L, dtype=np.uint64)),
+            "starts": (3, lambda: np.empty(L + 1, dtype=np.uint64)),
+            "rows": (4, lambda: np.empty(L * (ppl * 8 + 8), dtype=np.uint8)),
+        }[what]
+        a = a()
+        with self._ctx_lock:
+            if self._h is None:
+                raise RuntimeError("the trainer of this result has been closed: download the arrays first (materialize())")
+            rc = self._lib.rmi_hip_download_checked(self._h, code, rmi.generation, a.ctypes.data, a.nbytes)
+        if rc == -6:
+            raise RuntimeError("this trainer has trained again since: the per-leaf arrays of the earlier result are gone "
+                               "(call materialize() on a result before the next train call)")
+        _check(rc, self._h)
         return a
 
 
@@ -369,7 +386,6 @@ def train(keys, model_spec: str, branch_factor: int, device: int = 0) -> Trained
     """One-shot convenience mirror of ``rmi_lib::train(data, model_spec, branch_factor)``."""
     tr = Trainer(keys, device=device)
     out = tr.train(model_spec, branch_factor)
-    # materialise before the context goes away
-    _ = out.leaf_params, out.last_layer_max_l1s, out.leaf_counts, out.leaf_starts, out.rows
+    out.materialize()                  # before the context goes away
     tr.close()
     return out

@@ -56,8 +56,11 @@ def test_cli_param_grid(tmp_path):
     r = subprocess.run([sys.executable, "-m", "rmi_amd.cli", kfile, "--param-grid", "grid.json"], cwd=str(tmp_path),
                        env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    res = json.loads((tmp_path / "grid.json_results").read_text())
+    res = json.loads((tmp_path / "grid.json_results").read_text())["results"]     # src/main.rs:254-257
     assert len(res) == 2 and res[0]["layers"] == "linear,linear" and res[1]["namespace"] == "g2"
+    assert "namespace" in res[0] and res[0]["namespace"] is None                  # src/main.rs:207-221
+    assert set(res[0]) == {"layers", "branching factor", "average error", "average error %", "average l2 error",
+                           "average log2 error", "max error", "max error %", "max log2 error", "size binary search", "namespace"}
     assert (tmp_path / "g2.cpp").exists() and (tmp_path / "rmi_data" / "g2_L1_PARAMETERS").exists()
 
 
