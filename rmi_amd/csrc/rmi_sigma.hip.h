@@ -657,4 +657,377 @@ __global__ void __launch_bounds__(64) k_err_list(const K* __restrict__ keys, Spa
   }
 }
 
+
+// =============================================================================================
+// k_sigma2: the same one-pass path with AUTONOMOUS WAVES (what the counters of k_sigma asked for:
+// it spent half of its wave time in barriers / LDS round trips between its phases, and ~78 vector
+// instructions per 64 keys, a third of them boundary bookkeeping inside fixed 16-key rows).
+//
+// A wave (= a block of 64 threads) owns a contiguous chunk of the keys and never synchronises
+// with another wave.  Per batch of BATCH keys:
+//   phase 1  classification straight from the registers the coalesced 16-byte loads landed in (the
+//            keys of the next batch are in flight meanwhile): x = f64(key), root target, leaf
+//            boundary / duplicate test against the previous key (the previous lane's, by DPP);
+//            x goes to a ring in LDS (a duplicate key as NaN: its leaf then fails the checks below
+//            and goes to the exact kernels), a boundary appends (index, leaf id, flags) to a list.
+//   phase 2  every leaf that is complete in the ring (both boundaries seen) is handled by a GROUP of
+//            GL lanes, 64/GL leaves per round: the lanes stride over the leaf's container
+//            [s-1, e] (+ the Q1 duplicate of e) adding up (S dx, S dx^2, S dx dy) relative to the
+//            leaf's first key, butterfly all-reduce inside the group (DPP), every lane solves
+//            (alpha, beta, delta), then the lanes stride over the leaf's own keys for
+//            max |pred - y| and the closest approach of a prediction to an integer (+ the widening keys
+//            on six lanes), butterfly max, lane 0 of the group decides: leaf_maxerr, or the exact list.
+// A leaf that does not fit the ring (RING keys) is irregular ("long"); so are the leaves at the split
+// of the 2-way join, the first and the last leaf, and leaves with duplicate keys -- as in k_sigma.
+// =============================================================================================
+constexpr unsigned S2_SPLIT = 1u, S2_START = 2u, S2_END = 4u, S2_LONG = 8u;
+
+// butterfly all-reduce inside groups of GL lanes (GL = 4, 8, 16): every lane ends up with the total
+template <int CTRL>
+__device__ __forceinline__ double s2_dpp_f64(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned int s2_dpp_u32(unsigned int v) {
+  return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int GL> __device__ __forceinline__ double s2_group_sum(double v) {
+  v += s2_dpp_f64<0xB1>(v);                        // quad_perm [1,0,3,2]
+  v += s2_dpp_f64<0x4E>(v);                        // quad_perm [2,3,0,1]
+  if constexpr (GL >= 8) v += s2_dpp_f64<0x141>(v);    // row_half_mirror
+  if constexpr (GL >= 16) v += s2_dpp_f64<0x140>(v);   // row_mirror
+  return v;
+}
+template <int GL> __device__ __forceinline__ double s2_group_max(double v) {
+  v = fmax_raw(v, s2_dpp_f64<0xB1>(v));
+  v = fmax_raw(v, s2_dpp_f64<0x4E>(v));
+  if constexpr (GL >= 8) v = fmax_raw(v, s2_dpp_f64<0x141>(v));
+  if constexpr (GL >= 16) v = fmax_raw(v, s2_dpp_f64<0x140>(v));
+  return v;
+}
+template <int GL> __device__ __forceinline__ unsigned int s2_group_max(unsigned int v) {
+  v = max(v, s2_dpp_u32<0xB1>(v));
+  v = max(v, s2_dpp_u32<0x4E>(v));
+  if constexpr (GL >= 8) v = max(v, s2_dpp_u32<0x141>(v));
+  if constexpr (GL >= 16) v = max(v, s2_dpp_u32<0x140>(v));
+  return v;
+}
+
+// min(L-1, predict_to_int(key)) as u32 (L <= 2^31): float roots through v_cvt_u32_f64 (truncation,
+// saturation, NaN -> 0: exactly max(0, floor(f)) clamped), the others through the generic form.
+template <int ROOT, typename K>
+__device__ __forceinline__ unsigned int s2_target(const RootP& r, double Lm1f, unsigned int Lm1, K k, double x, bool& oob) {
+  if constexpr (ROOT == K_RADIX || ROOT == K_RADIX_TABLE) {
+    return (unsigned int)root_target_f<ROOT, K>(r, Lm1f, k, oob);
+  } else {
+    const unsigned int u = sg_cvt_u32(root_eval_f<ROOT>(r, x));
+    oob = u > Lm1;
+    return u < Lm1 ? u : Lm1;
+  }
+}
+
+template <int ROOT, typename K, int RING, int BATCH, int GL>
+__global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span sp, RootP r, SgParams sg,
+                                               unsigned long long* __restrict__ leaf_start, double* __restrict__ params,
+                                               unsigned long long* __restrict__ leaf_maxerr, DevState* __restrict__ st) {
+  constexpr int KPL = 16 / (int)sizeof(K);          // keys per lane and load
+  constexpr int NLOAD = BATCH / (64 * KPL);         // loads per batch
+  constexpr int NG = 64 / GL;                       // leaves per round
+  constexpr int BCAP = 256;                         // boundary list (more boundaries in a batch: see `dense`)
+  constexpr unsigned MASK = RING - 1;
+  static_assert((RING & (RING - 1)) == 0 && BATCH % (64 * KPL) == 0 && RING >= 2 * BATCH, "geometry");
+  __shared__ double xring[RING];
+  __shared__ unsigned int b_idx[BCAP], b_t[BCAP];
+  __shared__ unsigned char b_fl[BCAP];
+
+  const int lane = threadIdx.x;
+  const uint64_t c0 = sp.it_lo + (uint64_t)blockIdx.x * sg.chunk;
+  if (c0 >= sp.it_hi) return;
+  const uint64_t c1 = (c0 + sg.chunk < sp.it_hi) ? c0 + sg.chunk : sp.it_hi;
+  const unsigned int c0u = (unsigned int)c0, c1u = (unsigned int)c1;
+  const double Lm1f = (double)(r.L - 1);
+  const unsigned int Lm1 = (unsigned int)(r.L - 1);
+  const unsigned int mid = (unsigned int)(r.L / 2);                 // two_layer.rs:131
+  const unsigned int n32 = (unsigned int)sp.n;
+  const unsigned long long below = (1ull << lane) - 1ull;
+
+  uint4 cur[NLOAD], nxt[NLOAD];
+  auto load_batch = [&](uint4 (&dst)[NLOAD], uint64_t A) {
+#pragma unroll
+    for (int k = 0; k < NLOAD; k++) {
+      const uint64_t gi = A + (uint64_t)(k * 64 + lane) * KPL;
+      if (gi + KPL <= sp.rd_hi) dst[k] = sg_load16<K>(keys + gi);
+      else {
+        K t[KPL];
+        const uint64_t last = sp.rd_hi - 1;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) t[q] = keys[gi + q < last ? gi + q : last];
+        __builtin_memcpy(&dst[k], t, 16);
+      }
+    }
+  };
+
+  if (lane == 0 && sp.n - 1 >= c0 && sp.n - 1 < c1 && sp.n - 1 < sp.rd_hi) {
+    bool oob_;
+    st->last_target = (unsigned long long)root_target_f<ROOT, K>(r, Lm1f, keys[sp.n - 1], oob_);
+  }
+  // the key before the chunk
+  K carry_key = K();
+  unsigned int carry_t = 0u;
+  if (c0 > sp.rd_lo) {
+    bool oob_;
+    carry_key = keys[c0 - 1];
+    carry_t = s2_target<ROOT, K>(r, Lm1f, Lm1, carry_key, KeyTraits<K>::as_float(carry_key), oob_);
+  }
+  int bcnt = 0;                                                     // entries of the boundary list (wave-uniform)
+  bool stop = false;                                                // a boundary at or behind c1 is in the list
+  unsigned int eflags = 0;
+
+  // ---- phase 2: the complete leaves [entry i, entry i+1) of the list ----
+  auto rounds = [&](bool drop_open) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int g = lane / GL, l = lane % GL;
+    for (int i0 = 0; i0 + 1 < bcnt; i0 += NG) {
+      const int i = i0 + g;
+      const bool act = i + 1 < bcnt;
+      unsigned int s = 0, e = 0, leaf = 0, fl = 0;
+      if (act) {
+        s = b_idx[i]; e = b_idx[i + 1]; leaf = b_t[i];
+        fl = (b_fl[i] & (S2_SPLIT | S2_START | S2_LONG)) | (b_fl[i + 1] & (S2_SPLIT | S2_END));
+      }
+      const bool owned = act && s >= c0u && s < c1u;
+      bool irregular = fl != 0u;
+      const bool work = owned && !irregular;
+      // sums over the container [s-1, e] relative to (x[s], s)
+      double p = 0.0, xpl = 0.0, xe = 0.0;
+      double R0 = 0.0, R1 = 0.0, R2 = 0.0;
+      if (work) {
+        p = xring[s & MASK]; xpl = xring[(s - 1u) & MASK]; xe = xring[e & MASK];
+        double dy = (double)(l - 1);
+        for (unsigned int k = s - 1u + (unsigned int)l; k <= e; k += GL) {
+          const double dx = xring[k & MASK] - p;
+          R0 += dx; R1 = __builtin_fma(dx, dx, R1); R2 = __builtin_fma(dx, dy, R2);
+          dy += (double)GL;
+        }
+        if (l == 0) {                                               // the Q1 tail duplicate of the next-first point
+          const double dx = xe - p, dyy = (double)(e - s);
+          R0 += dx; R1 = __builtin_fma(dx, dx, R1); R2 = __builtin_fma(dx, dyy, R2);
+        }
+      }
+      R0 = s2_group_sum<GL>(R0); R1 = s2_group_sum<GL>(R1); R2 = s2_group_sum<GL>(R2);
+      // every lane of the group solves
+      const double len = (double)(e - s);
+      const double cnt = len + 3.0;
+      const double sy = (len + 2.0) * (len - 1.0) * 0.5 + len;      // S (i - s) over i = s-1 .. e, plus (e - s) once more
+      const double rn = 1.0 / cnt;
+      const double mx = R0 * rn, my = sy * rn;
+      const double m2 = __builtin_fma(-R0, mx, R1);
+      const double cxy = __builtin_fma(-R0, my, R2);
+      double alpha = 0.0, beta = 0.0, delta = 1.0;
+      if (!(m2 > 0.0) || !(R1 < 1.7e308)) irregular = true;         // all keys on one f64 (linear.rs:50-53), NaN (duplicates), overflow
+      else {
+        beta = cxy / m2;
+        alpha = ((double)s + my) - beta * (p + mx);
+        if (!(fabs(beta) < 1.7e308) || !(fabs(alpha) < 1.7e308)) irregular = true;
+        const double X = fmax(fabs(xpl), fabs(xe)), W = xe - xpl, ab = fabs(beta);
+        const double sigma = sqrt(m2 * rn);
+        const double cond = R1 / m2;
+        delta = sg.guard_k * 1.1102230246251565e-16 * (cnt * ab * X * (1.0 + W / sigma) + ab * X + (double)e + 4.0 * cond * ab * W);
+        if (!(delta < 0.5)) irregular = true;
+      }
+      // error pass over the own keys [s, e)
+      unsigned int emax = 0u;
+      double hmax = 0.0;
+      if (work && !irregular) {
+        for (unsigned int k = s + (unsigned int)l; k < e; k += GL) {
+          const double f = __builtin_fma(beta, xring[k & MASK], alpha);    // linear.rs:87-90
+          const unsigned int pr = min(sg_cvt_u32(f), n32);                  // models/mod.rs:735-737, two_layer.rs:14-18
+          emax = max(emax, sg_absdiff(pr, k));
+          hmax = fmax_abs_raw(hmax, __builtin_amdgcn_fract(f) - 0.5);
+        }
+        // widening keys (two_layer.rs:229-247), one candidate per lane: RN(key[e] - 1), RN(key[s-1] + 1)
+        if (l < 6) {
+          double xc;
+          const bool hiside = l < 3;
+          const double xb = hiside ? xe : xpl;
+          if constexpr (std::is_same<K, double>::value) xc = hiside ? KeyTraits<K>::minus_eps(xb) : KeyTraits<K>::plus_eps(xb);
+          else {
+            const int v = hiside ? l : l - 3;                       // 0: x -+ 1, 1: x, 2: the neighbouring double
+            const unsigned long long bits = __builtin_bit_cast(unsigned long long, xb);
+            xc = v == 0 ? (hiside ? xb - 1.0 : xb + 1.0) : (v == 1 ? xb : __builtin_bit_cast(double, hiside ? bits - 1ull : bits + 1ull));
+          }
+          const double f = __builtin_fma(beta, xc, alpha);
+          hmax = fmax_abs_raw(hmax, __builtin_amdgcn_fract(f) - 0.5);
+        }
+      }
+      emax = s2_group_max<GL>(emax);
+      hmax = s2_group_max<GL>(hmax);
+      if (owned && l == 0) {
+        bool exact = irregular;
+        if (!exact && !(0.5 - hmax >= delta)) {
+          atomicAdd(&st->guard_count, 1ull);
+          exact = sg.mode == 1;
+        }
+        if (!irregular) { params[2ull * leaf] = alpha; params[2ull * leaf + 1] = beta; }
+        if (exact) {
+          const unsigned long long pos = atomicAdd(&st->flag_count, 1ull);
+          if (pos < st->flag_cap) sg.flist[pos] = leaf;
+        } else leaf_maxerr[leaf] = (unsigned long long)emax;
+      }
+    }
+    // the last entry stays: the start of the open leaf (after a dense batch the list restarts empty)
+    if (drop_open) bcnt = 0;
+    else if (bcnt > 1) {
+      const unsigned int li = b_idx[bcnt - 1], lt = b_t[bcnt - 1];
+      const unsigned char lf = b_fl[bcnt - 1];
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { b_idx[0] = li; b_t[0] = lt; b_fl[0] = lf; }
+      bcnt = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  load_batch(nxt, c0);
+  for (uint64_t A = c0; !stop; A += BATCH) {
+#pragma unroll
+    for (int k = 0; k < NLOAD; k++) cur[k] = nxt[k];
+    load_batch(nxt, A + BATCH);
+    // does the open leaf still fit the ring once this batch is in?  (its container starts at s - 1)
+    if (bcnt > 0) {
+      const uint64_t s_open = b_idx[0];
+      if (A + BATCH - (s_open - 1) > (uint64_t)RING && lane == 0) b_fl[0] |= S2_LONG;
+    }
+    const bool interior = (A > sp.rd_lo) && (A + BATCH <= sp.rd_hi);
+    auto phase1 = [&](auto edge_tag, bool& dense) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+      for (int k = 0; k < NLOAD; k++) {
+        K kk[KPL];
+        __builtin_memcpy(kk, &cur[k], 16);
+        const uint64_t g0 = A + (uint64_t)(k * 64 + lane) * KPL;
+        // the key / target before this lane's first key: the previous lane's last one (lane 0: the carry)
+        K kp;
+        unsigned int tp;
+        double xs[KPL];
+        unsigned int ts[KPL];
+        bool oobany = false;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) {
+          xs[q] = KeyTraits<K>::as_float(kk[q]);
+          bool oob;
+          ts[q] = s2_target<ROOT, K>(r, Lm1f, Lm1, kk[q], xs[q], oob);
+          if constexpr (!root_needs_bounds_check<ROOT>()) {
+            if constexpr (EDGE) oobany |= oob && (g0 + q < sp.rd_hi); else oobany |= oob;
+          }
+        }
+        {
+          const unsigned long long lastb = key_to_bits<K>(kk[KPL - 1]), cb = key_to_bits<K>(carry_key);
+          const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp((int)(unsigned int)cb, (int)(unsigned int)lastb, 0x138, 0xF, 0xF, false);   // wave_shr:1
+          unsigned int hi = 0u;
+          if constexpr (sizeof(K) == 8) hi = (unsigned int)__builtin_amdgcn_update_dpp((int)(unsigned int)(cb >> 32), (int)(unsigned int)(lastb >> 32), 0x138, 0xF, 0xF, false);
+          kp = bits_to_key<K>(((unsigned long long)hi << 32) | lo);
+          tp = (unsigned int)__builtin_amdgcn_update_dpp((int)carry_t, (int)ts[KPL - 1], 0x138, 0xF, 0xF, false);
+        }
+        bool bq[KPL];
+        bool anyd = false, nonmono = false;
+        unsigned int fq[KPL];
+        unsigned int tprev[KPL];
+#pragma unroll
+        for (int q = 0; q < KPL; q++) {
+          bool cmp_ok = true, fstart = false, fend = false;
+          if constexpr (EDGE) {
+            const uint64_t idx = g0 + q;
+            cmp_ok = idx > sp.rd_lo && idx < sp.rd_hi;
+            fstart = (idx == sp.rd_lo && idx == sp.it_lo);
+            fend = (idx == sp.rd_hi);
+          }
+          const bool dupq = cmp_ok && (kk[q] == kp);
+          anyd |= dupq;
+          nonmono |= cmp_ok && ts[q] < tp;
+          bq[q] = (cmp_ok && ts[q] != tp) || fstart || fend;
+          fq[q] = ((cmp_ok && tp < mid && ts[q] >= mid) || (fstart && ts[q] >= mid) ? S2_SPLIT : 0u) | (fstart ? S2_START : 0u) | (fend ? S2_END : 0u);
+          tprev[q] = tp;
+          if (dupq) xs[q] = __builtin_nan("");                      // y of a duplicate is not its index: the leaf goes to the exact kernels
+          kp = kk[q]; tp = ts[q];
+        }
+        (void)tprev;
+        // x into the ring (16 bytes per store)
+        {
+          const unsigned int off = (unsigned int)g0 & MASK;
+#pragma unroll
+          for (int q = 0; q < KPL; q += 2) *reinterpret_cast<double2*>(&xring[off + q]) = make_double2(xs[q], xs[q + 1]);
+        }
+        // boundaries -> list, in index order
+        unsigned long long mq[KPL];
+        unsigned long long many = 0ull;
+#pragma unroll
+        for (int q = 0; q < KPL; q++) { mq[q] = __ballot(bq[q]); many |= mq[q]; }
+        if (many) {
+          int add = 0;
+#pragma unroll
+          for (int q = 0; q < KPL; q++) add += __popcll(mq[q]);
+          if (!dense && bcnt + add > BCAP) {
+            // More boundaries than the list holds (leaves of a few keys): for the rest of this batch every leaf
+            // goes straight to the exact kernels, the open one included; the list restarts with the next batch.
+            dense = true;
+            if (lane == 0 && bcnt > 0 && b_idx[bcnt - 1] >= c0u && b_idx[bcnt - 1] < c1u) {
+              const unsigned long long pos = atomicAdd(&st->flag_count, 1ull);
+              if (pos < st->flag_cap) sg.flist[pos] = b_t[bcnt - 1];
+            }
+          }
+          int rank = bcnt;
+#pragma unroll
+          for (int q = 0; q < KPL; q++) rank += __popcll(mq[q] & below);
+#pragma unroll
+          for (int q = 0; q < KPL; q++) {
+            if (bq[q]) {
+              const uint64_t idx = g0 + q;
+              const bool own = idx >= c0 && idx < c1 && !(fq[q] & S2_END);     // this wave owns the leaf that starts here
+              if (!dense) { b_idx[rank] = (unsigned int)idx; b_t[rank] = ts[q]; b_fl[rank] = (unsigned char)fq[q]; }
+              else if (own) {
+                const unsigned long long pos = atomicAdd(&st->flag_count, 1ull);
+                if (pos < st->flag_cap) sg.flist[pos] = ts[q];
+              }
+              rank++;
+              if (own) {
+                leaf_start[ts[q]] = idx;
+                if (fq[q] & S2_SPLIT) {
+                  st->split_idx = idx; st->split_target = ts[q];
+                  if (idx == 0 || idx + 1 >= sp.n) eflags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
+                }
+              }
+              if (idx >= c1) stop = true;
+            }
+          }
+          if (!dense) bcnt += add;
+          stop = __any(stop);
+        }
+        if (nonmono) eflags |= EF_NON_MONOTONE;                     // two_layer.rs:50 / :144
+        if (oobany) eflags |= EF_ROOT_OOB;                          // two_layer.rs:45-48
+        // carries for the next load
+        {
+          const unsigned long long lastb = key_to_bits<K>(kk[KPL - 1]);
+          const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)lastb, 63);
+          unsigned int hi = 0u;
+          if constexpr (sizeof(K) == 8) hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(lastb >> 32), 63);
+          carry_key = bits_to_key<K>(((unsigned long long)hi << 32) | lo);
+          carry_t = (unsigned int)__builtin_amdgcn_readlane((int)ts[KPL - 1], 63);
+        }
+        (void)anyd;
+      }
+    };
+    bool dense = false;
+    if (interior) phase1(std::false_type{}, dense); else phase1(std::true_type{}, dense);
+    rounds(dense);
+  }
+  if (eflags) atomicOr(&st->err_flags, eflags);
+}
+
 }  // namespace rmi

@@ -113,6 +113,9 @@ def test_more_than_2_pow_32_keys(oracle):
         assert np.all(np.abs(pred - ys[1:-1].astype(np.float64)) <= float(errs[j]) + 1), j   # (+1: fma vs mul+add in this check)
         picked += 1
     assert picked >= 20
+    rows1 = g.rows                                                          # (lives in the context until the next train call)
     g2 = tr.train_leaves(root, "linear", L)
-    assert np.array_equal(g2.rows, g.rows)
+    assert np.array_equal(g2.rows, rows1)
+    with pytest.raises(RuntimeError):
+        _ = g.leaf_counts.sum() if "counts" not in g._cache else g._trainer._download("counts", g)   # stale result: refused, not another training's arrays
     tr.close()
