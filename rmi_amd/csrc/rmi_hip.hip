@@ -73,8 +73,6 @@ struct rmi_hip_ctx {
   // guard (error integers bit-identical, flagged leaves re-fitted exactly), 2 = one pass, guard only counted
   int fit_mode = 0;
   double guard_k = 4.0;
-  uint64_t sigma_blocks = 512;                  // blocks of k_sigma (2 per CU)
-  int sigma_version = 2;                        // 1: k_sigma (block tiles), 2: k_sigma2 (autonomous waves)
   uint64_t sigma_waves = 4096;                  // k_sigma2: chunks the keys are cut into (one wave each)
   unsigned int sigma_min_leaf = 32;             // average keys per leaf below which the exact kernels are used
   unsigned int* d_flist = nullptr;              // leaves handed to the exact kernels
@@ -224,12 +222,8 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (fm && *fm) { const int v = std::atoi(fm); if (v >= 0 && v <= 2) c->fit_mode = v; }
   const char* gk = std::getenv("RMI_HIP_GUARD_K");
   if (gk && *gk) { const double v = std::atof(gk); if (v > 0.0) c->guard_k = v; }
-  const char* sv = std::getenv("RMI_HIP_SIGMA_V");
-  if (sv && *sv) c->sigma_version = std::atoi(sv) == 1 ? 1 : 2;
   const char* sw = std::getenv("RMI_HIP_SIGMA_WAVES");
   if (sw && *sw) { const long v = std::atol(sw); if (v > 0) c->sigma_waves = (uint64_t)v; }
-  const char* sb = std::getenv("RMI_HIP_SIGMA_BLOCKS");
-  if (sb && *sb) { const long v = std::atol(sb); if (v > 0) c->sigma_blocks = (uint64_t)v; }
   *out = c;
   return RMI_OK;
 }
@@ -925,7 +919,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
   // one pass from sufficient statistics: leaves of at least a few dozen keys on average (the rows of a tile hold
   // 16 keys; shorter leaves are cheap chains for the exact kernels anyway), indices below 2^32
-  const bool sigma = stream_fit && c->fit_mode != 0 && sp.n < (1ull << 32) && n_it >= (uint64_t)c->sigma_min_leaf * L_own;
+  const bool sigma = stream_fit && c->fit_mode != 0 && sp.n < (1ull << 32) && n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
   c->last_sigma = sigma;
   if (sigma) {
     if constexpr (LEAF == K_LINEAR) {
@@ -936,30 +930,19 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         c->flist_cap = L_own + 64;
       }
       SgParams sgp; sgp.guard_k = c->guard_k; sgp.mode = c->fit_mode; sgp.flist = c->d_flist;
-      if (c->sigma_version == 2) {
-        constexpr int RING = 2048, BATCH = 1024, GL = 8;
-        uint64_t chunk = (n_it + c->sigma_waves - 1) / c->sigma_waves;
-        chunk = ((chunk + BATCH - 1) / BATCH) * BATCH;
-        if (chunk < (uint64_t)BATCH * 8) chunk = (uint64_t)BATCH * 8;
-        sgp.chunk = chunk;
-        const uint64_t sblocks = (n_it + chunk - 1) / chunk;
-        hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH, GL>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state);
+      { const char* dbg = std::getenv("RMI_HIP_SIGMA_DBG"); sgp.dbg = dbg ? std::atoi(dbg) : 0; }
+      {
+        auto launch2 = [&](auto ring_tag, auto batch_tag) {
+          constexpr int RING = decltype(ring_tag)::value, BATCH = decltype(batch_tag)::value;
+          uint64_t chunk = (n_it + c->sigma_waves - 1) / c->sigma_waves;
+          chunk = ((chunk + BATCH - 1) / BATCH) * BATCH;
+          if (chunk < (uint64_t)BATCH * 16) chunk = (uint64_t)BATCH * 16;
+          sgp.chunk = chunk;
+          const uint64_t sblocks = (n_it + chunk - 1) / chunk;
+          hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state);
+        };
+        launch2(std::integral_constant<int, 2048>{}, std::integral_constant<int, 512>{});
         mark();
-      } else {
-      constexpr int ROWS = 256;
-      uint64_t chunk = (n_it + c->sigma_blocks - 1) / c->sigma_blocks;
-      chunk = ((chunk + 15) / 16) * 16;
-      if (chunk < (uint64_t)ROWS * 16) chunk = (uint64_t)ROWS * 16;
-      const uint64_t sblocks = (n_it + chunk - 1) / chunk;
-      sgp.chunk = chunk;
-      constexpr size_t smem = sg_smem_bytes<K, ROWS>();
-      static bool attr_set = false;
-      if (!attr_set) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<ROOT, K, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-      }
-      hipLaunchKernelGGL((k_sigma<ROOT, K, ROWS>), dim3((unsigned)sblocks), dim3(ROWS), smem, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state);
-      mark();
       }
     }
   } else if (n_it == 0) {
