@@ -82,6 +82,8 @@ struct DevState {
   unsigned long long flag_count;
   unsigned long long flag_cap;
   unsigned long long guard_count;
+  unsigned long long xlong_count;   // listed leaves too long for one wave's error pass (k_err_long)
+  unsigned long long xlong_cap;
 };
 
 template <typename K> struct KeyTraits;

@@ -75,8 +75,13 @@ struct rmi_hip_ctx {
   double guard_k = 4.0;
   uint64_t sigma_waves = 4096;                  // k_sigma2: chunks the keys are cut into (one wave each)
   unsigned int sigma_min_leaf = 32;             // average keys per leaf below which the exact kernels are used
-  unsigned int* d_flist = nullptr;              // leaves handed to the exact kernels
-  uint64_t flist_cap = 0;
+  unsigned int* d_flist = nullptr;              // leaves handed to the exact kernels: SG_REGIONS regions of flist_cap ids ...
+  unsigned long long* d_flist_cnt = nullptr;    // ... and their counters
+  unsigned int* d_xlong = nullptr;              // listed leaves too long for one wave's error pass
+  uint64_t xlong_cap = 0;
+  void* d_bkeys = nullptr;                      // one-pass mode: key[e] and key[s-1] of every leaf (2 x leaves keys), see k_finalize
+  uint64_t bkeys_cap = 0;
+  uint64_t flist_cap = 0;                       // entries per region
   bool last_sigma = false;
   // last result
   uint64_t last_L = 0;
@@ -235,6 +240,9 @@ static void free_outputs(rmi_hip_ctx* c) {
   if (c->d_long) { (void)hipFree(c->d_long); c->d_long = nullptr; c->long_cap = 0; }
   if (c->d_cube) { (void)hipFree(c->d_cube); c->d_cube = nullptr; c->cube_cap = 0; }
   if (c->d_flist) { (void)hipFree(c->d_flist); c->d_flist = nullptr; c->flist_cap = 0; }
+  if (c->d_flist_cnt) { (void)hipFree(c->d_flist_cnt); c->d_flist_cnt = nullptr; }
+  if (c->d_bkeys) { (void)hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_cap = 0; }
+  if (c->d_xlong) { (void)hipFree(c->d_xlong); c->d_xlong = nullptr; c->xlong_cap = 0; }
   c->d_leaf_start = nullptr; c->d_params = nullptr; c->d_maxerr = nullptr; c->d_run = nullptr;
   c->d_err = nullptr; c->d_count = nullptr; c->d_rows = nullptr; c->d_tilemin = nullptr;
   c->cap_leaves = 0; c->cap_ppl = 0;
@@ -893,7 +901,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
 
   // --- init ---
   // long-leaf list: a long leaf has at least long_min points, so n/long_min entries always suffice
-  const uint64_t need_long = n_it / c->long_min + 1024;
+  uint64_t need_long = n_it / c->long_min + 1024;
+  if (c->fit_mode != 0 && need_long < L_own + 1024) need_long = L_own + 1024;      // one-pass mode: every listed leaf goes through k_fit_long
   if (c->long_cap < need_long) {
     if (c->d_long) (void)hipFree(c->d_long);
     c->d_long = nullptr; c->long_cap = 0;
@@ -903,6 +912,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   DevState init; std::memset(&init, 0, sizeof init);
   init.long_cap = c->long_cap;
   init.flag_cap = (uint64_t)L_own + 64;
+  init.xlong_cap = n_it / SG_ERR_LONG + 16;
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
@@ -923,13 +933,29 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   c->last_sigma = sigma;
   if (sigma) {
     if constexpr (LEAF == K_LINEAR) {
-      if (c->flist_cap < L_own + 64) {
+      const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
+      if (c->flist_cap < rcap) {
         if (c->d_flist) (void)hipFree(c->d_flist);
         c->d_flist = nullptr; c->flist_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_flist, (L_own + 64) * 4));
-        c->flist_cap = L_own + 64;
+        HIPCHK(c, hipMalloc(&c->d_flist, rcap * SG_REGIONS * 4));
+        c->flist_cap = rcap;
       }
-      SgParams sgp; sgp.guard_k = c->guard_k; sgp.mode = c->fit_mode; sgp.flist = c->d_flist;
+      if (c->bkeys_cap < L_own) {
+        if (c->d_bkeys) (void)hipFree(c->d_bkeys);
+        c->d_bkeys = nullptr; c->bkeys_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_bkeys, 2 * L_own * 8));
+        c->bkeys_cap = L_own;
+      }
+      if (c->xlong_cap < n_it / SG_ERR_LONG + 16) {
+        if (c->d_xlong) (void)hipFree(c->d_xlong);
+        c->d_xlong = nullptr; c->xlong_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_xlong, (n_it / SG_ERR_LONG + 16) * 4));
+        c->xlong_cap = n_it / SG_ERR_LONG + 16;
+      }
+      if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, SG_REGIONS * 8));
+      HIPCHK(c, hipMemsetAsync(c->d_flist_cnt, 0, SG_REGIONS * 8, s));
+      SgParams sgp; sgp.guard_k = c->guard_k; sgp.mode = c->fit_mode;
+      sgp.flist.ids = c->d_flist; sgp.flist.cnt = c->d_flist_cnt; sgp.flist.cap = c->flist_cap;
       { const char* dbg = std::getenv("RMI_HIP_SIGMA_DBG"); sgp.dbg = dbg ? std::atoi(dbg) : 0; }
       {
         auto launch2 = [&](auto ring_tag, auto batch_tag) {
@@ -939,9 +965,11 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           if (chunk < (uint64_t)BATCH * 16) chunk = (uint64_t)BATCH * 16;
           sgp.chunk = chunk;
           const uint64_t sblocks = (n_it + chunk - 1) / chunk;
-          hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state);
+          hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state,
+                             (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
         };
-        launch2(std::integral_constant<int, 2048>{}, std::integral_constant<int, 512>{});
+        if (std::getenv("RMI_HIP_SIGMA_SMALL")) launch2(std::integral_constant<int, 1024>{}, std::integral_constant<int, 256>{});
+        else launch2(std::integral_constant<int, 2048>{}, std::integral_constant<int, 512>{});
         mark();
       }
     }
@@ -981,11 +1009,13 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   if (sigma) {
     if constexpr (LEAF == K_LINEAR) {
       // --- exact kernels for the leaves the one-pass kernel handed over ---
-      hipLaunchKernelGGL((k_fit_list<K>), dim3(256), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_flist, c->d_long, c->long_min);
-      const uint64_t lblocks = c->long_cap < 2048 ? c->long_cap : 2048;
+      SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
+      hipLaunchKernelGGL((k_fit_list<K>), dim3(4 * SG_REGIONS), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_long, c->d_xlong);
+      const uint64_t lblocks = c->long_cap < 8192 ? c->long_cap : 8192;
       hipLaunchKernelGGL((k_fit_long<ROOT, K>), dim3((unsigned)lblocks), dim3(64), 0, s, keys, sp, rp, leaf_start, c->d_state, params, c->d_long);
       mark();
-      hipLaunchKernelGGL((k_err_list<K>), dim3(4096), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_flist, maxerr, run);
+      hipLaunchKernelGGL((k_err_list<K>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, params, fl, maxerr, run);
+      hipLaunchKernelGGL((k_err_long<K>), dim3(2048), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_xlong, maxerr, run);
     }
   } else if (n_it == 0) {
   } else if (!stream_fit) {
@@ -1039,8 +1069,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   // --- finalize + stats ---
   {
     const uint64_t blocks = (L_own + 255) / 256;
+    const K* bn = sigma ? (const K*)c->d_bkeys - sp.leaf_lo : nullptr;
+    const K* bp = sigma ? (const K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo : nullptr;
     hipLaunchKernelGGL((k_finalize<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state,
-                       params, maxerr, run, err, count, rows, c->d_partials);
+                       params, maxerr, run, err, count, rows, c->d_partials, bn, bp);
     // (the last kernel also copies the device state into the pinned host copy: a separate 100-byte
     // copy command would cost ~15 us of the call)
     hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials, (int)blocks, c->d_state, c->h_state_dev);

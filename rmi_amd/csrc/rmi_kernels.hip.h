@@ -739,7 +739,8 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
                                                   unsigned long long* __restrict__ leaf_err,
                                                   unsigned long long* __restrict__ leaf_count,
                                                   unsigned char* __restrict__ rows,
-                                                  StatsPartial* __restrict__ partials) {
+                                                  StatsPartial* __restrict__ partials,
+                                                  const K* __restrict__ bnext = nullptr, const K* __restrict__ bprev = nullptr) {
   constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
   constexpr int ROWB = PPL * 8 + 8;
   const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -764,11 +765,15 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
   }
   const uint64_t curr = leaf_maxerr[j];
   // upper error: two_layer.rs:229-235 ; next(j) = first (idx,key) of the next non-empty leaf
-  const K key_next = e < n ? keys[e] : KeyTraits<K>::max_value();          // lower_bound_correction.rs:47-49
+  // (one-pass mode: the boundary keys of a non-empty leaf inside the launch's key range were recorded by
+  // k_sigma2 -- a coalesced read instead of two gathers from the key array; an empty leaf's constant model
+  // predicts the same for every key, so it needs none)
+  const bool rec = bnext != nullptr && s < e && s > sp.it_lo && e < sp.it_hi;
+  const K key_next = rec ? bnext[j] : (s == e && bnext != nullptr ? K() : (e < n ? keys[e] : KeyTraits<K>::max_value()));   // lower_bound_correction.rs:47-49
   const uint64_t up_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::minus_eps(key_next));
   const uint64_t upper = error_between(up_pred, e + 1, n);
   // lower error: two_layer.rs:237-247 ; prev_key(j) = last key of the nearest non-empty leaf below
-  const K key_prev = s > 0 ? keys[s - 1] : KeyTraits<K>::zero_value();     // lower_bound_correction.rs:62-63
+  const K key_prev = rec ? bprev[j] : (s == e && bnext != nullptr ? K() : (s > 0 ? keys[s - 1] : KeyTraits<K>::zero_value()));   // lower_bound_correction.rs:62-63
   const uint64_t first_idx = (j == 0) ? e : s;                             // next_index(max(j-1,0))
   const uint64_t lo_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::plus_eps(key_prev));
   const uint64_t lower = error_between(lo_pred, first_idx, n);

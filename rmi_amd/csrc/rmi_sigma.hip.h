@@ -33,12 +33,28 @@
 
 namespace rmi {
 
+// The list of leaves for the exact kernels is kept in SG_REGIONS regions, region = leaf id mod SG_REGIONS, each with
+// a counter of its own: appends from thousands of waves to ONE counter serialise at ~26 ns each (0.1 ms for the
+// 4 000 waves of a 200 M-key run); spread by leaf id no region can overflow its share of the capacity.
+constexpr int SG_REGIONS = 64;
+constexpr int SG_ERR_LONG = 16384;          // listed leaves with more keys: the whole grid per leaf (k_err_long)
+struct SgList {
+  unsigned int* ids;                       // [SG_REGIONS][cap]
+  unsigned long long* cnt;                 // [SG_REGIONS]
+  unsigned long long cap;                  // entries per region (>= ceil(leaves / SG_REGIONS))
+  __device__ __forceinline__ void push(unsigned int leaf) const {
+    const unsigned int rg = leaf % SG_REGIONS;
+    const unsigned long long pos = atomicAdd(&cnt[rg], 1ull);
+    if (pos < cap) ids[(unsigned long long)rg * cap + pos] = leaf;
+  }
+};
+
 struct SgParams {
   uint64_t chunk;                          // keys per block, a multiple of 16
   double guard_k;                          // safety factor of the guard bound
   int mode;                                // 1: guard-flagged leaves are re-fitted exactly; 2: only counted
   int dbg;                                 // timing experiments only (results wrong): 1 no leaf rounds, 2 no sums loop, 4 no error loop
-  unsigned int* flist;                     // leaf ids handed to the exact kernels (capacity: DevState.flag_cap)
+  SgList flist;                            // leaf ids handed to the exact kernels
 };
 
 // 16 bytes of keys, streamed once (non-temporal); the address is only key-aligned in a shard
@@ -54,40 +70,53 @@ __device__ __forceinline__ unsigned int sg_cvt_u32(double f) { unsigned int r; a
 __device__ __forceinline__ unsigned int sg_absdiff(unsigned int a, unsigned int b) { unsigned int r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // ---------------------------------------------------------------------------------------------
-// Exact kernels for the leaves k_sigma hands over (DevState.flag_count entries of `flist`).
-// k_fit_list: one lane per leaf, the reference's recurrence on the reference's container
-// (fit_one_leaf); leaves beyond `long_min` points go on to k_fit_long (one wave each).
+// Exact kernels for the leaves k_sigma2 hands over.
+// k_fit_list: leaves whose container is a real range go on to k_fit_long (ONE WAVE per leaf: the recurrence of a
+// leaf is a sequential chain, and a lane walking 200 keys of its own through uncached loads takes ~70 us whatever
+// the number of leaves; k_fit_long prepares 64 keys at a time in parallel and walks the chain at 28 ns per point);
+// the O(1) containers (empty, single borrowed point: Q4) are finished here by fit_one_leaf.
 // k_err_list: one wave per leaf, error pass + run lengths of its keys (two_layer.rs:207-217,
 // lower_bound_correction.rs:104-119), exactly what k_err computes per key.
+// Both walk the regions of the list: block b takes region b % SG_REGIONS.
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 __global__ void __launch_bounds__(256) k_fit_list(const K* __restrict__ keys, Span sp,
                                                   const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
-                                                  double* __restrict__ params, const unsigned int* __restrict__ flist,
-                                                  unsigned long long* __restrict__ long_idx, unsigned int long_min) {
-  const unsigned long long cnt = st->flag_count < st->flag_cap ? st->flag_count : st->flag_cap;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (unsigned long long)gridDim.x * blockDim.x) {
-    const uint64_t j = flist[i];
-    const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
-    if (e - s > (uint64_t)long_min) {
+                                                  double* __restrict__ params, SgList fl,
+                                                  unsigned long long* __restrict__ long_idx, unsigned int* __restrict__ xlong) {
+  const unsigned int rg = blockIdx.x % SG_REGIONS;
+  const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
+  if (blockIdx.x < SG_REGIONS && threadIdx.x == 0) atomicAdd(&st->flag_count, cnt);      // (total, for the caller)
+  const unsigned int* ids = fl.ids + (unsigned long long)rg * fl.cap;
+  for (unsigned long long i = (unsigned long long)(blockIdx.x / SG_REGIONS) * blockDim.x + threadIdx.x; i < cnt;
+       i += (unsigned long long)(gridDim.x / SG_REGIONS) * blockDim.x) {
+    const uint64_t j = ids[i];
+    uint64_t lo, hi;
+    const int ck = leaf_container(j, leaf_start[j], leaf_start[j + 1], sp.n, st->split_idx, st->split_target, lo, hi);
+    if (ck == 2) {
       const unsigned long long pos = atomicAdd(&st->long_count, 1ull);
-      if (pos < st->long_cap) long_idx[pos] = s;
-    } else {
-      fit_one_leaf<K_LINEAR, K>(j, keys, sp, leaf_start, st, params);
+      if (pos < st->long_cap) long_idx[pos] = leaf_start[j];
+    } else fit_one_leaf<K_LINEAR, K>(j, keys, sp, leaf_start, st, params);
+    if (leaf_start[j + 1] - leaf_start[j] > (uint64_t)SG_ERR_LONG) {
+      const unsigned long long pos = atomicAdd(&st->xlong_count, 1ull);
+      if (pos < st->xlong_cap) xlong[pos] = (unsigned int)j;
     }
   }
 }
 
 template <typename K>
 __global__ void __launch_bounds__(64) k_err_list(const K* __restrict__ keys, Span sp,
-                                                 const unsigned long long* __restrict__ leaf_start, const DevState* __restrict__ st,
-                                                 const double* __restrict__ params, const unsigned int* __restrict__ flist,
+                                                 const unsigned long long* __restrict__ leaf_start,
+                                                 const double* __restrict__ params, SgList fl,
                                                  unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
-  const unsigned long long cnt = st->flag_count < st->flag_cap ? st->flag_count : st->flag_cap;
+  const unsigned int rg = blockIdx.x % SG_REGIONS;
+  const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
+  const unsigned int* ids = fl.ids + (unsigned long long)rg * fl.cap;
   const int lane = threadIdx.x;
-  for (unsigned long long t = blockIdx.x; t < cnt; t += gridDim.x) {
-    const uint64_t j = flist[t];
+  for (unsigned long long t = blockIdx.x / SG_REGIONS; t < cnt; t += gridDim.x / SG_REGIONS) {
+    const uint64_t j = ids[t];
     const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+    if (e - s > (uint64_t)SG_ERR_LONG) continue;                   // k_err_long's
     unsigned long long err = 0, run = 0;
     for (uint64_t i = s + lane; i < e; i += 64) {
       const K k = keys[i];
@@ -106,6 +135,42 @@ __global__ void __launch_bounds__(64) k_err_list(const K* __restrict__ keys, Spa
   }
 }
 
+// The long leaves of the list (one wave would walk millions of keys): every block strides over the leaf's keys.
+template <typename K>
+__global__ void __launch_bounds__(256) k_err_long(const K* __restrict__ keys, Span sp,
+                                                  const unsigned long long* __restrict__ leaf_start, const DevState* __restrict__ st,
+                                                  const double* __restrict__ params, const unsigned int* __restrict__ xlong,
+                                                  unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
+  __shared__ unsigned long long sm_e[256], sm_r[256];
+  const unsigned long long cnt = st->xlong_count < st->xlong_cap ? st->xlong_count : st->xlong_cap;
+  for (unsigned long long t = 0; t < cnt; t++) {
+    const uint64_t j = xlong[t];
+    const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+    unsigned long long err = 0, run = 0;
+    for (uint64_t i = s + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < e; i += (uint64_t)gridDim.x * 256) {
+      const K k = keys[i];
+      const uint64_t y = first_occurrence(keys, i, sp.rd_lo);
+      const uint64_t pred = leaf_predict<K_LINEAR, K>(params + j * 2, k);
+      const uint64_t er = error_between(pred, y, sp.n);
+      err = er > err ? er : err;
+      if (i + 1 < sp.n && !(keys[i + 1] == k)) { const uint64_t rl = i - y + 1; run = rl > run ? rl : run; }
+    }
+    sm_e[threadIdx.x] = err; sm_r[threadIdx.x] = run;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+      if ((int)threadIdx.x < d) {
+        if (sm_e[threadIdx.x + d] > sm_e[threadIdx.x]) sm_e[threadIdx.x] = sm_e[threadIdx.x + d];
+        if (sm_r[threadIdx.x + d] > sm_r[threadIdx.x]) sm_r[threadIdx.x] = sm_r[threadIdx.x + d];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (sm_e[0]) atomicMax(&leaf_maxerr[j], sm_e[0]);
+      if (sm_r[0]) atomicMax(&leaf_run[j], sm_r[0]);
+    }
+    __syncthreads();
+  }
+}
 
 // =============================================================================================
 // k_sigma2: AUTONOMOUS WAVES.  (A first version with block-wide tiles, rows of 16 keys per thread and seven
@@ -206,7 +271,8 @@ template <int ROOT> __device__ __forceinline__ constexpr bool s2_root_monotone()
 template <int ROOT, typename K, int RING, int BATCH>
 __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span sp, RootP r, SgParams sg,
                                                unsigned long long* __restrict__ leaf_start, double* __restrict__ params,
-                                               unsigned long long* __restrict__ leaf_maxerr, DevState* __restrict__ st) {
+                                               unsigned long long* __restrict__ leaf_maxerr, DevState* __restrict__ st,
+                                               K* __restrict__ bnext, K* __restrict__ bprev) {
   constexpr int KPL = 16 / (int)sizeof(K);          // keys per lane and load
   constexpr int NLOAD = BATCH / (64 * KPL);         // loads per batch
   constexpr int BCAP = 192;                         // boundary list (more boundaries in a batch: see `dense`)
@@ -278,13 +344,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   auto flush_exact = [&]() {
-    if (lcnt == 0) return;
-    unsigned long long pos = 0;
-    if (lane == 0) pos = atomicAdd(&st->flag_count, (unsigned long long)lcnt);
-    pos = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(pos >> 32)) << 32) |
-          (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)pos);
-    for (int q = lane; q < lcnt; q += 64)
-      if (pos + q < st->flag_cap) sg.flist[pos + q] = l_buf[q];
+    for (int q = lane; q < lcnt; q += 64) sg.flist.push(l_buf[q]);
     lcnt = 0;
   };
   bool stop = false;                                                // a boundary at or behind c1 is in the list
@@ -433,7 +493,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
       const int pend = bcnt - 1 - head;
       const unsigned int span = b_idx[head + (pend < 8 ? pend : 8)] - b_idx[head];
       const unsigned int avg = span / (unsigned int)(pend < 8 ? pend : 8);
-      const int want = avg <= 320u ? 8 : (avg <= 640u ? 4 : 2);
+      const int want = (avg <= 320u && RING >= 2048) ? 8 : (avg <= 640u ? 4 : 2);
       if (pend >= want) {
         if (want == 8) round(std::integral_constant<int, 8>{}, head);
         else if (want == 4) round(std::integral_constant<int, 16>{}, head);
@@ -567,7 +627,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
         if (bm) {
           // ---- the boundary block (a load in three has one): per-key flags of the lanes that hold a boundary
           bool bq[KPL];
-          unsigned int fq[KPL];
+          unsigned int fq[KPL], told[KPL];
           int mine = 0;
           bool nonmono = false;
 #pragma unroll
@@ -578,8 +638,10 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
               for (int q = 0; q < KPL - 1; q++) { bool oob; ts[q] = s2_target<ROOT, K>(r, Lm1f, Lm1, kk[q], KeyTraits<K>::as_float(kk[q]), oob); }
             }
             unsigned int tp = tp0;
+            told[0] = tp0;
 #pragma unroll
             for (int q = 0; q < KPL; q++) {
+              if (q > 0) told[q] = ts[q - 1];
               bool cmp_ok = true, fstart = false, fend = false;
               if constexpr (EDGE) {
                 const uint64_t idx = g0 + q;
@@ -613,10 +675,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
             // More boundaries than the list holds (leaves of a few keys): for the rest of this batch every leaf
             // goes straight to the exact kernels, the open one included; the list restarts with the next batch.
             dense = true;
-            if (lane == 0 && bcnt > 0 && b_idx[bcnt - 1] >= c0u && b_idx[bcnt - 1] < c1u) {
-              const unsigned long long pos = atomicAdd(&st->flag_count, 1ull);
-              if (pos < st->flag_cap) sg.flist[pos] = b_t[bcnt - 1];
-            }
+            if (lane == 0 && bcnt > 0 && b_idx[bcnt - 1] >= c0u && b_idx[bcnt - 1] < c1u) sg.flist.push(b_t[bcnt - 1]);
           }
           if (lane_b) {
 #pragma unroll
@@ -625,12 +684,12 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
                 const uint64_t idx = g0 + q;
                 const bool own = idx >= c0 && idx < c1 && !(fq[q] & S2_END);     // this wave owns the leaf that starts here
                 if (!dense) { b_idx[rank] = (unsigned int)idx; b_t[rank] = ts[q]; b_fl[rank] = (unsigned char)fq[q]; }
-                else if (own) {
-                  const unsigned long long pos = atomicAdd(&st->flag_count, 1ull);
-                  if (pos < st->flag_cap) sg.flist[pos] = ts[q];
-                }
+                else if (own) sg.flist.push(ts[q]);
                 rank++;
                 if (own) {
+                  // the keys on both sides of the boundary, for the widening of the two leaves (k_finalize reads
+                  // them from here instead of gathering key[e] and key[s-1] from the key array)
+                  if (!(fq[q] & S2_START)) { bnext[told[q]] = kk[q]; bprev[ts[q]] = q == 0 ? kp0 : kk[q > 0 ? q - 1 : 0]; }
                   leaf_start[ts[q]] = idx;
                   if (fq[q] & S2_SPLIT) {
                     st->split_idx = idx; st->split_target = ts[q];
