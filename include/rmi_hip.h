@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RMI_HIP_ABI_VERSION 3
+#define RMI_HIP_ABI_VERSION 4
 
 /* src/load.rs:15-19 */
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
@@ -86,7 +86,9 @@ enum rmi_hip_error {
   RMI_ERR_LAYERS = -12,            /* != 2 layers: panic!() train/mod.rs:125 */
   RMI_ERR_NO_KEYS = -13,
   RMI_ERR_HIP = -14,               /* HIP runtime failure; see rmi_hip_last_error */
-  RMI_ERR_NO_DEVICE = -15
+  RMI_ERR_NO_DEVICE = -15,
+  RMI_ERR_NO_RCCL = -16,           /* librccl.so could not be loaded (multi-GPU entry points only) */
+  RMI_ERR_RCCL = -17               /* an RCCL call failed; see rmi_hip_last_error */
 };
 
 typedef struct rmi_hip_ctx rmi_hip_ctx;
@@ -180,6 +182,12 @@ int rmi_hip_parse_spec(const char* spec, int* root_kind, int* leaf_kind);
 /* ---- data ---- */
 /* Copy n keys from host memory into HBM (buffer borrowed for the duration of the call). */
 int rmi_hip_upload_keys(rmi_hip_ctx* ctx, const void* host_keys, uint64_t n, int dtype);
+/* The same copy on a thread of the library, so that the caller can work on the host keys meanwhile -- the exact
+ * root fit of a new key set (rmi_hip_fit_root with host_keys) is sequential host work that dwarfs the upload
+ * (src/load.rs:132-157 + two_layer.rs:109-110 in the reference).  The buffer must stay valid until
+ * rmi_hip_upload_wait returns (the copy's return code); no other call on the context in between. */
+int rmi_hip_upload_keys_async(rmi_hip_ctx* ctx, const void* host_keys, uint64_t n, int dtype);
+int rmi_hip_upload_wait(rmi_hip_ctx* ctx);
 /* Borrow a device buffer that already holds the sorted keys (stays owned by the caller). */
 int rmi_hip_attach_device_keys(rmi_hip_ctx* ctx, const void* device_keys, uint64_t n, int dtype);
 uint64_t rmi_hip_num_keys(const rmi_hip_ctx* ctx);
@@ -228,11 +236,48 @@ int rmi_hip_set_shard(rmi_hip_ctx* ctx, const rmi_hip_shard* shard);
  * all-gather buffer.  NULL restores the internal buffer. */
 int rmi_hip_set_rows_output(rmi_hip_ctx* ctx, void* device_rows);
 
+/* ---- multi-GPU inside the library: planner + RCCL all-gather of the rows ----
+ * One context per GPU -- one process per GPU, or several contexts in one process.  What it replaces: the only
+ * parallelism inside one reference training, the 2-way rayon::join of two_layer.rs:161-169; rmi_lib has no
+ * distributed surface at all (rmi_lib/src/lib.rs:6-12), so a caller binds these four calls next to train():
+ *   1. every rank:   rmi_hip_plan_shards(...)                   -> the same G shards everywhere (O(G log N) key probes)
+ *   2. rank 0:       rmi_hip_comm_unique_id(id); hand the 128 bytes to the other ranks (any channel)
+ *   3. every rank:   rmi_hip_comm_init(ctx, rank, G, id); rmi_hip_set_shard(ctx, &shards[rank]);
+ *                    upload / attach / generate exactly the keys [read_lo, read_hi) of its shard
+ *   4. every rank:   rmi_hip_train_sharded(ctx, root, leaf_kind, L, &result)   (as often as wanted)
+ * After step 4 the full row buffer of every rank (rmi_hip_device_rows_full / rmi_hip_download_rows_full) holds
+ * the L rows -- byte for byte what one GPU computes -- and `result` the aggregates of the whole model. */
+#define RMI_HIP_COMM_ID_BYTES 128
+/* key source of the planner: the bits of the key with global index i (u32 keys widened, f64 keys as their bits) */
+typedef uint64_t (*rmi_hip_key_at_fn)(void* user, uint64_t index);
+/* ctx may be NULL unless the root is a radix table (its hint table lives in the context).  num_leaves must be a
+ * multiple of world.  out: `world` shards. */
+int rmi_hip_plan_shards(const rmi_hip_ctx* ctx, const rmi_hip_model_params* root, int dtype, uint64_t n_global,
+                        uint64_t num_leaves, int world, rmi_hip_key_at_fn key_at, void* user, rmi_hip_shard* out);
+/* Closed form of the synthetic generators of rmi_hip_generate_keys (a key source for the planner when every rank
+ * generates its own shard in HBM). */
+int rmi_hip_generated_key(int generator, int dtype, uint64_t n_global, uint64_t seed, uint64_t index, uint64_t* key_bits);
+/* `radix` / `linear_spline` roots (O(1) keys: radix.rs:18-39, linear_spline.rs:13-35) through a key source. */
+int rmi_hip_fit_root_from_source(int root_kind, int dtype, uint64_t n_global, uint64_t num_leaves, rmi_hip_key_at_fn key_at,
+                                 void* user, rmi_hip_model_params* out);
+int rmi_hip_comm_unique_id(void* id_out /* RMI_HIP_COMM_ID_BYTES */);
+int rmi_hip_comm_init(rmi_hip_ctx* ctx, int rank, int world, const void* id /* RMI_HIP_COMM_ID_BYTES; NULL with world == 1 */);
+int rmi_hip_comm_destroy(rmi_hip_ctx* ctx);
+int rmi_hip_train_sharded(rmi_hip_ctx* ctx, const rmi_hip_model_params* root, int leaf_kind, uint64_t num_leaves,
+                          rmi_hip_result* out);
+void* rmi_hip_device_rows_full(rmi_hip_ctx* ctx);
+int rmi_hip_download_rows_full(rmi_hip_ctx* ctx, void* host_out, uint64_t capacity_bytes);
+
 /* ---- root model ---- */
 /* Fit the root exactly as the reference does.  `host_keys` may be NULL, in which case the keys
  * are read back from HBM for the order-dependent fits (linear / robust_linear / cubic). */
 int rmi_hip_fit_root(rmi_hip_ctx* ctx, int root_kind, uint64_t num_leaves, const void* host_keys,
                      rmi_hip_model_params* out);
+
+/* The host part alone (no context, no device), e.g. beside rmi_hip_upload_keys_async: the reference's fit of
+ * linear / robust_linear / linear_spline / cubic / radix / loglinear / normal roots over a host array. */
+int rmi_hip_fit_root_host(int root_kind, int dtype, const void* host_keys, uint64_t n, uint64_t num_leaves,
+                          rmi_hip_model_params* out);
 
 /* FAST root fit, opt-in: `linear` / `robust_linear` from parallel sums on the device
  * instead of the reference's sequential recurrence -- same points, coefficients within ~1e-12

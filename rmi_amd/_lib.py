@@ -53,6 +53,8 @@ SYMBOLS = [
     ("rmi_hip_model_name", C.c_char_p, [C.c_int]),
     ("rmi_hip_parse_spec", C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("rmi_hip_upload_keys", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    ("rmi_hip_upload_keys_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    ("rmi_hip_upload_wait", C.c_int, [C.c_void_p]),
     ("rmi_hip_attach_device_keys", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     ("rmi_hip_num_keys", C.c_uint64, [C.c_void_p]),
     ("rmi_hip_generate_keys", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -70,6 +72,7 @@ SYMBOLS = [
     ("rmi_hip_set_shard", C.c_int, [C.c_void_p, C.POINTER(Shard)]),
     ("rmi_hip_set_rows_output", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_fit_root", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(ModelParams)]),
+    ("rmi_hip_fit_root_host", C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(ModelParams)]),
     ("rmi_hip_fit_root_fast", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(ModelParams)]),
     ("rmi_hip_root_target", C.c_int, [C.POINTER(ModelParams), C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rmi_hip_root_stream_begin", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -83,7 +86,20 @@ SYMBOLS = [
     ("rmi_hip_download_rows", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_download_checked", C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64]),
     ("rmi_hip_device_rows", C.c_void_p, [C.c_void_p]),
+    ("rmi_hip_plan_shards", C.c_int, [C.c_void_p, C.POINTER(ModelParams), C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.POINTER(Shard)]),
+    ("rmi_hip_generated_key", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("rmi_hip_fit_root_from_source", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(ModelParams)]),
+    ("rmi_hip_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("rmi_hip_comm_init", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    ("rmi_hip_comm_destroy", C.c_int, [C.c_void_p]),
+    ("rmi_hip_train_sharded", C.c_int, [C.c_void_p, C.POINTER(ModelParams), C.c_int, C.c_uint64, C.POINTER(Result)]),
+    ("rmi_hip_device_rows_full", C.c_void_p, [C.c_void_p]),
+    ("rmi_hip_download_rows_full", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
 ]
+
+KEY_AT_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p, C.c_uint64)
+COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -87,8 +87,14 @@ struct rmi_hip_ctx {
   uint64_t last_L = 0;
   int last_ppl = 2;
   uint64_t generation = 0;                      // train calls so far on this context
+  std::thread upload_thread;                    // rmi_hip_upload_keys_async
+  int upload_rc = RMI_OK;
+  bool defer_sync = false;                      // rmi_hip_train_sharded: the caller queues the exchange, synchronises and finishes
+  struct rmi_hip_multi* multi = nullptr;        // multi-GPU state (rmi_multi.inc.h)
   std::string err;
 };
+
+static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_hip_result* out);
 
 static void set_err(rmi_hip_ctx* c, const char* fmt, ...) {
   char buf[512];
@@ -133,6 +139,8 @@ const char* rmi_hip_strerror(int code) {
     case RMI_ERR_NO_KEYS: return "no keys resident";
     case RMI_ERR_HIP: return "HIP runtime error";
     case RMI_ERR_NO_DEVICE: return "no HIP device";
+    case RMI_ERR_NO_RCCL: return "RCCL (librccl.so) could not be loaded";
+    case RMI_ERR_RCCL: return "RCCL error; see rmi_hip_last_error";
     default: return "unknown error";
   }
 }
@@ -248,10 +256,13 @@ static void free_outputs(rmi_hip_ctx* c) {
   c->cap_leaves = 0; c->cap_ppl = 0;
 }
 
+static void free_multi(rmi_hip_ctx* c);
 void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (!c) return;
+  if (c->upload_thread.joinable()) c->upload_thread.join();
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_multi(c);
   free_outputs(c);
   if (c->d_table) (void)hipFree(c->d_table);       // the root table is an input, not an output: it outlives re-sizing
   if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
@@ -296,6 +307,23 @@ int rmi_hip_upload_keys(rmi_hip_ctx* c, const void* host_keys, uint64_t n, int d
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->d_keys = c->d_keys_owned; c->n = n; c->dtype = dtype;
   return RMI_OK;
+}
+
+// The upload of a new key set next to host work on the same keys (the exact root fit of linear / robust_linear /
+// cubic roots is a sequential host pass of ~0.8 s per 200 M keys; the 1.6 GB upload takes ~29 ms of it): the copy
+// runs on a thread of the library, rmi_hip_upload_wait joins it.  Until then the context has no keys.
+int rmi_hip_upload_keys_async(rmi_hip_ctx* c, const void* host_keys, uint64_t n, int dtype) {
+  if (!c || !host_keys || n == 0 || dtype < 0 || dtype > 2) return RMI_ERR_BAD_ARG;
+  if (c->upload_thread.joinable()) c->upload_thread.join();
+  c->d_keys = nullptr; c->n = 0;
+  c->upload_rc = RMI_OK;
+  c->upload_thread = std::thread([c, host_keys, n, dtype]() { c->upload_rc = rmi_hip_upload_keys(c, host_keys, n, dtype); });
+  return RMI_OK;
+}
+int rmi_hip_upload_wait(rmi_hip_ctx* c) {
+  if (!c) return RMI_ERR_BAD_ARG;
+  if (c->upload_thread.joinable()) c->upload_thread.join();
+  return c->upload_rc;
 }
 
 int rmi_hip_attach_device_keys(rmi_hip_ctx* c, const void* device_keys, uint64_t n, int dtype) {
@@ -672,6 +700,19 @@ int rmi_hip_fit_root_fast(rmi_hip_ctx* c, int root_kind, uint64_t num_leaves, rm
     case RMI_KEY_U64: return fit_linear_fast_device<uint64_t>(c, root_kind, num_leaves, out);
     case RMI_KEY_U32: return fit_linear_fast_device<uint32_t>(c, root_kind, num_leaves, out);
     case RMI_KEY_F64: return fit_linear_fast_device<double>(c, root_kind, num_leaves, out);
+  }
+  return RMI_ERR_BAD_ARG;
+}
+
+// The host part of rmi_hip_fit_root on its own (no context, no device): the reference's fit over a host array.
+int rmi_hip_fit_root_host(int root_kind, int dtype, const void* host_keys, uint64_t n, uint64_t num_leaves, rmi_hip_model_params* out) {
+  if (!host_keys || !out || n == 0 || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  if (root_kind < 0 || root_kind >= kNumModels) return RMI_ERR_UNKNOWN_MODEL;
+  if (!root_on_device_path(root_kind) || rmi_host::radix_table_bits(root_kind) > 0 || root_kind == RMI_MODEL_BRADIX) return RMI_ERR_UNSUPPORTED_MODEL;
+  switch (dtype) {
+    case RMI_KEY_U64: return rmi_host::fit_root<uint64_t>(root_kind, (const uint64_t*)host_keys, n, num_leaves, out);
+    case RMI_KEY_U32: return rmi_host::fit_root<uint32_t>(root_kind, (const uint32_t*)host_keys, n, num_leaves, out);
+    case RMI_KEY_F64: return rmi_host::fit_root<double>(root_kind, (const double*)host_keys, n, num_leaves, out);
   }
   return RMI_ERR_BAD_ARG;
 }
@@ -1161,8 +1202,18 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
     default: rc = RMI_ERR_BAD_ARG;
   }
   if (rc) return rc;
+  if (c->defer_sync) return RMI_OK;                            // (rmi_hip_train_sharded goes on from here)
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return finish_train(c, leaf_kind, num_leaves, out);
+}
 
+}  // extern "C"
+
+// After the stream has been synchronised: the reference's panics as error codes, the result record, timings.
+static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_hip_result* out) {
+  int rc = RMI_OK;
+  const int ppl = leaf_kind == RMI_MODEL_CUBIC ? 4 : 2;
+  const uint64_t L_own = c->have_shard ? c->shard.leaf_hi - c->shard.leaf_lo : num_leaves;
   const DevState& st = *c->h_state;
   if (st.err_flags) {
     if (st.err_flags & EF_NON_MONOTONE) rc = RMI_ERR_NON_MONOTONE;
@@ -1202,6 +1253,8 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   return RMI_OK;
 }
 
+extern "C" {
+
 static int dl(rmi_hip_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c || !dst) return RMI_ERR_BAD_ARG;
   if (!c->last_L) return RMI_ERR_BAD_ARG;
@@ -1233,3 +1286,20 @@ int rmi_hip_download_checked(rmi_hip_ctx* c, int what, uint64_t generation, void
 void* rmi_hip_device_rows(rmi_hip_ctx* c) { return c ? (c->d_rows_ext ? c->d_rows_ext : (void*)c->d_rows) : nullptr; }
 
 }  // extern "C"
+
+#include "rmi_multi.inc.h"
+
+static rmi_hip_multi* multi_of(rmi_hip_ctx* c) {
+  if (!c->multi) c->multi = new rmi_hip_multi();
+  return c->multi;
+}
+static void free_multi(rmi_hip_ctx* c) {
+  rmi_hip_multi* m = c->multi;
+  if (!m) return;
+  if (m->comm && rmi_multi::api().CommDestroy) (void)rmi_multi::api().CommDestroy(m->comm);
+  if (m->d_rows_full) (void)hipFree(m->d_rows_full);
+  if (m->d_stats_all) (void)hipFree(m->d_stats_all);
+  if (m->h_stats_all) (void)hipHostFree(m->h_stats_all);
+  delete m;
+  c->multi = nullptr;
+}

@@ -1,0 +1,272 @@
+// rmi_multi.inc.h -- multi-GPU form of the leaf path BEHIND the C ABI (included at the end of rmi_hip.hip).
+//
+// One context per GPU.  Given the root parameters, every leaf's container, fit and error bound depend only on a
+// contiguous key range plus a one/two-key halo and on global indices: rank r owns the leaves
+// [r L/G, (r+1) L/G) and the keys the root maps to them; rmi_hip_plan_shards finds the cuts by binary search with
+// exactly the bucketing of the kernels; rmi_hip_train_sharded runs the usual kernels on the shard, with the rows
+// written straight into the rank's slot of the full row buffer, and exchanges the rows with ONE ncclAllGather
+// (RCCL over xGMI) on the context's stream; the aggregates are recombined exactly from per-shard partial sums.
+// Replaces the reference's only parallelism inside one training, the 2-way rayon::join (two_layer.rs:161-169).
+//
+// RCCL is bound at run time (dlopen): a process that already holds RCCL (torch ships one) shares it, and the
+// library keeps loading on a machine without RCCL (single-GPU use).
+#include <dlfcn.h>
+
+namespace rmi_multi {
+
+struct NcclId { char internal[RMI_HIP_COMM_ID_BYTES]; };
+typedef void* NcclComm;
+struct Api {
+  void* handle = nullptr;
+  int (*GetUniqueId)(NcclId*) = nullptr;
+  int (*CommInitRank)(NcclComm*, int, NcclId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather; }
+};
+
+static Api& api() {
+  static Api a;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (a.handle) break; }   // already in the process
+    if (!a.handle) {
+      const char* paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+      for (const char* n : paths) { a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (a.handle) break; }
+    }
+    if (a.handle) {
+      a.GetUniqueId = (int (*)(NcclId*))dlsym(a.handle, "ncclGetUniqueId");
+      a.CommInitRank = (int (*)(NcclComm*, int, NcclId, int))dlsym(a.handle, "ncclCommInitRank");
+      a.CommDestroy = (int (*)(NcclComm))dlsym(a.handle, "ncclCommDestroy");
+      a.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))dlsym(a.handle, "ncclAllGather");
+      a.GetErrorString = (const char* (*)(int))dlsym(a.handle, "ncclGetErrorString");
+    }
+  }
+  return a;
+}
+
+// closed forms of the synthetic generators (rmi_hip_generate_keys / rmi_amd/datagen.py)
+static inline uint64_t splitmix64_h(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+}  // namespace rmi_multi
+
+struct rmi_hip_multi {
+  rmi_multi::NcclComm comm = nullptr;
+  int rank = 0, world = 1;
+  unsigned char* d_rows_full = nullptr;     // L * row_bytes
+  uint64_t rows_full_bytes = 0;
+  unsigned char* d_stats_all = nullptr;     // world * 40 bytes
+  unsigned char* h_stats_all = nullptr;     // pinned
+};
+
+static rmi_hip_multi* multi_of(rmi_hip_ctx* c);    // (accessor defined in rmi_hip.hip)
+
+extern "C" {
+
+int rmi_hip_generated_key(int generator, int dtype, uint64_t n_global, uint64_t seed, uint64_t index, uint64_t* key_bits) {
+  if (!key_bits || n_global == 0 || index >= n_global || generator < 0 || generator > 1 || (dtype != RMI_KEY_U64 && dtype != RMI_KEY_U32))
+    return RMI_ERR_BAD_ARG;
+  const uint64_t span = dtype == RMI_KEY_U64 ? 0xFFFFFFFFFFFFFFFEull : 0xFFFFFFFDull;
+  const uint64_t stride = span / n_global;
+  if (stride == 0) return RMI_ERR_BAD_ARG;
+  const uint64_t base_seed = seed ? seed : (dtype == RMI_KEY_U64 ? 42ull : 46ull);
+  const uint64_t dup_seed = dtype == RMI_KEY_U64 ? 45ull : 47ull;
+  uint64_t i = index;
+  if (generator == 1) {
+    const uint64_t cc = rmi_multi::splitmix64_h((i >> 3) + dup_seed) % 5ull;
+    const uint64_t rr = cc < 3 ? 1ull : (cc == 3 ? 2ull : 8ull);
+    i = i - (i % rr);
+  }
+  *key_bits = 1ull + i * stride + (rmi_multi::splitmix64_h(i + base_seed) % stride);
+  return RMI_OK;
+}
+
+int rmi_hip_plan_shards(const rmi_hip_ctx* c, const rmi_hip_model_params* root, int dtype, uint64_t n, uint64_t L, int world,
+                        rmi_hip_key_at_fn key_at, void* user, rmi_hip_shard* out) {
+  if (!root || !key_at || !out || n == 0 || L == 0 || world < 1 || dtype < 0 || dtype > 2) return RMI_ERR_BAD_ARG;
+  if (L % (uint64_t)world != 0) return RMI_ERR_BAD_ARG;                 // equal leaf counts: one all-gather of equal pieces
+  const int table_bits = rmi_host::radix_table_bits(root->kind);
+  if (table_bits > 0 && (!c || c->h_table.size() != (1ull << table_bits))) return RMI_ERR_BAD_ARG;
+  if (!root_on_device_path(root->kind)) return RMI_ERR_UNSUPPORTED_MODEL;
+  auto target = [&](uint64_t i) -> uint64_t {
+    const uint64_t kb = key_at(user, i);
+    if (table_bits > 0) {                                                 // radix.rs:124-134, clamp two_layer.rs:49
+      uint64_t v = kb;
+      if (dtype == RMI_KEY_F64) { double d; std::memcpy(&d, &kb, 8); v = rmi_host::sat_u64(d); }
+      const uint64_t prefix = root->ip[0], bits = root->ip[1];
+      const uint64_t nb = prefix + bits > 64 ? 0 : 64 - (prefix + bits);
+      const uint64_t slot = ((v << (prefix & 63)) >> (prefix & 63)) >> (nb & 63);
+      const uint64_t t = c->h_table[slot];
+      return t < L - 1 ? t : L - 1;
+    }
+    uint64_t t = 0;
+    (void)rmi_hip_root_target(root, dtype, kb, L, &t);
+    return t;
+  };
+  auto first_ge = [&](uint64_t leaf) -> uint64_t {                       // lower_bound over the monotone targets (two_layer.rs:132-136)
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (target(mid) < leaf) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  auto key_less = [&](uint64_t a, uint64_t b) -> bool {                  // order of the key TYPE, on its bits
+    if (dtype == RMI_KEY_F64) { double x, y; std::memcpy(&x, &a, 8); std::memcpy(&y, &b, 8); return x < y; }
+    return a < b;
+  };
+  auto first_occurrence = [&](uint64_t i) -> uint64_t {
+    const uint64_t v = key_at(user, i);
+    if (i == 0 || key_at(user, i - 1) != v) return i;
+    uint64_t lo = 0, hi = i - 1;
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (key_less(key_at(user, mid), v)) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const uint64_t per = L / (uint64_t)world;
+  std::vector<uint64_t> cuts((size_t)world + 1);
+  cuts[0] = 0; cuts[(size_t)world] = n;
+  for (int r = 1; r < world; r++) cuts[(size_t)r] = first_ge((uint64_t)r * per);
+  const uint64_t split = first_ge(L / 2);
+  const uint64_t split_idx = split >= n ? ~0ull : split;
+  const uint64_t split_target = split >= n ? 0 : target(split);
+  for (int r = 0; r < world; r++) {
+    rmi_hip_shard& s = out[r];
+    s.n_global = n;
+    s.key_lo = cuts[(size_t)r]; s.key_hi = cuts[(size_t)r + 1];
+    s.leaf_lo = (uint64_t)r * per; s.leaf_hi = (uint64_t)(r + 1) * per;
+    // left halo: the whole duplicate run of key[key_lo-1] plus one more key (prev-last point with its first-occurrence
+    // offset; "was the previous key the split key" needs key_lo-2); right halo: key[key_hi] plus one spare
+    if (s.key_lo == 0) s.read_lo = 0;
+    else {
+      const uint64_t fo = first_occurrence(s.key_lo - 1);
+      const uint64_t a = fo < s.key_lo - 1 ? fo : s.key_lo - 1;
+      s.read_lo = a > 0 ? a - 1 : 0;
+    }
+    s.read_hi = s.key_hi + 2 < n ? s.key_hi + 2 : n;
+    s.split_idx = split_idx; s.split_target = split_target;
+  }
+  return RMI_OK;
+}
+
+// `radix` and `linear_spline` roots need a handful of keys (first, last, start of the last run): fitted through the
+// key source, for key sets no single rank holds (same code as rmi_hip_fit_root uses on HBM-resident keys).
+int rmi_hip_fit_root_from_source(int root_kind, int dtype, uint64_t n, uint64_t num_leaves, rmi_hip_key_at_fn key_at, void* user,
+                                 rmi_hip_model_params* out) {
+  if (!key_at || !out || n == 0 || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  switch (dtype) {
+    case RMI_KEY_U64: return rmi_host::fit_root_sparse<uint64_t>(root_kind, [&](uint64_t i) { return (uint64_t)key_at(user, i); }, n, num_leaves, out);
+    case RMI_KEY_U32: return rmi_host::fit_root_sparse<uint32_t>(root_kind, [&](uint64_t i) { return (uint32_t)key_at(user, i); }, n, num_leaves, out);
+    case RMI_KEY_F64: return rmi_host::fit_root_sparse<double>(root_kind, [&](uint64_t i) { const uint64_t b = key_at(user, i); double d; std::memcpy(&d, &b, 8); return d; }, n, num_leaves, out);
+  }
+  return RMI_ERR_BAD_ARG;
+}
+
+int rmi_hip_comm_unique_id(void* id_out) {
+  if (!id_out) return RMI_ERR_BAD_ARG;
+  rmi_multi::Api& a = rmi_multi::api();
+  if (!a.ok()) return RMI_ERR_NO_RCCL;
+  rmi_multi::NcclId id;
+  if (a.GetUniqueId(&id) != 0) return RMI_ERR_RCCL;
+  std::memcpy(id_out, &id, sizeof id);
+  return RMI_OK;
+}
+
+int rmi_hip_comm_init(rmi_hip_ctx* c, int rank, int world, const void* id_bytes) {
+  if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !id_bytes)) return RMI_ERR_BAD_ARG;
+  rmi_hip_multi* m = multi_of(c);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (m->comm) { (void)rmi_multi::api().CommDestroy(m->comm); m->comm = nullptr; }
+  m->rank = rank; m->world = world;
+  if (world == 1 && !id_bytes) return RMI_OK;                            // a communicator of one: nothing to exchange
+  rmi_multi::Api& a = rmi_multi::api();
+  if (!a.ok()) return RMI_ERR_NO_RCCL;
+  rmi_multi::NcclId id;
+  std::memcpy(&id, id_bytes, sizeof id);
+  const int rc = a.CommInitRank(&m->comm, world, id, rank);
+  if (rc != 0) { set_err(c, "ncclCommInitRank: %s", a.GetErrorString ? a.GetErrorString(rc) : "error"); m->comm = nullptr; return RMI_ERR_RCCL; }
+  return RMI_OK;
+}
+
+int rmi_hip_comm_destroy(rmi_hip_ctx* c) {
+  if (!c) return RMI_ERR_BAD_ARG;
+  rmi_hip_multi* m = multi_of(c);
+  if (m->comm) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)rmi_multi::api().CommDestroy(m->comm); m->comm = nullptr; }
+  m->world = 1; m->rank = 0;
+  return RMI_OK;
+}
+
+// One training of this rank's shard (rmi_hip_set_shard) + the exchange: when the call returns, the full row
+// buffer of EVERY rank holds the L rows, and `out` carries the aggregates of the whole model.
+int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int leaf_kind, uint64_t num_leaves, rmi_hip_result* out) {
+  if (!c || !root || !out) return RMI_ERR_BAD_ARG;
+  rmi_hip_multi* m = multi_of(c);
+  if (!c->have_shard) return RMI_ERR_BAD_ARG;
+  const int ppl = leaf_kind == RMI_MODEL_CUBIC ? 4 : 2;
+  const uint64_t rowb = (uint64_t)ppl * 8 + 8;
+  const uint64_t L_own = c->shard.leaf_hi - c->shard.leaf_lo;
+  if (L_own * (uint64_t)m->world != num_leaves || c->shard.leaf_lo != (uint64_t)m->rank * L_own) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (m->rows_full_bytes < num_leaves * rowb) {
+    if (m->d_rows_full) (void)hipFree(m->d_rows_full);
+    m->d_rows_full = nullptr; m->rows_full_bytes = 0;
+    HIPCHK(c, hipMalloc(&m->d_rows_full, num_leaves * rowb));
+    m->rows_full_bytes = num_leaves * rowb;
+  }
+  if (!m->d_stats_all) {
+    HIPCHK(c, hipMalloc(&m->d_stats_all, 40 * 64));
+    HIPCHK(c, hipHostMalloc((void**)&m->h_stats_all, 40 * 64, hipHostMallocDefault));
+  }
+  if (m->world > 64) return RMI_ERR_BAD_ARG;
+  void* const saved_ext = c->d_rows_ext;
+  c->d_rows_ext = m->d_rows_full + (uint64_t)m->rank * L_own * rowb;    // the kernels write this rank's rows into its slot
+  c->defer_sync = m->comm != nullptr;                                  // the exchange is queued behind the kernels, one sync for both
+  int rc = rmi_hip_train_two_layer(c, root, leaf_kind, num_leaves, out);
+  c->defer_sync = false;
+  if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
+  if (m->world > 1 && !m->comm) { c->d_rows_ext = saved_ext; return RMI_ERR_BAD_ARG; }
+  if (m->comm) {
+    rmi_multi::Api& a = rmi_multi::api();
+    // rows: in place (this rank's piece already sits in its slot); aggregates: the 40 bytes of DevState from max_err on
+    int n1 = a.AllGather(c->d_rows_ext, m->d_rows_full, (size_t)(L_own * rowb), 1 /* ncclUint8 */, m->comm, c->stream);
+    int n2 = a.AllGather(&c->d_state->max_err, m->d_stats_all, 40, 1, m->comm, c->stream);
+    if (n1 != 0 || n2 != 0) { c->d_rows_ext = saved_ext; set_err(c, "ncclAllGather: %s", a.GetErrorString ? a.GetErrorString(n1 ? n1 : n2) : "error"); return RMI_ERR_RCCL; }
+    HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, 40 * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[9], c->stream));                       // device time of the call now includes the exchange
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = finish_train(c, leaf_kind, num_leaves, out);                     // error flags, per-shard result, timings
+    if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
+    // two_layer.rs:267-287 over all shards: lexicographic maximum (last maximum wins), exact integer sum, f64 sums
+    unsigned long long mx = 0, mi = 0, sn = 0; double l2 = 0.0, lg = 0.0;
+    for (int r = 0; r < m->world; r++) {
+      unsigned long long v[3]; double d[2];
+      std::memcpy(v, m->h_stats_all + 40 * r, 24); std::memcpy(d, m->h_stats_all + 40 * r + 24, 16);
+      if (v[0] > mx || (v[0] == mx && v[1] >= mi)) { mx = v[0]; mi = v[1]; }
+      sn += v[2]; l2 += d[0]; lg += d[1];
+    }
+    const double ng = (double)c->shard.n;
+    out->model_max_error = mx; out->model_max_error_idx = mi;
+    out->model_avg_error = (double)sn / ng; out->model_avg_l2_error = l2; out->model_avg_log2_error = lg / ng;
+    out->model_max_log2_error = std::log2((double)mx);
+  }
+  c->d_rows_ext = saved_ext;
+  return RMI_OK;
+}
+
+void* rmi_hip_device_rows_full(rmi_hip_ctx* c) { return c ? multi_of(c)->d_rows_full : nullptr; }
+
+int rmi_hip_download_rows_full(rmi_hip_ctx* c, void* host_out, uint64_t capacity_bytes) {
+  if (!c || !host_out) return RMI_ERR_BAD_ARG;
+  rmi_hip_multi* m = multi_of(c);
+  if (!m->d_rows_full || capacity_bytes < m->rows_full_bytes) return RMI_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(host_out, m->d_rows_full, m->rows_full_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RMI_OK;
+}
+
+}  // extern "C"

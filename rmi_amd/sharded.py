@@ -177,99 +177,117 @@ def exchange_rows(dist, full_rows, mine, rank: int, world: int):
 
 
 class ShardedTrainer:
-    """Weak-scaling driver used by bench.py: every rank generates its own shard of the global
-    synthetic key array in HBM, rank 0 fits the root exactly (streamed) and broadcasts it."""
+    """Driver of the N-GPU form used by bench.py: every rank generates its own shard of the global synthetic key
+    array in HBM; rank 0 fits the root exactly (streamed) and broadcasts it; planning, the RCCL communicator and the
+    all-gather of the rows are the library's (rmi_hip_plan_shards, rmi_hip_comm_*, rmi_hip_train_sharded) --
+    torch.distributed only carries the 128-byte communicator id and the root parameters.  With the gloo backend
+    (functional tests without RCCL) the rows are exchanged through torch instead."""
 
     def __init__(self, tr: T.Trainer, dist, rank: int, world: int, dataset: str, np_dtype,
-                 n_global: int, num_leaves: int, spec: str, chunk: int = 50_000_000, pipeline: bool = False):
+                 n_global: int, num_leaves: int, spec: str, chunk: int = 50_000_000, fit_mode: int = 0):
         import torch
-        from . import datagen
         self.tr, self.dist, self.rank, self.world = tr, dist, rank, world
         self.n_global, self.L = n_global, num_leaves
         root_kind, self.leaf_kind = T.parse_spec(spec)
         lib = tr._lib
         np_dtype = np.dtype(np_dtype)
         dt = T._DTYPES[np_dtype]
+        gen_id = {"uniform": 0, "dups": 1}[dataset]
         t0 = time.perf_counter()
-        # ---- exact root fit, streamed on rank 0 (the recurrence is sequential: SURVEY.md section 7, H1) ----
-        on_gpu = dist.get_backend() != "gloo"
-        pbuf = torch.zeros(6, dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        self.on_gpu = dist.get_backend() != "gloo"
+        dev = "cuda" if self.on_gpu else "cpu"
+        # ---- root: exact fit on rank 0 (the linear recurrence is sequential: SURVEY.md section 7, H1), broadcast ----
+        pbuf = torch.zeros(8, dtype=torch.float64, device=dev)
         if rank == 0:
-            rs = C.c_void_p()
-            T._check(lib.rmi_hip_root_stream_begin(root_kind, dt, n_global, num_leaves, C.byref(rs)))
-            gen = T.Trainer(device=torch.cuda.current_device())
-            done = 0
-            while done < n_global:
-                cnt = min(chunk, n_global - done)
-                gen.generate_keys(dataset, np_dtype, n_global, done, cnt)
-                host = gen.download_keys()
-                T._check(lib.rmi_hip_root_stream_push(rs, host.ctypes.data, cnt))
-                gen._host_keys = None
-                done += cnt
-            gen.close()
-            m = _lib.ModelParams()
-            T._check(lib.rmi_hip_root_stream_finish(rs, C.byref(m)))
-            root = T.Model._from_c(m)
-            pbuf.copy_(torch.tensor(list(root.p) + [float(root.ip[0]), float(root.ip[1])], dtype=torch.float64))
+            if root_kind == 0:
+                rs = C.c_void_p()
+                T._check(lib.rmi_hip_root_stream_begin(root_kind, dt, n_global, num_leaves, C.byref(rs)))
+                gen = T.Trainer(device=torch.cuda.current_device())
+                done = 0
+                while done < n_global:
+                    cnt = min(chunk, n_global - done)
+                    gen.generate_keys(dataset, np_dtype, n_global, done, cnt)
+                    host = gen.download_keys()
+                    T._check(lib.rmi_hip_root_stream_push(rs, host.ctypes.data, cnt))
+                    gen._host_keys = None
+                    done += cnt
+                gen.close()
+                m = _lib.ModelParams()
+                T._check(lib.rmi_hip_root_stream_finish(rs, C.byref(m)))
+                root = T.Model._from_c(m)
+            elif root_kind in (1, 3):               # linear_spline, radix: a handful of keys, through the key source
+                kb0 = C.c_uint64()
+
+                def key_src(user, i):
+                    lib.rmi_hip_generated_key(gen_id, dt, n_global, 0, i, C.byref(kb0))
+                    return kb0.value
+                cb0 = _lib.KEY_AT_FN(key_src)
+                m = _lib.ModelParams()
+                T._check(lib.rmi_hip_fit_root_from_source(root_kind, dt, n_global, num_leaves, C.cast(cb0, C.c_void_p), None, C.byref(m)))
+                root = T.Model._from_c(m)
+            else:
+                raise ValueError("the sharded driver fits linear, linear_spline and radix roots")
+            pbuf.copy_(torch.tensor(list(root.p) + [float(v) for v in root.ip], dtype=torch.float64))
         dist.broadcast(pbuf, src=0)
         vals = pbuf.cpu().tolist()
-        self.root = T.Model(root_kind, tuple(vals[:4]), (int(vals[4]), int(vals[5])))
+        self.root = T.Model(root_kind, tuple(vals[:4]), tuple(int(v) for v in vals[4:8]))
         self.root_seconds = time.perf_counter() - t0
-        # ---- plan + resident keys ----
-        gen_fn = {("uniform", np.dtype(np.uint64)): datagen.uniform_u64, ("dups", np.dtype(np.uint64)): datagen.dups_u64,
-                  ("uniform", np.dtype(np.uint32)): datagen.uniform_u32, ("dups", np.dtype(np.uint32)): datagen.dups_u32}
-        if dataset == "uniform":
-            f = gen_fn[(dataset, np_dtype)]
-            key_at = lambda i: f(n_global, start=i, count=1)[0]
-        else:
-            raise ValueError("sharded bench supports the closed-form 'uniform' generator")
-        self.plan = Planner(key_at, n_global, np_dtype, self.root, num_leaves).plan(world)[rank]
+        # ---- plan (the library's planner over the generator's closed form) ----
+        kb = C.c_uint64()
+
+        def key_at(user, i):
+            lib.rmi_hip_generated_key(gen_id, dt, n_global, 0, i, C.byref(kb))
+            return kb.value
+        self._cb = _lib.KEY_AT_FN(key_at)
+        shards = (_lib.Shard * world)()
+        T._check(lib.rmi_hip_plan_shards(None, C.byref(self.root._c()), dt, n_global, num_leaves, world,
+                                         C.cast(self._cb, C.c_void_p), None, shards))
+        sh = shards[rank]
+        self.plan = ShardPlan(n_global, num_leaves, rank, world, int(sh.leaf_lo), int(sh.leaf_hi), int(sh.key_lo), int(sh.key_hi),
+                              int(sh.read_lo), int(sh.read_hi), int(sh.split_idx), int(sh.split_target))
         tr.generate_keys(dataset, np_dtype, n_global, self.plan.read_lo, self.plan.read_hi - self.plan.read_lo)
-        self.row_bytes = 24
-        per = (self.plan.leaf_hi - self.plan.leaf_lo) * self.row_bytes
-        # Two sets of buffers: with `pipeline` the all-gather of one training runs (on RCCL's stream)
-        # while the kernels of the next one write the other set -- trainings are independent jobs
-        # (the optimizer runs ~100 of them over one key set), so the exchange need not sit on the
-        # critical path of the next one.  finish() completes the last exchange.
-        self.pipeline = bool(pipeline) and on_gpu
-        nbuf = 2 if self.pipeline else 1
-        self._full = [torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-        self._mine = [torch.empty(per, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]   # the kernels write this rank's rows here
-        self._cur = 0
-        self._pending = None
-        self.full_rows = self._full[0]
-        self.my_rows = self._mine[0]
-        self._host = None if on_gpu else (torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8),
-                                          torch.empty(per, dtype=torch.uint8))
+        tr.set_fit_mode(fit_mode)
+        self.row_bytes = 24 if self.leaf_kind != 2 else 40
+        # ---- communicator: rank 0 makes the id, torch carries the 128 bytes ----
+        if self.on_gpu:
+            idt = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+                T._check(lib.rmi_hip_comm_unique_id(buf))
+                idt.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            idb = (C.c_ubyte * _lib.COMM_ID_BYTES)(*idt.cpu().tolist())
+            T._check(lib.rmi_hip_comm_init(tr._h, rank, world, idb), tr._h)
+            self._shard_c = self.plan.c_struct()
+            T._check(lib.rmi_hip_set_shard(tr._h, C.byref(self._shard_c)), tr._h)
+        else:
+            per = (self.plan.leaf_hi - self.plan.leaf_lo) * self.row_bytes
+            self._full = torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda")
+            self._mine = torch.empty(per, dtype=torch.uint8, device="cuda")
+            self._host = (torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8), torch.empty(per, dtype=torch.uint8))
         self._torch = torch
 
     def step(self):
-        b = self._cur
-        res = run_shard(self.tr, self.plan, self.root, self.leaf_kind, self._mine[b].data_ptr())   # (synchronises its stream)
-        if self._host is not None:                                               # gloo functional path: host bounce
-            full_h, mine_h = self._host
-            mine_h.copy_(self._mine[b])
-            exchange_rows(self.dist, full_h, mine_h, self.rank, self.world)
-            self._full[b].copy_(full_h)
-        elif self.pipeline:
-            if self._pending is not None:
-                # the exchange of the previous training ran beside this one's kernels; it must be
-                # complete on the HOST's timeline before its buffers are written again (the kernels
-                # run on the library's stream, which knows nothing of torch's stream waits)
-                self._pending.wait()
-                self._torch.cuda.current_stream().synchronize()
-            self._pending = self.dist.all_gather_into_tensor(self._full[b], self._mine[b], async_op=True)
-            self._cur = b ^ 1
-        else:
-            exchange_rows(self.dist, self._full[b], self._mine[b], self.rank, self.world)   # RCCL all-gather, device to device
-            self._torch.cuda.current_stream().synchronize()    # the step ends when every rank holds the full table
-        self.full_rows, self.my_rows = self._full[b], self._mine[b]
+        """One training: when it returns, every rank holds the full row table (the step of SURVEY 8d for N > 1)."""
+        if self.on_gpu:
+            res = _lib.Result()
+            with self.tr._ctx_lock:
+                rc = self.tr._lib.rmi_hip_train_sharded(self.tr._h, C.byref(self.root._c()), self.leaf_kind, self.L, C.byref(res))
+            T._check(rc, self.tr._h)
+            return res
+        res = run_shard(self.tr, self.plan, self.root, self.leaf_kind, self._mine.data_ptr())
+        full_h, mine_h = self._host
+        mine_h.copy_(self._mine)
+        exchange_rows(self.dist, full_h, mine_h, self.rank, self.world)
+        self._full.copy_(full_h)
         return res
 
+    def full_rows(self) -> np.ndarray:
+        if self.on_gpu:
+            out = np.empty(self.L * self.row_bytes, dtype=np.uint8)
+            T._check(self.tr._lib.rmi_hip_download_rows_full(self.tr._h, out.ctypes.data, out.nbytes), self.tr._h)
+            return out
+        return self._full.cpu().numpy()
+
     def finish(self):
-        """Complete the exchange that is still in flight (pipelined mode); the table of the last
-        training is then in `full_rows` on every rank."""
-        if self._pending is not None:
-            self._pending.wait()
-            self._pending = None
         self._torch.cuda.synchronize()

@@ -197,13 +197,20 @@ class Trainer:
         except Exception:
             pass
 
-    def set_keys(self, keys):
-        """numpy array (copied to HBM) or a torch CUDA tensor (borrowed in place)."""
+    def set_keys(self, keys, wait: bool = True):
+        """numpy array (copied to HBM) or a torch CUDA tensor (borrowed in place).  wait=False: the copy of a host
+        array runs on a thread of the library; ``wait_keys()`` (called by fit_root / train_leaves) joins it -- so
+        that the host root fit of a new key set overlaps its upload."""
         if isinstance(keys, np.ndarray) or isinstance(keys, np.memmap):
             arr = np.ascontiguousarray(keys)
             if arr.dtype not in _DTYPES:
                 raise TypeError(f"unsupported key dtype {arr.dtype}")
-            _check(self._lib.rmi_hip_upload_keys(self._h, arr.ctypes.data, arr.size, _DTYPES[arr.dtype]), self._h)
+            self.wait_keys()
+            if wait:
+                _check(self._lib.rmi_hip_upload_keys(self._h, arr.ctypes.data, arr.size, _DTYPES[arr.dtype]), self._h)
+            else:
+                _check(self._lib.rmi_hip_upload_keys_async(self._h, arr.ctypes.data, arr.size, _DTYPES[arr.dtype]), self._h)
+                self._uploading = True
             self._host_keys = arr
             self._keepalive = None
             self.n = arr.size
@@ -226,6 +233,11 @@ class Trainer:
             self.n = t.numel()
             return
         raise TypeError("keys must be a numpy array or a CUDA torch tensor")
+
+    def wait_keys(self):
+        if getattr(self, "_uploading", False):
+            self._uploading = False
+            _check(self._lib.rmi_hip_upload_wait(self._h), self._h)
 
     def generate_keys(self, generator: str, dtype, n_global: int, start: int = 0, count: int | None = None, seed: int = 0):
         """Synthetic sorted keys produced directly in HBM (datagen.uniform_* / dups_* shards)."""
@@ -274,12 +286,18 @@ class Trainer:
             raise RMIError(kind)
         m = _lib.ModelParams()
         if mode == "fast" and kind in (0, 4):
+            self.wait_keys()
             with self._ctx_lock:                    # device work on the context's stream
                 _check(self._lib.rmi_hip_fit_root_fast(self._h, kind, num_leaves, C.byref(m)), self._h)
             return Model._from_c(m)
         if mode not in ("exact", "fast"):
             raise ValueError("mode must be 'exact' or 'fast'")
         hk = C.c_void_p(self._host_keys.ctypes.data) if self._host_keys is not None else None
+        if kind in (0, 4) and hk is not None and getattr(self, "_uploading", False):
+            # sequential host recurrence over the host copy: no device involved, runs beside the upload
+            _check(self._lib.rmi_hip_fit_root_host(kind, _DTYPES[self._host_keys.dtype], hk, self.n, num_leaves, C.byref(m)))
+            return Model._from_c(m)
+        self.wait_keys()
         if kind in (2, 13):                         # cubic, bradix: device reductions / scans on the context's stream
             with self._ctx_lock:
                 _check(self._lib.rmi_hip_fit_root(self._h, kind, num_leaves, hk, C.byref(m)), self._h)
@@ -301,6 +319,7 @@ class Trainer:
         leaf_kind = leaf if isinstance(leaf, int) else self._lib.rmi_hip_model_from_name(leaf.encode())
         if leaf_kind < 0:
             raise RMIError(leaf_kind)
+        self.wait_keys()
         with self._ctx_lock:
             return self._train_leaves_locked(root, leaf_kind, num_leaves)
 
@@ -330,7 +349,8 @@ class Trainer:
             generation=int(res.generation), _trainer=self)
 
     def train(self, model_spec: str, branch_factor: int, root_mode: str = "exact") -> TrainedRMI:
-        """rmi_lib::train (train/mod.rs:100-126)."""
+        """rmi_lib::train (train/mod.rs:100-126).  With a key set whose upload is still running (set_keys(wait=False)) the
+        sequential host fit of a linear / robust_linear root runs beside the upload."""
         t0 = time.perf_counter_ns()
         root_kind, leaf_kind = parse_spec(model_spec)
         root = self.fit_root(root_kind, branch_factor, mode=root_mode)

@@ -83,3 +83,42 @@ def test_combine_stats():
     st = sharded.combine_stats(parts, 10)
     assert st["model_max_error"] == 5 and st["model_max_error_idx"] == 9    # last maximum wins (max_by_key)
     assert st["model_avg_error"] == 3.0 and st["model_avg_l2_error"] == 3.0 and st["model_avg_log2_error"] == 0.6
+
+
+def test_c_planner_matches_python(oracle):
+    """rmi_hip_plan_shards (the planner behind the C ABI) against the Python planner it replaces, with a host key
+    array as the key source and with the closed form of the synthetic generators (rmi_hip_generated_key)."""
+    import ctypes as C
+    from rmi_amd import _lib, sharded, train
+    lib = _lib.load()
+    for gen, gid, dt in (("uniform_u64", 0, 0), ("dups_u64", 1, 0), ("uniform_u32", 0, 1), ("dups_u32", 1, 1), ("books_u64", None, 0)):
+        keys = dg.GENERATORS[gen](60_000)
+        n, L = len(keys), 2048
+        o = oracle.train_two_layer("linear", "linear", keys, L)
+        root = train.Model(0, o.root.p, o.root.ip)
+        if gid is not None:                                  # the closed form reproduces the generator
+            kb = C.c_uint64()
+            for i in (0, 1, 7, 8, 4097, n - 1):
+                assert lib.rmi_hip_generated_key(gid, dt, n, 0, i, C.byref(kb)) == 0 and kb.value == int(keys[i])
+        cb = _lib.KEY_AT_FN(lambda user, i: int(keys[i]))
+        for world in (1, 2, 8):
+            want = sharded.Planner(lambda i: keys[i], n, keys.dtype, root, L).plan(world)
+            got = (_lib.Shard * world)()
+            rc = lib.rmi_hip_plan_shards(None, C.byref(root._c()), dt, n, L, world, C.cast(cb, C.c_void_p), None, got)
+            assert rc == 0
+            for w, g in zip(want, got):
+                assert (g.n_global, g.read_lo, g.read_hi, g.key_lo, g.key_hi, g.leaf_lo, g.leaf_hi, g.split_idx, g.split_target) == \
+                       (w.n_global, w.read_lo, w.read_hi, w.key_lo, w.key_hi, w.leaf_lo, w.leaf_hi, w.split_idx, w.split_target)
+        bad = (_lib.Shard * 3)()
+        assert lib.rmi_hip_plan_shards(None, C.byref(root._c()), dt, n, L, 3, C.cast(cb, C.c_void_p), None, bad) == -6   # L % world != 0
+
+
+def test_comm_entry_points_without_a_gpu():
+    """No GPU here: the communicator calls must fail with a code, never crash (RCCL is bound at run time)."""
+    import ctypes as C
+    from rmi_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+    assert lib.rmi_hip_comm_unique_id(buf) in (0, -16, -17)
+    assert lib.rmi_hip_comm_unique_id(None) == -6
+    assert lib.rmi_hip_comm_init(None, 0, 1, None) == -6
