@@ -13,8 +13,9 @@ Workloads (`--config`, BASELINE.json):
     C3             200M uniform uint64, cubic,linear, 2^20 leaves
     C4             800M uniform uint64, linear,linear, 2^21 leaves   (8 GPUs x 100M keys; strong scaling)
     C5             400M uint32 (uniform | --dataset dups), radix,linear_spline, 2^22 leaves  (strong scaling)
-`--scaling weak` (default): every rank holds `--keys` keys and `--leaves` leaves of its own, the global model is N times
-larger.  `--scaling strong`: the configuration is the GLOBAL problem, cut into N leaf-aligned shards.
+`--scaling strong` (default; BASELINE.json quotes its metric on ONE 200M-key problem "at 1/2/4/8 GPUs"): the configuration is the
+GLOBAL problem, cut into N leaf-aligned shards.  `--scaling weak`: every rank holds `--keys` keys and `--leaves` leaves of its own,
+the global model is N times larger.
 `--mode`: how linear leaves are fitted (include/rmi_hip.h, rmi_hip_set_fit_mode): exact | onepass_guarded
 (default: one HBM pass, per-leaf error integers still bit-identical to the reference) | onepass.
 
@@ -74,7 +75,7 @@ def parse_args():
     a.spec = a.spec or spec
     a.dataset = a.dataset or dataset
     a.dtype = a.dtype or dtype
-    a.scaling = a.scaling or scaling or "weak"
+    a.scaling = a.scaling or scaling or "strong"
     a.config = a.config or "M"
     return a
 
@@ -282,7 +283,7 @@ def main():
             t2 = time.perf_counter()
             out["pcie_inclusive"] = {"value": n_global / (t2 - t0), "unit": "keys/s", "upload_ms": (t1 - t0) * 1e3,
                                      "upload_GBps": n_global * key_bytes / (t1 - t0) / 1e9, "step_ms": (t2 - t1) * 1e3,
-                                     "note": "host buffer -> rmi_hip_upload_keys (pinned staging, chunked) -> one step; not the headline value"}
+                                     "note": "pageable host buffer -> rmi_hip_upload_keys (one hipMemcpy: the runtime stages it at ~53 GB/s of the 63 GB/s link) -> one step; not the headline value"}
             if root_kind in (0, 4):
                 # B_leaf + B_root over t_root + t_leaf when the root is fitted on the GPU -- the
                 # opt-in fast root (parallel sums, not bit-identical to the reference's sequential fit)

@@ -166,7 +166,9 @@ int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
  *   RMI_FIT_ONEPASS: the same without the re-fit of guard-flagged leaves (they are counted in
  *     rmi_hip_result.guard_leaves): error bounds are those of the emitted coefficients (the index is
  *     sound), a few may differ by one from the reference's.
- * guard_k <= 0 keeps the current factor (default 4).  Leaf kinds other than `linear` ignore the mode. */
+ * guard_k <= 0 keeps the current factor (default 2: the largest distance observed between the two lines, over
+ * uniform / heavy-tailed / clustered key sets of 200 M keys, is 0.46 of the bound with factor 1).  Leaf kinds other
+ * than `linear` ignore the mode. */
 enum rmi_hip_fit_mode { RMI_FIT_EXACT = 0, RMI_FIT_ONEPASS_GUARDED = 1, RMI_FIT_ONEPASS = 2 };
 int rmi_hip_set_fit_mode(rmi_hip_ctx* ctx, int mode, double guard_k);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = context's own. */

@@ -72,7 +72,7 @@ struct rmi_hip_ctx {
   // fit mode of linear leaves: 0 = exact (two streaming passes), 1 = one pass from sufficient statistics with the
   // guard (error integers bit-identical, flagged leaves re-fitted exactly), 2 = one pass, guard only counted
   int fit_mode = 0;
-  double guard_k = 4.0;
+  double guard_k = 2.0;
   uint64_t sigma_waves = 4096;                  // k_sigma2: chunks the keys are cut into (one wave each)
   unsigned int sigma_min_leaf = 32;             // average keys per leaf below which the exact kernels are used
   unsigned int* d_flist = nullptr;              // leaves handed to the exact kernels: SG_REGIONS regions of flist_cap ids ...

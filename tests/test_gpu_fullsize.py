@@ -29,6 +29,76 @@ def test_metric_config_full_size_vs_oracle(oracle):
     tr.close()
 
 
+def test_metric_config_full_size_one_pass_vs_oracle(oracle):
+    """The metric configuration in the guarded one-pass mode (what bench.py times): bucket table, error integers, counts
+    and aggregates bit-identical to the oracle; coefficients are the same lines to the reference's rounding noise."""
+    from rmi_amd import train
+    n, L = 200_000_000, 1 << 20
+    tr = train.Trainer()
+    tr.generate_keys("uniform", np.uint64, n)
+    keys = tr.download_keys()
+    root = tr.fit_root("linear", L)
+    tr.set_fit_mode("onepass_guarded")
+    g = tr.train_leaves(root, "linear", L).materialize()
+    tr.close()
+    o = oracle.train_two_layer("linear", "linear", keys, L, threads=2)
+    assert g.fit_mode_used == 1 and root.p == o.root.p
+    assert np.array_equal(g.leaf_starts, o.leaf_start)
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err), f"{np.count_nonzero(g.last_layer_max_l1s != o.leaf_err)} max-error ints differ"
+    assert np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx and g.model_avg_error == o.model_avg_error
+    gp, op = g.leaf_params, o.leaf_params
+    relb = np.abs(gp[:, 1] - op[:, 1]) / np.abs(op[:, 1])
+    assert relb.max() <= 1e-8 and np.mean(relb <= 1e-9) >= 0.95, (relb.max(), np.mean(relb <= 1e-9))
+    assert 0 < g.exact_leaves <= 0.03 * L
+    print(f"\none-pass at full size: {g.exact_leaves} leaves re-fitted exactly ({g.guard_leaves} by the guard), slope differences: "
+          f"max {relb.max():.2e}, {100 * np.mean(relb <= 1e-9):.2f} % within 1e-9, {int(np.count_nonzero(relb == 0))} bit-identical")
+
+
+@pytest.mark.parametrize("mode", ["exact", "onepass_guarded"])
+def test_config2_books_shaped_full_size_vs_oracle(oracle, mode):
+    """BASELINE config 2 at its stated size: 200M books-shaped uint64 keys, linear,linear, 262144 leaves (one leaf of
+    ~2.5M keys among them), bit for bit against the oracle."""
+    from rmi_amd import train, datagen
+    n, L = 200_000_000, 262_144
+    keys = datagen.books_u64(n)
+    tr = train.Trainer(keys)
+    root = tr.fit_root("linear", L)
+    tr.set_fit_mode(mode)
+    g = tr.train_leaves(root, "linear", L).materialize()
+    tr.close()
+    o = oracle.train_two_layer("linear", "linear", keys, L, threads=2)
+    assert root.p == o.root.p
+    assert np.array_equal(g.leaf_starts, o.leaf_start)
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err)
+    assert np.array_equal(g.leaf_counts, o.leaf_count)
+    if mode == "exact":
+        assert np.array_equal(g.leaf_params, o.leaf_params)
+    assert g.model_max_error == o.model_max_error and g.model_avg_error == o.model_avg_error
+
+
+def test_config3_cubic_root_full_size_vs_oracle(oracle):
+    """BASELINE config 3 at its stated size: 200M uniform uint64 keys, cubic root, linear leaves, 2^20 leaves."""
+    from rmi_amd import train
+    n, L = 200_000_000, 1 << 20
+    tr = train.Trainer()
+    tr.generate_keys("uniform", np.uint64, n)
+    keys = tr.download_keys()
+    root = tr.fit_root("cubic", L)
+    g = tr.train_leaves(root, "linear", L).materialize()
+    tr.set_fit_mode("onepass_guarded")
+    g1 = tr.train_leaves(root, "linear", L).materialize()
+    tr.close()
+    o = oracle.train_two_layer("cubic", "linear", keys, L, threads=2)
+    assert root.p == o.root.p
+    for r in (g, g1):
+        assert np.array_equal(r.leaf_starts, o.leaf_start)
+        assert np.array_equal(r.last_layer_max_l1s, o.leaf_err)
+        assert np.array_equal(r.leaf_counts, o.leaf_count)
+    assert np.array_equal(g.leaf_params, o.leaf_params)
+    assert g1.fit_mode_used == 1
+
+
 @pytest.mark.parametrize("n,dtype,spec,L,gen", [
     (800_000_000, np.uint64, "linear,linear", 1 << 21, "uniform"),          # config 4's size on one GPU
     (400_000_000, np.uint32, "radix,linear_spline", 1 << 22, "dups"),       # config 5's shape (u32, duplicate runs)
