@@ -53,7 +53,7 @@ struct SgParams {
   uint64_t chunk;                          // keys per block, a multiple of 16
   double guard_k;                          // safety factor of the guard bound
   int mode;                                // 1: guard-flagged leaves are re-fitted exactly; 2: only counted
-  int dbg;                                 // timing experiments only (results wrong): 1 no leaf rounds, 2 no sums loop, 4 no error loop
+  int dbg;                                 // timing experiments only (results wrong): 1 no leaf rounds, 2 no sums loop, 4 no error loop, 8 loads only
   SgList flist;                            // leaf ids handed to the exact kernels
 };
 
@@ -529,6 +529,14 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
     load_batch(nxt, A + BATCH);
     const bool interior = (A > sp.rd_lo) && (A + BATCH <= sp.rd_hi);
     bool dense = false;
+    if (sg.dbg & 8) {                                               // timing experiment: the loads alone
+      unsigned int acc = 0;
+#pragma unroll
+      for (int k = 0; k < NLOAD; k++) acc ^= cur[k].x ^ cur[k].y ^ cur[k].z ^ cur[k].w;
+      if (acc == 0x12345678u) eflags |= 64u;
+      if (A + BATCH >= c1) stop = true;
+      continue;
+    }
     auto phase1 = [&](auto edge_tag) {
       constexpr bool EDGE = decltype(edge_tag)::value;
       constexpr bool FULL = EDGE || !SPARSE;                        // every key's target is evaluated up front
