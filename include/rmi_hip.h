@@ -131,9 +131,10 @@ typedef struct {
   uint64_t long_leaves;           /* leaves too long for the lockstep fit pass, fitted one lane each
                                    * (skew diagnostic: each is a sequential chain of its own length) */
   /* one-pass mode (rmi_hip_set_fit_mode): did this call run it, how many leaves it handed to the exact
-   * kernels (irregular leaves + guard), and how many leaves the guard flagged */
+   * kernels (irregular leaves + guard), how many leaves the guard flagged, and (RMI_FIT_ONEPASS) how many long
+   * leaves -- longer than a wave's LDS ring, or cut at a chunk border -- were fitted from merged partial sums */
   int32_t fit_mode_used;
-  int32_t _pad2;
+  int32_t merged_leaves;
   uint64_t exact_leaves;
   uint64_t guard_leaves;
   uint64_t generation;            /* number of this train call on the context, for rmi_hip_download_checked */

@@ -31,7 +31,7 @@ class Result(C.Structure):
         ("sum_n_err", C.c_uint64), ("sum_l2", C.c_double), ("sum_log2", C.c_double),
         ("device_ns", C.c_uint64), ("kernel_ns", C.c_uint64 * 8),
         ("long_leaves", C.c_uint64),
-        ("fit_mode_used", C.c_int32), ("_pad2", C.c_int32),
+        ("fit_mode_used", C.c_int32), ("merged_leaves", C.c_int32),
         ("exact_leaves", C.c_uint64), ("guard_leaves", C.c_uint64),
         ("generation", C.c_uint64),
     ]

@@ -79,6 +79,11 @@ struct rmi_hip_ctx {
   unsigned long long* d_flist_cnt = nullptr;    // ... and their counters
   unsigned int* d_xlong = nullptr;              // listed leaves too long for one wave's error pass
   uint64_t xlong_cap = 0;
+  void* d_recs = nullptr;                       // one-pass mode 2: partial sums of long leaves, [blocks][rpw] + the counts
+  uint64_t recs_bytes = 0;
+  unsigned long long* d_segs = nullptr;         // ... and the stretches of the merged leaves for their error pass
+  uint64_t segs_cap = 0;
+  SgParams last_sg;                             // the parameters of the last k_sigma2 launch (k_fit_list reads the records)
   void* d_bkeys = nullptr;                      // one-pass mode: key[e] and key[s-1] of every leaf (2 x leaves keys), see k_finalize
   uint64_t bkeys_cap = 0;
   uint64_t flist_cap = 0;                       // entries per region
@@ -251,6 +256,8 @@ static void free_outputs(rmi_hip_ctx* c) {
   if (c->d_flist_cnt) { (void)hipFree(c->d_flist_cnt); c->d_flist_cnt = nullptr; }
   if (c->d_bkeys) { (void)hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_cap = 0; }
   if (c->d_xlong) { (void)hipFree(c->d_xlong); c->d_xlong = nullptr; c->xlong_cap = 0; }
+  if (c->d_recs) { (void)hipFree(c->d_recs); c->d_recs = nullptr; c->recs_bytes = 0; }
+  if (c->d_segs) { (void)hipFree(c->d_segs); c->d_segs = nullptr; c->segs_cap = 0; }
   c->d_leaf_start = nullptr; c->d_params = nullptr; c->d_maxerr = nullptr; c->d_run = nullptr;
   c->d_err = nullptr; c->d_count = nullptr; c->d_rows = nullptr; c->d_tilemin = nullptr;
   c->cap_leaves = 0; c->cap_ppl = 0;
@@ -954,6 +961,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   init.long_cap = c->long_cap;
   init.flag_cap = (uint64_t)L_own + 64;
   init.xlong_cap = n_it / SG_ERR_LONG + 16;
+  init.seg_cap = n_it / SG_SEG + L_own + 16;
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
@@ -999,18 +1007,45 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       sgp.flist.ids = c->d_flist; sgp.flist.cnt = c->d_flist_cnt; sgp.flist.cap = c->flist_cap;
       { const char* dbg = std::getenv("RMI_HIP_SIGMA_DBG"); sgp.dbg = dbg ? std::atoi(dbg) : 0; }
       {
-        auto launch2 = [&](auto ring_tag, auto batch_tag) {
+        auto launch2 = [&](auto ring_tag, auto batch_tag) -> int {
           constexpr int RING = decltype(ring_tag)::value, BATCH = decltype(batch_tag)::value;
           uint64_t chunk = (n_it + c->sigma_waves - 1) / c->sigma_waves;
           chunk = ((chunk + BATCH - 1) / BATCH) * BATCH;
           if (chunk < (uint64_t)BATCH * 16) chunk = (uint64_t)BATCH * 16;
           sgp.chunk = chunk;
           const uint64_t sblocks = (n_it + chunk - 1) / chunk;
-          hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state,
-                             (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
+          sgp.recs = nullptr; sgp.rec_cnt = nullptr; sgp.rpw = 0; sgp.segs = nullptr;
+          if (c->fit_mode == 2) {
+            // a stretch of a long leaf is at least RING / 2 - BATCH keys, or the only one of its wave
+            const uint64_t rpw = chunk / (RING / 2 - BATCH) + 3;
+            const uint64_t need = sblocks * rpw * sizeof(SgRec) + sblocks * 4;
+            if (c->recs_bytes < need) {
+              if (c->d_recs) (void)hipFree(c->d_recs);
+              c->d_recs = nullptr; c->recs_bytes = 0;
+              HIPCHK(c, hipMalloc(&c->d_recs, need));
+              c->recs_bytes = need;
+            }
+            sgp.recs = (SgRec*)c->d_recs; sgp.rec_cnt = (unsigned int*)((char*)c->d_recs + sblocks * rpw * sizeof(SgRec)); sgp.rpw = (unsigned int)rpw;
+            const uint64_t scap = n_it / SG_SEG + L_own + 16;
+            if (c->segs_cap < scap) {
+              if (c->d_segs) (void)hipFree(c->d_segs);
+              c->d_segs = nullptr; c->segs_cap = 0;
+              HIPCHK(c, hipMalloc(&c->d_segs, scap * 8));
+              c->segs_cap = scap;
+            }
+            sgp.segs = c->d_segs;
+          }
+          c->last_sg = sgp;
+          if (c->fit_mode == 2)
+            hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH, true>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state,
+                               (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
+          else
+            hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH, false>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state,
+                               (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
+          return RMI_OK;
         };
-        if (std::getenv("RMI_HIP_SIGMA_SMALL")) launch2(std::integral_constant<int, 1024>{}, std::integral_constant<int, 256>{});
-        else launch2(std::integral_constant<int, 2048>{}, std::integral_constant<int, 512>{});
+        const int lrc = launch2(std::integral_constant<int, 2048>{}, std::integral_constant<int, 512>{});
+        if (lrc != RMI_OK) return lrc;
         mark();
       }
     }
@@ -1051,12 +1086,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     if constexpr (LEAF == K_LINEAR) {
       // --- exact kernels for the leaves the one-pass kernel handed over ---
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
-      hipLaunchKernelGGL((k_fit_list<K>), dim3(4 * SG_REGIONS), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_long, c->d_xlong);
+      hipLaunchKernelGGL((k_fit_list<K>), dim3(4 * SG_REGIONS), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->last_sg, c->d_long, c->d_xlong);
       const uint64_t lblocks = c->long_cap < 8192 ? c->long_cap : 8192;
       hipLaunchKernelGGL((k_fit_long<ROOT, K>), dim3((unsigned)lblocks), dim3(64), 0, s, keys, sp, rp, leaf_start, c->d_state, params, c->d_long);
       mark();
       hipLaunchKernelGGL((k_err_list<K>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, params, fl, maxerr, run);
       hipLaunchKernelGGL((k_err_long<K>), dim3(2048), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_xlong, maxerr, run);
+      if (c->fit_mode == 2) {
+        const uint64_t sb = c->segs_cap < 16384 ? c->segs_cap : 16384;
+        hipLaunchKernelGGL((k_err_seg<K>), dim3((unsigned)sb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_segs, maxerr, run);
+      }
     }
   } else if (n_it == 0) {
   } else if (!stream_fit) {
@@ -1241,7 +1280,8 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   out->split_idx = st.split_idx; out->split_target = st.split_target;
   out->long_leaves = st.long_count;
   out->fit_mode_used = c->last_sigma ? c->fit_mode : 0;
-  out->exact_leaves = c->last_sigma ? st.flag_count : 0;
+  out->exact_leaves = c->last_sigma ? st.flag_count - st.merged_count : 0;
+  out->merged_leaves = c->last_sigma ? (int32_t)(st.merged_count < 0x7fffffffull ? st.merged_count : 0x7fffffffull) : 0;
   out->guard_leaves = c->last_sigma ? st.guard_count : 0;
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev[8], c->ev[9]));

@@ -37,6 +37,7 @@ namespace rmi {
 // a counter of its own: appends from thousands of waves to ONE counter serialise at ~26 ns each (0.1 ms for the
 // 4 000 waves of a 200 M-key run); spread by leaf id no region can overflow its share of the capacity.
 constexpr int SG_REGIONS = 64;
+constexpr int SG_SEG = 2048;                // error pass of a merged leaf: stretches of this many keys, one wave each (k_err_seg)
 constexpr int SG_ERR_LONG = 16384;          // listed leaves with more keys: the whole grid per leaf (k_err_long)
 struct SgList {
   unsigned int* ids;                       // [SG_REGIONS][cap]
@@ -49,12 +50,24 @@ struct SgList {
   }
 };
 
+// A long leaf (one that does not fit a wave's ring, or that runs across chunks) is summed piecewise: every wave that
+// holds a stretch of it leaves one record, shifted sums about the stretch's first key; k_fit_list merges them.
+constexpr unsigned int SG_TAG = 0x80000000u;   // list entry: "fitted from merged records" (leaf ids are below 2^31)
+struct SgRec {
+  unsigned int leaf, first, n, pad;        // keys [first, first + n) of the leaf
+  double piv, a0, a1, a2;                  // x[first]; S dx, S dx^2, S dx dy with dx = x - piv, dy = index - first
+};
+
 struct SgParams {
-  uint64_t chunk;                          // keys per block, a multiple of 16
+  uint64_t chunk;                          // keys per block, a multiple of the batch
   double guard_k;                          // safety factor of the guard bound
   int mode;                                // 1: guard-flagged leaves are re-fitted exactly; 2: only counted
   int dbg;                                 // timing experiments only (results wrong): 1 no leaf rounds, 2 no sums loop, 4 no error loop, 8 loads only
   SgList flist;                            // leaf ids handed to the exact kernels
+  SgRec* recs;                             // [blocks][rpw] (mode 2)
+  unsigned int* rec_cnt;                   // [blocks]
+  unsigned int rpw;                        // records a block can leave
+  unsigned long long* segs;                // (leaf << 32 | stretch) of the merged leaves, DevState::seg_count entries
 };
 
 // 16 bytes of keys, streamed once (non-temporal); the address is only key-aligned in a shard
@@ -79,21 +92,108 @@ __device__ __forceinline__ unsigned int sg_absdiff(unsigned int a, unsigned int 
 // lower_bound_correction.rs:104-119), exactly what k_err computes per key.
 // Both walk the regions of the list: block b takes region b % SG_REGIONS.
 // ---------------------------------------------------------------------------------------------
+// Moments of a set of points about a common origin, merged pairwise (Chan et al.): exact algebra, and the
+// cancellation stays at the scale of one stretch.
+struct SgMom {
+  double n, mx, my, m2, c;
+  __device__ __forceinline__ void add(const SgMom& b) {
+    const double nn = n + b.n, dx = b.mx - mx, dy = b.my - my, w = n * b.n / nn;
+    m2 += b.m2 + dx * dx * w;
+    c += b.c + dx * dy * w;
+    mx += dx * (b.n / nn);
+    my += dy * (b.n / nn);
+    n = nn;
+  }
+};
+// The line of leaf j = keys [s, e) from the records the waves of k_sigma2 left for it.  The records hold the sums
+// over the leaf's own keys; the container (leaf_container: [lo, hi], Q2/Q3 at the split and at the two ends of the
+// data) adds the borrowed points, drops the key at the split, and its last item counts twice (Q1).  x relative to
+// key s, y relative to s.  false: a duplicate or a missing record spoils the sums -> the exact path.
+template <typename K>
+__device__ bool sg_merge_long(uint64_t j, uint64_t s, uint64_t e, uint64_t lo, uint64_t hi, const K* __restrict__ keys, const Span& sp,
+                              const SgParams& sg, double* __restrict__ params) {
+  if (!(e > s) || lo < sp.rd_lo || hi >= sp.rd_hi) return false;
+  uint64_t w = (s - sp.it_lo) / sg.chunk;
+  const uint64_t nw = (sp.it_hi - sp.it_lo + sg.chunk - 1) / sg.chunk;
+  const SgRec* rec = nullptr;
+  {
+    const unsigned int cnt = sg.rec_cnt[w] < sg.rpw ? sg.rec_cnt[w] : sg.rpw;
+    const SgRec* base = sg.recs + w * sg.rpw;
+    for (unsigned int q = 0; q < cnt; q++) if (base[q].leaf == (unsigned int)j && base[q].first == (unsigned int)s) { rec = base + q; break; }
+  }
+  if (!rec) return false;
+  const double P = rec->piv;
+  SgMom m; m.n = 0.0; m.mx = 0.0; m.my = 0.0; m.m2 = 0.0; m.c = 0.0;
+  uint64_t next = s;
+  for (;;) {
+    if (rec->n == 0u) return false;
+    const double nr = (double)rec->n, h = (nr - 1.0) * 0.5;
+    SgMom b;
+    b.n = nr;
+    b.mx = (rec->piv - P) + rec->a0 / nr;
+    b.my = (double)(next - s) + h;
+    b.m2 = rec->a1 - rec->a0 * (rec->a0 / nr);
+    b.c = rec->a2 - rec->a0 * h;
+    if (m.n == 0.0) m = b; else m.add(b);
+    next += rec->n;
+    if (next >= e) break;
+    if (++w >= nw || sg.rec_cnt[w] == 0u) return false;
+    rec = sg.recs + w * sg.rpw;                                                // an inherited stretch is a wave's first record
+    if (rec->leaf != (unsigned int)j || rec->first != (unsigned int)next) return false;
+  }
+  if (next != e || !(m.m2 == m.m2)) return false;                              // (NaN: duplicate keys inside the leaf)
+  SgMom pt; pt.n = 1.0; pt.m2 = 0.0; pt.c = 0.0;
+  if (lo > s) {                                                                // Q2: the key at the split belongs to no container
+    if (lo != s + 1 || m.n < 2.0) return false;
+    const double x = KeyTraits<K>::as_float(keys[s]) - P, y = 0.0;
+    const double n1 = m.n - 1.0;
+    const double mxo = m.mx - (x - m.mx) / n1, myo = m.my - (y - m.my) / n1, dx = x - mxo;
+    m.c -= dx * (y - m.my); m.m2 -= dx * (x - m.mx);
+    m.mx = mxo; m.my = myo; m.n = n1;
+  } else if (lo < s) {                                                         // prev-last (two_layer.rs:74-78)
+    pt.mx = KeyTraits<K>::as_float(keys[lo]) - P;
+    pt.my = (double)first_occurrence(keys, lo, sp.rd_lo) - (double)s;
+    m.add(pt);
+  }
+  // the last item of the container, twice (models/mod.rs:180): next-first (key e, its own first occurrence) or the last own key
+  pt.mx = KeyTraits<K>::as_float(keys[hi]) - P; pt.my = (double)(hi - s);
+  if (hi >= e) m.add(pt);
+  m.add(pt);
+  if (!(m.m2 > 0.0) || !(m.m2 < 1.7e308)) return false;
+  const double beta = m.c / m.m2;
+  const double alpha = ((double)s + m.my) - beta * (P + m.mx);
+  if (!(fabs(beta) < 1.7e308) || !(fabs(alpha) < 1.7e308)) return false;
+  params[2ull * j] = alpha; params[2ull * j + 1] = beta;
+  return true;
+}
+
 template <typename K>
 __global__ void __launch_bounds__(256) k_fit_list(const K* __restrict__ keys, Span sp,
                                                   const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
-                                                  double* __restrict__ params, SgList fl,
+                                                  double* __restrict__ params, SgList fl, SgParams sg,
                                                   unsigned long long* __restrict__ long_idx, unsigned int* __restrict__ xlong) {
+  __shared__ unsigned int merged_blk;
+  if (threadIdx.x == 0) merged_blk = 0u;
+  __syncthreads();
   const unsigned int rg = blockIdx.x % SG_REGIONS;
   const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
   if (blockIdx.x < SG_REGIONS && threadIdx.x == 0) atomicAdd(&st->flag_count, cnt);      // (total, for the caller)
-  const unsigned int* ids = fl.ids + (unsigned long long)rg * fl.cap;
+  unsigned int* ids = fl.ids + (unsigned long long)rg * fl.cap;
   for (unsigned long long i = (unsigned long long)(blockIdx.x / SG_REGIONS) * blockDim.x + threadIdx.x; i < cnt;
        i += (unsigned long long)(gridDim.x / SG_REGIONS) * blockDim.x) {
-    const uint64_t j = ids[i];
+    const bool tagged = (ids[i] & SG_TAG) != 0u;
+    const uint64_t j = ids[i] & ~SG_TAG;
     uint64_t lo, hi;
     const int ck = leaf_container(j, leaf_start[j], leaf_start[j + 1], sp.n, st->split_idx, st->split_target, lo, hi);
-    if (ck == 2) {
+    if (ids[i] & SG_TAG) ids[i] = (unsigned int)j;                  // (the tag stays only where the merge succeeds)
+    if (tagged && ck == 2 && sg_merge_long<K>(j, leaf_start[j], leaf_start[j + 1], lo, hi, keys, sp, sg, params)) {
+      ids[i] = (unsigned int)j | SG_TAG;
+      atomicAdd(&merged_blk, 1u);
+      const uint64_t nseg = (leaf_start[j + 1] - leaf_start[j] + SG_SEG - 1) / SG_SEG;
+      const unsigned long long pos = atomicAdd(&st->seg_count, (unsigned long long)nseg);
+      for (uint64_t q = 0; q < nseg && pos + q < st->seg_cap; q++) sg.segs[pos + q] = ((unsigned long long)j << 32) | q;
+      continue;
+    } else if (ck == 2) {
       const unsigned long long pos = atomicAdd(&st->long_count, 1ull);
       if (pos < st->long_cap) long_idx[pos] = leaf_start[j];
     } else fit_one_leaf<K_LINEAR, K>(j, keys, sp, leaf_start, st, params);
@@ -102,6 +202,8 @@ __global__ void __launch_bounds__(256) k_fit_list(const K* __restrict__ keys, Sp
       if (pos < st->xlong_cap) xlong[pos] = (unsigned int)j;
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && merged_blk) atomicAdd(&st->merged_count, (unsigned long long)merged_blk);
 }
 
 template <typename K>
@@ -114,6 +216,7 @@ __global__ void __launch_bounds__(64) k_err_list(const K* __restrict__ keys, Spa
   const unsigned int* ids = fl.ids + (unsigned long long)rg * fl.cap;
   const int lane = threadIdx.x;
   for (unsigned long long t = blockIdx.x / SG_REGIONS; t < cnt; t += gridDim.x / SG_REGIONS) {
+    if (ids[t] & SG_TAG) continue;                                 // a merged leaf: k_err_seg's
     const uint64_t j = ids[t];
     const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
     if (e - s > (uint64_t)SG_ERR_LONG) continue;                   // k_err_long's
@@ -172,6 +275,43 @@ __global__ void __launch_bounds__(256) k_err_long(const K* __restrict__ keys, Sp
   }
 }
 
+// The merged leaves: no duplicate keys inside (the merge would have failed), so y is the key's index and every run
+// has length 1; a wave streams one stretch of SG_SEG keys, eight independent loads per lane in flight.
+template <typename K>
+__global__ void __launch_bounds__(64) k_err_seg(const K* __restrict__ keys, Span sp,
+                                                const unsigned long long* __restrict__ leaf_start, const DevState* __restrict__ st,
+                                                const double* __restrict__ params, const unsigned long long* __restrict__ segs,
+                                                unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
+  constexpr int U = 8;
+  const unsigned long long cnt = st->seg_count < st->seg_cap ? st->seg_count : st->seg_cap;
+  const int lane = threadIdx.x;
+  for (unsigned long long t = blockIdx.x; t < cnt; t += gridDim.x) {
+    const uint64_t j = segs[t] >> 32, q = segs[t] & 0xffffffffull;
+    const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+    const uint64_t a = s + q * SG_SEG, b = a + SG_SEG < e ? a + SG_SEG : e;
+    unsigned long long err = 0;
+    for (uint64_t i0 = a + lane; i0 < b; i0 += 64 * U) {
+      K kv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const uint64_t i = i0 + (uint64_t)u * 64; kv[u] = keys[i < b ? i : b - 1]; }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint64_t i = i0 + (uint64_t)u * 64;
+        if (i < b) {
+          const uint64_t er = error_between(leaf_predict<K_LINEAR, K>(params + j * 2, kv[u]), i, sp.n);
+          err = er > err ? er : err;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const unsigned long long oe = shfl_down_u64(err, d); err = oe > err ? oe : err; }
+    if (lane == 0) {
+      if (err) atomicMax(&leaf_maxerr[j], err);
+      if (q == 0 && s + 1 < sp.n) leaf_run[j] = 1;                 // (lower_bound_correction.rs:104-119: runs of equal keys)
+    }
+  }
+}
+
 // =============================================================================================
 // k_sigma2: AUTONOMOUS WAVES.  (A first version with block-wide tiles, rows of 16 keys per thread and seven
 // barriers per tile was correct but spent half of its wave time in those barriers: 1.24 ms for 200 M keys.)
@@ -195,7 +335,7 @@ __global__ void __launch_bounds__(256) k_err_long(const K* __restrict__ keys, Sp
 // A leaf that does not fit the ring (RING keys) is irregular ("long"); so are the leaves at the split
 // of the 2-way join, the first and the last leaf, and leaves with duplicate keys.
 // =============================================================================================
-constexpr unsigned S2_SPLIT = 1u, S2_START = 2u, S2_END = 4u, S2_LONG = 8u;
+constexpr unsigned S2_SPLIT = 1u, S2_START = 2u, S2_END = 4u, S2_LONG = 8u, S2_INHERIT = 16u;
 constexpr int S2_PAD = 128;                          // the first S2_PAD ring entries are mirrored behind its end
 constexpr int S2_U = 4;                              // keys per lane and unrolled step of the two leaf loops
 
@@ -268,7 +408,7 @@ __device__ __forceinline__ unsigned int s2_target(const RootP& r, double Lm1f, u
 // (cubic, loglinear, normal; a radix table may be caller-provided) are evaluated at every key.
 template <int ROOT> __device__ __forceinline__ constexpr bool s2_root_monotone() { return ROOT == K_LINEAR || ROOT == K_RADIX; }
 
-template <int ROOT, typename K, int RING, int BATCH>
+template <int ROOT, typename K, int RING, int BATCH, bool LSUM>
 __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span sp, RootP r, SgParams sg,
                                                unsigned long long* __restrict__ leaf_start, double* __restrict__ params,
                                                unsigned long long* __restrict__ leaf_maxerr, DevState* __restrict__ st,
@@ -350,6 +490,58 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   bool stop = false;                                                // a boundary at or behind c1 is in the list
   unsigned int eflags = 0;
 
+  // ---- long leaves.  A leaf that outgrows the ring, or that is still open XWIN keys behind the end of the chunk,
+  // cannot be finished from LDS.  Chunk rule (both sides evaluate it on the same keys): a leaf open at a chunk
+  // border c with no boundary in [c, c + XWIN) is cut at c -- the wave before stops there, the wave behind takes
+  // [c, ...) as an "inherited" stretch.  In mode 2 every stretch is summed while it passes through the ring (all 64
+  // lanes, shifted sums about the stretch's first key) and left as one record; k_fit_list merges the records and
+  // the error kernels of the list do the rest.  In mode 1 such a leaf cannot be certified: exact kernels.
+  constexpr unsigned int XWIN = RING / 2;
+  static_assert(XWIN % BATCH == 0, "the chunk rule is evaluated at batch ends");
+  // (the rarely touched scalars of this path live in LDS: as wave-uniform registers they pushed the hot loop's
+  //  scalars into spills -- 25 us on the 200 M-key run)
+  __shared__ unsigned int acc_u[4];                                 // first and next index of the stretch being summed, records left
+  __shared__ double acc_pxs;                                        // x of the stretch's first key
+  if (lane == 0) acc_u[2] = 0u;
+  unsigned int lst = 0u;                                            // LS_*: state of this path
+  constexpr unsigned int LS_OPEN = 1u, LS_ACC = 2u, LS_SEEN = 4u;   // entry 0 is an open long leaf; it is being summed; a boundary was seen
+  double P0 = 0.0, P1 = 0.0, P2 = 0.0;
+  auto acc_start = [&](unsigned int s0) {
+    lst |= LS_ACC;
+    const double px = xring[rpos(s0)];
+    if (lane == 0) { acc_u[0] = s0; acc_u[1] = s0; acc_pxs = px; }
+    P0 = 0.0; P1 = 0.0; P2 = 0.0;
+    wave_sync();
+  };
+  auto acc_run = [&](unsigned int upto) {                           // adds the keys [next, upto) (still in the ring)
+    const unsigned int first = acc_u[0], next = acc_u[1];
+    if (upto <= next) return;
+    const double px = acc_pxs;
+    for (unsigned int k = next + (unsigned int)lane; k < upto; k += 64u) {
+      const double dx = xring[rpos(k)] - px, dy = (double)(k - first);
+      P0 += dx; P1 = __builtin_fma(dx, dx, P1); P2 = __builtin_fma(dx, dy, P2);
+    }
+    wave_sync();
+    if (lane == 0) acc_u[1] = upto;
+    wave_sync();
+  };
+  auto acc_emit = [&](unsigned int leaf) {
+    double t0 = s2_group_sum<32>(P0), t1 = s2_group_sum<32>(P1), t2 = s2_group_sum<32>(P2);
+    t0 += __shfl_xor(t0, 32); t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+    const unsigned int rcnt = acc_u[2];
+    wave_sync();
+    if (lane == 0) {
+      if (rcnt < sg.rpw) {
+        SgRec rc; rc.leaf = leaf; rc.first = acc_u[0]; rc.n = acc_u[1] - acc_u[0]; rc.pad = 0u;
+        rc.piv = acc_pxs; rc.a0 = t0; rc.a1 = t1; rc.a2 = t2;
+        sg.recs[(unsigned long long)blockIdx.x * sg.rpw + rcnt] = rc;
+      }
+      acc_u[2] = rcnt + 1u;
+    }
+    lst &= ~LS_ACC;
+    wave_sync();
+  };
+
   // ---- phase 2: the complete leaves [entry i, entry i+1) of the list ----
   // One round: the leaves [entry i0 + g, entry i0 + g + 1), g < 64 / GL, one group of GL lanes each.
   auto round = [&](auto gl_tag, int i0) {
@@ -421,7 +613,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
         const double X = fmax(fabs(xpl), fabs(xe)), W = xe - xpl, ab = fabs(beta);
         const double wos = W * __builtin_amdgcn_rsq(m2 * rn);         // W / sigma_x
         delta = sg.guard_k * 1.1102230246251565e-16 * 1.0001 * (cnt * ab * X * (1.0 + wos) + ab * X + (double)e + 4.0 * (R1 * rm2) * ab * W);
-        if (!(delta < 0.5)) irregular = true;
+        if (!(delta < 0.5) && sg.mode == 1) irregular = true;         // (mode 2: counted with the guard-flagged leaves)
       }
       // ---- error pass over the own keys [s, e)
       unsigned int emax = 0u;
@@ -489,6 +681,18 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   auto process = [&](bool force, bool drop_open) {
     wave_sync();
     int head = 0;
+    if (LSUM && (lst & LS_OPEN) && bcnt >= 2) {                     // the long leaf at entry 0 ends at entry 1
+      const unsigned int leaf = b_t[0], f0 = b_fl[0];
+      bool tag = false;
+      if (lst & LS_ACC) { acc_run(b_idx[1]); acc_emit(leaf); tag = true; }
+      if (!(f0 & S2_INHERIT)) {                                     // (the owner lists it; the others only leave records)
+        if (lane == 0) l_buf[lcnt] = leaf | (tag ? SG_TAG : 0u);
+        lcnt++;
+        if (lcnt > LBUF - 16) { wave_sync(); flush_exact(); }
+      }
+      lst &= ~LS_OPEN;
+      head = 1;
+    }
     while (bcnt - 1 - head > 0) {
       const int pend = bcnt - 1 - head;
       const unsigned int span = b_idx[head + (pend < 8 ? pend : 8)] - b_idx[head];
@@ -506,7 +710,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
       } else break;
     }
     // compact: the entries from `head` on (pending leaves and the start of the open one) move to the front
-    if (drop_open) bcnt = 0;
+    if (drop_open) { bcnt = 0; lst &= ~(LS_OPEN | LS_ACC); }
     else if (head > 0) {
       const int keep = bcnt - head;
       wave_sync();
@@ -522,8 +726,13 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
     wave_sync();
   };
 
+  // batch counters of the chunk rule: the batch that ends at c0 + XWIN, and the first one that ends at or behind c1 + XWIN
+  const int bi_inherit = c0 > sp.rd_lo ? (int)(XWIN / BATCH) - 1 : -1;
+  const int bi_giveup = (int)((c1 - c0 + XWIN + BATCH - 1) / BATCH) - 1;
+  int bi = -1;
   load_batch(nxt, c0);
   for (uint64_t A = c0; !stop; A += BATCH) {
+    bi++;
 #pragma unroll
     for (int k = 0; k < NLOAD; k++) cur[k] = nxt[k];
     load_batch(nxt, A + BATCH);
@@ -633,6 +842,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
         } else lane_b = ts[KPL - 1] != tp0;
         const unsigned long long bm = __ballot(lane_b);
         if (bm) {
+          if constexpr (LSUM) lst |= LS_SEEN;
           // ---- the boundary block (a load in three has one): per-key flags of the lanes that hold a boundary
           bool bq[KPL];
           unsigned int fq[KPL], told[KPL];
@@ -683,7 +893,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
             // More boundaries than the list holds (leaves of a few keys): for the rest of this batch every leaf
             // goes straight to the exact kernels, the open one included; the list restarts with the next batch.
             dense = true;
-            if (lane == 0 && bcnt > 0 && b_idx[bcnt - 1] >= c0u && b_idx[bcnt - 1] < c1u) sg.flist.push(b_t[bcnt - 1]);
+            if (lane == 0 && bcnt > 0 && b_idx[bcnt - 1] >= c0u && b_idx[bcnt - 1] < c1u && !(b_fl[bcnt - 1] & S2_INHERIT)) sg.flist.push(b_t[bcnt - 1]);
           }
           if (lane_b) {
 #pragma unroll
@@ -725,15 +935,48 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
     };
     if (interior) phase1(std::false_type{}); else phase1(std::true_type{});
     // The next batch overwrites the ring from (A + 2 BATCH - RING) down: whatever the oldest listed leaf still needs
-    // (its container starts at s - 1) has to be processed first; an OPEN leaf that does not fit is irregular ("long").
-    const bool fits = bcnt == 0 || (A + 2 * (uint64_t)BATCH - ((uint64_t)b_idx[0] - 1) <= (uint64_t)RING);
+    // (its container starts at s - 1) has to be processed first; an OPEN leaf that does not fit is long.
+    const uint64_t bend = A + BATCH;
+    const bool fits = bcnt == 0 || (bend + BATCH - ((uint64_t)b_idx[0] - 1) <= (uint64_t)RING);
+    const bool giveup = LSUM && !stop && bi >= bi_giveup;           // (bend >= c1 + XWIN) the chunk rule: the leaf open at c1 is cut there
     if (sg.dbg & 1) { bcnt = bcnt > 0 ? 1 : 0; } else
-    process(stop || dense || !fits, dense);
-    if (bcnt > 0 && !(A + 2 * (uint64_t)BATCH - ((uint64_t)b_idx[0] - 1) <= (uint64_t)RING)) {
-      if (lane == 0) b_fl[0] |= S2_LONG;
-      wave_sync();
+    process(stop || giveup || dense || !fits, dense);
+    if constexpr (!LSUM) {
+      // (modes without partial sums: a long leaf is irregular, its owner walks to its end)
+      if (bcnt > 0 && !(bend + BATCH - ((uint64_t)b_idx[0] - 1) <= (uint64_t)RING)) {
+        if (lane == 0) b_fl[0] |= S2_LONG;
+        wave_sync();
+      }
+    } else {
+      if (bi == bi_inherit && !(lst & LS_SEEN)) {                   // (bend == c0 + XWIN) the chunk rule, seen from behind: an inherited stretch
+        if (lane == 0) { b_idx[0] = c0u; b_t[0] = carry_t; b_fl[0] = (unsigned char)(S2_LONG | S2_INHERIT); }
+        bcnt = 1; lst |= LS_OPEN | LS_SEEN;
+        wave_sync();
+        acc_start(c0u);
+      }
+      if (bcnt > 0 && !(lst & LS_OPEN) && !(bend + BATCH - ((uint64_t)b_idx[0] - 1) <= (uint64_t)RING)) {
+        if (lane == 0) b_fl[0] |= S2_LONG;
+        lst |= LS_OPEN;
+        wave_sync();
+        acc_start(b_idx[0]);
+      }
+      if (lst & LS_ACC) acc_run((unsigned int)(bend < c1 ? bend : c1));
+      if (giveup) {
+        if (bcnt > 0) {                                             // entry 0: the leaf open at c1 (it starts before c1)
+          const unsigned int leaf = b_t[0], f0 = b_fl[0];
+          if (!(lst & LS_ACC)) acc_start(b_idx[0]);
+          acc_run(c1u); acc_emit(leaf);
+          if (!(f0 & S2_INHERIT)) {
+            if (lane == 0) l_buf[lcnt] = leaf | SG_TAG;
+            lcnt++;
+          }
+        }
+        stop = true;
+      }
     }
   }
+  wave_sync();
+  if (LSUM && lane == 0) sg.rec_cnt[blockIdx.x] = acc_u[2] < sg.rpw ? acc_u[2] : sg.rpw;
   wave_sync();
   flush_exact();
   if (lane == 0 && guard_cnt) atomicAdd(&st->guard_count, (unsigned long long)guard_cnt);

@@ -115,6 +115,7 @@ class TrainedRMI:
     cache_fix: object = None
     fit_mode_used: int = 0          # 0 exact, 1 one pass + guard, 2 one pass (rmi_hip_set_fit_mode)
     exact_leaves: int = 0           # one-pass modes: leaves re-fitted by the exact kernels
+    merged_leaves: int = 0          # one-pass mode 2: long leaves fitted from merged partial sums
     guard_leaves: int = 0           # ... of which flagged by the guard (mode 2: counted only)
     generation: int = 0             # which train call of the trainer's context produced the per-leaf arrays
     _trainer: object = field(default=None, repr=False)
@@ -345,7 +346,7 @@ class Trainer:
             shard_leaf_lo=int(res.shard_leaf_lo), shard_leaves=int(res.shard_leaves),
             partial={"max_error": int(res.model_max_error), "max_error_idx": int(res.model_max_error_idx),
                      "sum_n_err": int(res.sum_n_err), "sum_l2": float(res.sum_l2), "sum_log2": float(res.sum_log2)},
-            fit_mode_used=int(res.fit_mode_used), exact_leaves=int(res.exact_leaves), guard_leaves=int(res.guard_leaves),
+            fit_mode_used=int(res.fit_mode_used), exact_leaves=int(res.exact_leaves), merged_leaves=int(res.merged_leaves), guard_leaves=int(res.guard_leaves),
             generation=int(res.generation), _trainer=self)
 
     def train(self, model_spec: str, branch_factor: int, root_mode: str = "exact") -> TrainedRMI:

@@ -6,8 +6,11 @@ mode (1); coefficients are those of the same least-squares line, not the referen
 roundings of it, and the reference's own recurrence (linear.rs:24-34) carries a noise of about
 n u X / sigma_x relative in the slope (2.3e-9 at most on 200 M uniform u64 keys, where 97.5 % of the
 leaves agree to 1e-9) -- asserted here as: slope within 1e-8 relative, intercept within 1e-8 of the size
-of its two terms, and at least 95 % of the leaves within the north_star's 1e-9.  Mode 2 (no exact re-fit
-of guard-flagged leaves): error integers may differ by one, in at most `guard_leaves` leaves.
+of its two terms, and at least 95 % of the leaves within the north_star's 1e-9.  Mode 2 (no exact re-fit for
+numerical reasons; long leaves from merged partial sums): the bucket table is identical, every error integer is the
+true maximum of |prediction - position| for the line this library returned (a valid index), and it differs from the
+reference's in at most `guard_leaves + merged_leaves` leaves -- by one at most on well-conditioned keys; where the
+reference's own recurrence is noise-dominated (clustered keys far from 0) its integers are not reproducible by sums.
 """
 import numpy as np
 import pytest
@@ -37,7 +40,30 @@ def _run(T, oracle, keys, root, L, mode, leaf="linear"):
     return g, o
 
 
-def _check(g, o, keys, mode, expect_used=True):
+def _self_consistent(g, keys, allow=2):
+    """The index is valid for the lines this library returned: every leaf's error integer (which also covers the
+    widening keys of two_layer.rs:226-259) bounds |floor(fma(beta, x, alpha)) - first occurrence| over its own keys.
+    (The fma is emulated in long double here: a floor may flip in a leaf or two.)"""
+    n = len(keys)
+    L = g.leaf_params.shape[0]
+    ls = g.leaf_starts.astype(np.int64)
+    cnt = (np.diff(ls) if len(ls) == L + 1 else np.diff(np.append(ls, n)))[:L]
+    leaf_of = np.repeat(np.arange(L), cnt)
+    x = keys.astype(np.float64).astype(np.longdouble)
+    f = g.leaf_params[leaf_of, 1].astype(np.longdouble) * x + g.leaf_params[leaf_of, 0].astype(np.longdouble)
+    pred = np.clip(np.floor(f), 0, n).astype(np.int64)
+    first = np.arange(n, dtype=np.int64)
+    dup = np.zeros(n, bool); dup[1:] = keys[1:] == keys[:-1]
+    first[dup] = 0
+    first = np.maximum.accumulate(first)
+    mx = np.zeros(L, np.int64)
+    np.maximum.at(mx, leaf_of, np.abs(pred - first))
+    rep = g.last_layer_max_l1s.astype(np.int64)
+    bad = np.nonzero(mx > rep)[0]
+    assert len(bad) <= allow and (len(bad) == 0 or (mx[bad] - rep[bad]).max() <= 1), (len(bad), bad[:5], mx[bad[:5]], rep[bad[:5]])
+
+
+def _check(g, o, keys, mode, expect_used=True, conditioned=True):
     L = o.num_leaves
     assert g.fit_mode_used == (mode if expect_used else 0)
     assert np.array_equal(g.leaf_starts, o.leaf_start), "bucket assignment differs"
@@ -51,7 +77,14 @@ def _check(g, o, keys, mode, expect_used=True):
         assert abs(g.model_avg_l2_error - o.model_avg_l2_error) <= 1e-9 * max(1.0, abs(o.model_avg_l2_error))
     else:
         diff = np.abs(ge.astype(np.int64) - oe.astype(np.int64))
-        assert diff.max() <= 1 and np.count_nonzero(diff) <= g.guard_leaves, (diff.max(), np.count_nonzero(diff), g.guard_leaves)
+        assert np.count_nonzero(diff) <= g.guard_leaves + g.merged_leaves, (np.count_nonzero(diff), g.guard_leaves, g.merged_leaves)
+        if conditioned:
+            assert diff.max() <= 1, diff.max()
+        _self_consistent(g, keys)
+        rows = g.rows.view(np.uint64).reshape(L, 3)
+        assert np.array_equal(rows[:, :2], g.leaf_params.view(np.uint64)) and np.array_equal(rows[:, 2], ge)
+        if not conditioned:
+            return 0.0
     # the same line: slope, and intercept relative to the size of its two terms mean_y and beta * mean_x
     nonempty = o.leaf_start[1:] > o.leaf_start[:-1]
     xs = keys.astype(np.float64)
@@ -85,12 +118,14 @@ def test_onepass_parity(T, oracle, gen, n, L, root, mode):
         g, o = _run(T, oracle, keys, root, L, mode)
     except oracle.OracleError as oe:
         pytest.skip(f"the reference panics on this combination ({oe})")
-    worst = _check(g, o, keys, mode)
+    worst = _check(g, o, keys, mode, conditioned=not gen.startswith("clustered"))
     nonempty = int(np.count_nonzero(o.leaf_start[1:] > o.leaf_start[:-1]))
     print(f"\n{gen} {root} L={L} mode={mode}: exact re-fits {g.exact_leaves} of {nonempty} non-empty leaves, guard {g.guard_leaves}, "
           f"worst slope difference {worst:.2e}")
-    if gen.startswith("dups") or gen.startswith("clustered"):
-        assert g.exact_leaves >= 0.9 * nonempty          # duplicates / collapsed f64 keys: the sums do not apply, (nearly) every leaf is exact
+    if gen.startswith("dups") or (gen.startswith("clustered") and mode == 1):
+        # duplicates: the sums do not apply; collapsed f64 keys: the reference's own recurrence is noise the guard
+        # cannot certify against -- (nearly) every leaf is exact.  (Mode 2 keeps the least-squares lines of the sums.)
+        assert g.exact_leaves >= 0.9 * nonempty
     elif gen.startswith("uniform"):
         assert g.exact_leaves <= 0.05 * nonempty + 8
 
@@ -117,6 +152,42 @@ def test_onepass_long_leaves(T, oracle):
     g, o = _run(T, oracle, keys, "linear", 64, 1)
     _check(g, o, keys, 1)
     assert g.exact_leaves == 64 and np.array_equal(g.leaf_params, o.leaf_params)
+
+
+@pytest.mark.parametrize("gen,n,L", [("uniform_u64", 2_000_000, 64), ("uniform_u64", 2_000_000, 1000), ("uniform_u64", 3_000_000, 2500),
+                                     ("books_u64", 5_000_000, 1024), ("uniform_u32", 3_000_000, 700), ("uniform_f64", 2_000_000, 300)])
+def test_onepass_merges_long_leaves(T, oracle, gen, n, L):
+    """Mode 2: leaves longer than a wave's ring, or cut at chunk borders, are summed piecewise and merged; only the
+    leaves the sums cannot describe (none here) are left to the exact kernels."""
+    keys = dg.GENERATORS[gen](n)
+    g, o = _run(T, oracle, keys, "linear", L, 2)
+    _check(g, o, keys, 2)
+    assert g.merged_leaves > 0 and g.exact_leaves <= 8, (g.merged_leaves, g.exact_leaves)
+    print(f"\n{gen} n={n} L={L}: merged {g.merged_leaves}, exact {g.exact_leaves}, guard {g.guard_leaves}")
+
+
+@pytest.mark.parametrize("where", ["first", "mid_lo", "mid_hi", "last"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_onepass_giant_leaf_at_the_special_positions(T, oracle, where, mode):
+    """A 400 000-key leaf that is the first leaf, the last leaf, or next to the split of the 2-way join (Q2/Q3 containers):
+    mode 1 hands it to the exact kernels (bit-identical), mode 2 merges its partial sums with that container's rules."""
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 1 << 40, 1_000_000, dtype=np.uint64)
+    nc = 400_000
+    center = {"first": 0, "mid_lo": (1 << 39) - (1 << 29) - (1 << 27), "mid_hi": (1 << 39) + (1 << 20), "last": (1 << 40) - nc * 1024 - 1}[where]
+    keys = np.unique(np.concatenate([base, np.uint64(center) + np.arange(nc, dtype=np.uint64) * np.uint64(1024)]))
+    L = 1024
+    g, o = _run(T, oracle, keys, "linear", L, mode)
+    _check(g, o, keys, mode, conditioned=(mode == 1))
+    cnt = np.diff(o.leaf_start.astype(np.int64))
+    big = int(np.argmax(cnt))
+    assert cnt[big] >= 250_000
+    rel = abs(g.leaf_params[big, 1] - o.leaf_params[big, 1]) / abs(o.leaf_params[big, 1])
+    print(f"\ngiant leaf {big} of {L} ({where}): {cnt[big]} keys, slope difference {rel:.2e}, merged {g.merged_leaves}, exact {g.exact_leaves}")
+    if mode == 2:
+        assert g.merged_leaves >= 1 and g.exact_leaves <= 8 and rel <= 1e-6
+    else:
+        assert np.array_equal(g.leaf_params[big], o.leaf_params[big])
 
 
 def test_onepass_results_do_not_depend_on_the_wave_count(T, oracle, monkeypatch):

@@ -19,7 +19,7 @@ def run(gen, n, L, root="linear", mode=1, tile=4096, blocks=512, show=12):
     t0 = time.time()
     g = tr.train_leaves(g_root, "linear", L)
     dt = time.time() - t0
-    print(f"== {gen} n={n} L={L} root={root} mode={mode}: used={g.fit_mode_used} exact_leaves={g.exact_leaves} guard={g.guard_leaves} "
+    print(f"== {gen} n={n} L={L} root={root} mode={mode}: used={g.fit_mode_used} exact_leaves={g.exact_leaves} merged={g.merged_leaves} guard={g.guard_leaves} "
           f"long={g.long_leaves} device={g.device_ns/1e6:.3f} ms kernels(ms)={[round(k/1e6,3) for k in g.kernel_ns[:5]]} wall={dt*1e3:.1f} ms")
     ls_ok = np.array_equal(g.leaf_starts, o.leaf_start)
     print("   leaf_starts equal:", ls_ok)
