@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 KERNELS_EXACT = ["k_fit_stream", "k_fill", "k_fit_long", "k_err_range", "k_finalize+stats"]
-KERNELS_ONEPASS = ["k_sigma2", "k_fill", "k_fit_list+k_fit_long", "k_err_list+k_err_long", "k_finalize+stats"]
+KERNELS_ONEPASS = ["k_sigma2", "k_fill", "k_fit_list+k_fit_long", "k_err_list+k_err_long+k_err_seg", "k_finalize+stats"]
 MODES = {"exact": 0, "onepass_guarded": 1, "onepass": 2}
 CONFIGS = {
     # name: (keys, leaves, spec, dataset, dtype, scaling)
@@ -228,9 +228,11 @@ def main():
                 "mode": {0: "exact: reference-order recurrence per leaf, two passes over the keys; coefficients bit-identical",
                          1: "one pass (sufficient statistics from LDS); error integers bit-identical through the guard, "
                             "flagged leaves re-fitted by the exact kernels; coefficients to the reference's rounding noise",
-                         2: "one pass, guard-flagged leaves only counted"}[used],
+                         2: "one pass, the least-squares line of the sums everywhere they are defined: guard-flagged leaves only "
+                            "counted, long leaves from merged per-wave partial sums; a valid index, integers not certified"}[used],
                 "mode_requested": args.mode,
                 "exact_refit_leaves": int(getattr(res, "exact_leaves", 0)), "guard_flagged_leaves": int(getattr(res, "guard_leaves", 0)),
+                "merged_long_leaves": int(getattr(res, "merged_leaves", 0)),
                 "exchange": None if world == 1 else "ncclAllGather of the rows inside the library at the end of every step "
                                                     "(rmi_hip_train_sharded); a step ends when every rank holds the table",
                 "root_fit_seconds_untimed": root_s,

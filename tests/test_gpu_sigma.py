@@ -168,7 +168,8 @@ def test_onepass_merges_long_leaves(T, oracle, gen, n, L):
 
 @pytest.mark.parametrize("where", ["first", "mid_lo", "mid_hi", "last"])
 @pytest.mark.parametrize("mode", [1, 2])
-def test_onepass_giant_leaf_at_the_special_positions(T, oracle, where, mode):
+@pytest.mark.parametrize("root", ["linear", "radix"])          # (radix: the cluster's leaf is exactly leaf 0 / 511 / 512 / 1023)
+def test_onepass_giant_leaf_at_the_special_positions(T, oracle, where, mode, root):
     """A 400 000-key leaf that is the first leaf, the last leaf, or next to the split of the 2-way join (Q2/Q3 containers):
     mode 1 hands it to the exact kernels (bit-identical), mode 2 merges its partial sums with that container's rules."""
     rng = np.random.default_rng(5)
@@ -177,13 +178,13 @@ def test_onepass_giant_leaf_at_the_special_positions(T, oracle, where, mode):
     center = {"first": 0, "mid_lo": (1 << 39) - (1 << 29) - (1 << 27), "mid_hi": (1 << 39) + (1 << 20), "last": (1 << 40) - nc * 1024 - 1}[where]
     keys = np.unique(np.concatenate([base, np.uint64(center) + np.arange(nc, dtype=np.uint64) * np.uint64(1024)]))
     L = 1024
-    g, o = _run(T, oracle, keys, "linear", L, mode)
+    g, o = _run(T, oracle, keys, root, L, mode)
     _check(g, o, keys, mode, conditioned=(mode == 1))
     cnt = np.diff(o.leaf_start.astype(np.int64))
     big = int(np.argmax(cnt))
     assert cnt[big] >= 250_000
     rel = abs(g.leaf_params[big, 1] - o.leaf_params[big, 1]) / abs(o.leaf_params[big, 1])
-    print(f"\ngiant leaf {big} of {L} ({where}): {cnt[big]} keys, slope difference {rel:.2e}, merged {g.merged_leaves}, exact {g.exact_leaves}")
+    print(f"\n{root}: giant leaf {big} of {L} ({where}): {cnt[big]} keys, slope difference {rel:.2e}, merged {g.merged_leaves}, exact {g.exact_leaves}")
     if mode == 2:
         assert g.merged_leaves >= 1 and g.exact_leaves <= 8 and rel <= 1e-6
     else:
@@ -221,3 +222,31 @@ def test_onepass_shards_match_the_oracle(T, oracle):
             assert np.array_equal(res.leaf_counts, o.leaf_count[pl.leaf_lo:pl.leaf_hi])
             assert np.array_equal(res.leaf_starts[:-1], o.leaf_start[pl.leaf_lo:pl.leaf_hi])
             tr.close()
+
+
+def test_onepass_mode2_shards_with_long_leaves(T, oracle):
+    """Mode 2 on leaf-aligned shards whose leaves are longer than the ring (merged partial sums inside a shard: chunks
+    are counted from the shard's first key): bucket table and counts are the oracle's, lines within 1e-8, error
+    integers equal on these well-conditioned keys."""
+    from rmi_amd import sharded
+    n, L = 3_000_000, 512
+    keys = dg.uniform_u64(n)
+    o = oracle.train_two_layer("linear", "linear", keys, L, threads=2)
+    root = T.Model(0, tuple(o.root.p), tuple(o.root.ip))
+    for world in (2, 4):
+        plans = sharded.Planner(lambda i: keys[i], n, keys.dtype, root, L).plan(world)
+        merged = 0
+        for pl in plans:
+            tr = T.Trainer(np.ascontiguousarray(keys[pl.read_lo:pl.read_hi]))
+            tr.set_fit_mode(2)
+            res = sharded.run_shard(tr, pl, root, "linear").materialize()
+            assert res.fit_mode_used == 2
+            merged += res.merged_leaves
+            sl = slice(pl.leaf_lo, pl.leaf_hi)
+            assert np.array_equal(res.leaf_starts[:-1], o.leaf_start[sl]) and np.array_equal(res.leaf_counts, o.leaf_count[sl])
+            d = np.abs(res.last_layer_max_l1s.astype(np.int64) - o.leaf_err[sl].astype(np.int64))
+            assert d.max() <= 1 and np.count_nonzero(d) <= res.guard_leaves + res.merged_leaves
+            rel = np.abs(res.leaf_params[:, 1] - o.leaf_params[sl, 1]) / np.abs(o.leaf_params[sl, 1])
+            assert np.nanmax(rel) <= 1e-8
+            tr.close()
+        assert merged >= L - 8 * world
