@@ -164,9 +164,16 @@ int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
  *     first / last leaf, leaves longer than a tile), is re-fitted by the exact kernels.  Coefficients of
  *     the other leaves agree with the reference's to its own rounding noise (~1e-9 relative on 200M u64
  *     keys), not bit for bit.
- *   RMI_FIT_ONEPASS: the same without the re-fit of guard-flagged leaves (they are counted in
- *     rmi_hip_result.guard_leaves): error bounds are those of the emitted coefficients (the index is
- *     sound), a few may differ by one from the reference's.
+ *   RMI_FIT_ONEPASS: the least-squares line of the sums wherever the sums are defined.  No re-fit of guard-flagged
+ *     leaves (counted in rmi_hip_result.guard_leaves); leaves longer than a wave's LDS ring, or cut at the border
+ *     of two waves' chunks, are summed piecewise and merged (rmi_hip_result.merged_leaves) -- also the first leaf,
+ *     the last leaf and the two leaves at the split of the reference's 2-way join, with their containers' rules.
+ *     Only leaves with duplicate keys, or without spread, go to the exact kernels.  Error bounds are those of the
+ *     emitted coefficients (the index is sound).  On well-conditioned keys a few bounds differ by one from the
+ *     reference's; where the reference's own recurrence is dominated by its rounding noise (long leaves, keys far
+ *     from 0 relative to their spread) its coefficients are not reproducible by sums and the bounds differ more.
+ *     This is the mode for heavy-tailed key sets: one leaf of millions of keys costs the exact kernels its whole
+ *     length as a sequential chain (28 ns per key) and this mode one more streaming read of its keys.
  * guard_k <= 0 keeps the current factor (default 2: the largest distance observed between the two lines, over
  * uniform / heavy-tailed / clustered key sets of 200 M keys, is 0.46 of the bound with factor 1).  Leaf kinds other
  * than `linear` ignore the mode. */

@@ -21,9 +21,10 @@
 //   these sums: cancellation of S dx^2 against (S dx)^2 / n, 4 u (S dx^2 / m2) |beta| W;
 //   delta = guard_k (default 2) times the sum.  tools/sigma/calibrate.py measures the actual distance against the
 //   oracle: at most 0.46 of the bound with guard_k = 1 over uniform / heavy-tailed / clustered key sets (200 M keys).
-// Leaves the sums cannot describe are "irregular" and always go to the exact kernels: duplicate keys
-// (y is a first-occurrence offset), the leaves next to the split of the 2-way join (Q2/Q3), the first and the
-// last leaf, leaves that do not fit the LDS ring, variance 0.
+// Leaves the ring cannot finish are "irregular": duplicate keys (y is a first-occurrence offset), the leaves next to
+// the split of the 2-way join (Q2/Q3), the first and the last leaf, leaves that do not fit the LDS ring, variance 0.
+// Mode 1 hands them to the exact kernels.  Mode 2 sums the LONG ones piecewise (one record per wave and stretch,
+// merged by k_fit_list with the container's rules, error pass by k_err_seg) and keeps every line the sums define.
 #pragma once
 #include <type_traits>
 
