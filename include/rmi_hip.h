@@ -174,6 +174,10 @@ int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
  *     from 0 relative to their spread) its coefficients are not reproducible by sums and the bounds differ more.
  *     This is the mode for heavy-tailed key sets: one leaf of millions of keys costs the exact kernels its whole
  *     length as a sequential chain (28 ns per key) and this mode one more streaming read of its keys.
+ * When a one-pass call hands more than a quarter of the leaves to the exact kernels (duplicate-heavy keys in either
+ * mode; f64-collapsed keys in the guarded mode) the context remembers it for this key set, leaf count and mode, and the
+ * following calls run the exact streaming passes instead (rmi_hip_result.fit_mode_used == 0; 1.1 ms against 13.8 ms
+ * on 200 M duplicate-heavy keys).  rmi_hip_set_fit_mode and new keys forget it.
  * guard_k <= 0 keeps the current factor (default 2: the largest distance observed between the two lines, over
  * uniform / heavy-tailed / clustered key sets of 200 M keys, is 0.46 of the bound with factor 1).  Leaf kinds other
  * than `linear` ignore the mode. */

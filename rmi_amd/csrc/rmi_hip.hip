@@ -84,6 +84,12 @@ struct rmi_hip_ctx {
   unsigned long long* d_segs = nullptr;         // ... and the stretches of the merged leaves for their error pass
   uint64_t segs_cap = 0;
   SgParams last_sg;                             // the parameters of the last k_sigma2 launch (k_fit_list reads the records)
+  // A key set on which the one-pass kernel hands most leaves to the exact list kernels (duplicate-heavy keys; keys
+  // whose f64 images collapse, in the guarded mode) is served faster by the exact streaming passes: 1.1 ms against
+  // 13.8 ms on 200 M duplicate-heavy keys.  Remembered per (key set, leaf count, mode); the next call takes the exact path.
+  uint64_t keys_epoch = 1;                      // bumped whenever the context gets new keys
+  uint64_t hint_epoch = 0, hint_L = 0;
+  int hint_mode = -1;
   void* d_bkeys = nullptr;                      // one-pass mode: key[e] and key[s-1] of every leaf (2 x leaves keys), see k_finalize
   uint64_t bkeys_cap = 0;
   uint64_t flist_cap = 0;                       // entries per region
@@ -293,6 +299,7 @@ int rmi_hip_set_fit_mode(rmi_hip_ctx* c, int mode, double guard_k) {
   if (!c || mode < 0 || mode > 2) return RMI_ERR_BAD_ARG;
   c->fit_mode = mode;
   if (guard_k > 0.0) c->guard_k = guard_k;
+  c->hint_epoch = 0;                               // (what the last mode learned about the key set does not carry over)
   return RMI_OK;
 }
 
@@ -312,7 +319,7 @@ int rmi_hip_upload_keys(rmi_hip_ctx* c, const void* host_keys, uint64_t n, int d
   HIPCHK(c, hipMalloc(&c->d_keys_owned, n * key_size(dtype)));
   HIPCHK(c, hipMemcpyAsync(c->d_keys_owned, host_keys, n * key_size(dtype), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->d_keys = c->d_keys_owned; c->n = n; c->dtype = dtype;
+  c->d_keys = c->d_keys_owned; c->n = n; c->dtype = dtype; c->keys_epoch++;
   return RMI_OK;
 }
 
@@ -338,7 +345,7 @@ int rmi_hip_attach_device_keys(rmi_hip_ctx* c, const void* device_keys, uint64_t
   HIPCHK(c, hipSetDevice(c->device));
   c->d_keys = nullptr; c->n = 0;
   if (c->d_keys_owned) { HIPCHK(c, hipFree(c->d_keys_owned)); c->d_keys_owned = nullptr; }
-  c->d_keys = device_keys; c->n = n; c->dtype = dtype;
+  c->d_keys = device_keys; c->n = n; c->dtype = dtype; c->keys_epoch++;
   return RMI_OK;
 }
 
@@ -393,7 +400,7 @@ int rmi_hip_generate_keys(rmi_hip_ctx* c, int generator, int dtype, uint64_t n_g
     hipLaunchKernelGGL((k_generate<uint32_t>), dim3(blocks), dim3(256), 0, c->stream, (uint32_t*)c->d_keys_owned, start, count, stride, base_seed, generator, dup_seed);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->d_keys = c->d_keys_owned; c->n = count; c->dtype = dtype;
+  c->d_keys = c->d_keys_owned; c->n = count; c->dtype = dtype; c->keys_epoch++;
   return RMI_OK;
 }
 
@@ -978,7 +985,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
   // one pass from sufficient statistics: leaves of at least a few dozen keys on average (the rows of a tile hold
   // 16 keys; shorter leaves are cheap chains for the exact kernels anyway), indices below 2^32
-  const bool sigma = stream_fit && c->fit_mode != 0 && sp.n < (1ull << 32) && n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
+  const bool hinted = c->hint_epoch == c->keys_epoch && c->hint_L == L_own && c->hint_mode == c->fit_mode;
+  const bool sigma = stream_fit && c->fit_mode != 0 && !hinted && sp.n < (1ull << 32) && n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
   c->last_sigma = sigma;
   if (sigma) {
     if constexpr (LEAF == K_LINEAR) {
@@ -1279,6 +1287,9 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   out->model_max_log2_error = std::log2((double)st.max_err);
   out->split_idx = st.split_idx; out->split_target = st.split_target;
   out->long_leaves = st.long_count;
+  if (c->last_sigma && (st.flag_count - st.merged_count) * 4 > L_own) {   // most leaves went through the list kernels: see hint_epoch
+    c->hint_epoch = c->keys_epoch; c->hint_L = L_own; c->hint_mode = c->fit_mode;
+  }
   out->fit_mode_used = c->last_sigma ? c->fit_mode : 0;
   out->exact_leaves = c->last_sigma ? st.flag_count - st.merged_count : 0;
   out->merged_leaves = c->last_sigma ? (int32_t)(st.merged_count < 0x7fffffffull ? st.merged_count : 0x7fffffffull) : 0;

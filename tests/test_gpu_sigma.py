@@ -250,3 +250,28 @@ def test_onepass_mode2_shards_with_long_leaves(T, oracle):
             assert np.nanmax(rel) <= 1e-8
             tr.close()
         assert merged >= L - 8 * world
+
+
+def test_onepass_learns_to_take_the_exact_path_on_duplicate_heavy_keys(T, oracle):
+    """Most leaves of a duplicate-heavy key set go through the exact list kernels; the context remembers it and the next
+    call on the same keys runs the exact streaming passes (fit_mode_used == 0).  Results are the oracle's both times."""
+    keys = dg.dups_u64(600_000)
+    L = 2048
+    o = oracle.train_two_layer("linear", "linear", keys, L, threads=2)
+    tr = T.Trainer(keys)
+    tr.set_fit_mode(1)
+    root = tr.fit_root("linear", L)
+    used = []
+    for _ in range(3):
+        g = tr.train_leaves(root, "linear", L).materialize()
+        used.append(g.fit_mode_used)
+        assert np.array_equal(g.leaf_params, o.leaf_params) and np.array_equal(g.last_layer_max_l1s, o.leaf_err)
+    assert used == [1, 0, 0]
+    tr.set_fit_mode(1)                                   # forgets
+    assert tr.train_leaves(root, "linear", L).materialize().fit_mode_used == 1
+    tr.close()
+    tr = T.Trainer(dg.uniform_u64(600_000))
+    tr.set_fit_mode(1)
+    root = tr.fit_root("linear", L)
+    assert [tr.train_leaves(root, "linear", L).materialize().fit_mode_used for _ in range(2)] == [1, 1]
+    tr.close()
