@@ -82,10 +82,8 @@ struct DevState {
   unsigned long long flag_count;
   unsigned long long flag_cap;
   unsigned long long guard_count;
-  unsigned long long xlong_count;   // listed leaves too long for one wave's error pass (k_err_long)
-  unsigned long long xlong_cap;
   unsigned long long merged_count;  // long leaves fitted from merged partial sums (one-pass mode 2)
-  unsigned long long seg_count;     // ... and the stretches of SG_SEG keys their error pass is cut into (k_err_seg)
+  unsigned long long seg_count;     // stretches of SG_SEG keys the error pass of the long listed leaves is cut into (k_list_tail)
   unsigned long long seg_cap;
 };
 

@@ -77,11 +77,9 @@ struct rmi_hip_ctx {
   unsigned int sigma_min_leaf = 32;             // average keys per leaf below which the exact kernels are used
   unsigned int* d_flist = nullptr;              // leaves handed to the exact kernels: SG_REGIONS regions of flist_cap ids ...
   unsigned long long* d_flist_cnt = nullptr;    // ... and their counters
-  unsigned int* d_xlong = nullptr;              // listed leaves too long for one wave's error pass
-  uint64_t xlong_cap = 0;
   void* d_recs = nullptr;                       // one-pass mode 2: partial sums of long leaves, [blocks][rpw] + the counts
   uint64_t recs_bytes = 0;
-  unsigned long long* d_segs = nullptr;         // ... and the stretches of the merged leaves for their error pass
+  unsigned long long* d_segs = nullptr;         // one-pass modes: the stretches of the long listed leaves for their error pass
   uint64_t segs_cap = 0;
   SgParams last_sg;                             // the parameters of the last k_sigma2 launch (k_fit_list reads the records)
   // A key set on which the one-pass kernel hands most leaves to the exact list kernels (duplicate-heavy keys; keys
@@ -261,7 +259,6 @@ static void free_outputs(rmi_hip_ctx* c) {
   if (c->d_flist) { (void)hipFree(c->d_flist); c->d_flist = nullptr; c->flist_cap = 0; }
   if (c->d_flist_cnt) { (void)hipFree(c->d_flist_cnt); c->d_flist_cnt = nullptr; }
   if (c->d_bkeys) { (void)hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_cap = 0; }
-  if (c->d_xlong) { (void)hipFree(c->d_xlong); c->d_xlong = nullptr; c->xlong_cap = 0; }
   if (c->d_recs) { (void)hipFree(c->d_recs); c->d_recs = nullptr; c->recs_bytes = 0; }
   if (c->d_segs) { (void)hipFree(c->d_segs); c->d_segs = nullptr; c->segs_cap = 0; }
   c->d_leaf_start = nullptr; c->d_params = nullptr; c->d_maxerr = nullptr; c->d_run = nullptr;
@@ -967,16 +964,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   DevState init; std::memset(&init, 0, sizeof init);
   init.long_cap = c->long_cap;
   init.flag_cap = (uint64_t)L_own + 64;
-  init.xlong_cap = n_it / SG_ERR_LONG + 16;
   init.seg_cap = n_it / SG_SEG + L_own + 16;
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
+  if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, 2 * SG_REGIONS * 8));  // (the one-pass mode's list + merge counters: zeroed by k_init)
   HIPCHK(c, hipEventRecord(c->ev[8], s));                      // start of the device work of this call
   {
     const uint64_t ib = (L_own + 1 + 255) / 256;
     hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, c->d_leaf_start, c->d_maxerr, c->d_run,
-                       L_own, (unsigned long long)sp.it_hi, c->d_state, init);
+                       L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS);
   }
 
   if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -1003,14 +1000,15 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         HIPCHK(c, hipMalloc(&c->d_bkeys, 2 * L_own * 8));
         c->bkeys_cap = L_own;
       }
-      if (c->xlong_cap < n_it / SG_ERR_LONG + 16) {
-        if (c->d_xlong) (void)hipFree(c->d_xlong);
-        c->d_xlong = nullptr; c->xlong_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_xlong, (n_it / SG_ERR_LONG + 16) * 4));
-        c->xlong_cap = n_it / SG_ERR_LONG + 16;
+      {
+        const uint64_t scap = n_it / SG_SEG + L_own + 16;        // stretches of the long listed leaves (k_list -> k_list_tail)
+        if (c->segs_cap < scap) {
+          if (c->d_segs) (void)hipFree(c->d_segs);
+          c->d_segs = nullptr; c->segs_cap = 0;
+          HIPCHK(c, hipMalloc(&c->d_segs, scap * 8));
+          c->segs_cap = scap;
+        }
       }
-      if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, SG_REGIONS * 8));
-      HIPCHK(c, hipMemsetAsync(c->d_flist_cnt, 0, SG_REGIONS * 8, s));
       SgParams sgp; sgp.guard_k = c->guard_k; sgp.mode = c->fit_mode;
       sgp.flist.ids = c->d_flist; sgp.flist.cnt = c->d_flist_cnt; sgp.flist.cap = c->flist_cap;
       { const char* dbg = std::getenv("RMI_HIP_SIGMA_DBG"); sgp.dbg = dbg ? std::atoi(dbg) : 0; }
@@ -1019,10 +1017,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           constexpr int RING = decltype(ring_tag)::value, BATCH = decltype(batch_tag)::value;
           uint64_t chunk = (n_it + c->sigma_waves - 1) / c->sigma_waves;
           chunk = ((chunk + BATCH - 1) / BATCH) * BATCH;
-          if (chunk < (uint64_t)BATCH * 16) chunk = (uint64_t)BATCH * 16;
+          if (chunk < (uint64_t)BATCH * 4) chunk = (uint64_t)BATCH * 4;     // (>= the window of the chunk rule, RING / 2)
           sgp.chunk = chunk;
           const uint64_t sblocks = (n_it + chunk - 1) / chunk;
-          sgp.recs = nullptr; sgp.rec_cnt = nullptr; sgp.rpw = 0; sgp.segs = nullptr;
+          sgp.recs = nullptr; sgp.rec_cnt = nullptr; sgp.rpw = 0; sgp.segs = c->d_segs;
           if (c->fit_mode == 2) {
             // a stretch of a long leaf is at least RING / 2 - BATCH keys, or the only one of its wave
             const uint64_t rpw = chunk / (RING / 2 - BATCH) + 3;
@@ -1034,14 +1032,6 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
               c->recs_bytes = need;
             }
             sgp.recs = (SgRec*)c->d_recs; sgp.rec_cnt = (unsigned int*)((char*)c->d_recs + sblocks * rpw * sizeof(SgRec)); sgp.rpw = (unsigned int)rpw;
-            const uint64_t scap = n_it / SG_SEG + L_own + 16;
-            if (c->segs_cap < scap) {
-              if (c->d_segs) (void)hipFree(c->d_segs);
-              c->d_segs = nullptr; c->segs_cap = 0;
-              HIPCHK(c, hipMalloc(&c->d_segs, scap * 8));
-              c->segs_cap = scap;
-            }
-            sgp.segs = c->d_segs;
           }
           c->last_sg = sgp;
           if (c->fit_mode == 2)
@@ -1092,18 +1082,11 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   mark();
   if (sigma) {
     if constexpr (LEAF == K_LINEAR) {
-      // --- exact kernels for the leaves the one-pass kernel handed over ---
+      // --- the leaves the one-pass kernel handed over: fit (or merge) + error pass, one wave per leaf; long ones in stretches ---
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
-      hipLaunchKernelGGL((k_fit_list<K>), dim3(4 * SG_REGIONS), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->last_sg, c->d_long, c->d_xlong);
-      const uint64_t lblocks = c->long_cap < 8192 ? c->long_cap : 8192;
-      hipLaunchKernelGGL((k_fit_long<ROOT, K>), dim3((unsigned)lblocks), dim3(64), 0, s, keys, sp, rp, leaf_start, c->d_state, params, c->d_long);
+      hipLaunchKernelGGL((k_list<K>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->last_sg, maxerr, run);
       mark();
-      hipLaunchKernelGGL((k_err_list<K>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, params, fl, maxerr, run);
-      hipLaunchKernelGGL((k_err_long<K>), dim3(2048), dim3(256), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_xlong, maxerr, run);
-      if (c->fit_mode == 2) {
-        const uint64_t sb = c->segs_cap < 16384 ? c->segs_cap : 16384;
-        hipLaunchKernelGGL((k_err_seg<K>), dim3((unsigned)sb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_segs, maxerr, run);
-      }
+      hipLaunchKernelGGL((k_list_tail<K>), dim3(8192), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
     }
   } else if (n_it == 0) {
   } else if (!stream_fit) {

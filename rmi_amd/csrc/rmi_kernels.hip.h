@@ -155,11 +155,14 @@ __global__ void __launch_bounds__(256) k_table_from_starts(const unsigned long l
 __global__ void __launch_bounds__(256) k_init(unsigned long long* __restrict__ leaf_start,
                                               unsigned long long* __restrict__ maxerr,
                                               unsigned long long* __restrict__ run, uint64_t L_own,
-                                              unsigned long long sentinel, DevState* __restrict__ st, DevState init) {
+                                              unsigned long long sentinel, DevState* __restrict__ st, DevState init,
+                                              unsigned long long* __restrict__ list_cnt, int n_list_cnt) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= L_own; j += stride) {
-    leaf_start[j] = (j == L_own) ? sentinel : NO_START;
+  const uint64_t lim = L_own + 1 > (uint64_t)n_list_cnt ? L_own + 1 : (uint64_t)n_list_cnt;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < lim; j += stride) {
+    if (j <= L_own) leaf_start[j] = (j == L_own) ? sentinel : NO_START;
     if (j < L_own) { maxerr[j] = 0; run[j] = 0; }
+    if (j < (uint64_t)n_list_cnt) list_cnt[j] = 0ull;      // the one-pass mode's list counters (a memset of their own costs ~4 us)
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *st = init;
 }

@@ -24,7 +24,7 @@
 // Leaves the ring cannot finish are "irregular": duplicate keys (y is a first-occurrence offset), the leaves next to
 // the split of the 2-way join (Q2/Q3), the first and the last leaf, leaves that do not fit the LDS ring, variance 0.
 // Mode 1 hands them to the exact kernels.  Mode 2 sums the LONG ones piecewise (one record per wave and stretch,
-// merged by k_fit_list with the container's rules, error pass by k_err_seg) and keeps every line the sums define.
+// merged by k_list with the container's rules, error pass by k_list_tail) and keeps every line the sums define.
 #pragma once
 #include <type_traits>
 
@@ -38,8 +38,8 @@ namespace rmi {
 // a counter of its own: appends from thousands of waves to ONE counter serialise at ~26 ns each (0.1 ms for the
 // 4 000 waves of a 200 M-key run); spread by leaf id no region can overflow its share of the capacity.
 constexpr int SG_REGIONS = 64;
-constexpr int SG_SEG = 2048;                // error pass of a merged leaf: stretches of this many keys, one wave each (k_err_seg)
-constexpr int SG_ERR_LONG = 16384;          // listed leaves with more keys: the whole grid per leaf (k_err_long)
+constexpr int SG_SEG = 2048;                // error pass of a long listed leaf: stretches of this many keys, one wave each (k_list_tail)
+constexpr int SG_ERR_LONG = 16384;          // listed leaves with more keys: error pass in stretches (k_list_tail)
 struct SgList {
   unsigned int* ids;                       // [SG_REGIONS][cap]
   unsigned long long* cnt;                 // [SG_REGIONS]
@@ -52,7 +52,7 @@ struct SgList {
 };
 
 // A long leaf (one that does not fit a wave's ring, or that runs across chunks) is summed piecewise: every wave that
-// holds a stretch of it leaves one record, shifted sums about the stretch's first key; k_fit_list merges them.
+// holds a stretch of it leaves one record, shifted sums about the stretch's first key; k_list merges them.
 constexpr unsigned int SG_TAG = 0x80000000u;   // list entry: "fitted from merged records" (leaf ids are below 2^31)
 struct SgRec {
   unsigned int leaf, first, n, pad;        // keys [first, first + n) of the leaf
@@ -84,14 +84,7 @@ __device__ __forceinline__ unsigned int sg_cvt_u32(double f) { unsigned int r; a
 __device__ __forceinline__ unsigned int sg_absdiff(unsigned int a, unsigned int b) { unsigned int r; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // ---------------------------------------------------------------------------------------------
-// Exact kernels for the leaves k_sigma2 hands over.
-// k_fit_list: leaves whose container is a real range go on to k_fit_long (ONE WAVE per leaf: the recurrence of a
-// leaf is a sequential chain, and a lane walking 200 keys of its own through uncached loads takes ~70 us whatever
-// the number of leaves; k_fit_long prepares 64 keys at a time in parallel and walks the chain at 28 ns per point);
-// the O(1) containers (empty, single borrowed point: Q4) are finished here by fit_one_leaf.
-// k_err_list: one wave per leaf, error pass + run lengths of its keys (two_layer.rs:207-217,
-// lower_bound_correction.rs:104-119), exactly what k_err computes per key.
-// Both walk the regions of the list: block b takes region b % SG_REGIONS.
+// The kernels for the leaves k_sigma2 hands over (k_list, k_list_tail below).
 // ---------------------------------------------------------------------------------------------
 // Moments of a set of points about a common origin, merged pairwise (Chan et al.): exact algebra, and the
 // cancellation stays at the scale of one stretch.
@@ -168,65 +161,67 @@ __device__ bool sg_merge_long(uint64_t j, uint64_t s, uint64_t e, uint64_t lo, u
   return true;
 }
 
+// k_list: ONE WAVE per listed leaf does everything the leaf needs -- a tagged leaf is merged from its records (lane 0),
+// any other one is fitted exactly (fit_long_leaf: the wave prepares 64 keys at a time and walks the recurrence at
+// 28 ns per point; the O(1) containers -- empty, single borrowed point: Q4 -- by fit_one_leaf), and then the same wave
+// runs the leaf's error pass + run lengths (two_layer.rs:207-217, lower_bound_correction.rs:104-119, exactly what
+// k_err computes per key) while its keys are still in L2.  Leaves of more than SG_ERR_LONG keys, and the merged ones,
+// leave their error pass to k_list_tail as stretches of SG_SEG keys: (leaf << 32 | stretch), bit 63 = "no duplicates
+// inside" (a merged leaf: y is the key's index, runs of 1).  Block b takes region b % SG_REGIONS of the list.
+// (Separate kernels for list fit, long fit, list errors and long errors cost four launches of ~4 us each; the
+// counters are per region because same-address atomics serialise.)
+constexpr unsigned long long SG_SEG_PLAIN = 1ull << 63;
 template <typename K>
-__global__ void __launch_bounds__(256) k_fit_list(const K* __restrict__ keys, Span sp,
-                                                  const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
-                                                  double* __restrict__ params, SgList fl, SgParams sg,
-                                                  unsigned long long* __restrict__ long_idx, unsigned int* __restrict__ xlong) {
-  __shared__ unsigned int merged_blk;
-  if (threadIdx.x == 0) merged_blk = 0u;
-  __syncthreads();
-  const unsigned int rg = blockIdx.x % SG_REGIONS;
-  const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
-  if (blockIdx.x < SG_REGIONS && threadIdx.x == 0) atomicAdd(&st->flag_count, cnt);      // (total, for the caller)
-  unsigned int* ids = fl.ids + (unsigned long long)rg * fl.cap;
-  for (unsigned long long i = (unsigned long long)(blockIdx.x / SG_REGIONS) * blockDim.x + threadIdx.x; i < cnt;
-       i += (unsigned long long)(gridDim.x / SG_REGIONS) * blockDim.x) {
-    const bool tagged = (ids[i] & SG_TAG) != 0u;
-    const uint64_t j = ids[i] & ~SG_TAG;
-    uint64_t lo, hi;
-    const int ck = leaf_container(j, leaf_start[j], leaf_start[j + 1], sp.n, st->split_idx, st->split_target, lo, hi);
-    if (ids[i] & SG_TAG) ids[i] = (unsigned int)j;                  // (the tag stays only where the merge succeeds)
-    if (tagged && ck == 2 && sg_merge_long<K>(j, leaf_start[j], leaf_start[j + 1], lo, hi, keys, sp, sg, params)) {
-      ids[i] = (unsigned int)j | SG_TAG;
-      atomicAdd(&merged_blk, 1u);
-      const uint64_t nseg = (leaf_start[j + 1] - leaf_start[j] + SG_SEG - 1) / SG_SEG;
-      const unsigned long long pos = atomicAdd(&st->seg_count, (unsigned long long)nseg);
-      for (uint64_t q = 0; q < nseg && pos + q < st->seg_cap; q++) sg.segs[pos + q] = ((unsigned long long)j << 32) | q;
-      continue;
-    } else if (ck == 2) {
-      const unsigned long long pos = atomicAdd(&st->long_count, 1ull);
-      if (pos < st->long_cap) long_idx[pos] = leaf_start[j];
-    } else fit_one_leaf<K_LINEAR, K>(j, keys, sp, leaf_start, st, params);
-    if (leaf_start[j + 1] - leaf_start[j] > (uint64_t)SG_ERR_LONG) {
-      const unsigned long long pos = atomicAdd(&st->xlong_count, 1ull);
-      if (pos < st->xlong_cap) xlong[pos] = (unsigned int)j;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && merged_blk) atomicAdd(&st->merged_count, (unsigned long long)merged_blk);
-}
-
-template <typename K>
-__global__ void __launch_bounds__(64) k_err_list(const K* __restrict__ keys, Span sp,
-                                                 const unsigned long long* __restrict__ leaf_start,
-                                                 const double* __restrict__ params, SgList fl,
-                                                 unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
+__global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp,
+                                             const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
+                                             double* __restrict__ params, SgList fl, SgParams sg,
+                                             unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
+  __shared__ FitLongLds lds;
   const unsigned int rg = blockIdx.x % SG_REGIONS;
   const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
   const unsigned int* ids = fl.ids + (unsigned long long)rg * fl.cap;
   const int lane = threadIdx.x;
+  unsigned int merged_here = 0u;
   for (unsigned long long t = blockIdx.x / SG_REGIONS; t < cnt; t += gridDim.x / SG_REGIONS) {
-    if (ids[t] & SG_TAG) continue;                                 // a merged leaf: k_err_seg's
-    const uint64_t j = ids[t];
+    const bool tagged = (ids[t] & SG_TAG) != 0u;
+    const uint64_t j = ids[t] & ~SG_TAG;
     const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
-    if (e - s > (uint64_t)SG_ERR_LONG) continue;                   // k_err_long's
+    uint64_t lo, hi;
+    const int ck = leaf_container(j, s, e, sp.n, st->split_idx, st->split_target, lo, hi);
+    bool merged = false;
+    if (tagged && ck == 2) {
+      int ok = 0;
+      if (lane == 0) ok = sg_merge_long<K>(j, s, e, lo, hi, keys, sp, sg, params) ? 1 : 0;
+      merged = __shfl(ok, 0) != 0;
+    }
+    if (merged) merged_here++;
+    else if (ck == 2) {
+      fit_long_leaf<K>(keys, sp, lo, hi, st, params + j * 2, lds);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // (the LDS buffers are reused by the next leaf)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else if (lane == 0) fit_one_leaf<K_LINEAR, K>(j, keys, sp, leaf_start, st, params);
+    if (merged || e - s > (uint64_t)SG_ERR_LONG) {
+      if (lane == 0) {
+        const uint64_t nseg = (e - s + SG_SEG - 1) / SG_SEG;
+        const unsigned long long pos = atomicAdd(&st->seg_count, (unsigned long long)nseg);
+        const unsigned long long tagb = merged ? SG_SEG_PLAIN : 0ull;
+        for (uint64_t q = 0; q < nseg && pos + q < st->seg_cap; q++) sg.segs[pos + q] = tagb | ((unsigned long long)j << 32) | q;
+      }
+      continue;
+    }
+    // the error pass of this leaf with the coefficients lane 0 has just written
+    double pp[2];
+    {
+      double a = 0.0, b = 0.0;
+      if (lane == 0) { a = params[j * 2]; b = params[j * 2 + 1]; }
+      pp[0] = __shfl(a, 0); pp[1] = __shfl(b, 0);
+    }
     unsigned long long err = 0, run = 0;
     for (uint64_t i = s + lane; i < e; i += 64) {
       const K k = keys[i];
       const uint64_t y = first_occurrence(keys, i, sp.rd_lo);
-      const uint64_t pred = leaf_predict<K_LINEAR, K>(params + j * 2, k);
-      const uint64_t er = error_between(pred, y, sp.n);
+      const uint64_t er = error_between(leaf_predict<K_LINEAR, K>(pp, k), y, sp.n);
       err = er > err ? er : err;
       if (i + 1 < sp.n && !(keys[i + 1] == k)) { const uint64_t rl = i - y + 1; run = rl > run ? rl : run; }
     }
@@ -237,78 +232,63 @@ __global__ void __launch_bounds__(64) k_err_list(const K* __restrict__ keys, Spa
     }
     if (lane == 0) { leaf_maxerr[j] = err; leaf_run[j] = run; }
   }
+  if (lane == 0 && merged_here) atomicAdd(&fl.cnt[SG_REGIONS + rg], (unsigned long long)merged_here);
 }
 
-// The long leaves of the list (one wave would walk millions of keys): every block strides over the leaf's keys.
+// k_list_tail: the error pass of the long listed leaves, one wave per stretch of SG_SEG keys, eight independent loads
+// per lane in flight; block 0 also adds up the region counters for the caller.
 template <typename K>
-__global__ void __launch_bounds__(256) k_err_long(const K* __restrict__ keys, Span sp,
-                                                  const unsigned long long* __restrict__ leaf_start, const DevState* __restrict__ st,
-                                                  const double* __restrict__ params, const unsigned int* __restrict__ xlong,
+__global__ void __launch_bounds__(64) k_list_tail(const K* __restrict__ keys, Span sp,
+                                                  const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
+                                                  const double* __restrict__ params, SgList fl, const unsigned long long* __restrict__ segs,
                                                   unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
-  __shared__ unsigned long long sm_e[256], sm_r[256];
-  const unsigned long long cnt = st->xlong_count < st->xlong_cap ? st->xlong_count : st->xlong_cap;
-  for (unsigned long long t = 0; t < cnt; t++) {
-    const uint64_t j = xlong[t];
-    const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
-    unsigned long long err = 0, run = 0;
-    for (uint64_t i = s + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < e; i += (uint64_t)gridDim.x * 256) {
-      const K k = keys[i];
-      const uint64_t y = first_occurrence(keys, i, sp.rd_lo);
-      const uint64_t pred = leaf_predict<K_LINEAR, K>(params + j * 2, k);
-      const uint64_t er = error_between(pred, y, sp.n);
-      err = er > err ? er : err;
-      if (i + 1 < sp.n && !(keys[i + 1] == k)) { const uint64_t rl = i - y + 1; run = rl > run ? rl : run; }
-    }
-    sm_e[threadIdx.x] = err; sm_r[threadIdx.x] = run;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-      if ((int)threadIdx.x < d) {
-        if (sm_e[threadIdx.x + d] > sm_e[threadIdx.x]) sm_e[threadIdx.x] = sm_e[threadIdx.x + d];
-        if (sm_r[threadIdx.x + d] > sm_r[threadIdx.x]) sm_r[threadIdx.x] = sm_r[threadIdx.x + d];
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      if (sm_e[0]) atomicMax(&leaf_maxerr[j], sm_e[0]);
-      if (sm_r[0]) atomicMax(&leaf_run[j], sm_r[0]);
-    }
-    __syncthreads();
-  }
-}
-
-// The merged leaves: no duplicate keys inside (the merge would have failed), so y is the key's index and every run
-// has length 1; a wave streams one stretch of SG_SEG keys, eight independent loads per lane in flight.
-template <typename K>
-__global__ void __launch_bounds__(64) k_err_seg(const K* __restrict__ keys, Span sp,
-                                                const unsigned long long* __restrict__ leaf_start, const DevState* __restrict__ st,
-                                                const double* __restrict__ params, const unsigned long long* __restrict__ segs,
-                                                unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
   constexpr int U = 8;
-  const unsigned long long cnt = st->seg_count < st->seg_cap ? st->seg_count : st->seg_cap;
   const int lane = threadIdx.x;
+  if (blockIdx.x == 0) {
+    unsigned long long a = fl.cnt[lane] < fl.cap ? fl.cnt[lane] : fl.cap, m = fl.cnt[SG_REGIONS + lane];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { a += shfl_down_u64(a, d); m += shfl_down_u64(m, d); }
+    if (lane == 0) { st->flag_count = a; st->merged_count = m; }
+  }
+  const unsigned long long cnt = st->seg_count < st->seg_cap ? st->seg_count : st->seg_cap;
   for (unsigned long long t = blockIdx.x; t < cnt; t += gridDim.x) {
-    const uint64_t j = segs[t] >> 32, q = segs[t] & 0xffffffffull;
+    const unsigned long long sv = segs[t];
+    const bool plain = (sv & SG_SEG_PLAIN) != 0ull;
+    const uint64_t j = (sv & ~SG_SEG_PLAIN) >> 32, q = sv & 0xffffffffull;
     const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
     const uint64_t a = s + q * SG_SEG, b = a + SG_SEG < e ? a + SG_SEG : e;
-    unsigned long long err = 0;
-    for (uint64_t i0 = a + lane; i0 < b; i0 += 64 * U) {
-      K kv[U];
+    const double pp[2] = {params[j * 2], params[j * 2 + 1]};
+    unsigned long long err = 0, run = 0;
+    if (plain) {
+      for (uint64_t i0 = a + lane; i0 < b; i0 += 64 * U) {
+        K kv[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) { const uint64_t i = i0 + (uint64_t)u * 64; kv[u] = keys[i < b ? i : b - 1]; }
+        for (int u = 0; u < U; u++) { const uint64_t i = i0 + (uint64_t)u * 64; kv[u] = keys[i < b ? i : b - 1]; }
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint64_t i = i0 + (uint64_t)u * 64;
-        if (i < b) {
-          const uint64_t er = error_between(leaf_predict<K_LINEAR, K>(params + j * 2, kv[u]), i, sp.n);
-          err = er > err ? er : err;
+        for (int u = 0; u < U; u++) {
+          const uint64_t i = i0 + (uint64_t)u * 64;
+          if (i < b) { const uint64_t er = error_between(leaf_predict<K_LINEAR, K>(pp, kv[u]), i, sp.n); err = er > err ? er : err; }
         }
+      }
+      if (q == 0 && s + 1 < sp.n) run = 1;                         // (lower_bound_correction.rs:104-119: runs of equal keys)
+    } else {
+      for (uint64_t i = a + lane; i < b; i += 64) {
+        const K k = keys[i];
+        const uint64_t y = first_occurrence(keys, i, sp.rd_lo);
+        const uint64_t er = error_between(leaf_predict<K_LINEAR, K>(pp, k), y, sp.n);
+        err = er > err ? er : err;
+        if (i + 1 < sp.n && !(keys[i + 1] == k)) { const uint64_t rl = i - y + 1; run = rl > run ? rl : run; }
       }
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const unsigned long long oe = shfl_down_u64(err, d); err = oe > err ? oe : err; }
+    for (int d = 32; d > 0; d >>= 1) {
+      const unsigned long long oe = shfl_down_u64(err, d), orn = shfl_down_u64(run, d);
+      err = oe > err ? oe : err; run = orn > run ? orn : run;
+    }
     if (lane == 0) {
-      if (err) atomicMax(&leaf_maxerr[j], err);
-      if (q == 0 && s + 1 < sp.n) leaf_run[j] = 1;                 // (lower_bound_correction.rs:104-119: runs of equal keys)
+      // (same-address atomics serialise at ~26 ns: most stretches of a long leaf do not raise its maximum)
+      if (err > __hip_atomic_load(&leaf_maxerr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&leaf_maxerr[j], err);
+      if (run > __hip_atomic_load(&leaf_run[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&leaf_run[j], run);
     }
   }
 }
@@ -495,7 +475,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   // cannot be finished from LDS.  Chunk rule (both sides evaluate it on the same keys): a leaf open at a chunk
   // border c with no boundary in [c, c + XWIN) is cut at c -- the wave before stops there, the wave behind takes
   // [c, ...) as an "inherited" stretch.  In mode 2 every stretch is summed while it passes through the ring (all 64
-  // lanes, shifted sums about the stretch's first key) and left as one record; k_fit_list merges the records and
+  // lanes, shifted sums about the stretch's first key) and left as one record; k_list merges the records and
   // the error kernels of the list do the rest.  In mode 1 such a leaf cannot be certified: exact kernels.
   constexpr unsigned int XWIN = RING / 2;
   static_assert(XWIN % BATCH == 0, "the chunk rule is evaluated at batch ends");

@@ -883,25 +883,21 @@ __device__ __forceinline__ double dpp_from_even_lane(double v) {           // qu
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
 }
 
-template <int ROOT, typename K>
-__global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Span sp, RootP r,
-                                                 const unsigned long long* __restrict__ leaf_start,
-                                                 DevState* __restrict__ st, double* __restrict__ params,
-                                                 const unsigned long long* __restrict__ long_idx) {
+struct FitLongLds {
+  double s_v[2][2][FL_TILE];                               // [buffer][x | y][step]
+  double s_rn[2][FL_TILE][2];                              // [buffer][step][1/count: head, tail]
+};
+
+// One wave fits the leaf whose container is [lo, hi] (see above); lane 0 writes (alpha, beta) to out.
+template <typename K>
+__device__ __forceinline__ void fit_long_leaf(const K* __restrict__ keys, const Span& sp, uint64_t lo, uint64_t hi,
+                                              DevState* __restrict__ st, double* __restrict__ out, FitLongLds& L) {
   constexpr bool SPLIT = UseRecipTable<K>::value;          // two-lane form with reciprocal division
-  __shared__ double s_v[2][2][FL_TILE];                    // [buffer][x | y][step]
-  __shared__ double s_rn[2][FL_TILE][2];                   // [buffer][step][1/count: head, tail]
-  const uint64_t cnt = st->long_count < st->long_cap ? st->long_count : st->long_cap;
+  auto& s_v = L.s_v;
+  auto& s_rn = L.s_rn;
   const int lane = threadIdx.x;
   const int half = lane & 1;
-  for (uint64_t t = blockIdx.x; t < cnt; t += gridDim.x) {
-    bool oob;
-    const uint64_t j = (uint64_t)root_target_f<ROOT, K>(r, (double)(r.L - 1), keys[long_idx[t]], oob);
-    const uint64_t n = sp.n;
-    const uint64_t s0 = leaf_start[j], e0 = leaf_start[j + 1];
-    uint64_t lo, hi;
-    const int ck = leaf_container(j, s0, e0, n, st->split_idx, st->split_target, lo, hi);
-    if (ck != 2) continue;                                   // cannot happen for a handed-over leaf
+  {
     double carry_y = (double)first_occurrence(keys, lo, sp.rd_lo);
     SlrState sl = {0.0, 0.0, 0.0, 0.0, 0.0};                 // !SPLIT: the whole state in every lane
     double m = 0.0, acc = 0.0;                               // SPLIT: mean_x | mean_y,  m2 | c
@@ -972,7 +968,6 @@ __global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Spa
       slr_push(sl, last_x, last_y);
     }
     if (lane == 0) {
-      double* out = params + j * 2;
       const double cov = sl.c / (sl.nf - 1.0);
       const double var = sl.m2 / (sl.nf - 1.0);
       if (!(var >= 0.0)) atomicOr(&st->err_flags, EF_NEG_VARIANCE);       // linear.rs:48
@@ -983,6 +978,26 @@ __global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Spa
         out[1] = beta;
       }
     }
+  }
+}
+
+template <int ROOT, typename K>
+__global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Span sp, RootP r,
+                                                 const unsigned long long* __restrict__ leaf_start,
+                                                 DevState* __restrict__ st, double* __restrict__ params,
+                                                 const unsigned long long* __restrict__ long_idx) {
+  __shared__ FitLongLds lds;
+  const uint64_t cnt = st->long_count < st->long_cap ? st->long_count : st->long_cap;
+  for (uint64_t t = blockIdx.x; t < cnt; t += gridDim.x) {
+    bool oob;
+    const uint64_t j = (uint64_t)root_target_f<ROOT, K>(r, (double)(r.L - 1), keys[long_idx[t]], oob);
+    uint64_t lo, hi;
+    const int ck = leaf_container(j, leaf_start[j], leaf_start[j + 1], sp.n, st->split_idx, st->split_target, lo, hi);
+    if (ck != 2) continue;                                   // cannot happen for a handed-over leaf
+    fit_long_leaf<K>(keys, sp, lo, hi, st, params + j * 2, lds);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the buffers are reused by the next leaf)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
