@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 KERNELS_EXACT = ["k_fit_stream", "k_fill", "k_fit_long", "k_err_range", "k_finalize+stats"]
-KERNELS_ONEPASS = ["k_sigma2", "k_fill", "k_fit_list+k_fit_long", "k_err_list+k_err_long+k_err_seg", "k_finalize+stats"]
+KERNELS_ONEPASS = ["k_sigma2", "k_fill", "k_list", "k_list_tail", "k_finalize+stats"]
 MODES = {"exact": 0, "onepass_guarded": 1, "onepass": 2}
 CONFIGS = {
     # name: (keys, leaves, spec, dataset, dtype, scaling)

@@ -3,14 +3,14 @@
 # per launch with 16-byte loads per lane -- NOT on the kernels under test.  -> gpurun_out/traffic_r02/traffic_r02.json
 set -u
 OUT=gpurun_out/traffic_r02; mkdir -p $OUT; export TMPDIR=/tmp
-INC='k_read_bw|k_sigma2|k_fit_stream|k_err_range|k_finalize|k_fit_long|k_err_list|k_fit_list'
+INC='k_read_bw|k_sigma2|k_fit_stream|k_err_range|k_finalize|k_fit_long|k_list'
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$INC" -d $OUT/f -o p -f csv -- python tools/traffic_r02.py > $OUT/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$INC" -d $OUT/w -o p -f csv -- python tools/traffic_r02.py > $OUT/w.log 2>&1
 python - <<'PY'
 import csv, glob, json
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
-names = ["k_read_bw", "k_sigma2", "k_fit_stream", "k_err_range", "k_finalize", "k_fit_long", "k_err_list", "k_fit_list"]
+names = ["k_read_bw", "k_sigma2", "k_fit_stream", "k_err_range", "k_finalize", "k_fit_long", "k_list_tail", "k_list"]
 for f in glob.glob("gpurun_out/traffic_r02/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = next((x for x in names if x in r["Kernel_Name"]), None)
