@@ -19,7 +19,7 @@
 //     and every step's dx inherits it -> n u |beta| X (offset) and n u |beta| W X / sigma_x (slope over W);
 //   both lines: one rounding of alpha at the size of the prediction, u (|beta| X + Y);
 //   these sums: cancellation of S dx^2 against (S dx)^2 / n, 4 u (S dx^2 / m2) |beta| W;
-//   delta = guard_k (default 2) times the sum.  tools/sigma/calibrate.py measures the actual distance against the
+//   delta = guard_k (default 2) times the sum.  tests/devtools/calibrate.py measures the actual distance against the
 //   oracle: at most 0.46 of the bound with guard_k = 1 over uniform / heavy-tailed / clustered key sets (200 M keys).
 // Leaves the ring cannot finish are "irregular": duplicate keys (y is a first-occurrence offset), the leaves next to
 // the split of the 2-way join (Q2/Q3), the first and the last leaf, leaves that do not fit the LDS ring, variance 0.

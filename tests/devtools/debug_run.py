@@ -1,5 +1,5 @@
 """One-pass (sufficient statistics) mode against the oracle, with a per-leaf dump of what differs.
-Development aid for the GPU box:  python tools/sigma/debug_run.py [gen n L root mode] ..."""
+Development aid for the GPU box:  python tests/devtools/debug_run.py [gen n L root mode] ..."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,0 +1,71 @@
+"""Randomised differential test of the one-pass modes against the CPU oracle (development aid for the GPU box):
+python tests/devtools/fuzz.py [cases seed].  Mode 1: bucket table, error integers, counts and aggregates must be the oracle's.
+Mode 2: bucket table and counts; error integers valid for the emitted lines; mismatches against the oracle only counted."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from rmi_amd import datagen as dg, train
+from oracle import binding as orc
+
+GENS = ["uniform_u64", "books_u64", "uniform_u32", "uniform_f64", "dups_u64", "dups_u32", "clustered_u64"]
+ROOTS = ["linear", "linear_spline", "radix", "cubic"]
+
+
+def run_case(rng, c=0):
+    """One random configuration; returns (ok or None when the reference itself panics on it, description)."""
+    import os
+    gen = GENS[rng.integers(len(GENS))]
+    root = ROOTS[rng.integers(len(ROOTS))]
+    n = int(2 ** rng.uniform(12.1, 21.5))
+    L = int(2 ** rng.uniform(3, np.log2(n / 32)))
+    if root == "radix":
+        L = 1 << max(3, int(np.log2(L)))
+    mode = int(rng.integers(1, 3))
+    waves = [None, "64", "1000", "100000"][rng.integers(4)]
+    if waves: os.environ["RMI_HIP_SIGMA_WAVES"] = waves
+    else: os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
+    keys = dg.GENERATORS[gen](n, seed=int(rng.integers(1, 1 << 30)))
+    try:
+        o = orc.train_two_layer(root, "linear", keys, L, threads=2)
+    except orc.OracleError:
+        return None, "reference panics"
+    tr = train.Trainer(keys)
+    tr.set_fit_mode(mode)
+    g_root = tr.fit_root(root, L)
+    g = tr.train_leaves(g_root, "linear", L).materialize()
+    tr.close()
+    ok = np.array_equal(g.leaf_starts, o.leaf_start) and np.array_equal(g.leaf_counts, o.leaf_count)
+    ge, oe = g.last_layer_max_l1s.astype(np.int64), o.leaf_err.astype(np.int64)
+    nd = int(np.count_nonzero(ge != oe))
+    if mode == 1:
+        ok = ok and nd == 0 and g.model_max_error == o.model_max_error and g.model_avg_error == o.model_avg_error
+    else:
+        ok = ok and nd <= g.guard_leaves + g.merged_leaves
+        # validity of the bounds for the emitted lines
+        cnt = np.diff(g.leaf_starts.astype(np.int64))[:L]
+        leaf_of = np.repeat(np.arange(L), cnt)
+        x = keys.astype(np.float64).astype(np.longdouble)
+        f = g.leaf_params[leaf_of, 1].astype(np.longdouble) * x + g.leaf_params[leaf_of, 0].astype(np.longdouble)
+        pred = np.clip(np.floor(f), 0, n).astype(np.int64)
+        first = np.arange(n, dtype=np.int64); dup = np.zeros(n, bool); dup[1:] = keys[1:] == keys[:-1]; first[dup] = 0
+        first = np.maximum.accumulate(first)
+        mx = np.zeros(L, np.int64); np.maximum.at(mx, leaf_of, np.abs(pred - first))
+        over = mx - ge
+        ok = ok and int(np.count_nonzero(over > 0)) <= 2 and (over.max() <= 1)
+    os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
+    return ok, (f"{c:3d} {gen:14s} {root:13s} n={n:8d} L={L:7d} mode={mode} waves={waves} used={g.fit_mode_used} exact={g.exact_leaves} "
+                f"merged={g.merged_leaves} guard={g.guard_leaves} diff={nd}")
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    t_start = time.time()
+    for c in range(cases):
+        ok, desc = run_case(rng, c)
+        if ok is None:
+            continue
+        bad += 0 if ok else 1
+        print("ok " if ok else "BAD", desc, flush=True)
+    print(f"{cases} cases, {bad} bad, {time.time() - t_start:.0f} s")

@@ -275,3 +275,22 @@ def test_onepass_learns_to_take_the_exact_path_on_duplicate_heavy_keys(T, oracle
     root = tr.fit_root("linear", L)
     assert [tr.train_leaves(root, "linear", L).materialize().fit_mode_used for _ in range(2)] == [1, 1]
     tr.close()
+
+
+def test_onepass_randomised_configurations(T, oracle):
+    """150 random (key set, root, n, L, mode, wave count) configurations (tests/devtools/fuzz.py): guarded mode -- bucket table,
+    error integers, counts, aggregates are the oracle's; mode 2 -- bucket table and counts, bounds valid for the emitted lines."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "devtools"))
+    import fuzz
+    rng = np.random.default_rng(20260927)
+    failed = []
+    ran = 0
+    for c in range(150):
+        ok, desc = fuzz.run_case(rng, c)
+        if ok is None:
+            continue
+        ran += 1
+        if not ok:
+            failed.append(desc)
+    assert ran >= 100 and not failed, failed[:5]
