@@ -983,7 +983,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   // one pass from sufficient statistics: leaves of at least a few dozen keys on average (the rows of a tile hold
   // 16 keys; shorter leaves are cheap chains for the exact kernels anyway), indices below 2^32
   const bool hinted = c->hint_epoch == c->keys_epoch && c->hint_L == L_own && c->hint_mode == c->fit_mode;
-  const bool sigma = stream_fit && c->fit_mode != 0 && !hinted && sp.n < (1ull << 32) && n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
+  const bool sigma = stream_fit && c->fit_mode != 0 && !hinted && sp.n < (1ull << 32) - (1ull << 16) && n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
   c->last_sigma = sigma;
   if (sigma) {
     if constexpr (LEAF == K_LINEAR) {

@@ -419,6 +419,8 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   const unsigned int Lm1 = (unsigned int)(r.L - 1);
   const unsigned int mid = (unsigned int)(r.L / 2);                 // two_layer.rs:131
   const unsigned int n32 = (unsigned int)sp.n;
+  // every index of this kernel is below 2^32 - 2^16 (the launch checks it): 32-bit index arithmetic throughout
+  const unsigned int rdlo = (unsigned int)sp.rd_lo, rdhi = (unsigned int)sp.rd_hi, itlo = (unsigned int)sp.it_lo;
   const unsigned long long below = (1ull << lane) - 1ull;
 
   uint4 cur[NLOAD], nxt[NLOAD];
@@ -426,11 +428,11 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   // the number of loads in flight unknown to the compiler, which then waits for all of them at once: no prefetch).
   // A piece that would reach past the readable keys is fetched from the last full piece instead and realigned in
   // phase 1 (edge batches only).
-  const uint64_t lim = sp.rd_hi - KPL;
-  auto load_batch = [&](uint4 (&dst)[NLOAD], uint64_t A) {
+  const unsigned int lim = rdhi - (unsigned int)KPL;
+  auto load_batch = [&](uint4 (&dst)[NLOAD], unsigned int A) {
 #pragma unroll
     for (int k = 0; k < NLOAD; k++) {
-      const uint64_t gi = A + (uint64_t)(k * 64 + lane) * KPL;
+      const unsigned int gi = A + (unsigned int)((k * 64 + lane) * KPL);
       dst[k] = sg_load16<K>(keys + (gi < lim ? gi : lim));
     }
   };
@@ -711,22 +713,28 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   const int bi_inherit = c0 > sp.rd_lo ? (int)(XWIN / BATCH) - 1 : -1;
   const int bi_giveup = (int)((c1 - c0 + XWIN + BATCH - 1) / BATCH) - 1;
   int bi = -1;
-  load_batch(nxt, c0);
-  for (uint64_t A = c0; !stop; A += BATCH) {
+  load_batch(nxt, c0u);
+  for (unsigned int A = c0u; !stop; A += BATCH) {
     bi++;
 #pragma unroll
     for (int k = 0; k < NLOAD; k++) cur[k] = nxt[k];
     load_batch(nxt, A + BATCH);
-    const bool interior = (A > sp.rd_lo) && (A + BATCH <= sp.rd_hi);
+    const bool interior = (A > rdlo) && (A + BATCH <= rdhi);
     bool dense = false;
     if (sg.dbg & 8) {                                               // timing experiment: the loads alone
       unsigned int acc = 0;
 #pragma unroll
       for (int k = 0; k < NLOAD; k++) acc ^= cur[k].x ^ cur[k].y ^ cur[k].z ^ cur[k].w;
       if (acc == 0x12345678u) eflags |= 64u;
-      if (A + BATCH >= c1) stop = true;
+      if (A + BATCH >= c1u) stop = true;
       continue;
     }
+    // Interior batches: the lanes that hold a boundary are only noted per load (LB), with the key / target in front of the
+    // load; ONE pass behind the batch's loads then handles the boundaries of all of them, each lane with the load it has
+    // one in.  The boundary code costs a wave ~90 vector instructions whether 1 or 64 lanes are in it, and 2.7 loads of
+    // a 512-key batch held a boundary at ~190 keys per leaf: per load it was 41 % of the kernel's vector instructions.
+    unsigned long long LB[NLOAD];
+    K ck[NLOAD];
     auto phase1 = [&](auto edge_tag) {
       constexpr bool EDGE = decltype(edge_tag)::value;
       constexpr bool FULL = EDGE || !SPARSE;                        // every key's target is evaluated up front
@@ -734,7 +742,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
       for (int k = 0; k < NLOAD; k++) {
         K kk[KPL];
         __builtin_memcpy(kk, &cur[k], 16);
-        const uint64_t g0 = A + (uint64_t)(k * 64 + lane) * KPL;
+        const unsigned int g0 = A + (unsigned int)((k * 64 + lane) * KPL);
         if constexpr (EDGE) {
           if (g0 > lim) {                                           // fetched from `lim`: realign, pad with the last key
             const unsigned int sh = (unsigned int)(g0 - lim);
@@ -759,7 +767,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
             bool oob;
             ts[q] = s2_target<ROOT, K>(r, Lm1f, Lm1, kk[q], xs[q], oob);
             if constexpr (!root_needs_bounds_check<ROOT>()) {
-              if constexpr (EDGE) oobany |= oob && (g0 + q < sp.rd_hi); else oobany |= oob;
+              if constexpr (EDGE) oobany |= oob && (g0 + (unsigned int)q < rdhi); else oobany |= oob;
             }
           } else ts[q] = 0u;
         }
@@ -782,7 +790,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
 #pragma unroll
           for (int q = 0; q < KPL; q++) {
             bool ok = true;
-            if constexpr (EDGE) { const uint64_t idx = g0 + q; ok = idx > sp.rd_lo && idx < sp.rd_hi; }
+            if constexpr (EDGE) { const unsigned int idx = g0 + (unsigned int)q; ok = idx > rdlo && idx < rdhi; }
             dq[q] = ok && (kk[q] == kp);
             anyd |= dq[q];
             kp = kk[q];
@@ -812,9 +820,9 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
           lane_b = false;
 #pragma unroll
           for (int q = 0; q < KPL; q++) {
-            const uint64_t idx = g0 + q;
+            const unsigned int idx = g0 + (unsigned int)q;
             const unsigned int tprev = q == 0 ? tp0 : ts[q - 1];
-            lane_b |= (idx > sp.rd_lo && idx < sp.rd_hi && ts[q] != tprev) || (idx == sp.rd_lo && idx == sp.it_lo) || (idx == sp.rd_hi);
+            lane_b |= (idx > rdlo && idx < rdhi && ts[q] != tprev) || (idx == rdlo && idx == itlo) || (idx == rdhi);
           }
         } else if constexpr (FULL) {
           lane_b = ts[0] != tp0;
@@ -822,7 +830,8 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
           for (int q = 1; q < KPL; q++) lane_b |= ts[q] != ts[q - 1];
         } else lane_b = ts[KPL - 1] != tp0;
         const unsigned long long bm = __ballot(lane_b);
-        if (bm) {
+        if constexpr (!EDGE) { LB[k] = bm; ck[k] = carry_key; }
+        if (EDGE && bm) {
           if constexpr (LSUM) lst |= LS_SEEN;
           // ---- the boundary block (a load in three has one): per-key flags of the lanes that hold a boundary
           bool bq[KPL];
@@ -843,10 +852,10 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
               if (q > 0) told[q] = ts[q - 1];
               bool cmp_ok = true, fstart = false, fend = false;
               if constexpr (EDGE) {
-                const uint64_t idx = g0 + q;
-                cmp_ok = idx > sp.rd_lo && idx < sp.rd_hi;
-                fstart = (idx == sp.rd_lo && idx == sp.it_lo);      // the first key of the data: no previous key
-                fend = (idx == sp.rd_hi);                           // the end of the (readable) data: no next key
+                const unsigned int idx = g0 + (unsigned int)q;
+                cmp_ok = idx > rdlo && idx < rdhi;
+                fstart = (idx == rdlo && idx == itlo);              // the first key of the data: no previous key
+                fend = (idx == rdhi);                               // the end of the (readable) data: no next key
               }
               nonmono |= cmp_ok && ts[q] < tp;
               bq[q] = (cmp_ok && ts[q] != tp) || fstart || fend;
@@ -880,22 +889,22 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
 #pragma unroll
             for (int q = 0; q < KPL; q++) {
               if (bq[q]) {
-                const uint64_t idx = g0 + q;
-                const bool own = idx >= c0 && idx < c1 && !(fq[q] & S2_END);     // this wave owns the leaf that starts here
-                if (!dense) { b_idx[rank] = (unsigned int)idx; b_t[rank] = ts[q]; b_fl[rank] = (unsigned char)fq[q]; }
+                const unsigned int idx = g0 + (unsigned int)q;
+                const bool own = idx >= c0u && idx < c1u && !(fq[q] & S2_END);     // this wave owns the leaf that starts here
+                if (!dense) { b_idx[rank] = idx; b_t[rank] = ts[q]; b_fl[rank] = (unsigned char)fq[q]; }
                 else if (own) sg.flist.push(ts[q]);
                 rank++;
                 if (own) {
                   // the keys on both sides of the boundary, for the widening of the two leaves (k_finalize reads
                   // them from here instead of gathering key[e] and key[s-1] from the key array)
                   if (!(fq[q] & S2_START)) { bnext[told[q]] = kk[q]; bprev[ts[q]] = q == 0 ? kp0 : kk[q > 0 ? q - 1 : 0]; }
-                  leaf_start[ts[q]] = idx;
+                  leaf_start[ts[q]] = (unsigned long long)idx;
                   if (fq[q] & S2_SPLIT) {
-                    st->split_idx = idx; st->split_target = ts[q];
-                    if (idx == 0 || idx + 1 >= sp.n) eflags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
+                    st->split_idx = (unsigned long long)idx; st->split_target = ts[q];
+                    if (idx == 0u || idx + 1u >= n32) eflags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
                   }
                 }
-                if (idx >= c1) stop = true;
+                if (idx >= c1u) stop = true;
               }
             }
           }
@@ -913,18 +922,131 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
           carry_t = (unsigned int)__builtin_amdgcn_readlane((int)ts[KPL - 1], 63);
         }
       }
+      if constexpr (!EDGE) {
+        unsigned long long anyb = 0ull;
+#pragma unroll
+        for (int k = 0; k < NLOAD; k++) anyb |= LB[k];
+        if (anyb) {
+          if constexpr (LSUM) lst |= LS_SEEN;
+          unsigned int pmask = 0u;                                  // the loads this lane holds a boundary in
+#pragma unroll
+          for (int k = 0; k < NLOAD; k++) pmask |= (unsigned int)((LB[k] >> lane) & 1ull) << k;
+          // one pass when no lane has two such loads (nearly always); else one pass per load, in order
+          const bool multi = __ballot((pmask & (pmask - 1u)) != 0u) != 0ull;
+          const int npass = multi ? NLOAD : 1;
+          K kprev[NLOAD];                                           // the key in front of the lane's first key, per load
+#pragma unroll
+          for (int k = 0; k < NLOAD; k++) {
+            K kl[KPL];
+            __builtin_memcpy(kl, &cur[k], 16);
+            const unsigned long long lastb = key_to_bits<K>(kl[KPL - 1]), cb = key_to_bits<K>(ck[k]);
+            const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp((int)(unsigned int)cb, (int)(unsigned int)lastb, 0x138, 0xF, 0xF, false);
+            unsigned int hi = 0u;
+            if constexpr (sizeof(K) == 8) hi = (unsigned int)__builtin_amdgcn_update_dpp((int)(unsigned int)(cb >> 32), (int)(unsigned int)(lastb >> 32), 0x138, 0xF, 0xF, false);
+            kprev[k] = bits_to_key<K>(((unsigned long long)hi << 32) | lo);
+          }
+          for (int pass = 0; pass < npass; pass++) {
+            const bool active = multi ? ((pmask >> pass) & 1u) != 0u : pmask != 0u;
+            if (__ballot(active) == 0ull) continue;
+            const unsigned int ksel = multi ? (unsigned int)pass : ((unsigned int)__builtin_ctz(pmask | (1u << (NLOAD - 1))));
+            uint4 v = cur[0];
+            K kp0 = kprev[0];
+#pragma unroll
+            for (int j = 1; j < NLOAD; j++) {
+              // (opaque conditions: the compiler otherwise turns the select chain into a per-lane indexed read of `cur`
+              //  from scratch memory, and the whole batch's registers go through scratch: 0.65 -> 0.84 ms)
+              unsigned int kj = ksel ^ (unsigned int)j;
+              asm volatile("" : "+v"(kj));
+              if (kj == 0u) { v = cur[j]; kp0 = kprev[j]; }
+            }
+            K kk[KPL];
+            __builtin_memcpy(kk, &v, 16);
+            const unsigned int g0 = A + (ksel * 64u + (unsigned int)lane) * (unsigned int)KPL;
+            unsigned int ts[KPL];
+            bool oobp;
+#pragma unroll
+            for (int q = 0; q < KPL; q++) ts[q] = s2_target<ROOT, K>(r, Lm1f, Lm1, kk[q], KeyTraits<K>::as_float(kk[q]), oobp);
+            const unsigned int tp0 = s2_target<ROOT, K>(r, Lm1f, Lm1, kp0, KeyTraits<K>::as_float(kp0), oobp);
+            bool bq[KPL];
+            unsigned int fq[KPL], told[KPL];
+            int mine = 0;
+            bool nonmono = false;
+            {
+              unsigned int tp = tp0;
+#pragma unroll
+              for (int q = 0; q < KPL; q++) {
+                told[q] = tp;
+                nonmono |= active && ts[q] < tp;
+                bq[q] = active && ts[q] != tp;
+                fq[q] = (tp < mid && ts[q] >= mid) ? S2_SPLIT : 0u;
+                mine += bq[q] ? 1 : 0;
+                tp = ts[q];
+              }
+            }
+            if (nonmono) eflags |= EF_NON_MONOTONE;                 // two_layer.rs:50 / :144
+            // ranks in index order: the loads before the lane's, the lanes below in its load, then its own in order
+            int add = 0;
+            unsigned int rank = (unsigned int)bcnt;
+            {
+              unsigned long long Kj[NLOAD], own = 0ull;
+#pragma unroll
+              for (int j = 0; j < NLOAD; j++) { Kj[j] = __ballot(active && ksel == (unsigned int)j); if (ksel == (unsigned int)j) own = Kj[j]; }
+#pragma unroll
+              for (int c = 1; c <= KPL; c++) {
+                const unsigned long long mc = __ballot(mine >= c);
+                if (c == 1 || mc) {
+#pragma unroll
+                  for (int j = 0; j < NLOAD; j++) {
+                    const int w = __popcll(mc & Kj[j]);
+                    add += w;
+                    if (ksel > (unsigned int)j) rank += (unsigned int)w;
+                  }
+                  rank += (unsigned int)__popcll(mc & own & below);
+                }
+              }
+            }
+            if (!dense && bcnt + add > BCAP) {
+              dense = true;
+              if (lane == 0 && bcnt > 0 && b_idx[bcnt - 1] >= c0u && b_idx[bcnt - 1] < c1u && !(b_fl[bcnt - 1] & S2_INHERIT)) sg.flist.push(b_t[bcnt - 1]);
+            }
+            if (mine) {
+#pragma unroll
+              for (int q = 0; q < KPL; q++) {
+                if (bq[q]) {
+                  const unsigned int idx = g0 + (unsigned int)q;
+                  const bool own_leaf = idx >= c0u && idx < c1u;    // this wave owns the leaf that starts here
+                  if (!dense) { b_idx[rank] = idx; b_t[rank] = ts[q]; b_fl[rank] = (unsigned char)fq[q]; }
+                  else if (own_leaf) sg.flist.push(ts[q]);
+                  rank++;
+                  if (own_leaf) {
+                    bnext[told[q]] = kk[q]; bprev[ts[q]] = q == 0 ? kp0 : kk[q > 0 ? q - 1 : 0];
+                    leaf_start[ts[q]] = (unsigned long long)idx;
+                    if (fq[q] & S2_SPLIT) {
+                      st->split_idx = (unsigned long long)idx; st->split_target = ts[q];
+                      if (idx == 0u || idx + 1u >= n32) eflags |= EF_DEGENERATE_SPLIT;   // two_layer.rs:27
+                    }
+                  }
+                  if (idx >= c1u) stop = true;
+                }
+              }
+            }
+            if (!dense) bcnt += add;
+            stop = __any(stop);
+          }
+        }
+      }
     };
     if (interior) phase1(std::false_type{}); else phase1(std::true_type{});
     // The next batch overwrites the ring from (A + 2 BATCH - RING) down: whatever the oldest listed leaf still needs
     // (its container starts at s - 1) has to be processed first; an OPEN leaf that does not fit is long.
-    const uint64_t bend = A + BATCH;
-    const bool fits = bcnt == 0 || (bend + BATCH - ((uint64_t)b_idx[0] - 1) <= (uint64_t)RING);
+    const unsigned int bend = A + BATCH;
+    const bool fits = bcnt == 0 || (bend + BATCH - (b_idx[0] - 1u) <= (unsigned int)RING);
     const bool giveup = LSUM && !stop && bi >= bi_giveup;           // (bend >= c1 + XWIN) the chunk rule: the leaf open at c1 is cut there
     if (sg.dbg & 1) { bcnt = bcnt > 0 ? 1 : 0; } else
     process(stop || giveup || dense || !fits, dense);
     if constexpr (!LSUM) {
       // (modes without partial sums: a long leaf is irregular, its owner walks to its end)
-      if (bcnt > 0 && !(bend + BATCH - ((uint64_t)b_idx[0] - 1) <= (uint64_t)RING)) {
+      if (bcnt > 0 && !(bend + BATCH - (b_idx[0] - 1u) <= (unsigned int)RING)) {
         if (lane == 0) b_fl[0] |= S2_LONG;
         wave_sync();
       }
@@ -935,13 +1057,13 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
         wave_sync();
         acc_start(c0u);
       }
-      if (bcnt > 0 && !(lst & LS_OPEN) && !(bend + BATCH - ((uint64_t)b_idx[0] - 1) <= (uint64_t)RING)) {
+      if (bcnt > 0 && !(lst & LS_OPEN) && !(bend + BATCH - (b_idx[0] - 1u) <= (unsigned int)RING)) {
         if (lane == 0) b_fl[0] |= S2_LONG;
         lst |= LS_OPEN;
         wave_sync();
         acc_start(b_idx[0]);
       }
-      if (lst & LS_ACC) acc_run((unsigned int)(bend < c1 ? bend : c1));
+      if (lst & LS_ACC) acc_run(bend < c1u ? bend : c1u);
       if (giveup) {
         if (bcnt > 0) {                                             // entry 0: the leaf open at c1 (it starts before c1)
           const unsigned int leaf = b_t[0], f0 = b_fl[0];
