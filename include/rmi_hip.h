@@ -333,6 +333,18 @@ int rmi_hip_root_stream_finish(rmi_hip_root_stream* rs, rmi_hip_model_params* ou
 int rmi_hip_train_two_layer(rmi_hip_ctx* ctx, const rmi_hip_model_params* root, int leaf_kind,
                             uint64_t num_leaves, rmi_hip_result* out);
 
+/* Upload and train at once (replaces the reference's loader + train for a key set in host memory, src/load.rs:132-157,
+ * train/mod.rs:100-126).  The keys go to HBM in chunks through two pinned staging buffers (host copy of chunk c+1 beside
+ * the DMA of chunk c); the key set is cut into `chunks` leaf-aligned shards (rmi_hip_plan_shards on the host keys) and
+ * shard s is trained as soon as its keys have arrived, behind the upload of the following ones.  When the call returns
+ * the keys are resident (as after rmi_hip_upload_keys), the per-leaf arrays hold all `num_leaves` leaves and `out` the
+ * aggregates of the whole model: the same results as upload + rmi_hip_train_two_layer, bit for bit in RMI_FIT_EXACT
+ * (the f64 sums of the aggregates are recombined per shard: equal to 1e-12).  num_leaves must be a multiple of chunks
+ * (1 .. RMI_STREAM_MAX_CHUNKS); the root has to be known (fit it from the host keys: rmi_hip_fit_root_host). */
+#define RMI_STREAM_MAX_CHUNKS 64
+int rmi_hip_train_streamed(rmi_hip_ctx* ctx, const void* host_keys, uint64_t n, int dtype, const rmi_hip_model_params* root,
+                           int leaf_kind, uint64_t num_leaves, int chunks, rmi_hip_result* out);
+
 /* ---- results (valid until the next train call on this context) ---- */
 int rmi_hip_download_leaf_params(rmi_hip_ctx* ctx, double* host_out /* L*ppl */);
 int rmi_hip_download_leaf_errors(rmi_hip_ctx* ctx, uint64_t* host_out /* L */);

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("rmi_hip_root_stream_push", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("rmi_hip_root_stream_finish", C.c_int, [C.c_void_p, C.POINTER(ModelParams)]),
     ("rmi_hip_train_two_layer", C.c_int, [C.c_void_p, C.POINTER(ModelParams), C.c_int, C.c_uint64, C.POINTER(Result)]),
+    ("rmi_hip_train_streamed", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(ModelParams), C.c_int, C.c_uint64, C.c_int, C.POINTER(Result)]),
     ("rmi_hip_download_leaf_params", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_download_leaf_errors", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_download_leaf_counts", C.c_int, [C.c_void_p, C.c_void_p]),

@@ -60,6 +60,13 @@ struct rmi_hip_ctx {
   Span shard = {};
   unsigned long long shard_split_idx = ~0ull, shard_split_target = 0;
   void* d_rows_ext = nullptr;                   // caller-provided row buffer (e.g. the all-gather buffer)
+  // streamed training (rmi_hip_train_streamed): the key buffer and the output arrays are those of the WHOLE key set, a
+  // launch works on the shard in c->shard; its aggregates go to slot stream_slot of the pinned state array
+  bool stream_mode = false;
+  int stream_slot = 0;
+  void* h_stage[2] = {nullptr, nullptr};        // pinned staging buffers of the chunked upload
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
   hipEvent_t ev[10] = {};
   int profile_level = 0;                        // 0: whole call only; 1: + the first (dominant) kernel; 2: every kernel group
   DevState* h_state_dev = nullptr;              // device address of the pinned h_state (written by the last kernel)
@@ -224,7 +231,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   c->stream = c->own_stream;
   if (hipMalloc(&c->d_state, sizeof(DevState)) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
-  if (hipHostMalloc((void**)&c->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
+  if (hipHostMalloc((void**)&c->h_state, sizeof(DevState) * RMI_STREAM_MAX_CHUNKS, hipHostMallocDefault) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->h_state_dev, c->h_state, 0) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_sentinel, 64, hipHostMallocDefault) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
@@ -279,6 +286,8 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_sentinel) (void)hipHostFree(c->h_sentinel);
+  for (int b = 0; b < 2; b++) { if (c->h_stage[b]) (void)hipHostFree(c->h_stage[b]); if (c->ev_stage[b]) (void)hipEventDestroy(c->ev_stage[b]); }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -941,15 +950,20 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   const uint64_t n_it = sp.it_hi - sp.it_lo;            // keys this launch works on
   const uint64_t L_own = sp.leaf_hi - sp.leaf_lo;
   // pointers pre-offset so that ptr[global index] is the right element
-  const K* keys = (const K*)c->d_keys - sp.rd_lo;
-  unsigned long long* leaf_start = c->d_leaf_start - sp.leaf_lo;
-  double* params = c->d_params - sp.leaf_lo * PPL;
-  unsigned long long* maxerr = c->d_maxerr - sp.leaf_lo;
-  unsigned long long* run = c->d_run - sp.leaf_lo;
-  unsigned long long* err = c->d_err - sp.leaf_lo;
-  unsigned long long* count = c->d_count - sp.leaf_lo;
+  // (streamed training: buffers of the whole key set / all leaves, indexed globally)
+  const uint64_t kb = c->stream_mode ? sp.rd_lo : 0, lb = c->stream_mode ? sp.leaf_lo : 0;
+  const K* keys = (const K*)c->d_keys + kb - sp.rd_lo;
+  unsigned long long* const a_leaf_start = c->d_leaf_start + lb;
+  unsigned long long* const a_maxerr = c->d_maxerr + lb;
+  unsigned long long* const a_run = c->d_run + lb;
+  unsigned long long* leaf_start = a_leaf_start - sp.leaf_lo;
+  double* params = c->d_params + lb * PPL - sp.leaf_lo * PPL;
+  unsigned long long* maxerr = a_maxerr - sp.leaf_lo;
+  unsigned long long* run = a_run - sp.leaf_lo;
+  unsigned long long* err = c->d_err + lb - sp.leaf_lo;
+  unsigned long long* count = c->d_count + lb - sp.leaf_lo;
   unsigned char* rows_base = c->d_rows_ext ? (unsigned char*)c->d_rows_ext : c->d_rows;
-  unsigned char* rows = rows_base - sp.leaf_lo * ROWB;
+  unsigned char* rows = rows_base + lb * ROWB - sp.leaf_lo * ROWB;
 
   // --- init ---
   // long-leaf list: a long leaf has at least long_min points, so n/long_min entries always suffice
@@ -969,10 +983,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
   if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, 2 * SG_REGIONS * 8));  // (the one-pass mode's list + merge counters: zeroed by k_init)
-  HIPCHK(c, hipEventRecord(c->ev[8], s));                      // start of the device work of this call
+  if (!c->stream_mode || c->stream_slot == 0) HIPCHK(c, hipEventRecord(c->ev[8], s));   // start of the device work of this call
   {
     const uint64_t ib = (L_own + 1 + 255) / 256;
-    hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, c->d_leaf_start, c->d_maxerr, c->d_run,
+    hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
                        L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS);
   }
 
@@ -1075,9 +1089,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   {
     const uint64_t count_e = L_own + 1;
     const uint64_t ntiles = (count_e + FILL_TILE - 1) / FILL_TILE;
-    hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count_e, c->d_tilemin);
+    hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, a_leaf_start, count_e, c->d_tilemin);
     hipLaunchKernelGGL(k_fill_scan_tiles, dim3(1), dim3(1024), 0, s, c->d_tilemin, ntiles);
-    hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, c->d_leaf_start, count_e, c->d_tilemin);
+    hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, a_leaf_start, count_e, c->d_tilemin);
   }
   mark();
   if (sigma) {
@@ -1146,7 +1160,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
                        params, maxerr, run, err, count, rows, c->d_partials, bn, bp);
     // (the last kernel also copies the device state into the pinned host copy: a separate 100-byte
     // copy command would cost ~15 us of the call)
-    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials, (int)blocks, c->d_state, c->h_state_dev);
+    hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials, (int)blocks, c->d_state, c->h_state_dev + (c->stream_mode ? c->stream_slot : 0));
   }
   mark();
   HIPCHK(c, hipEventRecord(c->ev[9], s));
@@ -1200,8 +1214,8 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   uint64_t L_own = num_leaves;
   if (c->have_shard) {
     const Span& sp = c->shard;
-    if (sp.leaf_hi > num_leaves || sp.rd_hi - sp.rd_lo != c->n) return RMI_ERR_BAD_ARG;
-    L_own = sp.leaf_hi - sp.leaf_lo;
+    if (sp.leaf_hi > num_leaves || (c->stream_mode ? sp.rd_hi > c->n : sp.rd_hi - sp.rd_lo != c->n)) return RMI_ERR_BAD_ARG;
+    L_own = c->stream_mode ? num_leaves : sp.leaf_hi - sp.leaf_lo;
   }
   int rc = ensure_outputs(c, L_own, ppl);
   if (rc) return rc;

@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   const unsigned int n32 = (unsigned int)sp.n;
   // every index of this kernel is below 2^32 - 2^16 (the launch checks it): 32-bit index arithmetic throughout
   const unsigned int rdlo = (unsigned int)sp.rd_lo, rdhi = (unsigned int)sp.rd_hi, itlo = (unsigned int)sp.it_lo;
+  const unsigned int leaf_lo32 = (unsigned int)sp.leaf_lo;
   const unsigned long long below = (1ull << lane) - 1ull;
 
   uint4 cur[NLOAD], nxt[NLOAD];
@@ -897,7 +898,8 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
                 if (own) {
                   // the keys on both sides of the boundary, for the widening of the two leaves (k_finalize reads
                   // them from here instead of gathering key[e] and key[s-1] from the key array)
-                  if (!(fq[q] & S2_START)) { bnext[told[q]] = kk[q]; bprev[ts[q]] = q == 0 ? kp0 : kk[q > 0 ? q - 1 : 0]; }
+                  // (the leaf that ends at a shard's first key belongs to the shard before: outside this launch's arrays)
+                  if (!(fq[q] & S2_START)) { if (told[q] >= leaf_lo32) bnext[told[q]] = kk[q]; bprev[ts[q]] = q == 0 ? kp0 : kk[q > 0 ? q - 1 : 0]; }
                   leaf_start[ts[q]] = (unsigned long long)idx;
                   if (fq[q] & S2_SPLIT) {
                     st->split_idx = (unsigned long long)idx; st->split_target = ts[q];
@@ -1019,7 +1021,8 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
                   else if (own_leaf) sg.flist.push(ts[q]);
                   rank++;
                   if (own_leaf) {
-                    bnext[told[q]] = kk[q]; bprev[ts[q]] = q == 0 ? kp0 : kk[q > 0 ? q - 1 : 0];
+                    if (told[q] >= leaf_lo32) bnext[told[q]] = kk[q];     // (the leaf before a shard's first key: not this launch's)
+                    bprev[ts[q]] = q == 0 ? kp0 : kk[q > 0 ? q - 1 : 0];
                     leaf_start[ts[q]] = (unsigned long long)idx;
                     if (fq[q] & S2_SPLIT) {
                       st->split_idx = (unsigned long long)idx; st->split_target = ts[q];

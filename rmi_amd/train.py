@@ -334,6 +334,9 @@ class Trainer:
         res = _lib.Result()
         rc = self._lib.rmi_hip_train_two_layer(self._h, C.byref(root._c()), leaf_kind, num_leaves, C.byref(res))
         _check(rc, self._h)
+        return self._result(res, root, leaf_kind, num_leaves)
+
+    def _result(self, res, root: Model, leaf_kind: int, num_leaves: int) -> TrainedRMI:
         return TrainedRMI(
             num_rmi_rows=int(res.num_rows), num_data_rows=int(res.num_rows),
             model_avg_error=res.model_avg_error, model_avg_l2_error=res.model_avg_l2_error,
@@ -348,6 +351,38 @@ class Trainer:
                      "sum_n_err": int(res.sum_n_err), "sum_l2": float(res.sum_l2), "sum_log2": float(res.sum_log2)},
             fit_mode_used=int(res.fit_mode_used), exact_leaves=int(res.exact_leaves), merged_leaves=int(res.merged_leaves), guard_leaves=int(res.guard_leaves),
             generation=int(res.generation), _trainer=self)
+
+    def fit_root_host(self, keys: np.ndarray, root: str | int, num_leaves: int) -> Model:
+        """The exact root fit from keys in HOST memory, no device involved (linear, robust_linear; linear_spline and radix
+        through the same entry point): what train_streamed needs before the keys are uploaded."""
+        kind = root if isinstance(root, int) else self._lib.rmi_hip_model_from_name(root.encode())
+        if kind < 0:
+            raise RMIError(kind)
+        arr = np.ascontiguousarray(keys)
+        m = _lib.ModelParams()
+        _check(self._lib.rmi_hip_fit_root_host(kind, _DTYPES[arr.dtype], C.c_void_p(arr.ctypes.data), arr.size, num_leaves, C.byref(m)))
+        return Model._from_c(m)
+
+    def train_streamed(self, keys: np.ndarray, root: Model, leaf: str | int, num_leaves: int, chunks: int = 16) -> TrainedRMI:
+        """Upload + train, overlapped (rmi_hip_train_streamed): the keys go to HBM in chunks through pinned staging
+        buffers and every leaf-aligned shard is trained as soon as its keys have arrived.  Afterwards the keys are
+        resident like after set_keys; the result is that of set_keys + train_leaves."""
+        leaf_kind = leaf if isinstance(leaf, int) else self._lib.rmi_hip_model_from_name(leaf.encode())
+        if leaf_kind < 0:
+            raise RMIError(leaf_kind)
+        arr = np.ascontiguousarray(keys)
+        if arr.dtype not in _DTYPES:
+            raise TypeError(f"unsupported key dtype {arr.dtype}")
+        self.wait_keys()
+        with self._ctx_lock:
+            res = _lib.Result()
+            rc = self._lib.rmi_hip_train_streamed(self._h, C.c_void_p(arr.ctypes.data), arr.size, _DTYPES[arr.dtype], C.byref(root._c()),
+                                                  leaf_kind, num_leaves, chunks, C.byref(res))
+            _check(rc, self._h)
+            self._host_keys = arr
+            self._keepalive = None
+            self.n = int(arr.size)
+            return self._result(res, root, leaf_kind, num_leaves)
 
     def train(self, model_spec: str, branch_factor: int, root_mode: str = "exact") -> TrainedRMI:
         """rmi_lib::train (train/mod.rs:100-126).  With a key set whose upload is still running (set_keys(wait=False)) the

@@ -189,3 +189,28 @@ def test_more_than_2_pow_32_keys(oracle):
     with pytest.raises(RuntimeError):
         _ = g.leaf_counts.sum() if "counts" not in g._cache else g._trainer._download("counts", g)   # stale result: refused, not another training's arrays
     tr.close()
+
+
+def test_metric_config_streamed_equals_resident():
+    """rmi_hip_train_streamed at the metric configuration (16 leaf-aligned shards trained behind the chunked upload), exact
+    and guarded one-pass mode: every per-leaf output equals the resident run's.  (Guards the shard edges of the one-pass
+    kernel: the leaf that ends at a shard's first key belongs to the shard before.)"""
+    from rmi_amd import train
+    n, L = 200_000_000, 1 << 20
+    tr = train.Trainer()
+    tr.generate_keys("uniform", np.uint64, n)
+    keys = tr.download_keys()
+    root = tr.fit_root("linear", L, mode="fast")
+    for mode in (0, 1):
+        tr.set_fit_mode(mode)
+        r = tr.train_leaves(root, "linear", L).materialize()
+        s = tr.train_streamed(keys, root, "linear", L, chunks=16).materialize()
+        assert s.fit_mode_used == mode
+        assert np.array_equal(s.leaf_starts, r.leaf_starts) and np.array_equal(s.leaf_counts, r.leaf_counts)
+        assert np.array_equal(s.last_layer_max_l1s, r.last_layer_max_l1s)
+        assert s.model_max_error == r.model_max_error and s.model_avg_error == r.model_avg_error
+        if mode == 0:
+            assert np.array_equal(s.leaf_params, r.leaf_params) and np.array_equal(s.rows, r.rows)
+        else:
+            assert np.allclose(s.leaf_params[:, 1], r.leaf_params[:, 1], rtol=1e-8, atol=0.0)
+    tr.close()
