@@ -66,7 +66,11 @@ def main(argv=None) -> int:
         return 2
     keys = datagen.read_keys(args.input)                                              # src/load.rs:132-157
     key_c = "double" if keys.dtype == np.float64 else "uint64_t"                       # src/main.rs:122-132
-    tr = train.Trainer(np.ascontiguousarray(keys), device=args.device)
+    keys = np.ascontiguousarray(keys)
+    # a single exact training takes the keys from host memory with the upload overlapped (Trainer.train_from_host);
+    # the optimizer, a parameter grid and the bounded mode train many times on resident keys
+    single = not args.optimize and not args.param_grid and args.bounded is None and args.max_size is None and not args.fast_root
+    tr = train.Trainer(device=args.device) if single else train.Trainer(keys, device=args.device)
     n = len(keys)
     try:
         if args.optimize:                                                              # src/main.rs:134-163
@@ -111,7 +115,10 @@ def main(argv=None) -> int:
                 return 1
             rmi = tr.train_bounded(args.models, args.branching_factor, args.bounded)
         else:
-            rmi = tr.train(args.models, args.branching_factor, root_mode="fast" if args.fast_root else "exact")
+            if single:
+                rmi = tr.train_from_host(keys, args.models, args.branching_factor)
+            else:
+                rmi = tr.train(args.models, args.branching_factor, root_mode="fast" if args.fast_root else "exact")
         print(f"Model build time: {rmi.build_time // 1_000_000} ms (device {rmi.device_ns / 1e6:.3f} ms)")
         print(f"Average model error: {rmi.model_avg_error} ({rmi.model_avg_error / n * 100.0}%)")
         print(f"Average model L2 error: {rmi.model_avg_l2_error}")

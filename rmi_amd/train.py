@@ -384,6 +384,26 @@ class Trainer:
             self.n = int(arr.size)
             return self._result(res, root, leaf_kind, num_leaves)
 
+    def train_from_host(self, keys: np.ndarray, model_spec: str, branch_factor: int, chunks: int = 16) -> TrainedRMI:
+        """rmi_lib::train for keys in host memory with the upload overlapped: the exact root fit on the host (no device),
+        then train_streamed.  Root kinds whose fit needs the device (radix tables, bradix) and leaf counts that no power
+        of two up to `chunks` divides take the plain path: set_keys + train."""
+        t0 = time.perf_counter_ns()
+        root_kind, leaf_kind = parse_spec(model_spec)
+        c = 1
+        while c * 2 <= chunks and branch_factor % (c * 2) == 0:
+            c *= 2
+        try:
+            root = self.fit_root_host(keys, root_kind, branch_factor)
+        except RMIError as e:
+            if e.code != -11:                       # RMI_ERR_UNSUPPORTED_MODEL: a root the host alone cannot fit
+                raise
+            self.set_keys(keys)
+            return self.train(model_spec, branch_factor)
+        out = self.train_streamed(keys, root, leaf_kind, branch_factor, chunks=c)
+        out.build_time = time.perf_counter_ns() - t0
+        return out
+
     def train(self, model_spec: str, branch_factor: int, root_mode: str = "exact") -> TrainedRMI:
         """rmi_lib::train (train/mod.rs:100-126).  With a key set whose upload is still running (set_keys(wait=False)) the
         sequential host fit of a linear / robust_linear root runs beside the upload."""
@@ -440,6 +460,12 @@ class Trainer:
 
 def train(keys, model_spec: str, branch_factor: int, device: int = 0) -> TrainedRMI:
     """One-shot convenience mirror of ``rmi_lib::train(data, model_spec, branch_factor)``."""
+    if isinstance(keys, np.ndarray):
+        tr = Trainer(device=device)
+        out = tr.train_from_host(keys, model_spec, branch_factor)
+        out.materialize()
+        tr.close()
+        return out
     tr = Trainer(keys, device=device)
     out = tr.train(model_spec, branch_factor)
     out.materialize()                  # before the context goes away
