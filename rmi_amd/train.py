@@ -375,6 +375,12 @@ class Trainer:
             raise TypeError(f"unsupported key dtype {arr.dtype}")
         self.wait_keys()
         with self._ctx_lock:
+            if root.is_radix_table and self._table_in_ctx is not root.table:
+                if root.table is None:
+                    raise ValueError("a radix-table root needs its hint table (Model.table)")
+                t = np.ascontiguousarray(root.table, dtype=np.uint32)
+                _check(self._lib.rmi_hip_set_root_table(self._h, t.ctypes.data, t.size), self._h)
+                self._table_in_ctx = root.table
             res = _lib.Result()
             rc = self._lib.rmi_hip_train_streamed(self._h, C.c_void_p(arr.ctypes.data), arr.size, _DTYPES[arr.dtype], C.byref(root._c()),
                                                   leaf_kind, num_leaves, chunks, C.byref(res))
