@@ -88,7 +88,7 @@ struct rmi_hip_ctx {
   uint64_t recs_bytes = 0;
   unsigned long long* d_segs = nullptr;         // one-pass modes: the stretches of the long listed leaves for their error pass
   uint64_t segs_cap = 0;
-  SgParams last_sg;                             // the parameters of the last k_sigma2 launch (k_fit_list reads the records)
+  SgParams last_sg;                             // the parameters of the last k_sigma2 launch (k_list reads the records)
   // A key set on which the one-pass kernel hands most leaves to the exact list kernels (duplicate-heavy keys; keys
   // whose f64 images collapse, in the guarded mode) is served faster by the exact streaming passes: 1.1 ms against
   // 13.8 ms on 200 M duplicate-heavy keys.  Remembered per (key set, leaf count, mode); the next call takes the exact path.
