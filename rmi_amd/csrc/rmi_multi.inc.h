@@ -313,6 +313,7 @@ int rmi_hip_train_streamed(rmi_hip_ctx* c, const void* host_keys, uint64_t n, in
   const size_t total = n * ks;
   int next = 0;
   bool used[2] = {false, false};
+  bool any_sigma = false;
   c->stream_mode = true;
   auto fail = [&](int code) { c->stream_mode = false; c->defer_sync = false; (void)rmi_hip_set_shard(c, nullptr); (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream); return code; };
   size_t off = 0;
@@ -335,6 +336,7 @@ int rmi_hip_train_streamed(rmi_hip_ctx* c, const void* host_keys, uint64_t n, in
       rc = rmi_hip_train_two_layer(c, root, leaf_kind, num_leaves, out);
       c->defer_sync = false;
       if (rc != RMI_OK) return fail(rc);
+      any_sigma = any_sigma || c->last_sigma;                             // (a shard with few keys per leaf takes the exact passes)
       next++;
     }
   }
@@ -353,6 +355,7 @@ int rmi_hip_train_streamed(rmi_hip_ctx* c, const void* host_keys, uint64_t n, in
     tot.long_count += d.long_count; tot.flag_count += d.flag_count; tot.guard_count += d.guard_count; tot.merged_count += d.merged_count;
   }
   c->h_state[0] = tot;
+  c->last_sigma = any_sigma;
   return finish_train(c, leaf_kind, num_leaves, out);
 }
 

@@ -20,7 +20,8 @@ def run_case(rng, c=0):
     L = int(2 ** rng.uniform(3, np.log2(n / 32)))
     if root == "radix":
         L = 1 << max(3, int(np.log2(L)))
-    mode = int(rng.integers(1, 3))
+    mode = int(rng.integers(0, 3))
+    streamed = bool(rng.integers(0, 2))
     waves = [None, "64", "1000", "100000"][rng.integers(4)]
     if waves: os.environ["RMI_HIP_SIGMA_WAVES"] = waves
     else: os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
@@ -29,15 +30,30 @@ def run_case(rng, c=0):
         o = orc.train_two_layer(root, "linear", keys, L, threads=2)
     except orc.OracleError:
         return None, "reference panics"
-    tr = train.Trainer(keys)
-    tr.set_fit_mode(mode)
-    g_root = tr.fit_root(root, L)
-    g = tr.train_leaves(g_root, "linear", L).materialize()
+    chunks = 1
+    if streamed:
+        while chunks < 8 and L % (chunks * 2) == 0 and rng.integers(0, 3) > 0:
+            chunks *= 2
+        tr = train.Trainer()
+        tr.set_fit_mode(mode)
+        try:
+            g_root = tr.fit_root_host(keys, root, L)
+        except train.RMIError:
+            tr.close()
+            return None, "root not fitted on the host"
+        g = tr.train_streamed(keys, g_root, "linear", L, chunks=chunks).materialize()
+    else:
+        tr = train.Trainer(keys)
+        tr.set_fit_mode(mode)
+        g_root = tr.fit_root(root, L)
+        g = tr.train_leaves(g_root, "linear", L).materialize()
     tr.close()
     ok = np.array_equal(g.leaf_starts, o.leaf_start) and np.array_equal(g.leaf_counts, o.leaf_count)
     ge, oe = g.last_layer_max_l1s.astype(np.int64), o.leaf_err.astype(np.int64)
     nd = int(np.count_nonzero(ge != oe))
-    if mode == 1:
+    if mode == 0:
+        ok = ok and nd == 0 and np.array_equal(g.leaf_params, o.leaf_params) and g.model_max_error == o.model_max_error and g.model_avg_error == o.model_avg_error
+    elif mode == 1:
         ok = ok and nd == 0 and g.model_max_error == o.model_max_error and g.model_avg_error == o.model_avg_error
     else:
         ok = ok and nd <= g.guard_leaves + g.merged_leaves
@@ -53,7 +69,7 @@ def run_case(rng, c=0):
         over = mx - ge
         ok = ok and int(np.count_nonzero(over > 0)) <= 2 and (over.max() <= 1)
     os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
-    return ok, (f"{c:3d} {gen:14s} {root:13s} n={n:8d} L={L:7d} mode={mode} waves={waves} used={g.fit_mode_used} exact={g.exact_leaves} "
+    return ok, (f"{c:3d} {gen:14s} {root:13s} n={n:8d} L={L:7d} mode={mode} streamed={chunks if streamed else 0} waves={waves} used={g.fit_mode_used} exact={g.exact_leaves} "
                 f"merged={g.merged_leaves} guard={g.guard_leaves} diff={nd}")
 
 
