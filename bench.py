@@ -228,6 +228,8 @@ def main():
                 "mode": {0: "exact: reference-order recurrence per leaf, two passes over the keys; coefficients bit-identical",
                          1: "one pass (sufficient statistics from LDS); error integers bit-identical through the guard, "
                             "flagged leaves re-fitted by the exact kernels; coefficients to the reference's rounding noise",
+                         3: "one pass, bit-identical: linear_spline leaves (the line through a container's end points) from the "
+                            "LDS ring, error pass from LDS",
                          2: "one pass, the least-squares line of the sums everywhere they are defined: guard-flagged leaves only "
                             "counted, long leaves from merged per-wave partial sums; a valid index, integers not certified"}[used],
                 "mode_requested": args.mode,

@@ -182,6 +182,10 @@ int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
  * uniform / heavy-tailed / clustered key sets of 200 M keys, is 0.46 of the bound with factor 1).  Leaf kinds other
  * than `linear` ignore the mode. */
 enum rmi_hip_fit_mode { RMI_FIT_EXACT = 0, RMI_FIT_ONEPASS_GUARDED = 1, RMI_FIT_ONEPASS = 2 };
+/* linear_spline leaves (the line through the two end points of a container, linear_spline.rs:13-35) need no sums: the
+ * one-pass kernel reproduces them bit for bit and serves them in EVERY mode; rmi_hip_result.fit_mode_used then reads
+ * RMI_FIT_USED_ONEPASS_EXACT. */
+enum { RMI_FIT_USED_ONEPASS_EXACT = 3 };
 int rmi_hip_set_fit_mode(rmi_hip_ctx* ctx, int mode, double guard_k);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = context's own. */
 int rmi_hip_set_stream(rmi_hip_ctx* ctx, void* hip_stream);

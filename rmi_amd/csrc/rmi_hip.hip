@@ -81,6 +81,7 @@ struct rmi_hip_ctx {
   int fit_mode = 0;
   double guard_k = 2.0;
   uint64_t sigma_waves = 4096;                  // k_sigma2: chunks the keys are cut into (one wave each)
+  bool spline_onepass = true;                   // linear_spline leaves through the one-pass kernel, in every fit mode
   unsigned int sigma_min_leaf = 32;             // average keys per leaf below which the exact kernels are used
   unsigned int* d_flist = nullptr;              // leaves handed to the exact kernels: SG_REGIONS regions of flist_cap ids ...
   unsigned long long* d_flist_cnt = nullptr;    // ... and their counters
@@ -99,6 +100,7 @@ struct rmi_hip_ctx {
   uint64_t bkeys_cap = 0;
   uint64_t flist_cap = 0;                       // entries per region
   bool last_sigma = false;
+  bool last_spline = false;                     // ... for linear_spline leaves (bit-identical in one pass)
   // last result
   uint64_t last_L = 0;
   int last_ppl = 2;
@@ -253,6 +255,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (gk && *gk) { const double v = std::atof(gk); if (v > 0.0) c->guard_k = v; }
   const char* sw = std::getenv("RMI_HIP_SIGMA_WAVES");
   if (sw && *sw) { const long v = std::atol(sw); if (v > 0) c->sigma_waves = (uint64_t)v; }
+  { const char* so = std::getenv("RMI_HIP_SPLINE_ONEPASS"); if (so && *so) c->spline_onepass = std::atoi(so) != 0; }
   *out = c;
   return RMI_OK;
 }
@@ -997,10 +1000,15 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   // one pass from sufficient statistics: leaves of at least a few dozen keys on average (the rows of a tile hold
   // 16 keys; shorter leaves are cheap chains for the exact kernels anyway), indices below 2^32
   const bool hinted = c->hint_epoch == c->keys_epoch && c->hint_L == L_own && c->hint_mode == c->fit_mode;
-  const bool sigma = stream_fit && c->fit_mode != 0 && !hinted && sp.n < (1ull << 32) - (1ull << 16) && n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
+  // linear_spline leaves (the line through a container's two end points) need no sums and no guard: the one-pass kernel
+  // reproduces them bit for bit, so it serves EVERY fit mode (RMI_HIP_SPLINE_ONEPASS=0: the per-pass kernels)
+  const bool spline1 = (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_onepass;
+  const bool sigma = ((stream_fit && c->fit_mode != 0) || spline1) && !hinted && sp.n < (1ull << 32) - (1ull << 16) &&
+                     n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
   c->last_sigma = sigma;
+  c->last_spline = sigma && LEAF == K_LINEAR_SPLINE;
   if (sigma) {
-    if constexpr (LEAF == K_LINEAR) {
+    if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
       const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
       if (c->flist_cap < rcap) {
         if (c->d_flist) (void)hipFree(c->d_flist);
@@ -1035,7 +1043,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           sgp.chunk = chunk;
           const uint64_t sblocks = (n_it + chunk - 1) / chunk;
           sgp.recs = nullptr; sgp.rec_cnt = nullptr; sgp.rpw = 0; sgp.segs = c->d_segs;
-          if (c->fit_mode == 2) {
+          if (LEAF == K_LINEAR && c->fit_mode == 2) {
             // a stretch of a long leaf is at least RING / 2 - BATCH keys, or the only one of its wave
             const uint64_t rpw = chunk / (RING / 2 - BATCH) + 3;
             const uint64_t need = sblocks * rpw * sizeof(SgRec) + sblocks * 4;
@@ -1048,7 +1056,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
             sgp.recs = (SgRec*)c->d_recs; sgp.rec_cnt = (unsigned int*)((char*)c->d_recs + sblocks * rpw * sizeof(SgRec)); sgp.rpw = (unsigned int)rpw;
           }
           c->last_sg = sgp;
-          if (c->fit_mode == 2)
+          if constexpr (LEAF == K_LINEAR_SPLINE)
+            hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH, false, K_LINEAR_SPLINE>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state,
+                               (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
+          else if (c->fit_mode == 2)
             hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH, true>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state,
                                (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
           else
@@ -1095,10 +1106,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   }
   mark();
   if (sigma) {
-    if constexpr (LEAF == K_LINEAR) {
+    if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
       // --- the leaves the one-pass kernel handed over: fit (or merge) + error pass, one wave per leaf; long ones in stretches ---
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
-      hipLaunchKernelGGL((k_list<K>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->last_sg, maxerr, run);
+      hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->last_sg, maxerr, run);
       mark();
       hipLaunchKernelGGL((k_list_tail<K>), dim3(8192), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
     }
@@ -1287,7 +1298,7 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   if (c->last_sigma && (st.flag_count - st.merged_count) * 4 > L_own) {   // most leaves went through the list kernels: see hint_epoch
     c->hint_epoch = c->keys_epoch; c->hint_L = L_own; c->hint_mode = c->fit_mode;
   }
-  out->fit_mode_used = c->last_sigma ? c->fit_mode : 0;
+  out->fit_mode_used = c->last_sigma ? (c->last_spline ? RMI_FIT_USED_ONEPASS_EXACT : c->fit_mode) : 0;
   out->exact_leaves = c->last_sigma ? st.flag_count - st.merged_count : 0;
   out->merged_leaves = c->last_sigma ? (int32_t)(st.merged_count < 0x7fffffffull ? st.merged_count : 0x7fffffffull) : 0;
   out->guard_leaves = c->last_sigma ? st.guard_count : 0;

@@ -171,7 +171,7 @@ __device__ bool sg_merge_long(uint64_t j, uint64_t s, uint64_t e, uint64_t lo, u
 // (Separate kernels for list fit, long fit, list errors and long errors cost four launches of ~4 us each; the
 // counters are per region because same-address atomics serialise.)
 constexpr unsigned long long SG_SEG_PLAIN = 1ull << 63;
-template <typename K>
+template <typename K, int LEAFK = K_LINEAR>
 __global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp,
                                              const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
                                              double* __restrict__ params, SgList fl, SgParams sg,
@@ -195,12 +195,12 @@ __global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp
       merged = __shfl(ok, 0) != 0;
     }
     if (merged) merged_here++;
-    else if (ck == 2) {
+    else if (LEAFK == K_LINEAR && ck == 2) {
       fit_long_leaf<K>(keys, sp, lo, hi, st, params + j * 2, lds);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // (the LDS buffers are reused by the next leaf)
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else if (lane == 0) fit_one_leaf<K_LINEAR, K>(j, keys, sp, leaf_start, st, params);
+    } else if (lane == 0) fit_one_leaf<LEAFK, K>(j, keys, sp, leaf_start, st, params);
     if (merged || e - s > (uint64_t)SG_ERR_LONG) {
       if (lane == 0) {
         const uint64_t nseg = (e - s + SG_SEG - 1) / SG_SEG;
@@ -389,7 +389,7 @@ __device__ __forceinline__ unsigned int s2_target(const RootP& r, double Lm1f, u
 // (cubic, loglinear, normal; a radix table may be caller-provided) are evaluated at every key.
 template <int ROOT> __device__ __forceinline__ constexpr bool s2_root_monotone() { return ROOT == K_LINEAR || ROOT == K_RADIX; }
 
-template <int ROOT, typename K, int RING, int BATCH, bool LSUM>
+template <int ROOT, typename K, int RING, int BATCH, bool LSUM, int LEAFK = K_LINEAR>
 __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span sp, RootP r, SgParams sg,
                                                unsigned long long* __restrict__ leaf_start, double* __restrict__ params,
                                                unsigned long long* __restrict__ leaf_maxerr, DevState* __restrict__ st,
@@ -543,8 +543,22 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
       const bool owned = act && s >= c0u && s < c1u;
       bool irregular = fl != 0u;
       const bool work = owned && !irregular;
+      double alpha = 0.0, beta = 0.0, delta = 1.0;
+      double xpl = 0.0, xe = 0.0;
+      if constexpr (LEAFK == K_LINEAR_SPLINE) {
+        // linear_spline.rs:13-35: the line through the first and the last point of the container [s-1, e] -- the same two
+        // points, the same operations, so the same bits as the reference; nothing to sum and nothing to guard.
+        if (work) { xpl = xring[rpos(s - 1u)]; xe = xring[rpos(e)]; }
+        if (!(xpl < xe)) irregular = true;                            // NaN (a duplicate: y is not the index), or two keys on one f64
+        else {
+          const double y0 = (double)(s - 1u), y1 = (double)e;
+          beta = (y0 - y1) / (xpl - xe);
+          alpha = y0 - beta * xpl;                                    // plain multiply and subtract
+        }
+        delta = 0.0;                                                  // (no rounding differences to guard against)
+      } else {
       // ---- sums over the container [s-1, e] relative to (x[s], s); a lane takes the keys s-1+l, s-1+l+GL, ...
-      double p = 0.0, xpl = 0.0, xe = 0.0;
+      double p = 0.0;
       double R0 = 0.0, R1 = 0.0, Q = 0.0;                            // Q = sum of the running R0: S (index in the lane) dx = T R0 - Q
       unsigned int T = 0;
       if (work) {
@@ -585,7 +599,6 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
       const double mx = R0 * rn, my = sy * rn;
       const double m2 = __builtin_fma(-R0, mx, R1);
       const double cxy = __builtin_fma(-R0, my, R2);
-      double alpha = 0.0, beta = 0.0, delta = 1.0;
       if (!(m2 > 0.0) || !(R1 < 1.7e308)) irregular = true;         // all keys on one f64 (linear.rs:50-53), NaN (duplicates), overflow
       else {
         const double rm2 = s2_rcp(m2);
@@ -599,9 +612,11 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
         delta = sg.guard_k * 1.1102230246251565e-16 * 1.0001 * (cnt * ab * X * (1.0 + wos) + ab * X + (double)e + 4.0 * (R1 * rm2) * ab * W);
         if (!(delta < 0.5) && sg.mode == 1) irregular = true;         // (mode 2: counted with the guard-flagged leaves)
       }
+      }
       // ---- error pass over the own keys [s, e)
       unsigned int emax = 0u;
       double hmax = 0.0;
+      unsigned int nanf = 0u;                                        // (linear_spline: a duplicate key inside the leaf shows as NaN here)
       if (work && !irregular) {
         unsigned int k = s + (unsigned int)l;
         if (sg.dbg & 4) k = e;
@@ -615,18 +630,20 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
             const double f = __builtin_fma(beta, xv[u], alpha);            // linear.rs:87-90
             const unsigned int pr = min(sg_cvt_u32(f), n32);              // models/mod.rs:735-737, two_layer.rs:14-18
             emax = max(emax, sg_absdiff(pr, k + (unsigned)(u * GL)));
-            hmax = fmax_abs_raw(hmax, __builtin_amdgcn_fract(f) - 0.5);
+            if constexpr (LEAFK == K_LINEAR) hmax = fmax_abs_raw(hmax, __builtin_amdgcn_fract(f) - 0.5);
+            else nanf |= (f != f) ? 1u : 0u;
           }
         }
         for (; k < e; k += GL) {
           const double f = __builtin_fma(beta, xring[rpos(k)], alpha);
           const unsigned int pr = min(sg_cvt_u32(f), n32);
           emax = max(emax, sg_absdiff(pr, k));
-          hmax = fmax_abs_raw(hmax, __builtin_amdgcn_fract(f) - 0.5);
+          if constexpr (LEAFK == K_LINEAR) hmax = fmax_abs_raw(hmax, __builtin_amdgcn_fract(f) - 0.5);
+          else nanf |= (f != f) ? 1u : 0u;
         }
         // widening keys (two_layer.rs:229-247), one candidate per lane: RN(key[e] - 1), RN(key[s-1] + 1).  For u64
         // keys only x = RN(key) is at hand: RN(key -+ 1) is x -+ 1 below 2^53 and x or its neighbour above.
-        if (l < 6) {
+        if (LEAFK == K_LINEAR && l < 6) {
           double xc;
           const bool hiside = l < 3;
           const double xb = hiside ? xe : xpl;
@@ -641,7 +658,8 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
         }
       }
       emax = s2_group_max<GL>(emax);
-      hmax = s2_group_max<GL>(hmax);
+      if constexpr (LEAFK == K_LINEAR) hmax = s2_group_max<GL>(hmax);
+      else if (s2_group_max<GL>(nanf)) irregular = true;              // y of a duplicate is not its index: exact kernels
       const bool head = owned && l == 0;                             // the lane that speaks for the leaf
       const bool guarded = head && !irregular && !(0.5 - hmax >= delta);
       guard_cnt += (unsigned int)__popcll(__ballot(guarded));

@@ -22,12 +22,13 @@ def run_case(rng, c=0):
         L = 1 << max(3, int(np.log2(L)))
     mode = int(rng.integers(0, 3))
     streamed = bool(rng.integers(0, 2))
+    leaf = "linear_spline" if rng.integers(0, 4) == 0 else "linear"      # (linear_spline: one-pass in every mode, bit for bit)
     waves = [None, "64", "1000", "100000"][rng.integers(4)]
     if waves: os.environ["RMI_HIP_SIGMA_WAVES"] = waves
     else: os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
     keys = dg.GENERATORS[gen](n, seed=int(rng.integers(1, 1 << 30)))
     try:
-        o = orc.train_two_layer(root, "linear", keys, L, threads=2)
+        o = orc.train_two_layer(root, leaf, keys, L, threads=2)
     except orc.OracleError:
         return None, "reference panics"
     chunks = 1
@@ -41,17 +42,17 @@ def run_case(rng, c=0):
         except train.RMIError:
             tr.close()
             return None, "root not fitted on the host"
-        g = tr.train_streamed(keys, g_root, "linear", L, chunks=chunks).materialize()
+        g = tr.train_streamed(keys, g_root, leaf, L, chunks=chunks).materialize()
     else:
         tr = train.Trainer(keys)
         tr.set_fit_mode(mode)
         g_root = tr.fit_root(root, L)
-        g = tr.train_leaves(g_root, "linear", L).materialize()
+        g = tr.train_leaves(g_root, leaf, L).materialize()
     tr.close()
     ok = np.array_equal(g.leaf_starts, o.leaf_start) and np.array_equal(g.leaf_counts, o.leaf_count)
     ge, oe = g.last_layer_max_l1s.astype(np.int64), o.leaf_err.astype(np.int64)
     nd = int(np.count_nonzero(ge != oe))
-    if mode == 0:
+    if mode == 0 or leaf != "linear":
         ok = ok and nd == 0 and np.array_equal(g.leaf_params, o.leaf_params) and g.model_max_error == o.model_max_error and g.model_avg_error == o.model_avg_error
     elif mode == 1:
         ok = ok and nd == 0 and g.model_max_error == o.model_max_error and g.model_avg_error == o.model_avg_error
@@ -69,7 +70,7 @@ def run_case(rng, c=0):
         over = mx - ge
         ok = ok and int(np.count_nonzero(over > 0)) <= 2 and (over.max() <= 1)
     os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
-    return ok, (f"{c:3d} {gen:14s} {root:13s} n={n:8d} L={L:7d} mode={mode} streamed={chunks if streamed else 0} waves={waves} used={g.fit_mode_used} exact={g.exact_leaves} "
+    return ok, (f"{c:3d} {gen:14s} {root:13s} n={n:8d} L={L:7d} leaf={leaf} mode={mode} streamed={chunks if streamed else 0} waves={waves} used={g.fit_mode_used} exact={g.exact_leaves} "
                 f"merged={g.merged_leaves} guard={g.guard_leaves} diff={nd}")
 
 
