@@ -23,6 +23,8 @@
 //   oracle: at most 0.46 of the bound with guard_k = 1 over uniform / heavy-tailed / clustered key sets (200 M keys).
 // Leaves the ring cannot finish are "irregular": duplicate keys (y is a first-occurrence offset), the leaves next to
 // the split of the 2-way join (Q2/Q3), the first and the last leaf, leaves that do not fit the LDS ring, variance 0.
+// linear_spline leaves (template parameter LEAFK) take the same kernel without sums or guard: two end points, the
+// reference's two operations, the same bits -- in every fit mode.
 // Mode 1 hands them to the exact kernels.  Mode 2 sums the LONG ones piecewise (one record per wave and stretch,
 // merged by k_list with the container's rules, error pass by k_list_tail) and keeps every line the sums define.
 #pragma once
@@ -304,8 +306,9 @@ __global__ void __launch_bounds__(64) k_list_tail(const K* __restrict__ keys, Sp
 //            in LDS (a duplicate key as NaN: its leaf then fails the checks below and goes to the
 //            exact kernels); the root target is evaluated for the LAST key of each lane only and
 //            compared with the previous lane's (DPP) -- targets are monotone, so a lane whose last
-//            target equals its predecessor's holds no boundary; lanes that do, evaluate their other
-//            keys in the (rare) boundary block, which appends (index, leaf id, flags) to a list.
+//            target equals its predecessor's holds no boundary; the lanes that do are noted per load and
+//            ONE pass behind the batch's loads evaluates their other keys and appends (index, leaf id,
+//            flags) to a list (edge batches: per load).
 //   phase 2  every leaf that is complete in the ring (both boundaries seen) is handled by a GROUP of
 //            GL lanes, 64/GL leaves per round: the lanes stride over the leaf's container
 //            [s-1, e] (+ the Q1 duplicate of e) adding up (S dx, S dx^2, S dx dy) relative to the
