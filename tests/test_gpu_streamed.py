@@ -30,6 +30,8 @@ def _same(a, b, exact_params=True):
     ("uniform_f64", 1_000_000, 1024, "linear,cubic", 2),
     ("uniform_u64", 1_000_003, 4096, "linear,linear", 64),
     ("clustered_u64", 1_200_000, 1024, "linear,linear", 1),
+    ("uniform_u64", 1_000_000, 1024, "linear,robust_linear", 4),
+    ("books_u64", 1_500_000, 2048, "cubic,linear", 8),
 ])
 def test_streamed_equals_resident_and_oracle(oracle, gen, n, L, spec, chunks):
     from rmi_amd import train
@@ -82,3 +84,17 @@ def test_streamed_bad_arguments():
     g = tr.train_streamed(keys, root, "linear", 1000, chunks=8)
     assert g.branching_factor == 1000
     tr.close()
+
+
+@pytest.mark.parametrize("spec,L", [("radix18,linear", 4096), ("bradix,linear", 2048), ("linear,linear", 1000), ("radix,linear_spline", 4096)])
+def test_train_from_host_matches_the_oracle(oracle, spec, L):
+    """train.train(keys, ...) for keys in host memory: host root fit + streamed training where the root allows it
+    (a leaf count that no power of two divides trains in one shard), the plain path for radix tables and bradix."""
+    from rmi_amd import train
+    keys = dg.uniform_u64(1_500_000)
+    root_name, leaf_name = spec.split(",")
+    o = oracle.train_two_layer(root_name, leaf_name, keys, L, threads=2)
+    g = train.train(keys, spec, L)
+    assert np.array_equal(g.leaf_starts, o.leaf_start) and np.array_equal(g.leaf_params, o.leaf_params)
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err) and np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error and g.model_avg_error == o.model_avg_error
