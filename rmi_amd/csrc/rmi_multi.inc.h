@@ -315,7 +315,13 @@ int rmi_hip_train_streamed(rmi_hip_ctx* c, const void* host_keys, uint64_t n, in
   bool used[2] = {false, false};
   bool any_sigma = false;
   c->stream_mode = true;
-  auto fail = [&](int code) { c->stream_mode = false; c->defer_sync = false; (void)rmi_hip_set_shard(c, nullptr); (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream); return code; };
+  auto fail = [&](int code) {                                           // (no half-uploaded key set stays behind)
+    c->stream_mode = false; c->defer_sync = false;
+    (void)rmi_hip_set_shard(c, nullptr);
+    (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream);
+    c->d_keys = nullptr; c->n = 0; c->last_L = 0;
+    return code;
+  };
   size_t off = 0;
   for (int q = 0; off < total; q++) {
     const int b = q & 1;
