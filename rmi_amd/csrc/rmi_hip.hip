@@ -1067,7 +1067,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
                                (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
           return RMI_OK;
         };
-        const int lrc = launch2(std::integral_constant<int, 2048>{}, std::integral_constant<int, 512>{});
+        // (4-byte keys: the ring holds them raw, twice as many in the same LDS, and the batch is four loads as well)
+        int lrc;
+        if constexpr (sizeof(K) == 4) lrc = launch2(std::integral_constant<int, 4096>{}, std::integral_constant<int, 1024>{});
+        else lrc = launch2(std::integral_constant<int, 2048>{}, std::integral_constant<int, 512>{});
         if (lrc != RMI_OK) return lrc;
         mark();
       }

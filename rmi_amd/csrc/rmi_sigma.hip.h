@@ -405,7 +405,16 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   constexpr unsigned MASK = RING - 1;
   constexpr bool SPARSE = s2_root_monotone<ROOT>();
   static_assert((RING & (RING - 1)) == 0 && BATCH % (64 * KPL) == 0 && RING >= 2 * BATCH && (U - 1) * 32 + 1 <= S2_PAD, "geometry");
-  __shared__ double xring[RING + S2_PAD];
+  // 4-byte keys stay RAW in the ring (converted on read: one instruction): twice the keys in the same LDS, so the batch
+  // is four loads like an 8-byte key's.  A raw key cannot carry the NaN that marks a duplicate: the loads that hold
+  // one are noted in a bit mask over the ring's load slots (`dupw`, a wave-uniform register) instead.
+  constexpr bool RAW = std::is_same<K, uint32_t>::value;
+  using RingT = std::conditional_t<RAW, unsigned int, double>;
+  constexpr int SLOT = 64 * KPL;                    // keys per load = ring positions per slot
+  static_assert(!RAW || RING / SLOT <= 32, "dupw");
+  __shared__ RingT xring[RING + S2_PAD];
+  unsigned int dupw = 0u;
+  auto rx = [&](unsigned int pos) -> double { return (double)xring[pos]; };
   __shared__ unsigned int b_idx[BCAP], b_t[BCAP];
   __shared__ unsigned char b_fl[BCAP];
   __shared__ unsigned int l_buf[LBUF];
@@ -440,9 +449,19 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
       dst[k] = sg_load16<K>(keys + (gi < lim ? gi : lim));
     }
   };
-  auto ring_store = [&](unsigned int pos, double v) {                // one x (rare paths)
+  auto ring_store = [&](unsigned int pos, RingT v) {                 // one entry (rare paths)
     xring[pos] = v;
     if (pos < (unsigned)S2_PAD) xring[pos + RING] = v;
+  };
+  // duplicates among the ring positions [a, b] (RAW): any noted load slot the stretch touches
+  auto dup_in = [&](unsigned int pa, unsigned int pb) -> bool {
+    if constexpr (!RAW) return false;
+    else {
+      const unsigned int sa = pa / (unsigned)SLOT, sb = pb / (unsigned)SLOT;
+      const unsigned int upto_b = (2u << sb) - 1u, from_a = ~((1u << sa) - 1u);
+      const unsigned int m = sa <= sb ? (upto_b & from_a) : (upto_b | from_a);      // (wrapped: the slots from sa up, and up to sb)
+      return (dupw & m & ((RING / SLOT >= 32) ? 0xFFFFFFFFu : ((1u << (RING / SLOT)) - 1u))) != 0u;
+    }
   };
 
   if (lane == 0 && sp.n - 1 >= c0 && sp.n - 1 < c1 && sp.n - 1 < sp.rd_hi) {
@@ -458,7 +477,12 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
     carry_t = s2_target<ROOT, K>(r, Lm1f, Lm1, carry_key, KeyTraits<K>::as_float(carry_key), oob_);
     // it is the prev-last point of a leaf that starts exactly at c0 (NaN if it is a duplicate: y is not its index)
     const bool dupc = (c0 - 1 > sp.rd_lo) && (keys[c0 - 2] == carry_key);
-    if (lane == 0) ring_store(rpos((unsigned int)(c0 - 1)), dupc ? __builtin_nan("") : KeyTraits<K>::as_float(carry_key));
+    if constexpr (RAW) {
+      if (lane == 0) ring_store(rpos((unsigned int)(c0 - 1)), (RingT)key_to_bits<K>(carry_key));
+      if (dupc) dupw |= 1u << (rpos((unsigned int)(c0 - 1)) / (unsigned)SLOT);
+    } else {
+      if (lane == 0) ring_store(rpos((unsigned int)(c0 - 1)), (RingT)(dupc ? __builtin_nan("") : KeyTraits<K>::as_float(carry_key)));
+    }
   }
   int bcnt = 0;                                                     // entries of the boundary list (wave-uniform)
   // Leaves for the exact kernels are collected per wave and appended to the global list in one piece:
@@ -495,7 +519,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
   double P0 = 0.0, P1 = 0.0, P2 = 0.0;
   auto acc_start = [&](unsigned int s0) {
     lst |= LS_ACC;
-    const double px = xring[rpos(s0)];
+    const double px = rx(rpos(s0));
     if (lane == 0) { acc_u[0] = s0; acc_u[1] = s0; acc_pxs = px; }
     P0 = 0.0; P1 = 0.0; P2 = 0.0;
     wave_sync();
@@ -505,9 +529,10 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
     if (upto <= next) return;
     const double px = acc_pxs;
     for (unsigned int k = next + (unsigned int)lane; k < upto; k += 64u) {
-      const double dx = xring[rpos(k)] - px, dy = (double)(k - first);
+      const double dx = rx(rpos(k)) - px, dy = (double)(k - first);
       P0 += dx; P1 = __builtin_fma(dx, dx, P1); P2 = __builtin_fma(dx, dy, P2);
     }
+    if (dup_in(rpos(next), rpos(upto - 1u))) P0 = __builtin_nan("");      // (RAW: a duplicate in the stretch spoils the sums like a NaN x would)
     wave_sync();
     if (lane == 0) acc_u[1] = upto;
     wave_sync();
@@ -551,8 +576,8 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
       if constexpr (LEAFK == K_LINEAR_SPLINE) {
         // linear_spline.rs:13-35: the line through the first and the last point of the container [s-1, e] -- the same two
         // points, the same operations, so the same bits as the reference; nothing to sum and nothing to guard.
-        if (work) { xpl = xring[rpos(s - 1u)]; xe = xring[rpos(e)]; }
-        if (!(xpl < xe)) irregular = true;                            // NaN (a duplicate: y is not the index), or two keys on one f64
+        if (work) { xpl = rx(rpos(s - 1u)); xe = rx(rpos(e)); }
+        if (!(xpl < xe) || (work && dup_in(rpos(s - 1u), rpos(e)))) irregular = true;                            // NaN (a duplicate: y is not the index), or two keys on one f64
         else {
           const double y0 = (double)(s - 1u), y1 = (double)e;
           beta = (y0 - y1) / (xpl - xe);
@@ -565,15 +590,16 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
       double R0 = 0.0, R1 = 0.0, Q = 0.0;                            // Q = sum of the running R0: S (index in the lane) dx = T R0 - Q
       unsigned int T = 0;
       if (work) {
-        p = xring[rpos(s)]; xpl = xring[rpos(s - 1u)]; xe = xring[rpos(e)];
+        p = rx(rpos(s)); xpl = rx(rpos(s - 1u)); xe = rx(rpos(e));
+        if (dup_in(rpos(s - 1u), rpos(e))) R0 = __builtin_nan("");    // (RAW: the leaf then fails m2 > 0 below like one with a NaN x)
         unsigned int k = s - 1u + (unsigned int)l;
         if (sg.dbg & 2) k = e + 1u;
         // U keys per step while the whole group has them: all loads first, no wrap inside a step (mirror)
         for (; k + (unsigned)((U - 1) * GL) <= e; k += U * GL) {
-          const double* xp = &xring[rpos(k)];
+          const RingT* xp = &xring[rpos(k)];
           double xv[U];
 #pragma unroll
-          for (int u = 0; u < U; u++) xv[u] = xp[u * GL];
+          for (int u = 0; u < U; u++) xv[u] = (double)xp[u * GL];
 #pragma unroll
           for (int u = 0; u < U; u++) {
             const double dx = xv[u] - p;
@@ -582,7 +608,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
           T += U;
         }
         for (; k <= e; k += GL) {
-          const double dx = xring[rpos(k)] - p;
+          const double dx = rx(rpos(k)) - p;
           R0 += dx; R1 = __builtin_fma(dx, dx, R1); Q += R0;
           T += 1;
         }
@@ -624,10 +650,10 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
         unsigned int k = s + (unsigned int)l;
         if (sg.dbg & 4) k = e;
         for (; k + (unsigned)((U - 1) * GL) < e; k += U * GL) {
-          const double* xp = &xring[rpos(k)];
+          const RingT* xp = &xring[rpos(k)];
           double xv[U];
 #pragma unroll
-          for (int u = 0; u < U; u++) xv[u] = xp[u * GL];
+          for (int u = 0; u < U; u++) xv[u] = (double)xp[u * GL];
 #pragma unroll
           for (int u = 0; u < U; u++) {
             const double f = __builtin_fma(beta, xv[u], alpha);            // linear.rs:87-90
@@ -638,7 +664,7 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
           }
         }
         for (; k < e; k += GL) {
-          const double f = __builtin_fma(beta, xring[rpos(k)], alpha);
+          const double f = __builtin_fma(beta, rx(rpos(k)), alpha);
           const unsigned int pr = min(sg_cvt_u32(f), n32);
           emax = max(emax, sg_absdiff(pr, k));
           if constexpr (LEAFK == K_LINEAR) hmax = fmax_abs_raw(hmax, __builtin_amdgcn_fract(f) - 0.5);
@@ -818,19 +844,31 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
             kp = kk[q];
           }
         }
-        if (__ballot(anyd) != 0ull) {                                // y of a duplicate is not its index: its leaf goes to the exact kernels
-          asm volatile("" ::: "memory");                            // (keep this a branch: as selects it costs every load 8 instructions)
+        {
+          const bool dl = __ballot(anyd) != 0ull;                    // y of a duplicate is not its index: its leaf goes to the exact kernels
+          if constexpr (RAW) {
+            const unsigned int slot = rpos((unsigned int)A + (unsigned int)(k * SLOT)) / (unsigned)SLOT;
+            dupw = dl ? (dupw | (1u << slot)) : (dupw & ~(1u << slot));
+          } else if (dl) {
+            asm volatile("" ::: "memory");                          // (keep this a branch: as selects it costs every load 8 instructions)
 #pragma unroll
-          for (int q = 0; q < KPL; q++) if (dq[q]) xs[q] = __builtin_nan("");
+            for (int q = 0; q < KPL; q++) if (dq[q]) xs[q] = __builtin_nan("");
+          }
         }
-        // x into the ring (16 bytes per store; the first entries once more behind the end)
+        // the keys into the ring (16 bytes per store; the first entries once more behind the end)
         {
           const unsigned int off = rpos((unsigned int)g0);
-#pragma unroll
-          for (int q = 0; q < KPL; q += 2) *reinterpret_cast<double2*>(&xring[off + q]) = make_double2(xs[q], xs[q + 1]);
           // (a load's 64 * KPL keys land on a 64 * KPL-aligned stretch of the ring: the mirror is hit by whole loads)
-          if (rpos((unsigned int)A + (unsigned int)(k * 64 * KPL)) < (unsigned)S2_PAD) {
-            if (off < (unsigned)S2_PAD) {                           // (a load of 4-byte keys covers 256 positions, the mirror 128)
+          const bool mirror = rpos((unsigned int)A + (unsigned int)(k * SLOT)) < (unsigned)S2_PAD && off < (unsigned)S2_PAD;   // (a load of 4-byte keys covers 256 positions, the mirror 128)
+          if constexpr (RAW) {
+            uint4 raw4;
+            __builtin_memcpy(&raw4, kk, 16);
+            *reinterpret_cast<uint4*>(&xring[off]) = raw4;
+            if (mirror) *reinterpret_cast<uint4*>(&xring[off + RING]) = raw4;
+          } else {
+#pragma unroll
+            for (int q = 0; q < KPL; q += 2) *reinterpret_cast<double2*>(&xring[off + q]) = make_double2(xs[q], xs[q + 1]);
+            if (mirror) {
 #pragma unroll
               for (int q = 0; q < KPL; q += 2) *reinterpret_cast<double2*>(&xring[off + RING + q]) = make_double2(xs[q], xs[q + 1]);
             }
@@ -954,9 +992,9 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
           unsigned int pmask = 0u;                                  // the loads this lane holds a boundary in
 #pragma unroll
           for (int k = 0; k < NLOAD; k++) pmask |= (unsigned int)((LB[k] >> lane) & 1ull) << k;
-          // one pass when no lane has two such loads (nearly always); else one pass per load, in order
-          const bool multi = __ballot((pmask & (pmask - 1u)) != 0u) != 0ull;
-          const int npass = multi ? NLOAD : 1;
+          // One pass handles a RANGE of consecutive loads in which no lane holds boundaries of two loads (ranks in index
+          // order need every lane's count before its successors'): nearly always the whole batch; a lane with two such
+          // loads (leaves of a few dozen keys) splits the batch into two ranges.
           K kprev[NLOAD];                                           // the key in front of the lane's first key, per load
 #pragma unroll
           for (int k = 0; k < NLOAD; k++) {
@@ -968,10 +1006,21 @@ __global__ void __launch_bounds__(64) k_sigma2(const K* __restrict__ keys, Span 
             if constexpr (sizeof(K) == 8) hi = (unsigned int)__builtin_amdgcn_update_dpp((int)(unsigned int)(cb >> 32), (int)(unsigned int)(lastb >> 32), 0x138, 0xF, 0xF, false);
             kprev[k] = bits_to_key<K>(((unsigned long long)hi << 32) | lo);
           }
-          for (int pass = 0; pass < npass; pass++) {
-            const bool active = multi ? ((pmask >> pass) & 1u) != 0u : pmask != 0u;
+          // (8-byte keys, ~190 keys per leaf: 4 % of the batches have such a lane -- one pass per load then, which keeps
+          //  the common path free of the range bookkeeping; 4-byte keys: 16 keys per lane and batch, half of the batches)
+          const bool multi = !RAW && __ballot((pmask & (pmask - 1u)) != 0u) != 0ull;
+          for (int gs = 0; gs < NLOAD;) {
+            int ge = gs;
+            if constexpr (RAW) {
+              unsigned long long gm = 0ull;
+#pragma unroll
+              for (int k = 0; k < NLOAD; k++) if (k == ge && k >= gs && (k == gs || !(LB[k] & gm))) { gm |= LB[k]; ge = k + 1; }
+            } else ge = multi ? gs + 1 : NLOAD;
+            const unsigned int pm = pmask & ((1u << ge) - 1u) & ~((1u << gs) - 1u);
+            gs = ge;
+            const bool active = pm != 0u;
             if (__ballot(active) == 0ull) continue;
-            const unsigned int ksel = multi ? (unsigned int)pass : ((unsigned int)__builtin_ctz(pmask | (1u << (NLOAD - 1))));
+            const unsigned int ksel = (unsigned int)__builtin_ctz(pm | (1u << (NLOAD - 1)));
             uint4 v = cur[0];
             K kp0 = kprev[0];
 #pragma unroll
