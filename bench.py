@@ -235,8 +235,7 @@ def main():
                 "mode_requested": args.mode,
                 "exact_refit_leaves": int(getattr(res, "exact_leaves", 0)), "guard_flagged_leaves": int(getattr(res, "guard_leaves", 0)),
                 "merged_long_leaves": int(getattr(res, "merged_leaves", 0)),
-                "exchange": None if world == 1 else "ncclAllGather of the rows inside the library at the end of every step "
-                                                    "(rmi_hip_train_sharded); a step ends when every rank holds the table",
+                "exchange": None if world == 1 else getattr(sh, "exchange", "") + "; a step ends when every rank holds the table",
                 "root_fit_seconds_untimed": root_s,
             },
             "roofline": {

@@ -31,6 +31,7 @@ static Api& api() {
   static bool tried = false;
   if (!tried) {
     tried = true;
+    if (std::getenv("RMI_HIP_NO_RCCL")) return a;                        // (tests: behave like a machine without RCCL)
     const char* names[] = {"librccl.so.1", "librccl.so"};
     for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (a.handle) break; }   // already in the process
     if (!a.handle) {

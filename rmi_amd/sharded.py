@@ -249,18 +249,32 @@ class ShardedTrainer:
         tr.set_fit_mode(fit_mode)
         self.row_bytes = 24 if self.leaf_kind != 2 else 40
         # ---- communicator: rank 0 makes the id, torch carries the 128 bytes ----
+        self.exchange = "library (ncclAllGather in rmi_hip_train_sharded)"
         if self.on_gpu:
+            # the library's own communicator; should RCCL not be loadable or the communicator not come up on some rank, EVERY
+            # rank falls back to torch.distributed's all-gather of device tensors (the kernels are the same)
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
             idt = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
             if rank == 0:
                 buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
-                T._check(lib.rmi_hip_comm_unique_id(buf))
+                if lib.rmi_hip_comm_unique_id(buf) != 0:
+                    ok.zero_()
                 idt.copy_(torch.tensor(list(buf), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
-            idb = (C.c_ubyte * _lib.COMM_ID_BYTES)(*idt.cpu().tolist())
-            T._check(lib.rmi_hip_comm_init(tr._h, rank, world, idb), tr._h)
-            self._shard_c = self.plan.c_struct()
-            T._check(lib.rmi_hip_set_shard(tr._h, C.byref(self._shard_c)), tr._h)
-        else:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                idb = (C.c_ubyte * _lib.COMM_ID_BYTES)(*idt.cpu().tolist())
+                if lib.rmi_hip_comm_init(tr._h, rank, world, idb) != 0:
+                    ok.zero_()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                self._shard_c = self.plan.c_struct()
+                T._check(lib.rmi_hip_set_shard(tr._h, C.byref(self._shard_c)), tr._h)
+            else:
+                lib.rmi_hip_comm_destroy(tr._h)
+                self.on_gpu = False
+                self.exchange = "torch.distributed all_gather_into_tensor (the library's communicator did not come up)"
+        if not self.on_gpu:
             per = (self.plan.leaf_hi - self.plan.leaf_lo) * self.row_bytes
             self._full = torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda")
             self._mine = torch.empty(per, dtype=torch.uint8, device="cuda")
@@ -276,6 +290,10 @@ class ShardedTrainer:
             T._check(rc, self.tr._h)
             return res
         res = run_shard(self.tr, self.plan, self.root, self.leaf_kind, self._mine.data_ptr())
+        if self.dist.get_backend() != "gloo":                  # device tensors straight through torch's RCCL
+            self._torch.cuda.synchronize()
+            exchange_rows(self.dist, self._full, self._mine, self.rank, self.world)
+            return res
         full_h, mine_h = self._host
         mine_h.copy_(self._mine)
         exchange_rows(self.dist, full_h, mine_h, self.rank, self.world)

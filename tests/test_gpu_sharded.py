@@ -193,6 +193,13 @@ def test_train_sharded_rccl_single_rank(mode):
     assert _spawn(1, 3_000_000, 4096, mode) == [(0, True)]
 
 
+def test_sharded_trainer_falls_back_to_torch_all_gather(monkeypatch):
+    """Without RCCL for the library (RMI_HIP_NO_RCCL) every rank takes torch.distributed's all-gather of device tensors:
+    the same table."""
+    monkeypatch.setenv("RMI_HIP_NO_RCCL", "1")
+    assert _spawn(1, 3_000_000, 4096, 0) == [(0, True)]
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_train_sharded_rccl_two_ranks(mode):
     """Two processes, two GPUs, RCCL over xGMI: runs wherever the box has them (the first multi-GPU box proves that the
