@@ -94,8 +94,9 @@ struct rmi_hip_ctx {
   // whose f64 images collapse, in the guarded mode) is served faster by the exact streaming passes: 1.1 ms against
   // 13.8 ms on 200 M duplicate-heavy keys.  Remembered per (key set, leaf count, mode); the next call takes the exact path.
   uint64_t keys_epoch = 1;                      // bumped whenever the context gets new keys
-  uint64_t hint_epoch = 0, hint_L = 0;
-  int hint_mode = -1;
+  uint64_t hint_epoch = 0;                      // the key set the remembered leaf counts belong to
+  uint64_t hint_L[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (a parameter grid trains several leaf counts on one key set)
+  int hint_n = 0, hint_mode = -1;
   void* d_bkeys = nullptr;                      // one-pass mode: key[e] and key[s-1] of every leaf (2 x leaves keys), see k_finalize
   uint64_t bkeys_cap = 0;
   uint64_t flist_cap = 0;                       // entries per region
@@ -999,7 +1000,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
   // one pass from sufficient statistics: leaves of at least a few dozen keys on average (the rows of a tile hold
   // 16 keys; shorter leaves are cheap chains for the exact kernels anyway), indices below 2^32
-  const bool hinted = c->hint_epoch == c->keys_epoch && c->hint_L == L_own && c->hint_mode == c->fit_mode;
+  bool hinted = false;
+  if (c->hint_epoch == c->keys_epoch && c->hint_mode == c->fit_mode)
+    for (int h = 0; h < c->hint_n && h < 8; h++) hinted = hinted || c->hint_L[h] == L_own;
   // linear_spline leaves (the line through a container's two end points) need no sums and no guard: the one-pass kernel
   // reproduces them bit for bit, so it serves EVERY fit mode (RMI_HIP_SPLINE_ONEPASS=0: the per-pass kernels)
   const bool spline1 = (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_onepass;
@@ -1299,7 +1302,8 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   out->split_idx = st.split_idx; out->split_target = st.split_target;
   out->long_leaves = st.long_count;
   if (c->last_sigma && (st.flag_count - st.merged_count) * 4 > L_own) {   // most leaves went through the list kernels: see hint_epoch
-    c->hint_epoch = c->keys_epoch; c->hint_L = L_own; c->hint_mode = c->fit_mode;
+    if (c->hint_epoch != c->keys_epoch || c->hint_mode != c->fit_mode) { c->hint_epoch = c->keys_epoch; c->hint_mode = c->fit_mode; c->hint_n = 0; }
+    c->hint_L[c->hint_n % 8] = L_own; c->hint_n++;
   }
   out->fit_mode_used = c->last_sigma ? (c->last_spline ? RMI_FIT_USED_ONEPASS_EXACT : c->fit_mode) : 0;
   out->exact_leaves = c->last_sigma ? st.flag_count - st.merged_count : 0;

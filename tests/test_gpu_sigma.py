@@ -267,6 +267,9 @@ def test_onepass_learns_to_take_the_exact_path_on_duplicate_heavy_keys(T, oracle
         used.append(g.fit_mode_used)
         assert np.array_equal(g.leaf_params, o.leaf_params) and np.array_equal(g.last_layer_max_l1s, o.leaf_err)
     assert used == [1, 0, 0]
+    other = tr.fit_root("linear", 1024)                  # another leaf count on the same keys is learned beside the first
+    assert [tr.train_leaves(other, "linear", 1024).materialize().fit_mode_used for _ in range(2)] == [1, 0]
+    assert tr.train_leaves(root, "linear", L).materialize().fit_mode_used == 0
     tr.set_fit_mode(1)                                   # forgets
     assert tr.train_leaves(root, "linear", L).materialize().fit_mode_used == 1
     tr.close()
