@@ -17,6 +17,7 @@
 #include "rmi_kernels.hip.h"
 #include "rmi_stream.hip.h"
 #include "rmi_sigma.hip.h"
+#include "rmi_lanes.hip.h"
 #include "rmi_root_host.h"
 
 using namespace rmi;
@@ -70,7 +71,11 @@ struct rmi_hip_ctx {
   hipEvent_t ev[10] = {};
   int profile_level = 0;                        // 0: whole call only; 1: + the first (dominant) kernel; 2: every kernel group
   DevState* h_state_dev = nullptr;              // device address of the pinned h_state (written by the last kernel)
-  int pipeline = 2;                             // 1 = one kernel per reference pass; 2 = tiled/streaming kernels
+  int pipeline = 3;                             // 1 = one kernel per reference pass; 2 = streaming passes A/B; 3 = leaf-lane kernels (rmi_lanes.hip.h)
+  LnStep* d_lntab = nullptr;                    // per-step operands of the leaf-lane walk (RN(1/k), k, (k-1)/2, k-1)
+  bool lanes_fuse = true;                       // error pass fused behind the fit in k_leaf_lanes (else k_err_range)
+  bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
+  bool last_lanes = false;
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
   uint64_t err_threads = 262144;                // lanes of pass B (4 waves/SIMD)
   int fit_min_chunk = 64;
@@ -242,12 +247,17 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   c->profile_level = (pk && *pk && *pk != '0') ? 2 : 0;
   const char* pl = std::getenv("RMI_HIP_PIPELINE");
   if (pl && *pl) c->pipeline = std::atoi(pl);
+  { const char* lf = std::getenv("RMI_HIP_LANES_FUSE"); if (lf && *lf) c->lanes_fuse = std::atoi(lf) != 0; }
+  { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
+  if (hipMalloc(&c->d_lntab, sizeof(LnStep) * LN_TMAX) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
+  hipLaunchKernelGGL(k_lane_table, dim3((LN_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_lntab, LN_TMAX);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
   if (ft && *ft) c->fit_threads = std::strtoull(ft, nullptr, 10);
   const char* et = std::getenv("RMI_HIP_ERR_THREADS");
   if (et && *et) c->err_threads = std::strtoull(et, nullptr, 10);
   const char* lm = std::getenv("RMI_HIP_LONG_MIN");
-  if (lm && *lm) { long v = std::atol(lm); if (v >= FS_TMAX) c->long_min = (unsigned int)v; }
+  if (lm && *lm) { long v = std::atol(lm); if (v >= 64) c->long_min = (unsigned int)v; }
   const char* fc = std::getenv("RMI_HIP_FIT_MIN_CHUNK");
   if (fc && *fc) c->fit_min_chunk = std::atoi(fc);
   const char* fm = std::getenv("RMI_HIP_FIT_MODE");
@@ -288,6 +298,7 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->d_table) (void)hipFree(c->d_table);       // the root table is an input, not an output: it outlives re-sizing
   if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
   if (c->d_state) (void)hipFree(c->d_state);
+  if (c->d_lntab) (void)hipFree(c->d_lntab);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_sentinel) (void)hipHostFree(c->h_sentinel);
   for (int b = 0; b < 2; b++) { if (c->h_stage[b]) (void)hipHostFree(c->h_stage[b]); if (c->ev_stage[b]) (void)hipEventDestroy(c->ev_stage[b]); }
@@ -971,7 +982,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
 
   // --- init ---
   // long-leaf list: a long leaf has at least long_min points, so n/long_min entries always suffice
-  uint64_t need_long = n_it / c->long_min + 1024;
+  const unsigned int long_min_a = c->long_min < (unsigned int)FS_TMAX ? (unsigned int)FS_TMAX : c->long_min;   // pass A's table covers FS_TMAX counts
+  uint64_t need_long = n_it / long_min_a + 1024;
   if (c->fit_mode != 0 && need_long < L_own + 1024) need_long = L_own + 1024;      // one-pass mode: every listed leaf goes through k_fit_long
   if (c->long_cap < need_long) {
     if (c->d_long) (void)hipFree(c->d_long);
@@ -994,7 +1006,6 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
                        L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS);
   }
 
-  if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));
   // pipeline 1 launches one thread per key: a grid dimension holds fewer than 2^32 threads
   const int pipeline = (c->pipeline == 1 && n_it < (1ull << 32) - 1024) ? 1 : 2;
   const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
@@ -1010,29 +1021,79 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
                      n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
   c->last_sigma = sigma;
   c->last_spline = sigma && LEAF == K_LINEAR_SPLINE;
-  if (sigma) {
-    if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
-      const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
-      if (c->flist_cap < rcap) {
-        if (c->d_flist) (void)hipFree(c->d_flist);
-        c->d_flist = nullptr; c->flist_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_flist, rcap * SG_REGIONS * 4));
-        c->flist_cap = rcap;
+  // exact linear leaves, pipeline 3: the leaf-lane kernels (rmi_lanes.hip.h)
+  const bool lanes = c->pipeline >= 3 && stream_fit && !sigma && n_it > 0;
+  c->last_lanes = lanes;
+  auto ensure_lists = [&]() -> int {
+    const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
+    if (c->flist_cap < rcap) {
+      if (c->d_flist) (void)hipFree(c->d_flist);
+      c->d_flist = nullptr; c->flist_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_flist, rcap * SG_REGIONS * 4));
+      c->flist_cap = rcap;
+    }
+    const uint64_t scap = n_it / SG_SEG + L_own + 16;                     // stretches of the long listed leaves (k_list -> k_list_tail)
+    if (c->segs_cap < scap) {
+      if (c->d_segs) (void)hipFree(c->d_segs);
+      c->d_segs = nullptr; c->segs_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_segs, scap * 8));
+      c->segs_cap = scap;
+    }
+    return RMI_OK;
+  };
+  bool lanes_fused = false;
+  if (lanes) {
+    if constexpr (LEAF == K_LINEAR) {
+      { const int lrc = ensure_lists(); if (lrc != RMI_OK) return lrc; }
+      // --- leaf boundaries: lower bounds by search where the root is monotone by arithmetic, else the bucketing scan + fill ---
+      bool searched = false;
+      if constexpr (ROOT == K_LINEAR) {
+        if (c->lanes_search && rp.p1 >= 0.0 && std::isfinite(rp.p0) && std::isfinite(rp.p1)) {
+          const uint64_t sb = (L_own + LS_BLOCK - 1) / LS_BLOCK;
+          hipLaunchKernelGGL((k_leaf_search<K>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state);
+          searched = true;
+        }
       }
+      if (!searched) {
+        constexpr uint64_t V = 16 / sizeof(K);
+        const uint64_t blocks = ((n_it + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
+        hipLaunchKernelGGL((k_bounds_vec<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
+        const uint64_t count_e = L_own + 1;
+        const uint64_t ntiles = (count_e + FILL_TILE - 1) / FILL_TILE;
+        hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, a_leaf_start, count_e, c->d_tilemin);
+        hipLaunchKernelGGL(k_fill_scan_tiles, dim3(1), dim3(1024), 0, s, c->d_tilemin, ntiles);
+        hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, a_leaf_start, count_e, c->d_tilemin);
+      }
+      if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));              // (the bracket of the dominant kernel starts here)
+      // --- exact fit of 64 leaves per wave in lockstep, and their error pass behind it ---
+      lanes_fused = c->lanes_fuse && sp.n < (1ull << 32) - (1ull << 16);
+      SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
+      const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
+      const uint64_t wb = (L_own + 63) / 64;
+      if (lanes_fused)
+        hipLaunchKernelGGL((k_leaf_lanes<K, true>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run);
+      else
+        hipLaunchKernelGGL((k_leaf_lanes<K, false>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run);
+      mark();
+      // --- the leaves handed over (containers too long for the lockstep walk): one wave each, fit + error pass ---
+      SgParams sgp; std::memset(&sgp, 0, sizeof sgp);
+      sgp.flist = fl; sgp.segs = c->d_segs; sgp.mode = 0; sgp.guard_k = c->guard_k;
+      c->last_sg = sgp;
+      hipLaunchKernelGGL((k_list<K, K_LINEAR>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run);
+      mark();
+      hipLaunchKernelGGL((k_list_tail<K>), dim3(8192), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
+      mark();
+    }
+  } else if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));
+  if (lanes) {
+  } else if (sigma) {
+    if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
+      { const int lrc = ensure_lists(); if (lrc != RMI_OK) return lrc; }
       if (c->bkeys_cap < L_own) {
         if (c->d_bkeys) (void)hipFree(c->d_bkeys);
         c->d_bkeys = nullptr; c->bkeys_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_bkeys, 2 * L_own * 8));
         c->bkeys_cap = L_own;
-      }
-      {
-        const uint64_t scap = n_it / SG_SEG + L_own + 16;        // stretches of the long listed leaves (k_list -> k_list_tail)
-        if (c->segs_cap < scap) {
-          if (c->d_segs) (void)hipFree(c->d_segs);
-          c->d_segs = nullptr; c->segs_cap = 0;
-          HIPCHK(c, hipMalloc(&c->d_segs, scap * 8));
-          c->segs_cap = scap;
-        }
       }
       SgParams sgp; sgp.guard_k = c->guard_k; sgp.mode = c->fit_mode;
       sgp.flist.ids = c->d_flist; sgp.flist.cnt = c->d_flist_cnt; sgp.flist.cap = c->flist_cap;
@@ -1099,19 +1160,20 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     const uint64_t chunks = (n_it + C - 1) / C;
     const uint64_t waves = (chunks + 63) / 64;
     const uint64_t fblocks = (waves + FA_WAVES - 1) / FA_WAVES;
-    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, sp, rp, C, leaf_start, params, c->d_state, c->d_long, c->long_min);
+    hipLaunchKernelGGL((k_fit_stream<ROOT, K>), dim3((unsigned)fblocks), dim3(64 * FA_WAVES), 0, s, keys, sp, rp, C, leaf_start, params, c->d_state, c->d_long, long_min_a);
     mark();
   }
   // --- fill empty leaves ---
-  {
+  if (!lanes) {
     const uint64_t count_e = L_own + 1;
     const uint64_t ntiles = (count_e + FILL_TILE - 1) / FILL_TILE;
     hipLaunchKernelGGL(k_fill_tilemin, dim3((unsigned)ntiles), dim3(256), 0, s, a_leaf_start, count_e, c->d_tilemin);
     hipLaunchKernelGGL(k_fill_scan_tiles, dim3(1), dim3(1024), 0, s, c->d_tilemin, ntiles);
     hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, a_leaf_start, count_e, c->d_tilemin);
   }
-  mark();
-  if (sigma) {
+  if (!lanes) mark();
+  if (lanes) {
+  } else if (sigma) {
     if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
       // --- the leaves the one-pass kernel handed over: fit (or merge) + error pass, one wave per leaf; long ones in stretches ---
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
@@ -1153,9 +1215,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     const uint64_t blocks = c->long_cap < 2048 ? c->long_cap : 2048;   // ~2 waves per SIMD saturate its f64 issue
     hipLaunchKernelGGL((k_fit_long<ROOT, K>), dim3((unsigned)blocks), dim3(64), 0, s, keys, sp, rp, leaf_start, c->d_state, params, c->d_long);
   }
-  if (!sigma) mark();
+  if (!sigma && !lanes) mark();
   // --- error pass ---
-  if (n_it == 0 || sigma) {
+  if (n_it == 0 || sigma || lanes_fused) {
   } else if (pipeline == 1) {
     const uint64_t blocks = (n_it + 255) / 256;
     hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, params, maxerr, run);
@@ -1300,7 +1362,7 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   out->model_avg_log2_error = st.sum_log2 / (double)n_glob;
   out->model_max_log2_error = std::log2((double)st.max_err);
   out->split_idx = st.split_idx; out->split_target = st.split_target;
-  out->long_leaves = st.long_count;
+  out->long_leaves = c->last_lanes ? st.flag_count : st.long_count;
   if (c->last_sigma && (st.flag_count - st.merged_count) * 4 > L_own) {   // most leaves went through the list kernels: see hint_epoch
     if (c->hint_epoch != c->keys_epoch || c->hint_mode != c->fit_mode) { c->hint_epoch = c->keys_epoch; c->hint_mode = c->fit_mode; c->hint_n = 0; }
     c->hint_L[c->hint_n % 8] = L_own; c->hint_n++;

@@ -22,7 +22,7 @@ def trainer_mod():
     return train
 
 
-@pytest.fixture(autouse=True, params=["2", "1"], ids=["pipeline2", "pipeline1"])
+@pytest.fixture(autouse=True, params=["3", "2", "1"], ids=["pipeline3", "pipeline2", "pipeline1"])
 def pipeline(request, monkeypatch):
     """Both device pipelines (streaming/tiled kernels and the one-kernel-per-pass version) are
     held to the same parity bar; small chunks force leaves to straddle lane/wave boundaries."""
