@@ -72,7 +72,7 @@ struct rmi_hip_ctx {
   int profile_level = 0;                        // 0: whole call only; 1: + the first (dominant) kernel; 2: every kernel group
   DevState* h_state_dev = nullptr;              // device address of the pinned h_state (written by the last kernel)
   int pipeline = 3;                             // 1 = one kernel per reference pass; 2 = streaming passes A/B; 3 = leaf-lane kernels (rmi_lanes.hip.h)
-  LnStep* d_lntab = nullptr;                    // per-step operands of the leaf-lane walk (RN(1/k), k, (k-1)/2, k-1)
+  double* d_lntab = nullptr;                    // RN(1 / k) for the running count of the leaf-lane walk (k_lane_table)
   bool lanes_fuse = true;                       // error pass fused behind the fit in k_leaf_lanes (else k_err_range)
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
   bool last_lanes = false;
@@ -249,7 +249,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (pl && *pl) c->pipeline = std::atoi(pl);
   { const char* lf = std::getenv("RMI_HIP_LANES_FUSE"); if (lf && *lf) c->lanes_fuse = std::atoi(lf) != 0; }
   { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
-  if (hipMalloc(&c->d_lntab, sizeof(LnStep) * LN_TMAX) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
+  if (hipMalloc(&c->d_lntab, sizeof(double) * LN_TMAX) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   hipLaunchKernelGGL(k_lane_table, dim3((LN_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_lntab, LN_TMAX);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
@@ -925,7 +925,7 @@ static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   HIPCHK(c, hipMalloc(&c->d_count, L * 8));
   HIPCHK(c, hipMalloc(&c->d_rows, L * (ppl * 8 + 8)));
   HIPCHK(c, hipMalloc(&c->d_tilemin, ((L + 1 + FILL_TILE - 1) / FILL_TILE + 1) * 8));
-  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 255) / 256)));
+  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 63) / 64 + FL_BLOCKS + 1)));   // (per block of k_finalize, or per wave of k_leaf_lanes + per block of k_finalize_listed)
   c->cap_leaves = L; c->cap_ppl = ppl;
   return RMI_OK;
 }
@@ -999,13 +999,6 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
   if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, 2 * SG_REGIONS * 8));  // (the one-pass mode's list + merge counters: zeroed by k_init)
-  if (!c->stream_mode || c->stream_slot == 0) HIPCHK(c, hipEventRecord(c->ev[8], s));   // start of the device work of this call
-  {
-    const uint64_t ib = (L_own + 1 + 255) / 256;
-    hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
-                       L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS);
-  }
-
   // pipeline 1 launches one thread per key: a grid dimension holds fewer than 2^32 threads
   const int pipeline = (c->pipeline == 1 && n_it < (1ull << 32) - 1024) ? 1 : 2;
   const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
@@ -1022,8 +1015,20 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   c->last_sigma = sigma;
   c->last_spline = sigma && LEAF == K_LINEAR_SPLINE;
   // exact linear leaves, pipeline 3: the leaf-lane kernels (rmi_lanes.hip.h)
-  const bool lanes = c->pipeline >= 3 && stream_fit && !sigma && n_it > 0;
+  const bool lanes = c->pipeline >= 3 && stream_fit && !sigma && n_it >= 1024;   // (tiny key sets: the streaming passes)
   c->last_lanes = lanes;
+  // the fused error pass of k_leaf_lanes needs 32-bit indices; with it and the search, k_init has no array to prepare
+  const bool lanes_fused_plan = lanes && c->lanes_fuse && sp.n < (1ull << 32) - (1ull << 16);
+  bool lanes_search_plan = false;
+  if constexpr (ROOT == K_LINEAR) lanes_search_plan = lanes && c->lanes_search && rp.p1 >= 0.0 && std::isfinite(rp.p0) && std::isfinite(rp.p1);
+  const bool init_arrays = !(lanes_fused_plan && lanes_search_plan);
+  if (!c->stream_mode || c->stream_slot == 0) HIPCHK(c, hipEventRecord(c->ev[8], s));   // start of the device work of this call
+  {
+    const uint64_t ib = init_arrays ? (L_own + 1 + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
+                       L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS, init_arrays);
+  }
+
   auto ensure_lists = [&]() -> int {
     const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
     if (c->flist_cap < rcap) {
@@ -1048,7 +1053,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // --- leaf boundaries: lower bounds by search where the root is monotone by arithmetic, else the bucketing scan + fill ---
       bool searched = false;
       if constexpr (ROOT == K_LINEAR) {
-        if (c->lanes_search && rp.p1 >= 0.0 && std::isfinite(rp.p0) && std::isfinite(rp.p1)) {
+        if (lanes_search_plan) {
           const uint64_t sb = (L_own + LS_BLOCK - 1) / LS_BLOCK;
           hipLaunchKernelGGL((k_leaf_search<K>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state);
           searched = true;
@@ -1066,23 +1071,32 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       }
       if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));              // (the bracket of the dominant kernel starts here)
       // --- exact fit of 64 leaves per wave in lockstep, and their error pass behind it ---
-      lanes_fused = c->lanes_fuse && sp.n < (1ull << 32) - (1ull << 16);
+      lanes_fused = lanes_fused_plan;
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
       const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
       const uint64_t wb = (L_own + 63) / 64;
       if (lanes_fused)
-        hipLaunchKernelGGL((k_leaf_lanes<K, true>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run);
+        hipLaunchKernelGGL((k_leaf_lanes<K, true>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
+                           L, err, count, rows, c->d_partials);
       else
-        hipLaunchKernelGGL((k_leaf_lanes<K, false>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run);
+        hipLaunchKernelGGL((k_leaf_lanes<K, false>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
+                           L, err, count, rows, c->d_partials);
       mark();
       // --- the leaves handed over (containers too long for the lockstep walk): one wave each, fit + error pass ---
       SgParams sgp; std::memset(&sgp, 0, sizeof sgp);
       sgp.flist = fl; sgp.segs = c->d_segs; sgp.mode = 0; sgp.guard_k = c->guard_k;
       c->last_sg = sgp;
-      hipLaunchKernelGGL((k_list<K, K_LINEAR>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run);
+      // (a grid-stride list of usually few leaves: a small grid -- 8192 blocks that find nothing cost 4 us each time)
+      hipLaunchKernelGGL((k_list<K, K_LINEAR>), dim3(16 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run);
       mark();
-      hipLaunchKernelGGL((k_list_tail<K>), dim3(8192), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
+      hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
       mark();
+      if (lanes_fused) {
+        // --- the listed leaves' share of the finalize, the first level of the aggregates, then the result record ---
+        hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, params, maxerr, run, err, count, rows,
+                           fl, c->d_partials, (unsigned int)wb, c->d_partials + wb);
+        hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials + wb, (int)FL_BLOCKS, c->d_state, c->h_state_dev + (c->stream_mode ? c->stream_slot : 0));
+      }
     }
   } else if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));
   if (lanes) {
@@ -1231,7 +1245,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   }
   mark();
   // --- finalize + stats ---
-  {
+  if (!lanes_fused) {
     const uint64_t blocks = (L_own + 255) / 256;
     const K* bn = sigma ? (const K*)c->d_bkeys - sp.leaf_lo : nullptr;
     const K* bp = sigma ? (const K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo : nullptr;

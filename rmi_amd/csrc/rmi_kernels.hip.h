@@ -152,19 +152,21 @@ __global__ void __launch_bounds__(256) k_table_from_starts(const unsigned long l
 // k_init: one launch instead of four memsets and two small copies: leaf_start := "no start" with
 // the sentinel entry leaf_start[L_own] = it_hi, maxerr := run := 0, device state := initial state.
 // ---------------------------------------------------------------------------------------------
+// `arrays` = false (the leaf-lane pipeline with its search and its fused error pass: every entry of the three arrays is
+// written by a plain store later on): only the sentinel, the list counters and the state -- a launch of one block.
 __global__ void __launch_bounds__(256) k_init(unsigned long long* __restrict__ leaf_start,
                                               unsigned long long* __restrict__ maxerr,
                                               unsigned long long* __restrict__ run, uint64_t L_own,
                                               unsigned long long sentinel, DevState* __restrict__ st, DevState init,
-                                              unsigned long long* __restrict__ list_cnt, int n_list_cnt) {
+                                              unsigned long long* __restrict__ list_cnt, int n_list_cnt, bool arrays) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t lim = L_own + 1 > (uint64_t)n_list_cnt ? L_own + 1 : (uint64_t)n_list_cnt;
+  const uint64_t lim = (arrays && L_own + 1 > (uint64_t)n_list_cnt) ? L_own + 1 : (uint64_t)n_list_cnt;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < lim; j += stride) {
-    if (j <= L_own) leaf_start[j] = (j == L_own) ? sentinel : NO_START;
-    if (j < L_own) { maxerr[j] = 0; run[j] = 0; }
+    if (arrays && j <= L_own) leaf_start[j] = (j == L_own) ? sentinel : NO_START;
+    if (arrays && j < L_own) { maxerr[j] = 0; run[j] = 0; }
     if (j < (uint64_t)n_list_cnt) list_cnt[j] = 0ull;      // the one-pass mode's list counters (a memset of their own costs ~4 us)
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *st = init;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *st = init; if (!arrays) leaf_start[L_own] = sentinel; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -727,6 +729,35 @@ __device__ __forceinline__ void stats_block_reduce(unsigned long long& mx, unsig
     __syncthreads();
   }
   mx = s_max[0]; mi = s_idx[0]; sm = s_sum[0]; l2 = s_l2[0]; lg = s_lg[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// One leaf's share of two_layer.rs:185-197 (empty-leaf model), :226-259 (widening by the two boundary keys, longest run)
+// and the Q7 count, from its fitted parameters `p`, its raw maximum `curr` and longest run `run` (runs of 1 reported
+// as 0, see k_err_range): what k_finalize does per thread, for the kernels that finish a leaf where they fit it.
+// ---------------------------------------------------------------------------------------------
+template <int LEAF, typename K>
+__device__ __forceinline__ void finalize_one(uint64_t j, uint64_t s, uint64_t e, const Span& sp, uint64_t L, const K* __restrict__ keys,
+                                             double* p, uint64_t curr, uint64_t run, uint64_t last_target,
+                                             uint64_t& final_err, uint64_t& cnt_j) {
+  const uint64_t n = sp.n;
+  if (!(s < e)) {
+    if constexpr (LEAF == K_CUBIC) { p[0] = 0.0; p[1] = 0.0; p[2] = (j + 1 < L) ? 0.0 : 1.0; p[3] = (j + 1 < L) ? (double)e : 0.0; }
+    else { p[0] = (j + 1 < L) ? (double)e : 0.0; p[1] = 0.0; }
+  }
+  const K key_next = e < n ? keys[e] : KeyTraits<K>::max_value();            // lower_bound_correction.rs:47-49
+  const uint64_t up_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::minus_eps(key_next));
+  const uint64_t upper = error_between(up_pred, e + 1, n);                   // two_layer.rs:229-235
+  const K key_prev = s > 0 ? keys[s - 1] : KeyTraits<K>::zero_value();       // lower_bound_correction.rs:62-63
+  const uint64_t first_idx = (j == 0) ? e : s;                               // next_index(max(j-1,0))
+  const uint64_t lo_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::plus_eps(key_prev));
+  const uint64_t lower = error_between(lo_pred, first_idx, n);               // two_layer.rs:237-247
+  uint64_t m = curr;
+  m = upper > m ? upper : m;
+  m = lower > m ? lower : m;
+  if (run == 0 && s < e && !(e == n && keys[s] == keys[n - 1])) run = 1;    // (Q5: the globally last run is never recorded)
+  final_err = m + run;                                                       // two_layer.rs:250-251
+  cnt_j = (e - s) + (last_target == j ? 1ull : 0ull);                        // Q7: tail duplicate
 }
 
 // ---------------------------------------------------------------------------------------------

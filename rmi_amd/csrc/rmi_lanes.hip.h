@@ -47,106 +47,142 @@
 #ifndef RMI_LN_NT_ERR
 #define RMI_LN_NT_ERR 1          // error-phase loads: non-temporal (last use)
 #endif
+#ifndef RMI_LN_WPE
+#define RMI_LN_WPE 2             // waves per SIMD the register allocation of k_leaf_lanes aims at
+#endif
+#ifndef RMI_LN_NBUF
+#define RMI_LN_NBUF 3            // panels in flight per wave (8 KB each, landing in registers): the kernel is bound by the
+#endif                           // bytes in flight per CU (~7 us loaded latency): 8 waves x 24 KB = 192 KB
 
 namespace rmi {
 
-constexpr int LN_ROW = 16;        // keys per panel row = lockstep steps per panel
-constexpr int LN_STRIDE = 17;     // padded row stride (slots)
+constexpr int LN_ROW = 16;        // keys per panel row = lockstep steps per panel = one aligned 128-byte line of 8-byte keys
+constexpr int LN_RING = 32;       // LDS slots per row: two aligned panels (a lane's 16 steps straddle two of them)
+constexpr int LN_MIRROR = 7;      // the first slots once more behind the ring: 8 consecutive reads never wrap
+constexpr int LN_STRIDE = LN_RING + LN_MIRROR;   // 39, odd: lane-per-row reads spread over the banks
 constexpr int LN_LONG_MAX = 8192; // longest container the lockstep walk takes (longer: the list kernels, one wave per leaf)
-constexpr int LN_TMAX = LN_LONG_MAX + 64;
+constexpr int LN_TMAX = LN_LONG_MAX + 64;   // entries of the reciprocal table
 constexpr int LS_BLOCK = 256;     // leaves per block of k_leaf_search
 
-// per step k (= running count of the recurrence): wave-uniform operands
-struct LnStep { double r, kf, h, km1; };   // RN(1/k), k, (k-1)/2, k-1
-
-__global__ void __launch_bounds__(256) k_lane_table(LnStep* __restrict__ tab, int count) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= count) return;
-  const double kf = (double)(k > 0 ? k : 1);
-  LnStep t; t.r = 1.0 / kf; t.kf = kf; t.h = (kf - 1.0) * 0.5; t.km1 = kf - 1.0;
-  tab[k] = t;
+// RN(1 / k) for the running count k of the lockstep walk: rtab[i] = 1 / (i + 1).  Wave-uniform, read through the
+// scalar cache in two 64-byte loads per panel (SGPR operands of the quotient: no vector instruction, no VGPR).
+__global__ void __launch_bounds__(256) k_lane_table(double* __restrict__ rtab, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) rtab[i] = 1.0 / (double)(i + 1);
 }
 
+template <typename K> struct LnBits { using type = unsigned long long; };   // the raw bits of a key
+template <> struct LnBits<uint32_t> { using type = unsigned int; };
+
 // ---------------------------------------------------------------------------------------------
-// k_leaf_search (linear-like roots with slope >= 0; the host checks)
+// k_leaf_search (linear-like roots with slope >= 0; the host checks).  leaf_start[j] = lower bound of "target >= j"
+// in the sorted keys, one thread per leaf, a block of 256 threads for 256 consecutive leaves, in two levels:
+//   anchors   every 16th leaf of the block (and the block's end).  The root model IS an approximation of the keys'
+//             distribution function scaled to L, good to about a leaf: two independent loads 1.5 leaves below and above
+//             the global guess j n / L bracket the boundary, the (unfloored) root values at the two keys place the
+//             first probe by interpolation (keys are locally uniform at that scale), gallop + bisection finish;
+//   leaves    interpolate between their two anchors (good to a few keys), then the same search: two or three probes.
+// A probe is ONE 16-byte load (two neighbouring keys).  What limits this kernel is the number of scattered line requests
+// and the length of the dependent chain: 64-byte sector probes (four loads per lane) took 0.17 ms for 2^20 leaves,
+// every leaf on its own from the global guess (chains of ~12) 0.21 ms, anchors by gallop from the global guess 0.08 ms.
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ keys, Span sp, RootP r,
                                                           unsigned long long* __restrict__ leaf_start,
                                                           DevState* __restrict__ st) {
-  const int t = threadIdx.x;
+  __shared__ unsigned long long anch[LS_BLOCK / 16 + 1];
   const double Lm1f = (double)(r.L - 1);
+  const int t = threadIdx.x;
   const uint64_t jb = sp.leaf_lo + (uint64_t)blockIdx.x * LS_BLOCK;
-  if (jb >= sp.leaf_hi) return;
-  const uint64_t je = jb + LS_BLOCK < sp.leaf_hi ? jb + LS_BLOCK : sp.leaf_hi;
+  const uint64_t A = sp.it_lo, Bn = sp.it_hi, L_own = sp.leaf_hi - sp.leaf_lo;
   auto tgt = [&](uint64_t i) -> double { bool oob; return root_target_f<K_LINEAR, K>(r, Lm1f, keys[i], oob); };
-  // ---- the block's bracket [A, B]: lower bounds of jb and je, both by the same rounds of 256 probes
-  uint64_t loA = sp.it_lo, hiA = sp.it_hi, loB = sp.it_lo, hiB = sp.it_hi;
-  const double jA = (double)jb, jB = (double)je;
-  if (!(je < sp.leaf_hi)) { loB = sp.it_hi; hiB = sp.it_hi; }       // leaf_start[leaf_hi] = it_hi: the sentinel of k_init
-  while (hiA > loA || hiB > loB) {                                   // (block-uniform)
-    const uint64_t stA = (hiA - loA + LS_BLOCK - 1) / LS_BLOCK, stB = (hiB - loB + LS_BLOCK - 1) / LS_BLOCK;
-    const uint64_t qA = loA + (uint64_t)t * stA, qB = loB + (uint64_t)t * stB;
-    const int belowA = (hiA > loA && qA < hiA) ? (tgt(qA) < jA ? 1 : 0) : 0;
-    const int belowB = (hiB > loB && qB < hiB) ? (tgt(qB) < jB ? 1 : 0) : 0;
-    const int cA = __syncthreads_count(belowA);
-    const int cB = __syncthreads_count(belowB);
-    if (hiA > loA) {
-      if (cA == 0) hiA = loA;
-      else {
-        const uint64_t nl = loA + (uint64_t)(cA - 1) * stA + 1, nh = loA + (uint64_t)cA * stA;
-        hiA = (cA < LS_BLOCK && nh < hiA) ? nh : hiA;
-        loA = nl;
-      }
-    }
-    if (hiB > loB) {
-      if (cB == 0) hiB = loB;
-      else {
-        const uint64_t nl = loB + (uint64_t)(cB - 1) * stB + 1, nh = loB + (uint64_t)cB * stB;
-        hiB = (cB < LS_BLOCK && nh < hiB) ? nh : hiB;
-        loB = nl;
-      }
-    }
-  }
-  const uint64_t A = loA, B = loB;
-  // ---- every thread its own leaf: interpolate inside [A, B], gallop, bisect
-  const uint64_t j = jb + (uint64_t)t;
-  if (j < je) {
-    uint64_t lo = A, hi = B;
-    if (t > 0 && B > A) {
-      const double jf = (double)j;
-      const uint64_t R = B - A;
-      uint64_t g = A + (uint64_t)t * R / (je - jb);
-      if (g >= B) g = B - 1;
-      uint64_t d = R >> 12;
-      if (d < 1) d = 1;
-      if (tgt(g) < jf) {
-        lo = g + 1;
+  // lower bound of "target >= jf" in [lo, hi] (the answer lies between them), first probe at g, first gallop step d
+  auto search = [&](double jf, uint64_t lo, uint64_t hi, uint64_t g, uint64_t d) -> uint64_t {
+    // pair probe at i (lo <= i < hi): narrows [lo, hi] by the keys i and i + 1
+    auto probe = [&](uint64_t i) {
+      typedef typename LnBits<K>::type BT;
+      K k0, k1;
+      if (i + 1 < sp.rd_hi) {
+        typedef BT vec_t __attribute__((ext_vector_type(2), aligned(sizeof(K))));
+        const vec_t v = *reinterpret_cast<const vec_t*>(keys + i);
+        k0 = bits_to_key<K>(v.x); k1 = bits_to_key<K>(v.y);
+      } else { k0 = keys[i]; k1 = k0; }
+      bool oob;
+      const bool b0 = root_target_f<K_LINEAR, K>(r, Lm1f, k0, oob) < jf;
+      const bool b1 = root_target_f<K_LINEAR, K>(r, Lm1f, k1, oob) < jf;
+      if (!b0) hi = i;
+      else if (!b1 || i + 1 >= hi) { lo = i + 1; if (!b1) hi = i + 1; }
+      else lo = i + 2 < hi ? i + 2 : hi;
+    };
+    if (!(lo < hi)) return lo;
+    if (g < lo) g = lo;
+    if (g >= hi) g = hi - 1;
+    probe(g);
+    if (lo < hi) {
+      if (lo > g) {                                                  // the keys at the guess are below: gallop upwards
         while (lo < hi) {
           const uint64_t q = lo + d - 1;
           if (q >= hi) break;
-          if (tgt(q) < jf) { lo = q + 1; d <<= 1; } else { hi = q; break; }
+          const uint64_t before = lo;
+          probe(q);
+          if (!(lo > q && lo > before)) break;                       // not "both below": bracketed
+          d <<= 1;
         }
-      } else {
-        hi = g;
+      } else {                                                       // downwards
         while (lo < hi) {
-          if (hi - lo < d) break;
+          if (hi - lo <= d) break;
           const uint64_t q = hi - d;
-          if (tgt(q) < jf) { lo = q + 1; break; } else { hi = q; d <<= 1; }
+          const uint64_t before = hi;
+          probe(q);
+          if (!(hi == q && hi < before)) break;                      // not "none below"
+          d <<= 1;
         }
       }
-      while (lo < hi) {
-        const uint64_t mid = lo + ((hi - lo) >> 1);
-        if (tgt(mid) < jf) lo = mid + 1; else hi = mid;
-      }
-    } else hi = lo;
-    leaf_start[j] = (unsigned long long)lo;
-    if (j == r.L / 2 && lo < sp.it_hi) {                              // two_layer.rs:131-136, 152-156
-      if (lo == 0) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);     // split_idx == 0 -> :27
-      else if (lo > sp.rd_lo) {
-        st->split_idx = (unsigned long long)lo;
-        st->split_target = (unsigned long long)tgt(lo);
-        if (lo + 1 >= sp.n) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);   // second half empty -> :27
+      while (lo < hi) probe(lo + ((hi - lo) >> 1));
+    }
+    return lo;
+  };
+  if (jb < sp.leaf_hi) {
+    // ---- anchors: leaf jb + 16 a for a = 0 .. 16 (threads 0, 16, .. and, for the last one, thread 8)
+    const double per_leaf = (double)(Bn - A) / (double)L_own;
+    if ((t & 15) == 0 || t == 8) {
+      const int a = t == 8 ? LS_BLOCK / 16 : t / 16;
+      const uint64_t ja = jb + 16ull * (uint64_t)a;
+      const double jf = (double)ja;
+      uint64_t pos = Bn;                                             // leaves from leaf_hi on: the end of the launch's keys
+      if (ja <= sp.leaf_lo) pos = (Bn > A && tgt(A) < jf) ? search(jf, A + 1, Bn, A + 1, 2) : A;
+      else if (ja < sp.leaf_hi && Bn > A) {
+        uint64_t w = (uint64_t)(per_leaf * 1.5);
+        if (w < 4) w = 4;
+        const uint64_t g = A + (uint64_t)((double)(ja - sp.leaf_lo) * per_leaf);
+        const uint64_t i1 = g > A + w ? (g - w < Bn ? g - w : Bn - 1) : A;
+        const uint64_t i2 = g + w < Bn ? g + w : Bn - 1;
+        const double f1 = root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(keys[i1]));
+        const double f2 = root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(keys[i2]));
+        // (for the integer 1 <= ja <= L - 1:  target(i) < ja  <=>  f(i) < ja;  the probes decide, f1 and f2 only place the first)
+        if (i1 < i2 && f1 < jf && f2 >= jf) pos = search(jf, i1 + 1, i2, i1 + (uint64_t)((jf - f1) / (f2 - f1) * (double)(i2 - i1)), 4);
+        else {
+          uint64_t d = w >> 3;
+          if (d < 2) d = 2;
+          pos = search(jf, A, Bn, g < Bn ? g : Bn - 1, d);
+        }
+      } else if (ja < sp.leaf_hi) pos = A;
+      anch[a] = (unsigned long long)pos;
+    }
+    __syncthreads();
+    const uint64_t j = jb + (uint64_t)t;
+    if (j < sp.leaf_hi) {
+      const uint64_t p0 = anch[t / 16], p1 = anch[t / 16 + 1];
+      uint64_t lo = p0;
+      if ((t & 15) != 0) lo = search((double)j, p0, p1, p0 + (uint64_t)(t & 15) * (p1 - p0) / 16, 2);
+      leaf_start[j] = (unsigned long long)lo;
+      if (j == r.L / 2 && lo < sp.it_hi) {                            // two_layer.rs:131-136, 152-156
+        if (lo == 0) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);   // split_idx == 0 -> :27
+        else if (lo > sp.rd_lo) {
+          st->split_idx = (unsigned long long)lo;
+          st->split_target = (unsigned long long)tgt(lo);
+          if (lo + 1 >= sp.n) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);   // second half empty -> :27
+        }
       }
     }
   }
@@ -156,21 +192,22 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // k_leaf_lanes
 // ---------------------------------------------------------------------------------------------
-template <typename K> struct LnBits { using type = unsigned long long; };
-template <> struct LnBits<uint32_t> { using type = unsigned int; };
-
 template <typename K, bool ERR>
-__global__ void __launch_bounds__(64) k_leaf_lanes(const K* __restrict__ keys, Span sp,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_WPE, RMI_LN_WPE))) k_leaf_lanes(const K* __restrict__ keys, Span sp,
                                                    const unsigned long long* __restrict__ leaf_start,
                                                    DevState* __restrict__ st, double* __restrict__ params,
-                                                   const LnStep* __restrict__ tab, SgList fl, unsigned int long_min,
+                                                   const double* __restrict__ rtab, SgList fl, unsigned int long_min,
                                                    unsigned long long* __restrict__ leaf_maxerr,
-                                                   unsigned long long* __restrict__ leaf_run) {
+                                                   unsigned long long* __restrict__ leaf_run, uint64_t L,
+                                                   unsigned long long* __restrict__ leaf_err,
+                                                   unsigned long long* __restrict__ leaf_count,
+                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials) {
   using B = typename LnBits<K>::type;
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
   constexpr int LPR = 8;                                              // lanes per row (2 keys each)
-  __shared__ B panel[64 * LN_STRIDE];
-  __shared__ unsigned int s_off[64], s_end[64];
+  __shared__ B panel[64 * LN_STRIDE];                                 // 19 968 B for 8-byte keys: 8 waves per CU
+  unsigned int* const s_off = reinterpret_cast<unsigned int*>(panel);   // (row descriptors of a phase: exchanged before its first panel is staged)
+  unsigned int* const s_end = s_off + 64;
 
   const int lane = threadIdx.x;
   const uint64_t j0 = sp.leaf_lo + (uint64_t)blockIdx.x * 64;
@@ -189,12 +226,14 @@ __global__ void __launch_bounds__(64) k_leaf_lanes(const K* __restrict__ keys, S
     const uint64_t s0 = ((uint64_t)s0h << 32) | s0l;
     wb = s0 > sp.rd_lo ? s0 - 1 : sp.rd_lo;
   }
+  // ... moved down to the start of the 16-key line it lies in (by ADDRESS: whole aligned lines are fetched; the keys
+  // of a line in front of the first / behind the last readable key share its page and are never used)
+  wb -= (uint64_t)((reinterpret_cast<uintptr_t>(keys + wb) / sizeof(K)) % (uintptr_t)LN_ROW);
   const K* __restrict__ kb = keys + wb;
-  const uint64_t rd_last = sp.rd_hi - 1 - wb;                         // relative index of the last readable key
   const unsigned int npts = ck == 2 ? (unsigned int)((hi - lo + 1 < 0xFFFFFFFFull) ? hi - lo + 1 : 0xFFFFFFFFull) : 0u;
   // leaves for the list kernels (one wave per leaf: exact fit + its error pass): containers longer than the lockstep
   // walk takes, and whatever lies beyond 32-bit offsets from the wave base
-  constexpr uint64_t FAR = 1ull << 31;
+  constexpr uint64_t FAR = 1ull << 30;
   const bool handed = valid && ((ck == 2 && (npts + 1u > long_min || hi - wb >= FAR)) || (e > s && e - wb >= FAR));
   if (handed) fl.push((unsigned int)j);
   const bool act = ck == 2 && !handed;
@@ -204,43 +243,59 @@ __global__ void __launch_bounds__(64) k_leaf_lanes(const K* __restrict__ keys, S
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  // ---- row descriptors: lane l of load instruction i fetches 2 keys of row 8 i + l / 8
+  // ---- row descriptors.  A row is fetched in ALIGNED chunks of 16 keys (128-byte lines of 8-byte keys): lane l of load
+  // instruction i fetches 2 keys of chunk p of row 8 i + l / 8, so an instruction asks for 8 whole lines and every line
+  // of the key array is requested once per phase.  (Rows fetched from their own first key, i.e. at arbitrary 8-byte
+  // offsets, straddle two lines per chunk: twice the requests, every line fetched twice, and the kernel stalled on the
+  // issue of its loads -- 57 % of the wave time -- at 4.4 TB/s.)  A lane's key k then sits at ring slot (a + k) mod 32,
+  // a = its row's offset inside its first chunk.  Every load is unconditional (the compiler counts them: NBUF panels
+  // are in flight); a finished row keeps re-reading its last chunk.
   unsigned int roff[8], rlim[8];
-  auto make_rows = [&](unsigned int my_off, unsigned int my_len) {
+  auto make_rows = [&](unsigned int my_off, unsigned int my_len) {   // my_off: relative to wb
     wave_sync();
-    s_off[lane] = my_off;
-    s_end[lane] = my_len ? my_off + my_len - 1u : my_off;
+    s_off[lane] = my_off & ~15u;
+    s_end[lane] = (my_len ? my_off + my_len - 1u : my_off) & ~15u;
     wave_sync();
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const int row = i * 8 + lane / LPR;
-      roff[i] = s_off[row] + 2u * (unsigned int)(lane % LPR);
-      rlim[i] = s_end[row];
+      const unsigned int piece = 2u * (unsigned int)(lane % LPR);
+      roff[i] = s_off[row] + piece;
+      rlim[i] = s_end[row] + piece;
     }
+    wave_sync();                                                      // (the descriptors alias the panel)
   };
-  B nxt[8][2];
-  auto load_panel = [&](unsigned int p16, bool edge, bool nt) {
+  constexpr int NBUF = RMI_LN_NBUF;
+  B bufs[NBUF][8][2];
+  auto load_panel = [&](B (&buf)[8][2], unsigned int p16, bool nt) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       unsigned int idx = roff[i] + p16;
-      idx = idx < rlim[i] ? idx : rlim[i];                             // a finished row keeps re-reading its last line (cache hits)
-      if (!edge) {
-        typedef B vec_t __attribute__((ext_vector_type(2), aligned(sizeof(K))));
-        const vec_t* pv = reinterpret_cast<const vec_t*>(kb + idx);
-        const vec_t v = nt ? __builtin_nontemporal_load(pv) : *pv;
-        nxt[i][0] = v.x; nxt[i][1] = v.y;
-      } else {
-        const uint64_t i0 = (uint64_t)idx < rd_last ? (uint64_t)idx : rd_last;
-        const uint64_t i1 = (uint64_t)idx + 1 < rd_last ? (uint64_t)idx + 1 : rd_last;
-        nxt[i][0] = key_to_bits<K>(kb[i0]); nxt[i][1] = key_to_bits<K>(kb[i1]);
-      }
+      idx = idx < rlim[i] ? idx : rlim[i];
+      typedef B vec_t __attribute__((ext_vector_type(2)));
+      const vec_t* pv = reinterpret_cast<const vec_t*>(kb + idx);     // (16-byte aligned: wb is line aligned, idx is even)
+      const vec_t v = nt ? __builtin_nontemporal_load(pv) : *pv;
+      buf[i][0] = v.x; buf[i][1] = v.y;
     }
   };
-  auto stage = [&]() {
+  // aligned panel p goes to the ring slots [16 (p & 1), +16); an even panel's first slots once more behind the ring
+  auto stage = [&](B (&buf)[8][2], unsigned int p) {
+    const unsigned int sb = (p & 1u) * 16u;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const int base = (i * 8 + lane / LPR) * LN_STRIDE + 2 * (lane % LPR);
-      panel[base] = nxt[i][0]; panel[base + 1] = nxt[i][1];
+      const unsigned int base = (unsigned int)(i * 8 + lane / LPR) * LN_STRIDE + sb + 2u * (unsigned int)(lane % LPR);
+      panel[base] = buf[i][0]; panel[base + 1] = buf[i][1];
+    }
+    if (sb == 0u) {
+      const unsigned int piece = (unsigned int)(lane % LPR);
+      if (piece < 4u) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const unsigned int base = (unsigned int)(i * 8 + lane / LPR) * LN_STRIDE + LN_RING + 2u * piece;
+          panel[base] = buf[i][0];
+          if (piece < 3u) panel[base + 1] = buf[i][1];
+        }
+      }
     }
   };
 
@@ -248,70 +303,95 @@ __global__ void __launch_bounds__(64) k_leaf_lanes(const K* __restrict__ keys, S
   double pa = 0.0, pb = 0.0;                                          // this lane's leaf: (alpha, beta)
   // =========================== the fit: lockstep walk of the containers ===========================
   {
+    make_rows(act ? (unsigned int)(lo - wb) : 0u, act ? npts : 0u);
+    const unsigned int a0 = act ? (unsigned int)(lo - wb) & 15u : 0u;   // ring slot of the container's first point
+#pragma unroll
+    for (int u = 0; u < NBUF; u++) load_panel(bufs[u], 16u * (unsigned int)u, RMI_LN_NT_FIT != 0);
     uint64_t y0 = lo;
     if (act) y0 = first_occurrence(keys, lo, sp.rd_lo);               // FixDups offset of the container's first point
     const double y0f = (double)y0, lof = (double)lo;
-    make_rows(act ? (unsigned int)(lo - wb) : 0u, act ? npts : 0u);
-    const bool edge = __any((act ? (hi - wb) + 1 : 1ull) >= rd_last + 1);   // a 16-byte load could reach past the readable keys
     double mx = 0.0, cc = 0.0, m2 = 0.0, my = 0.0, yprev = y0f;
+    double kf = 0.0, hh = -0.5;                                       // running count k and (k - 1) / 2: the same in every lane
     B kprev = 0;
     bool gen = false;                                                 // explicit my-chain (a duplicate key was met)
-    load_panel(0u, edge, RMI_LN_NT_FIT != 0);
-    for (unsigned int p16 = 0; __any(act && p16 < npts); p16 += 16) {
+    // the 16 steps [p16, p16 + 16) of every lane: they read the aligned panels p16 / 16 (staged one trip ago) and
+    // p16 / 16 + 1 (staged now, from `buf`, which is refilled with the panel NBUF further on)
+    auto fit_panel = [&](B (&buf)[8][2], unsigned int p16) {
       wave_sync();
-      stage();
-      load_panel(p16 + 16u, edge, RMI_LN_NT_FIT != 0);                // prefetch: lands during the steps
+      stage(buf, p16 / 16u + 1u);
+      load_panel(buf, p16 + 16u * (unsigned int)(NBUF + 1), RMI_LN_NT_FIT != 0);
+      double rr[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) rr[q] = rtab[p16 + (unsigned int)q];   // wave-uniform: RN(1 / k) of the 16 steps
       wave_sync();
-      B kk[16];
 #pragma unroll
-      for (int q = 0; q < 16; q++) kk[q] = panel[lane * LN_STRIDE + q];
-      const unsigned int rem = (act && npts > p16) ? npts - p16 : 0u;
-      const unsigned int vmask = rem >= 16u ? 0xFFFFu : ((1u << rem) - 1u);
-      unsigned int dmask = 0;
-      {
-        B kp = kprev;
+      for (int hb = 0; hb < 2; hb++) {
+        const unsigned int b0 = p16 + 8u * (unsigned int)hb;
+        B kk[8];
+        {
+          const unsigned int rb = (unsigned int)lane * LN_STRIDE + ((a0 + b0) & 31u);
 #pragma unroll
-        for (int q = 0; q < 16; q++) { dmask |= (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)) ? (1u << q) : 0u; kp = kk[q]; }
-      }
-      // the first point: y is y0, which is its own index unless the key before the container equals it
-      if (p16 == 0) dmask = (dmask & ~1u) | ((y0 != lo) ? 1u : 0u);
-      dmask &= vmask;
-      kprev = kk[15];
-      const bool full = __all(vmask == 0xFFFFu);
-      const bool anygen = __any((gen && rem > 0u) || dmask != 0u);
-      auto steps = [&](auto full_tag, auto gen_tag) {
-        constexpr bool FULL = decltype(full_tag)::value, GEN = decltype(gen_tag)::value;
+          for (int q = 0; q < 8; q++) kk[q] = panel[rb + (unsigned int)q];
+        }
+        const unsigned int rem = (act && npts > b0) ? npts - b0 : 0u;
+        const unsigned int vmask = rem >= 8u ? 0xFFu : ((1u << rem) - 1u);
+        unsigned int dmask = 0;
+        {
+          B kp = kprev;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const LnStep t = tab[p16 + (unsigned int)q + 1u];             // wave-uniform: scalar loads
-          if (FULL || ((vmask >> q) & 1u)) {
-            const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[q]));
-            const double dx = x - mx;                                   // linear.rs:26
-            if constexpr (DIVK) mx += dx / t.kf; else mx += div_by_count(dx, t.kf, t.r);   // :27
-            if constexpr (GEN) {
-              const double y = ((dmask >> q) & 1u) ? yprev : lof + t.km1;   // FixDups: a duplicate keeps its first occurrence's offset
-              const double dy = y - my;
-              if constexpr (DIVK) my += dy / t.kf; else my += div_by_count(dy, t.kf, t.r);  // :28
-              cc += dx * (y - my);                                      // :29
-              yprev = y;
-            } else {
-              cc += dx * t.h;                                           // :28-29 in closed form (see the head of this file)
+          for (int q = 0; q < 8; q++) { dmask |= (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)) ? (1u << q) : 0u; kp = kk[q]; }
+        }
+        // the first point: y is y0, which is its own index unless the key before the container equals it
+        if (b0 == 0) dmask = (dmask & ~1u) | ((y0 != lo) ? 1u : 0u);
+        dmask &= vmask;
+        kprev = kk[7];
+        const bool full = __all(vmask == 0xFFu);
+        const bool anygen = __any((gen && rem > 0u) || dmask != 0u);
+        auto steps = [&](auto full_tag, auto gen_tag) {
+          constexpr bool FULL = decltype(full_tag)::value, GEN = decltype(gen_tag)::value;
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const double km1 = kf;
+            kf += 1.0; hh += 0.5;
+            const double r = rr[8 * hb + q];
+            if (FULL || ((vmask >> q) & 1u)) {
+              const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[q]));
+              const double dx = x - mx;                                   // linear.rs:26
+              if constexpr (DIVK) mx += dx / kf; else mx += div_by_count(dx, kf, r);   // :27
+              if constexpr (GEN) {
+                const double y = ((dmask >> q) & 1u) ? yprev : lof + km1;   // FixDups: a duplicate keeps its first occurrence's offset
+                const double dy = y - my;
+                if constexpr (DIVK) my += dy / kf; else my += div_by_count(dy, kf, r);    // :28
+                cc += dx * (y - my);                                      // :29
+                yprev = y;
+              } else {
+                cc += dx * hh;                                            // :28-29 in closed form (see the head of this file)
+              }
+              m2 += dx * (x - mx);                                        // :30-31
             }
-            m2 += dx * (x - mx);                                        // :30-31
           }
+        };
+        if (!anygen) {
+          if (full) steps(std::true_type{}, std::false_type{});
+          else steps(std::false_type{}, std::false_type{});
+        } else {
+          if (!gen) {                                                  // closed form after b0 points
+            my = b0 ? y0f + (double)(b0 - 1u) * 0.5 : 0.0;
+            yprev = b0 ? y0f + (double)(b0 - 1u) : y0f;
+          }
+          steps(std::false_type{}, std::true_type{});
+          gen = gen || dmask != 0u;
         }
-      };
-      if (!anygen) {
-        if (full) steps(std::true_type{}, std::false_type{});
-        else steps(std::false_type{}, std::false_type{});
-      } else {
-        if (!gen) {                                                    // closed form after p16 points
-          my = p16 ? y0f + (double)(p16 - 1u) * 0.5 : 0.0;
-          yprev = p16 ? y0f + (double)(p16 - 1u) : y0f;
-        }
-        steps(std::false_type{}, std::true_type{});
-        gen = gen || dmask != 0u;
       }
+    };
+    // (NBUF panels per trip, no exit in between: with a branch between the panels the compiler loses count of the loads
+    //  in flight and waits for ALL of them at every panel -- vmcnt(7..0) instead of vmcnt(23..16) -- i.e. no prefetch)
+    wave_sync();
+    stage(bufs[0], 0u);
+    load_panel(bufs[0], 16u * (unsigned int)NBUF, RMI_LN_NT_FIT != 0);
+    for (unsigned int p16 = 0; __any(act && p16 < npts); p16 += 16u * (unsigned int)NBUF) {
+#pragma unroll
+      for (int u = 0; u < NBUF; u++) fit_panel(bufs[(u + 1) % NBUF], p16 + 16u * (unsigned int)u);
     }
     // ---- the container's last item once more (Q1, models/mod.rs:180), then linear.rs:36-58
     if (act) {
@@ -336,73 +416,164 @@ __global__ void __launch_bounds__(64) k_leaf_lanes(const K* __restrict__ keys, S
     const bool eact = valid && !handed && e > s;
     const unsigned int len = eact ? (unsigned int)(e - s) : 0u;
     make_rows(eact ? (unsigned int)(s - wb) : 0u, len);
-    const bool edge = __any((eact ? (e - 1 - wb) + 1 : 1ull) >= rd_last + 1);
+    const unsigned int a0 = eact ? (unsigned int)(s - wb) & 15u : 0u;
+#pragma unroll
+    for (int u = 0; u < NBUF; u++) load_panel(bufs[u], 16u * (unsigned int)u, RMI_LN_NT_ERR != 0);
     const unsigned int n32 = (unsigned int)sp.n, s32 = (unsigned int)s;
     unsigned int emax = 0u, run = 0u, yprev = s32;
     bool tr = false;                                                   // yprev is being tracked (a run of equal keys is open)
     B kprev = 0;
-    load_panel(0u, edge, RMI_LN_NT_ERR != 0);
-    for (unsigned int p16 = 0; __any(p16 < len); p16 += 16) {
+    auto err_panel = [&](B (&buf)[8][2], unsigned int p16) {
       wave_sync();
-      stage();
-      load_panel(p16 + 16u, edge, RMI_LN_NT_ERR != 0);
+      stage(buf, p16 / 16u + 1u);
+      load_panel(buf, p16 + 16u * (unsigned int)(NBUF + 1), RMI_LN_NT_ERR != 0);
       wave_sync();
-      B kk[16];
 #pragma unroll
-      for (int q = 0; q < 16; q++) kk[q] = panel[lane * LN_STRIDE + q];
-      const unsigned int rem = len > p16 ? len - p16 : 0u;
-      const unsigned int vmask = rem >= 16u ? 0xFFFFu : ((1u << rem) - 1u);
-      unsigned int dmask = 0;
-      {
-        B kp = kprev;
+      for (int hb = 0; hb < 2; hb++) {
+        const unsigned int b0 = p16 + 8u * (unsigned int)hb;
+        B kk[8];
+        {
+          const unsigned int rb = (unsigned int)lane * LN_STRIDE + ((a0 + b0) & 31u);
 #pragma unroll
-        for (int q = 0; q < 16; q++) { dmask |= (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)) ? (1u << q) : 0u; kp = kk[q]; }
-      }
-      if (p16 == 0) dmask &= ~1u;                                      // a leaf's first key differs from the key before it
-      dmask &= vmask;
-      kprev = kk[15];
-      const bool full = __all(vmask == 0xFFFFu);
-      const bool anygen = __any((tr && rem > 0u) || dmask != 0u);
-      const unsigned int i0 = s32 + p16;
-      auto steps = [&](auto full_tag, auto gen_tag) {
-        constexpr bool FULL = decltype(full_tag)::value, GEN = decltype(gen_tag)::value;
+          for (int q = 0; q < 8; q++) kk[q] = panel[rb + (unsigned int)q];
+        }
+        const unsigned int rem = len > b0 ? len - b0 : 0u;
+        const unsigned int vmask = rem >= 8u ? 0xFFu : ((1u << rem) - 1u);
+        unsigned int dmask = 0;
+        {
+          B kp = kprev;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-          if (FULL || ((vmask >> q) & 1u)) {
-            const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[q]));
-            const double f = __builtin_fma(pb, x, pa);                  // linear.rs:87-90
-            const unsigned int pr = min(sg_cvt_u32(f), n32);           // models/mod.rs:735-737, two_layer.rs:14-18
-            const unsigned int idx = i0 + (unsigned int)q;
-            if constexpr (GEN) {
-              const bool dup = (dmask >> q) & 1u;
-              if (!dup && (p16 | (unsigned int)q) != 0u) run = max(run, idx - yprev);   // a new key value ends the run before it (lower_bound_correction.rs:108-119)
-              const unsigned int y = dup ? yprev : idx;
-              emax = max(emax, sg_absdiff(pr, y));
-              yprev = y;
-            } else {
-              emax = max(emax, sg_absdiff(pr, idx));
+          for (int q = 0; q < 8; q++) { dmask |= (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)) ? (1u << q) : 0u; kp = kk[q]; }
+        }
+        if (b0 == 0) dmask &= ~1u;                                     // a leaf's first key differs from the key before it
+        dmask &= vmask;
+        kprev = kk[7];
+        const bool full = __all(vmask == 0xFFu);
+        const bool anygen = __any((tr && rem > 0u) || dmask != 0u);
+        const unsigned int i0 = s32 + b0;
+        auto steps = [&](auto full_tag, auto gen_tag) {
+          constexpr bool FULL = decltype(full_tag)::value, GEN = decltype(gen_tag)::value;
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            if (FULL || ((vmask >> q) & 1u)) {
+              const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[q]));
+              const double f = __builtin_fma(pb, x, pa);                // linear.rs:87-90
+              const unsigned int pr = min(sg_cvt_u32(f), n32);         // models/mod.rs:735-737, two_layer.rs:14-18
+              const unsigned int idx = i0 + (unsigned int)q;
+              if constexpr (GEN) {
+                const bool dup = (dmask >> q) & 1u;
+                if (!dup && (b0 | (unsigned int)q) != 0u) run = max(run, idx - yprev);   // a new key value ends the run before it (lower_bound_correction.rs:108-119)
+                const unsigned int y = dup ? yprev : idx;
+                emax = max(emax, sg_absdiff(pr, y));
+                yprev = y;
+              } else {
+                emax = max(emax, sg_absdiff(pr, idx));
+              }
             }
           }
+        };
+        if (!anygen) {
+          if (full) steps(std::true_type{}, std::false_type{});
+          else steps(std::false_type{}, std::false_type{});
+        } else {
+          if (rem > 0u && !tr) yprev = b0 ? i0 - 1u : s32;              // the key before this half is its own first occurrence
+          steps(std::false_type{}, std::true_type{});
+          if (rem > 0u) tr = rem <= 8u || ((dmask >> 7) & 1u) != 0u;    // (a row that ends here keeps the y of its last key)
         }
-      };
-      if (!anygen) {
-        if (full) steps(std::true_type{}, std::false_type{});
-        else steps(std::false_type{}, std::false_type{});
-      } else {
-        if (rem > 0u && !tr) yprev = p16 ? i0 - 1u : s32;              // the key before this panel is its own first occurrence
-        steps(std::false_type{}, std::true_type{});
-        if (rem > 0u) tr = rem <= 16u || ((dmask >> 15) & 1u) != 0u;   // (a row that ends here keeps the y of its last key)
       }
+    };
+    wave_sync();
+    stage(bufs[0], 0u);
+    load_panel(bufs[0], 16u * (unsigned int)NBUF, RMI_LN_NT_ERR != 0);
+    for (unsigned int p16 = 0; __any(p16 < len); p16 += 16u * (unsigned int)NBUF) {
+#pragma unroll
+      for (int u = 0; u < NBUF; u++) err_panel(bufs[(u + 1) % NBUF], p16 + 16u * (unsigned int)u);
     }
-    if (eact) {
-      // the key behind the leaf is a different one: it ends the run of the leaf's last key (the globally last run is
-      // never recorded, Q5)
-      if (e < sp.n) { const unsigned int yl = tr ? yprev : (unsigned int)e - 1u; run = max(run, (unsigned int)e - yl); }
-      leaf_maxerr[j] = (unsigned long long)emax;
-      leaf_run[j] = run > 1u ? (unsigned long long)run : 0ull;          // (runs of 1: k_finalize's rule, like pass B)
+    // the key behind the leaf is a different one: it ends the run of the leaf's last key (the globally last run is
+    // never recorded, Q5)
+    if (eact && e < sp.n) { const unsigned int yl = tr ? yprev : (unsigned int)e - 1u; run = max(run, (unsigned int)e - yl); }
+    // ---- finish the leaf here (two_layer.rs:185-197, 226-259, the row of codegen.rs:288-315, the terms of :267-287):
+    // the two boundary keys are the ends of the container this wave has just streamed
+    unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;
+    double st_l2 = 0.0, st_lg = 0.0;
+    if (valid && !handed) {
+      double pp[2] = {pa, pb};
+      uint64_t final_err, cnt_j;
+      finalize_one<K_LINEAR, K>(j, s, e, sp, L, keys, pp, (uint64_t)emax, run > 1u ? (uint64_t)run : 0ull, st->last_target, final_err, cnt_j);
+      if (!(s < e)) { params[2 * j] = pp[0]; params[2 * j + 1] = pp[1]; }
+      leaf_err[j] = final_err;
+      leaf_count[j] = cnt_j;
+      double* rp = reinterpret_cast<double*>(rows + j * 24);
+      rp[0] = pp[0]; rp[1] = pp[1];
+      *reinterpret_cast<unsigned long long*>(rows + j * 24 + 16) = final_err;
+      st_mx = final_err; st_mi = j;
+      st_sum = cnt_j * final_err;                                      // wrapping u64, like the reference's sum
+      const double v = (double)st_sum;
+      st_l2 = (v * v) / (double)sp.n;
+      st_lg = (double)cnt_j * log2((double)(2 * final_err + 2));
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {                                 // (lexicographic maximum and sums: any order combines)
+      const unsigned long long omx = shfl_down_u64(st_mx, d), omi = shfl_down_u64(st_mi, d);
+      if (omx > st_mx || (omx == st_mx && omi > st_mi)) { st_mx = omx; st_mi = omi; }
+      st_sum += shfl_down_u64(st_sum, d);
+      st_l2 += __shfl_down(st_l2, d);
+      st_lg += __shfl_down(st_lg, d);
+    }
+    if (lane == 0) partials[blockIdx.x] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
   }
   if (flags) atomicOr(&st->err_flags, flags);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_finalize_listed: what is left of k_finalize when k_leaf_lanes finishes its own leaves -- the leaves of the list
+// kernels (fitted and measured by k_list / k_list_tail) -- and the first level of the aggregates: block b also
+// combines its slice of the waves' partial records, so that k_stats_reduce reads FL_BLOCKS records.
+// ---------------------------------------------------------------------------------------------
+constexpr int FL_BLOCKS = 64;
+template <typename K>
+__global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ keys, Span sp, uint64_t L,
+                                                         const unsigned long long* __restrict__ leaf_start,
+                                                         const DevState* __restrict__ st, double* __restrict__ params,
+                                                         const unsigned long long* __restrict__ leaf_maxerr,
+                                                         const unsigned long long* __restrict__ leaf_run,
+                                                         unsigned long long* __restrict__ leaf_err,
+                                                         unsigned long long* __restrict__ leaf_count,
+                                                         unsigned char* __restrict__ rows, SgList fl,
+                                                         const StatsPartial* __restrict__ wave_partials, unsigned int nwave,
+                                                         StatsPartial* __restrict__ out) {
+  unsigned long long mx = 0, mi = 0, sm = 0;
+  double l2 = 0.0, lg = 0.0;
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x, gsz = gridDim.x * 256u;
+  for (int rg = 0; rg < SG_REGIONS; rg++) {
+    const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
+    for (unsigned long long t = gid; t < cnt; t += gsz) {
+      const uint64_t j = fl.ids[(unsigned long long)rg * fl.cap + t] & ~SG_TAG;
+      const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+      double pp[2] = {params[2 * j], params[2 * j + 1]};
+      uint64_t final_err, cnt_j;
+      finalize_one<K_LINEAR, K>(j, s, e, sp, L, keys, pp, leaf_maxerr[j], leaf_run[j], st->last_target, final_err, cnt_j);
+      if (!(s < e)) { params[2 * j] = pp[0]; params[2 * j + 1] = pp[1]; }
+      leaf_err[j] = final_err;
+      leaf_count[j] = cnt_j;
+      double* rp = reinterpret_cast<double*>(rows + j * 24);
+      rp[0] = pp[0]; rp[1] = pp[1];
+      *reinterpret_cast<unsigned long long*>(rows + j * 24 + 16) = final_err;
+      const unsigned long long ts = cnt_j * final_err;
+      if (final_err > mx || (final_err == mx && j > mi)) { mx = final_err; mi = j; }
+      sm += ts;
+      const double v = (double)ts;
+      l2 += (v * v) / (double)sp.n;
+      lg += (double)cnt_j * log2((double)(2 * final_err + 2));
+    }
+  }
+  for (unsigned int q = gid; q < nwave; q += gsz) {
+    const StatsPartial p = wave_partials[q];
+    if (p.mx > mx || (p.mx == mx && p.mi > mi)) { mx = p.mx; mi = p.mi; }
+    sm += p.sum; l2 += p.l2; lg += p.lg;
+  }
+  stats_block_reduce(mx, mi, sm, l2, lg);
+  if (threadIdx.x == 0) out[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
 }
 
 }  // namespace rmi

@@ -205,6 +205,7 @@ __global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp
     } else if (lane == 0) fit_one_leaf<LEAFK, K>(j, keys, sp, leaf_start, st, params);
     if (merged || e - s > (uint64_t)SG_ERR_LONG) {
       if (lane == 0) {
+        leaf_maxerr[j] = 0ull; leaf_run[j] = 0ull;                   // (k_list_tail raises them with atomicMax)
         const uint64_t nseg = (e - s + SG_SEG - 1) / SG_SEG;
         const unsigned long long pos = atomicAdd(&st->seg_count, (unsigned long long)nseg);
         const unsigned long long tagb = merged ? SG_SEG_PLAIN : 0ull;

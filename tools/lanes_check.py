@@ -80,10 +80,12 @@ def check():
     print("CHECK", "ALL OK" if bad_total == 0 else f"{bad_total} BAD")
 
 
-def timing(n, L, steps, gen="uniform"):
+def timing(n, L, steps, gen="uniform", only=""):
     variants = dict(VARIANTS)
     variants["p2 exact (pass A/B)"] = {"RMI_HIP_PIPELINE": "2"}
     variants["p2 onepass guarded"] = {"RMI_HIP_PIPELINE": "2", "RMI_HIP_FIT_MODE": "1"}
+    if only:
+        variants = {k: v for k, v in variants.items() if only in k}
     base = None
     for name, env in variants.items():
         tr = mk(env)
@@ -125,4 +127,5 @@ if __name__ == "__main__":
         L = int(rest[1]) if len(rest) > 1 else 1 << 20
         steps = int(rest[2]) if len(rest) > 2 else 30
         gen = rest[3] if len(rest) > 3 else "uniform"
-        timing(n, L, steps, gen)
+        only = rest[4] if len(rest) > 4 else ""
+        timing(n, L, steps, gen, only)
