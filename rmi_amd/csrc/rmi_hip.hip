@@ -249,7 +249,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (pl && *pl) c->pipeline = std::atoi(pl);
   { const char* lf = std::getenv("RMI_HIP_LANES_FUSE"); if (lf && *lf) c->lanes_fuse = std::atoi(lf) != 0; }
   { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
-  if (hipMalloc(&c->d_lntab, sizeof(double) * LN_TMAX) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
+  if (hipMalloc(&c->d_lntab, sizeof(double) * 3 * LN_TMAX) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   hipLaunchKernelGGL(k_lane_table, dim3((LN_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_lntab, LN_TMAX);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
@@ -998,7 +998,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
-  if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, 2 * SG_REGIONS * 8));  // (the one-pass mode's list + merge counters: zeroed by k_init)
+  if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, (2 * SG_REGIONS + 8) * 8));  // (the one-pass mode's list + merge counters: zeroed by k_init)
   // pipeline 1 launches one thread per key: a grid dimension holds fewer than 2^32 threads
   const int pipeline = (c->pipeline == 1 && n_it < (1ull << 32) - 1024) ? 1 : 2;
   const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
@@ -1026,7 +1026,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   {
     const uint64_t ib = init_arrays ? (L_own + 1 + 255) / 256 : 1;
     hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
-                       L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS, init_arrays);
+                       L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS + 8, init_arrays);
   }
 
   auto ensure_lists = [&]() -> int {
@@ -1094,8 +1094,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       if (lanes_fused) {
         // --- the listed leaves' share of the finalize, the first level of the aggregates, then the result record ---
         hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, params, maxerr, run, err, count, rows,
-                           fl, c->d_partials, (unsigned int)wb, c->d_partials + wb);
-        hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials + wb, (int)FL_BLOCKS, c->d_state, c->h_state_dev + (c->stream_mode ? c->stream_slot : 0));
+                           fl, c->d_partials, (unsigned int)wb, c->d_partials + wb, c->d_flist_cnt + 2 * SG_REGIONS, c->d_state,
+                           c->h_state_dev + (c->stream_mode ? c->stream_slot : 0));
       }
     }
   } else if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));

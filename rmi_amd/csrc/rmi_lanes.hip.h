@@ -51,8 +51,8 @@
 #define RMI_LN_WPE 2             // waves per SIMD the register allocation of k_leaf_lanes aims at
 #endif
 #ifndef RMI_LN_NBUF
-#define RMI_LN_NBUF 3            // panels in flight per wave (8 KB each, landing in registers): the kernel is bound by the
-#endif                           // bytes in flight per CU (~7 us loaded latency): 8 waves x 24 KB = 192 KB
+#define RMI_LN_NBUF 2            // panels in flight per wave (8 KB each, landing in registers) beside the one being staged;
+#endif                           // measured 2 / 3 / 4: 515 / 539 / 580 us for the fused kernel (the trips are NBUF panels long)
 
 namespace rmi {
 
@@ -66,9 +66,10 @@ constexpr int LS_BLOCK = 256;     // leaves per block of k_leaf_search
 
 // RN(1 / k) for the running count k of the lockstep walk: rtab[i] = 1 / (i + 1).  Wave-uniform, read through the
 // scalar cache in two 64-byte loads per panel (SGPR operands of the quotient: no vector instruction, no VGPR).
-__global__ void __launch_bounds__(256) k_lane_table(double* __restrict__ rtab, int count) {
+// ... and next to it the count itself and (k - 1) / 2 as doubles: tab[i], tab[LN_TMAX + i], tab[2 LN_TMAX + i] for k = i + 1.
+__global__ void __launch_bounds__(256) k_lane_table(double* __restrict__ tab, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) rtab[i] = 1.0 / (double)(i + 1);
+  if (i < count) { tab[i] = 1.0 / (double)(i + 1); tab[count + i] = (double)(i + 1); tab[2 * count + i] = (double)i * 0.5; }
 }
 
 template <typename K> struct LnBits { using type = unsigned long long; };   // the raw bits of a key
@@ -260,8 +261,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     for (int i = 0; i < 8; i++) {
       const int row = i * 8 + lane / LPR;
       const unsigned int piece = 2u * (unsigned int)(lane % LPR);
-      roff[i] = s_off[row] + piece;
-      rlim[i] = s_end[row] + piece;
+      roff[i] = (s_off[row] + piece) * (unsigned int)sizeof(K);       // byte offsets from kb: a scalar base + a 32-bit lane offset per load
+      rlim[i] = (s_end[row] + piece) * (unsigned int)sizeof(K);
     }
     wave_sync();                                                      // (the descriptors alias the panel)
   };
@@ -270,10 +271,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   auto load_panel = [&](B (&buf)[8][2], unsigned int p16, bool nt) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      unsigned int idx = roff[i] + p16;
-      idx = idx < rlim[i] ? idx : rlim[i];
+      unsigned int off = roff[i] + p16 * (unsigned int)sizeof(K);
+      off = off < rlim[i] ? off : rlim[i];
       typedef B vec_t __attribute__((ext_vector_type(2)));
-      const vec_t* pv = reinterpret_cast<const vec_t*>(kb + idx);     // (16-byte aligned: wb is line aligned, idx is even)
+      const vec_t* pv = reinterpret_cast<const vec_t*>(reinterpret_cast<const char*>(kb) + off);   // (16-byte aligned: wb is line aligned, the piece even)
       const vec_t v = nt ? __builtin_nontemporal_load(pv) : *pv;
       buf[i][0] = v.x; buf[i][1] = v.y;
     }
@@ -301,6 +302,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
 
   unsigned int flags = 0;
   double pa = 0.0, pb = 0.0;                                          // this lane's leaf: (alpha, beta)
+  bool wave_dups = true;                                              // some container of this wave holds a duplicate key
   // =========================== the fit: lockstep walk of the containers ===========================
   {
     make_rows(act ? (unsigned int)(lo - wb) : 0u, act ? npts : 0u);
@@ -311,7 +313,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     if (act) y0 = first_occurrence(keys, lo, sp.rd_lo);               // FixDups offset of the container's first point
     const double y0f = (double)y0, lof = (double)lo;
     double mx = 0.0, cc = 0.0, m2 = 0.0, my = 0.0, yprev = y0f;
-    double kf = 0.0, hh = -0.5;                                       // running count k and (k - 1) / 2: the same in every lane
     B kprev = 0;
     bool gen = false;                                                 // explicit my-chain (a duplicate key was met)
     // the 16 steps [p16, p16 + 16) of every lane: they read the aligned panels p16 / 16 (staged one trip ago) and
@@ -320,13 +321,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
       wave_sync();
       stage(buf, p16 / 16u + 1u);
       load_panel(buf, p16 + 16u * (unsigned int)(NBUF + 1), RMI_LN_NT_FIT != 0);
-      double rr[16];
-#pragma unroll
-      for (int q = 0; q < 16; q++) rr[q] = rtab[p16 + (unsigned int)q];   // wave-uniform: RN(1 / k) of the 16 steps
       wave_sync();
 #pragma unroll
       for (int hb = 0; hb < 2; hb++) {
         const unsigned int b0 = p16 + 8u * (unsigned int)hb;
+        // wave-uniform operands of the 8 steps, through the scalar cache: RN(1 / k), k, (k - 1) / 2
+        double rr[8], kq[8], hq[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { rr[q] = rtab[b0 + (unsigned int)q]; kq[q] = rtab[LN_TMAX + b0 + (unsigned int)q]; hq[q] = rtab[2 * LN_TMAX + b0 + (unsigned int)q]; }
         B kk[8];
         {
           const unsigned int rb = (unsigned int)lane * LN_STRIDE + ((a0 + b0) & 31u);
@@ -335,31 +337,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
         }
         const unsigned int rem = (act && npts > b0) ? npts - b0 : 0u;
         const unsigned int vmask = rem >= 8u ? 0xFFu : ((1u << rem) - 1u);
-        unsigned int dmask = 0;
+        // duplicates: first only WHETHER some lane may hold one (a compare into a scalar mask per key; positions behind a
+        // row's end may raise it needlessly); the per-lane bit masks are formed only on the general path
+        bool dq = (b0 == 0u) && (y0 != lo);       // the first point: y is y0, its own index unless the key before the container equals it
         {
           B kp = kprev;
 #pragma unroll
-          for (int q = 0; q < 8; q++) { dmask |= (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)) ? (1u << q) : 0u; kp = kk[q]; }
+          for (int q = 0; q < 8; q++) { if (q > 0 || b0 != 0u) dq = dq || (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)); kp = kk[q]; }
         }
-        // the first point: y is y0, which is its own index unless the key before the container equals it
-        if (b0 == 0) dmask = (dmask & ~1u) | ((y0 != lo) ? 1u : 0u);
-        dmask &= vmask;
-        kprev = kk[7];
         const bool full = __all(vmask == 0xFFu);
-        const bool anygen = __any((gen && rem > 0u) || dmask != 0u);
+        const bool anygen = __any((gen || dq) && rem > 0u);
+        unsigned int dmask = 0;
+        if (anygen) {
+          B kp = kprev;
+#pragma unroll
+          for (int q = 0; q < 8; q++) { dmask |= (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)) ? (1u << q) : 0u; kp = kk[q]; }
+          if (b0 == 0) dmask = (dmask & ~1u) | ((y0 != lo) ? 1u : 0u);
+          dmask &= vmask;
+        }
+        kprev = kk[7];
         auto steps = [&](auto full_tag, auto gen_tag) {
           constexpr bool FULL = decltype(full_tag)::value, GEN = decltype(gen_tag)::value;
 #pragma unroll
           for (int q = 0; q < 8; q++) {
-            const double km1 = kf;
-            kf += 1.0; hh += 0.5;
-            const double r = rr[8 * hb + q];
+            const double r = rr[q], kf = kq[q], hh = hq[q];
             if (FULL || ((vmask >> q) & 1u)) {
               const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[q]));
               const double dx = x - mx;                                   // linear.rs:26
               if constexpr (DIVK) mx += dx / kf; else mx += div_by_count(dx, kf, r);   // :27
               if constexpr (GEN) {
-                const double y = ((dmask >> q) & 1u) ? yprev : lof + km1;   // FixDups: a duplicate keeps its first occurrence's offset
+                const double y = ((dmask >> q) & 1u) ? yprev : lof + (kf - 1.0);   // FixDups: a duplicate keeps its first occurrence's offset
                 const double dy = y - my;
                 if constexpr (DIVK) my += dy / kf; else my += div_by_count(dy, kf, r);    // :28
                 cc += dx * (y - my);                                      // :29
@@ -372,8 +379,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
           }
         };
         if (!anygen) {
-          if (full) steps(std::true_type{}, std::false_type{});
-          else steps(std::false_type{}, std::false_type{});
+          if (full) {
+            __builtin_amdgcn_s_setprio(2);                             // (the dependent chain gets the issue slots it asks for)
+            steps(std::true_type{}, std::false_type{});
+            __builtin_amdgcn_s_setprio(0);
+          } else steps(std::false_type{}, std::false_type{});
         } else {
           if (!gen) {                                                  // closed form after b0 points
             my = b0 ? y0f + (double)(b0 - 1u) * 0.5 : 0.0;
@@ -409,6 +419,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
       if (var == 0.0) { pa = my; pb = 0.0; }                           // linear.rs:50-53
       else { pb = cov / var; pa = my - pb * mx; }                      // no fma: linear.rs:56
     } else if (ck == 1) { pa = (double)lo; pb = 0.0; }                 // Q4: one borrowed point (two identical items)
+    wave_dups = __any(gen);
     if (valid && !handed) { params[2 * j] = pa; params[2 * j + 1] = pb; }
   }
   // =========================== the error pass over the leaves' own keys ===========================
@@ -439,17 +450,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
         }
         const unsigned int rem = len > b0 ? len - b0 : 0u;
         const unsigned int vmask = rem >= 8u ? 0xFFu : ((1u << rem) - 1u);
+        // (a wave whose containers held no duplicate has none in its leaves either: no compares)
+        bool dq = false;
+        if (wave_dups) {
+          B kp = kprev;
+#pragma unroll
+          for (int q = 0; q < 8; q++) { if (q > 0 || b0 != 0u) dq = dq || (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)); kp = kk[q]; }
+        }
+        const bool full = __all(vmask == 0xFFu);
+        const bool anygen = wave_dups && __any((tr || dq) && rem > 0u);
         unsigned int dmask = 0;
-        {
+        if (anygen) {
           B kp = kprev;
 #pragma unroll
           for (int q = 0; q < 8; q++) { dmask |= (bits_to_key<K>(kk[q]) == bits_to_key<K>(kp)) ? (1u << q) : 0u; kp = kk[q]; }
+          if (b0 == 0) dmask &= ~1u;                                   // a leaf's first key differs from the key before it
+          dmask &= vmask;
         }
-        if (b0 == 0) dmask &= ~1u;                                     // a leaf's first key differs from the key before it
-        dmask &= vmask;
         kprev = kk[7];
-        const bool full = __all(vmask == 0xFFu);
-        const bool anygen = __any((tr && rem > 0u) || dmask != 0u);
         const unsigned int i0 = s32 + b0;
         auto steps = [&](auto full_tag, auto gen_tag) {
           constexpr bool FULL = decltype(full_tag)::value, GEN = decltype(gen_tag)::value;
@@ -541,7 +559,8 @@ __global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ k
                                                          unsigned long long* __restrict__ leaf_count,
                                                          unsigned char* __restrict__ rows, SgList fl,
                                                          const StatsPartial* __restrict__ wave_partials, unsigned int nwave,
-                                                         StatsPartial* __restrict__ out) {
+                                                         StatsPartial* __restrict__ out, unsigned long long* __restrict__ ticket,
+                                                         DevState* __restrict__ stw, DevState* __restrict__ host_copy) {
   unsigned long long mx = 0, mi = 0, sm = 0;
   double l2 = 0.0, lg = 0.0;
   const unsigned int gid = blockIdx.x * 256u + threadIdx.x, gsz = gridDim.x * 256u;
@@ -573,7 +592,27 @@ __global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ k
     sm += p.sum; l2 += p.l2; lg += p.lg;
   }
   stats_block_reduce(mx, mi, sm, l2, lg);
-  if (threadIdx.x == 0) out[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
+  // the last block to arrive combines the FL_BLOCKS records (64 arrivals on one counter: ~2 us; a launch of its own: ~5)
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    out[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
+    __threadfence();
+    last = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  mx = 0; mi = 0; sm = 0; l2 = 0.0; lg = 0.0;
+  if (threadIdx.x < gridDim.x) {
+    const volatile StatsPartial* vo = out;
+    mx = vo[threadIdx.x].mx; mi = vo[threadIdx.x].mi; sm = vo[threadIdx.x].sum; l2 = vo[threadIdx.x].l2; lg = vo[threadIdx.x].lg;
+  }
+  __syncthreads();                                                   // (stats_block_reduce reuses its LDS arrays)
+  stats_block_reduce(mx, mi, sm, l2, lg);
+  if (threadIdx.x == 0) {
+    stw->max_err = mx; stw->max_err_idx = mi; stw->sum_n_err = sm; stw->sum_l2 = l2; stw->sum_log2 = lg;
+    if (host_copy) *host_copy = *stw;                                // pinned host memory: visible to the host once the stream is synchronised
+  }
 }
 
 }  // namespace rmi
