@@ -61,6 +61,7 @@ struct rmi_hip_ctx {
   Span shard = {};
   unsigned long long shard_split_idx = ~0ull, shard_split_target = 0;
   void* d_rows_ext = nullptr;                   // caller-provided row buffer (e.g. the all-gather buffer)
+  const void* last_rows = nullptr;              // where the LAST training wrote its rows (d_rows, or the caller's buffer at that time)
   // streamed training (rmi_hip_train_streamed): the key buffer and the output arrays are those of the WHOLE key set, a
   // launch works on the shard in c->shard; its aggregates go to slot stream_slot of the pinned state array
   bool stream_mode = false;
@@ -978,6 +979,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   unsigned long long* err = c->d_err + lb - sp.leaf_lo;
   unsigned long long* count = c->d_count + lb - sp.leaf_lo;
   unsigned char* rows_base = c->d_rows_ext ? (unsigned char*)c->d_rows_ext : c->d_rows;
+  c->last_rows = rows_base;
   unsigned char* rows = rows_base + lb * ROWB - sp.leaf_lo * ROWB;
 
   // --- init ---
@@ -1359,6 +1361,7 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
     else if (st.err_flags & EF_NEG_VARIANCE) rc = RMI_ERR_NEGATIVE_VARIANCE;
     else if (st.err_flags & EF_ROBUST_TOO_SMALL) rc = RMI_ERR_ROBUST_TOO_SMALL;
     else if (st.err_flags & EF_CUBIC_DEGENERATE) rc = RMI_ERR_CUBIC_DEGENERATE;
+    else if (st.err_flags & EF_LIST_OVERFLOW) { set_err(c, "internal: a hand-over list of the leaf kernels overflowed (flags 0x%x)", st.err_flags); return RMI_ERR_HIP; }
     set_err(c, "%s", rmi_hip_strerror(rc));
     return rc;
   }
@@ -1409,7 +1412,7 @@ int rmi_hip_download_leaf_params(rmi_hip_ctx* c, double* o) { return dl(c, o, c 
 int rmi_hip_download_leaf_errors(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_err : nullptr, c ? c->last_L * 8 : 0); }
 int rmi_hip_download_leaf_counts(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_count : nullptr, c ? c->last_L * 8 : 0); }
 int rmi_hip_download_leaf_starts(rmi_hip_ctx* c, uint64_t* o) { return dl(c, o, c ? c->d_leaf_start : nullptr, c ? (c->last_L + 1) * 8 : 0); }
-int rmi_hip_download_rows(rmi_hip_ctx* c, void* o) { return dl(c, o, c ? (c->d_rows_ext ? (unsigned char*)c->d_rows_ext : c->d_rows) : nullptr, c ? c->last_L * (c->last_ppl * 8 + 8) : 0); }
+int rmi_hip_download_rows(rmi_hip_ctx* c, void* o) { return dl(c, o, c ? c->last_rows : nullptr, c ? c->last_L * (c->last_ppl * 8 + 8) : 0); }
 int rmi_hip_download_checked(rmi_hip_ctx* c, int what, uint64_t generation, void* o, uint64_t capacity) {
   if (!c || !o || !c->last_L || generation != c->generation) return RMI_ERR_BAD_ARG;
   const void* src = nullptr;
@@ -1419,13 +1422,13 @@ int rmi_hip_download_checked(rmi_hip_ctx* c, int what, uint64_t generation, void
     case RMI_DL_ERRORS: src = c->d_err; bytes = c->last_L * 8; break;
     case RMI_DL_COUNTS: src = c->d_count; bytes = c->last_L * 8; break;
     case RMI_DL_STARTS: src = c->d_leaf_start; bytes = (c->last_L + 1) * 8; break;
-    case RMI_DL_ROWS: src = c->d_rows_ext ? (const unsigned char*)c->d_rows_ext : c->d_rows; bytes = c->last_L * (c->last_ppl * 8 + 8); break;
+    case RMI_DL_ROWS: src = c->last_rows; bytes = c->last_L * (c->last_ppl * 8 + 8); break;   // (the rows of the last training, wherever they were written)
     default: return RMI_ERR_BAD_ARG;
   }
   if (capacity < bytes) return RMI_ERR_BAD_ARG;
   return dl(c, o, src, bytes);
 }
-void* rmi_hip_device_rows(rmi_hip_ctx* c) { return c ? (c->d_rows_ext ? c->d_rows_ext : (void*)c->d_rows) : nullptr; }
+void* rmi_hip_device_rows(rmi_hip_ctx* c) { return c ? (c->last_rows ? const_cast<void*>(c->last_rows) : (c->d_rows_ext ? c->d_rows_ext : (void*)c->d_rows)) : nullptr; }
 
 }  // extern "C"
 

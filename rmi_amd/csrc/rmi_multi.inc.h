@@ -12,6 +12,7 @@
 // library keeps loading on a machine without RCCL (single-GPU use).
 #include <dlfcn.h>
 
+#include <mutex>
 namespace rmi_multi {
 
 struct NcclId { char internal[RMI_HIP_COMM_ID_BYTES]; };
@@ -28,10 +29,9 @@ struct Api {
 
 static Api& api() {
   static Api a;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    if (std::getenv("RMI_HIP_NO_RCCL")) return a;                        // (tests: behave like a machine without RCCL)
+  static std::once_flag once;                                          // (several contexts may bring up communicators from different threads)
+  std::call_once(once, [&]() {
+    if (std::getenv("RMI_HIP_NO_RCCL")) return;                          // (tests: behave like a machine without RCCL)
     const char* names[] = {"librccl.so.1", "librccl.so"};
     for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (a.handle) break; }   // already in the process
     if (!a.handle) {
@@ -45,7 +45,7 @@ static Api& api() {
       a.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))dlsym(a.handle, "ncclAllGather");
       a.GetErrorString = (const char* (*)(int))dlsym(a.handle, "ncclGetErrorString");
     }
-  }
+  });
   return a;
 }
 
@@ -63,7 +63,8 @@ struct rmi_hip_multi {
   rmi_multi::NcclComm comm = nullptr;
   int rank = 0, world = 1;
   unsigned char* d_rows_full = nullptr;     // L * row_bytes
-  uint64_t rows_full_bytes = 0;
+  uint64_t rows_full_bytes = 0;                 // allocated
+  uint64_t rows_last_bytes = 0;                 // num_leaves * row_bytes of the last sharded training
   unsigned char* d_stats_all = nullptr;     // world * 40 bytes
   unsigned char* h_stats_all = nullptr;     // pinned
 };
@@ -223,6 +224,7 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
     HIPCHK(c, hipHostMalloc((void**)&m->h_stats_all, 40 * 64, hipHostMallocDefault));
   }
   if (m->world > 64) return RMI_ERR_BAD_ARG;
+  m->rows_last_bytes = num_leaves * rowb;
   void* const saved_ext = c->d_rows_ext;
   c->d_rows_ext = m->d_rows_full + (uint64_t)m->rank * L_own * rowb;    // the kernels write this rank's rows into its slot
   c->defer_sync = m->comm != nullptr;                                  // the exchange is queued behind the kernels, one sync for both
@@ -232,6 +234,7 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
   if (m->world > 1 && !m->comm) { c->d_rows_ext = saved_ext; return RMI_ERR_BAD_ARG; }
   if (m->comm) {
     rmi_multi::Api& a = rmi_multi::api();
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));                       // (kernel_ns[7] of the result: the exchange alone)
     // rows: in place (this rank's piece already sits in its slot); aggregates: the 40 bytes of DevState from max_err on
     int n1 = a.AllGather(c->d_rows_ext, m->d_rows_full, (size_t)(L_own * rowb), 1 /* ncclUint8 */, m->comm, c->stream);
     int n2 = a.AllGather(&c->d_state->max_err, m->d_stats_all, 40, 1, m->comm, c->stream);
@@ -241,6 +244,7 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rc = finish_train(c, leaf_kind, num_leaves, out);                     // error flags, per-shard result, timings
     if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
+    { float xms = 0.f; if (hipEventElapsedTime(&xms, c->ev[7], c->ev[9]) == hipSuccess) out->kernel_ns[7] = (uint64_t)((double)xms * 1e6); }
     // two_layer.rs:267-287 over all shards: lexicographic maximum (last maximum wins), exact integer sum, f64 sums
     unsigned long long mx = 0, mi = 0, sn = 0; double l2 = 0.0, lg = 0.0;
     for (int r = 0; r < m->world; r++) {
@@ -371,9 +375,9 @@ void* rmi_hip_device_rows_full(rmi_hip_ctx* c) { return c ? multi_of(c)->d_rows_
 int rmi_hip_download_rows_full(rmi_hip_ctx* c, void* host_out, uint64_t capacity_bytes) {
   if (!c || !host_out) return RMI_ERR_BAD_ARG;
   rmi_hip_multi* m = multi_of(c);
-  if (!m->d_rows_full || capacity_bytes < m->rows_full_bytes) return RMI_ERR_BAD_ARG;
+  if (!m->d_rows_full || !m->rows_last_bytes || capacity_bytes < m->rows_last_bytes) return RMI_ERR_BAD_ARG;   // (the table of the LAST training, not the high-water allocation)
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(host_out, m->d_rows_full, m->rows_full_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host_out, m->d_rows_full, m->rows_last_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return RMI_OK;
 }

@@ -251,6 +251,9 @@ __global__ void __launch_bounds__(64) k_list_tail(const K* __restrict__ keys, Sp
     unsigned long long a = fl.cnt[lane] < fl.cap ? fl.cnt[lane] : fl.cap, m = fl.cnt[SG_REGIONS + lane];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { a += shfl_down_u64(a, d); m += shfl_down_u64(m, d); }
+    // (an entry dropped by a full region or a full stretch list would leave its leaf unfitted: say so instead)
+    const bool over = fl.cnt[lane] > fl.cap || (lane == 0 && st->seg_count > st->seg_cap);
+    if (__any(over)) { if (lane == 0) atomicOr(&st->err_flags, EF_LIST_OVERFLOW); }
     if (lane == 0) { st->flag_count = a; st->merged_count = m; }
   }
   const unsigned long long cnt = st->seg_count < st->seg_cap ? st->seg_count : st->seg_cap;

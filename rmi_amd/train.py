@@ -176,6 +176,7 @@ class Trainer:
     def view(self) -> "Trainer":
         """A second context on the same resident keys (borrowed, not copied): trainings issued through
         different views can be in flight together, one host thread each."""
+        self.wait_keys()
         ptr, n, dt = C.c_void_p(), C.c_uint64(), C.c_int()
         _check(self._lib.rmi_hip_key_buffer(self._h, C.byref(ptr), C.byref(n), C.byref(dt)), self._h)
         v = Trainer(device=self._device)
@@ -219,6 +220,7 @@ class Trainer:
         # torch tensor on the GPU: uint64 is carried as int64 bit patterns
         import torch
         if isinstance(keys, torch.Tensor) and keys.is_cuda:
+            self.wait_keys()                       # (an upload still running on the library's thread would replace these keys)
             t = keys.contiguous()
             if t.dtype in (torch.int64, torch.uint64):
                 dt = KEY_U64
@@ -243,6 +245,7 @@ class Trainer:
     def generate_keys(self, generator: str, dtype, n_global: int, start: int = 0, count: int | None = None, seed: int = 0):
         """Synthetic sorted keys produced directly in HBM (datagen.uniform_* / dups_* shards)."""
         gen = {"uniform": 0, "dups": 1}[generator]
+        self.wait_keys()
         dt = _DTYPES[np.dtype(dtype)]
         count = n_global - start if count is None else count
         _check(self._lib.rmi_hip_generate_keys(self._h, gen, dt, n_global, start, count, seed), self._h)
@@ -254,6 +257,7 @@ class Trainer:
     def download_keys(self) -> np.ndarray:
         if self._host_keys is not None:
             return self._host_keys
+        self.wait_keys()
         a = np.empty(self.n, dtype=getattr(self, "_np_dtype", np.dtype(np.uint64)))
         _check(self._lib.rmi_hip_download_keys(self._h, a.ctypes.data), self._h)
         self._host_keys = a
@@ -262,6 +266,7 @@ class Trainer:
     def measure_read_bandwidth(self, iters: int = 10) -> float:
         """GB/s of a read-only streaming kernel over the resident keys (the box's achievable HBM rate)."""
         v = C.c_double()
+        self.wait_keys()
         _check(self._lib.rmi_hip_measure_read_bandwidth(self._h, iters, C.byref(v)), self._h)
         return float(v.value)
 
