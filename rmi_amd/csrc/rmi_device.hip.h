@@ -86,7 +86,13 @@ struct DevState {
   unsigned long long merged_count;  // long leaves fitted from merged partial sums (one-pass mode 2)
   unsigned long long seg_count;     // stretches of SG_SEG keys the error pass of the long listed leaves is cut into (k_list_tail)
   unsigned long long seg_cap;
+  unsigned long long giant_count;   // listed leaves whose exact fit is left to the host (GiantLeaf entries), see rmi_hip.hip
+  unsigned long long giant_cap;
 };
+
+// A leaf whose container is so long that its sequential recurrence is faster on a host core (~4 ns per point against
+// ~28 on a wave): k_list records it here instead of fitting it.
+struct GiantLeaf { unsigned long long j, lo, hi, y0; };    // leaf, container [lo, hi], FixDups offset of its first point
 
 template <typename K> struct KeyTraits;
 template <> struct KeyTraits<uint64_t> {

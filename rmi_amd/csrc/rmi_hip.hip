@@ -77,6 +77,15 @@ struct rmi_hip_ctx {
   bool lanes_fuse = true;                       // error pass fused behind the fit in k_leaf_lanes (else k_err_range)
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
   bool last_lanes = false;
+  // giant leaves (containers of more than host_min points): recorded by k_list, fitted on host cores after the device
+  // pipeline, their error pass and finalize in a short epilogue (giant_epilogue).  Plain single-context trainings only.
+  GiantLeaf* d_giant = nullptr;
+  uint64_t giant_cap = 0;
+  uint64_t host_min = 262144;                   // RMI_HIP_HOST_MIN; 0: never.  (A wave walks 262 144 points in ~7 ms, a host core in ~1: below that the
+                                                //  leaves of a skewed key set are many and run side by side on the device)
+  bool giant_armed = false;                     // the last launch recorded giant leaves for the host
+  struct { const void* keys; Span sp; uint64_t L; unsigned long long* leaf_start; double* params; unsigned long long* maxerr; unsigned long long* run;
+           unsigned long long* err; unsigned long long* count; unsigned char* rows; uint64_t waves; } lp = {};
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
   uint64_t err_threads = 262144;                // lanes of pass B (4 waves/SIMD)
   int fit_min_chunk = 64;
@@ -250,6 +259,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (pl && *pl) c->pipeline = std::atoi(pl);
   { const char* lf = std::getenv("RMI_HIP_LANES_FUSE"); if (lf && *lf) c->lanes_fuse = std::atoi(lf) != 0; }
   { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
+  { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
   if (hipMalloc(&c->d_lntab, sizeof(double) * 3 * LN_TMAX) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   hipLaunchKernelGGL(k_lane_table, dim3((LN_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_lntab, LN_TMAX);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
@@ -300,6 +310,7 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_lntab) (void)hipFree(c->d_lntab);
+  if (c->d_giant) (void)hipFree(c->d_giant);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_sentinel) (void)hipHostFree(c->h_sentinel);
   for (int b = 0; b < 2; b++) { if (c->h_stage[b]) (void)hipHostFree(c->h_stage[b]); if (c->ev_stage[b]) (void)hipEventDestroy(c->ev_stage[b]); }
@@ -926,7 +937,7 @@ static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   HIPCHK(c, hipMalloc(&c->d_count, L * 8));
   HIPCHK(c, hipMalloc(&c->d_rows, L * (ppl * 8 + 8)));
   HIPCHK(c, hipMalloc(&c->d_tilemin, ((L + 1 + FILL_TILE - 1) / FILL_TILE + 1) * 8));
-  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 63) / 64 + FL_BLOCKS + 1)));   // (per block of k_finalize, or per wave of k_leaf_lanes + per block of k_finalize_listed)
+  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 63) / 64 + 2 * FL_BLOCKS + 1)));   // (per block of k_finalize, or per wave of k_leaf_lanes + per block of k_finalize_listed)
   c->cap_leaves = L; c->cap_ppl = ppl;
   return RMI_OK;
 }
@@ -997,9 +1008,11 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   init.long_cap = c->long_cap;
   init.flag_cap = (uint64_t)L_own + 64;
   init.seg_cap = n_it / SG_SEG + L_own + 16;
+  init.giant_cap = c->host_min > 0 ? n_it / c->host_min + 64 : 0;
   init.split_idx = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_idx : sp.n;
   init.split_target = (c->have_shard && c->shard_split_idx != ~0ull) ? c->shard_split_target : 0;
   init.last_target = ~0ull;
+  c->giant_armed = false;
   if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, (2 * SG_REGIONS + 8) * 8));  // (the one-pass mode's list + merge counters: zeroed by k_init)
   // pipeline 1 launches one thread per key: a grid dimension holds fewer than 2^32 threads
   const int pipeline = (c->pipeline == 1 && n_it < (1ull << 32) - 1024) ? 1 : 2;
@@ -1075,6 +1088,20 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // --- exact fit of 64 leaves per wave in lockstep, and their error pass behind it ---
       lanes_fused = lanes_fused_plan;
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
+      // giant leaves go to the host when this call ends with its own synchronisation (not inside a streamed or a sharded training)
+      const bool giants = lanes_fused_plan && c->host_min > 0 && !c->stream_mode && !c->defer_sync;
+      if (giants) {
+        const uint64_t gcap = n_it / c->host_min + 64;
+        if (c->giant_cap < gcap) {
+          if (c->d_giant) (void)hipFree(c->d_giant);
+          c->d_giant = nullptr; c->giant_cap = 0;
+          HIPCHK(c, hipMalloc(&c->d_giant, gcap * sizeof(GiantLeaf)));
+          c->giant_cap = gcap;
+        }
+        c->giant_armed = true;
+        c->lp.keys = keys; c->lp.sp = sp; c->lp.L = L; c->lp.leaf_start = leaf_start; c->lp.params = params; c->lp.maxerr = maxerr; c->lp.run = run;
+        c->lp.err = err; c->lp.count = count; c->lp.rows = rows; c->lp.waves = (L_own + 63) / 64;
+      }
       const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
       const uint64_t wb = (L_own + 63) / 64;
       if (lanes_fused)
@@ -1088,8 +1115,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       SgParams sgp; std::memset(&sgp, 0, sizeof sgp);
       sgp.flist = fl; sgp.segs = c->d_segs; sgp.mode = 0; sgp.guard_k = c->guard_k;
       c->last_sg = sgp;
-      // (a grid-stride list of usually few leaves: a small grid -- 8192 blocks that find nothing cost 4 us each time)
-      hipLaunchKernelGGL((k_list<K, K_LINEAR>), dim3(16 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run);
+      // (one wave per listed leaf wherever possible: on skewed keys thousands of leaves are listed and each is a sequential chain)
+      hipLaunchKernelGGL((k_list<K, K_LINEAR>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run,
+                         giants ? c->d_giant : (GiantLeaf*)nullptr, giants ? (unsigned long long)c->host_min : ~0ull);
       mark();
       hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
       mark();
@@ -1097,7 +1125,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         // --- the listed leaves' share of the finalize, the first level of the aggregates, then the result record ---
         hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, params, maxerr, run, err, count, rows,
                            fl, c->d_partials, (unsigned int)wb, c->d_partials + wb, c->d_flist_cnt + 2 * SG_REGIONS, c->d_state,
-                           c->h_state_dev + (c->stream_mode ? c->stream_slot : 0));
+                           c->h_state_dev + (c->stream_mode ? c->stream_slot : 0), (const GiantLeaf*)nullptr, giants ? (unsigned long long)c->host_min : ~0ull);
       }
     }
   } else if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -1193,7 +1221,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
       // --- the leaves the one-pass kernel handed over: fit (or merge) + error pass, one wave per leaf; long ones in stretches ---
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
-      hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->last_sg, maxerr, run);
+      hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->last_sg, maxerr, run,
+                         (GiantLeaf*)nullptr, ~0ull);
       mark();
       hipLaunchKernelGGL((k_list_tail<K>), dim3(8192), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
     }
@@ -1260,6 +1289,52 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   mark();
   HIPCHK(c, hipEventRecord(c->ev[9], s));
   HIPCHK(c, hipGetLastError());
+  return RMI_OK;
+}
+
+// The giant leaves of the last launch (k_list recorded them: containers of more than host_min points).  The exact fit of
+// a leaf is a sequential chain of its length (linear.rs:24-34): ~28 ns per point on a wave, ~4 on a host core with the
+// reciprocal form of the step (rmi_root_host.h).  So: their keys come to the host, one thread per leaf fits them in
+// reference order, the coefficients go back, and a short device epilogue runs their error pass (k_list_tail in
+// stretches), their finalize and the aggregates again.  books-shaped 200 M keys / 262 144 leaves (one leaf of 2.5 M
+// keys): 78 ms -> ~13 ms per training, same bits.
+template <typename K>
+static int giant_epilogue(rmi_hip_ctx* c) {
+  hipStream_t s = c->stream;
+  const DevState& st0 = *c->h_state;
+  if (st0.giant_count > c->giant_cap) { set_err(c, "internal: giant-leaf list overflow"); return RMI_ERR_HIP; }
+  const uint64_t cnt = st0.giant_count;
+  std::vector<GiantLeaf> g(cnt);
+  HIPCHK(c, hipMemcpy(g.data(), c->d_giant, cnt * sizeof(GiantLeaf), hipMemcpyDeviceToHost));
+  const K* keys = (const K*)c->lp.keys;
+  std::vector<std::vector<K>> bufs(cnt);
+  std::vector<double> ab(2 * cnt);
+  std::vector<int> rcs(cnt, RMI_OK);
+  std::vector<std::thread> th;
+  for (uint64_t i = 0; i < cnt; i++) {
+    const uint64_t npts = g[i].hi - g[i].lo + 1;
+    bufs[i].resize(npts);
+    HIPCHK(c, hipMemcpy(bufs[i].data(), keys + g[i].lo, npts * sizeof(K), hipMemcpyDeviceToHost));
+    th.emplace_back([&, i, npts]() { rcs[i] = rmi_host::leaf_slr<K>(bufs[i].data(), npts, g[i].lo, g[i].y0, &ab[2 * i], &ab[2 * i + 1]); });
+    if (th.size() >= 16) { for (auto& t : th) t.join(); th.clear(); }
+  }
+  for (auto& t : th) t.join();
+  for (uint64_t i = 0; i < cnt; i++) {
+    if (rcs[i] != RMI_OK) { set_err(c, "%s", rmi_hip_strerror(rcs[i])); return rcs[i]; }
+    HIPCHK(c, hipMemcpyAsync(c->lp.params + 2 * g[i].j, &ab[2 * i], 16, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(c, hipMemsetAsync(&c->d_state->seg_count, 0, 8, s));
+  HIPCHK(c, hipMemsetAsync(c->d_flist_cnt + 2 * SG_REGIONS, 0, 8, s));
+  SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
+  hipLaunchKernelGGL(k_giant_segments, dim3(16), dim3(64), 0, s, c->d_giant, c->lp.leaf_start, c->d_state, c->d_segs, c->lp.maxerr, c->lp.run);
+  hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, c->lp.sp, c->lp.leaf_start, c->d_state, c->lp.params, fl, c->d_segs, c->lp.maxerr, c->lp.run);
+  StatsPartial* first = c->d_partials + c->lp.waves;                 // the records of the launch's own k_finalize_listed
+  hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(256), 0, s, keys, c->lp.sp, c->lp.L, c->lp.leaf_start, c->d_state, c->lp.params,
+                     c->lp.maxerr, c->lp.run, c->lp.err, c->lp.count, c->lp.rows, fl, first, (unsigned int)FL_BLOCKS, first + FL_BLOCKS,
+                     c->d_flist_cnt + 2 * SG_REGIONS, c->d_state, c->h_state_dev, (const GiantLeaf*)c->d_giant, ~0ull);
+  HIPCHK(c, hipEventRecord(c->ev[9], s));                            // (the device time of the call covers the epilogue, host fit included)
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(s));
   return RMI_OK;
 }
 
@@ -1343,6 +1418,14 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (rc) return rc;
   if (c->defer_sync) return RMI_OK;                            // (rmi_hip_train_sharded goes on from here)
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->giant_armed && c->h_state->giant_count > 0 && !c->h_state->err_flags) {
+    switch (c->dtype) {
+      case RMI_KEY_U64: rc = giant_epilogue<uint64_t>(c); break;
+      case RMI_KEY_U32: rc = giant_epilogue<uint32_t>(c); break;
+      default: rc = giant_epilogue<double>(c); break;
+    }
+    if (rc) return rc;
+  }
   return finish_train(c, leaf_kind, num_leaves, out);
 }
 

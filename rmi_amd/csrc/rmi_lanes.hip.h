@@ -560,15 +560,24 @@ __global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ k
                                                          unsigned char* __restrict__ rows, SgList fl,
                                                          const StatsPartial* __restrict__ wave_partials, unsigned int nwave,
                                                          StatsPartial* __restrict__ out, unsigned long long* __restrict__ ticket,
-                                                         DevState* __restrict__ stw, DevState* __restrict__ host_copy) {
+                                                         DevState* __restrict__ stw, DevState* __restrict__ host_copy,
+                                                         const GiantLeaf* __restrict__ flat, unsigned long long host_min) {
   unsigned long long mx = 0, mi = 0, sm = 0;
   double l2 = 0.0, lg = 0.0;
   const unsigned int gid = blockIdx.x * 256u + threadIdx.x, gsz = gridDim.x * 256u;
-  for (int rg = 0; rg < SG_REGIONS; rg++) {
-    const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
+  // `flat` (the giant-leaf epilogue): the leaves of that array, fitted by the host meanwhile; else the regions of the
+  // list, without the leaves k_list left to the host (the same test as there)
+  const int nreg = flat ? 1 : SG_REGIONS;
+  for (int rg = 0; rg < nreg; rg++) {
+    const unsigned long long cnt = flat ? (st->giant_count < st->giant_cap ? st->giant_count : st->giant_cap)
+                                        : (fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap);
     for (unsigned long long t = gid; t < cnt; t += gsz) {
-      const uint64_t j = fl.ids[(unsigned long long)rg * fl.cap + t] & ~SG_TAG;
+      const uint64_t j = flat ? flat[t].j : (uint64_t)(fl.ids[(unsigned long long)rg * fl.cap + t] & ~SG_TAG);
       const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+      if (!flat && host_min != ~0ull) {
+        uint64_t lo, hi;
+        if (leaf_container(j, s, e, sp.n, st->split_idx, st->split_target, lo, hi) == 2 && hi - lo + 1 > host_min) continue;
+      }
       double pp[2] = {params[2 * j], params[2 * j + 1]};
       uint64_t final_err, cnt_j;
       finalize_one<K_LINEAR, K>(j, s, e, sp, L, keys, pp, leaf_maxerr[j], leaf_run[j], st->last_target, final_err, cnt_j);
@@ -612,6 +621,21 @@ __global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ k
   if (threadIdx.x == 0) {
     stw->max_err = mx; stw->max_err_idx = mi; stw->sum_n_err = sm; stw->sum_l2 = l2; stw->sum_log2 = lg;
     if (host_copy) *host_copy = *stw;                                // pinned host memory: visible to the host once the stream is synchronised
+  }
+}
+
+// the error pass of the giant leaves, once the host has written their coefficients: stretches for k_list_tail
+__global__ void __launch_bounds__(64) k_giant_segments(const GiantLeaf* __restrict__ giant, const unsigned long long* __restrict__ leaf_start,
+                                                       DevState* __restrict__ st, unsigned long long* __restrict__ segs,
+                                                       unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
+  const unsigned long long cnt = st->giant_count < st->giant_cap ? st->giant_count : st->giant_cap;
+  for (unsigned long long t = blockIdx.x * 64ull + threadIdx.x; t < cnt; t += (unsigned long long)gridDim.x * 64ull) {
+    const uint64_t j = giant[t].j;
+    const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+    leaf_maxerr[j] = 0ull; leaf_run[j] = 0ull;
+    const uint64_t nseg = (e - s + SG_SEG - 1) / SG_SEG;
+    const unsigned long long pos = atomicAdd(&st->seg_count, (unsigned long long)nseg);
+    for (uint64_t q = 0; q < nseg && pos + q < st->seg_cap; q++) segs[pos + q] = ((unsigned long long)j << 32) | q;
   }
 }
 

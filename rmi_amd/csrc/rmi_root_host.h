@@ -145,6 +145,27 @@ RMI_HOST_FMA inline void slr_run_recip(const Data<K>& d, uint64_t skip, uint64_t
 template <typename K> constexpr bool integer_keys() { return true; }
 template <> constexpr bool integer_keys<double>() { return false; }
 
+// slr over one leaf's container given as a host copy ck[0 .. npts) of the keys [lo, lo + npts) (linear.rs:12-59 over
+// C_j.iter(), two_layer.rs:52-90): y is the FixDups offset -- y0 for the first point (its first occurrence may lie in
+// front of the container), the index of a run's first key afterwards -- and the last item counts twice (Q1).
+template <typename K, bool RECIP>
+RMI_HOST_FMA inline int leaf_slr_impl(const K* ck, uint64_t npts, uint64_t lo, uint64_t y0, double* alpha, double* beta) {
+  Slr s;
+  double y = (double)y0, x = 0.0;
+  for (uint64_t i = 0; i < npts; i++) {
+    if (i > 0 && !(ck[i] == ck[i - 1])) y = (double)(lo + i);
+    x = as_float(ck[i]);
+    if (RECIP) slr_push_recip(s, x, y); else s.push(x, y);
+  }
+  if (npts > 0) { if (RECIP) slr_push_recip(s, x, y); else s.push(x, y); }      // models/mod.rs:180
+  return s.finish(alpha, beta);
+}
+template <typename K>
+inline int leaf_slr(const K* ck, uint64_t npts, uint64_t lo, uint64_t y0, double* alpha, double* beta) {
+  if (integer_keys<K>() && host_has_fma() && npts < (1ull << 40)) return leaf_slr_impl<K, true>(ck, npts, lo, y0, alpha, beta);
+  return leaf_slr_impl<K, false>(ck, npts, lo, y0, alpha, beta);
+}
+
 template <typename K>
 inline void slr_run(const Data<K>& d, uint64_t skip, uint64_t take, Slr& s) {
   if (integer_keys<K>() && host_has_fma() && d.n < (1ull << 40)) slr_run_recip(d, skip, take, s);

@@ -177,7 +177,8 @@ template <typename K, int LEAFK = K_LINEAR>
 __global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp,
                                              const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
                                              double* __restrict__ params, SgList fl, SgParams sg,
-                                             unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
+                                             unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run,
+                                             GiantLeaf* __restrict__ giant = nullptr, unsigned long long host_min = ~0ull) {
   __shared__ FitLongLds lds;
   const unsigned int rg = blockIdx.x % SG_REGIONS;
   const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
@@ -190,6 +191,15 @@ __global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp
     const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
     uint64_t lo, hi;
     const int ck = leaf_container(j, s, e, sp.n, st->split_idx, st->split_target, lo, hi);
+    // a container of more than host_min points: its fit is a sequential chain of that length, ~28 ns per point on a wave
+    // and ~4 on a host core -- recorded for the host (rmi_hip.hip: the giant-leaf epilogue), nothing else done here
+    if (LEAFK == K_LINEAR && giant != nullptr && !tagged && ck == 2 && hi - lo + 1 > host_min) {
+      if (lane == 0) {
+        const unsigned long long pos = atomicAdd(&st->giant_count, 1ull);
+        if (pos < st->giant_cap) giant[pos] = GiantLeaf{j, lo, hi, first_occurrence(keys, lo, sp.rd_lo)};
+      }
+      continue;
+    }
     bool merged = false;
     if (tagged && ck == 2) {
       int ok = 0;

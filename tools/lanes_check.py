@@ -27,6 +27,7 @@ VARIANTS = {
     "p3 fused search": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_FUSE": "1", "RMI_HIP_LANES_SEARCH": "1"},
     "p3 unfused search": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_FUSE": "0", "RMI_HIP_LANES_SEARCH": "1"},
     "p3 fused scan": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_FUSE": "1", "RMI_HIP_LANES_SEARCH": "0"},
+    "p3 giants": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_HOST_MIN": "2000", "RMI_HIP_LONG_MIN": "512"},
 }
 
 
@@ -37,7 +38,9 @@ def check():
     cases = [("uniform_u64", 300_000, 1024, "linear"), ("uniform_u64", 300_000, 16384, "linear"), ("books_u64", 300_000, 4096, "linear"),
              ("dups_u64", 300_000, 4096, "linear"), ("clustered_u64", 300_000, 1024, "linear"), ("uniform_u32", 300_000, 4096, "linear"),
              ("dups_u32", 300_000, 1024, "linear"), ("uniform_u64", 5_000, 8, "linear"), ("uniform_u64", 300_000, 4096, "cubic"),
-             ("dups_u64", 200_000, 40_000, "linear"), ("uniform_u64", 1_000_000, 64, "linear"), ("uniform_u64", 300_000, 4096, "radix")]
+             ("dups_u64", 200_000, 40_000, "linear"), ("uniform_u64", 1_000_000, 64, "linear"), ("uniform_u64", 300_000, 4096, "radix"),
+             ("dups_u64", 300_000, 64, "linear"), ("books_u64", 300_000, 100, "linear"), ("uniform_u64", 2_000_000, 8, "linear"),
+             ("dups_u32", 300_000, 32, "linear"), ("clustered_u64", 300_000, 16, "linear")]
     for name, env in VARIANTS.items():
         for gen, n, L, root in cases:
             keys = dg.GENERATORS[gen](n)
