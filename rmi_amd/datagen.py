@@ -100,6 +100,42 @@ def uniform_f64(n: int, seed: int = 49) -> np.ndarray:
     return k.astype(np.float64) * (2.0 ** -20)
 
 
+# ---- adversarial sets for the one-pass mode's guard and for every floor(): exact linear structure puts every
+# ---- prediction on an integer +- rounding (auto-increment ids, fixed-interval timestamps)
+def progression_u64(n: int, stride: int = 10, start: int = 1) -> np.ndarray:
+    """Arithmetic progression start + i stride (u64)."""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return _U64(start) + i * _U64(stride)
+
+
+def progression_u32(n: int, stride: int = 2, start: int = 1) -> np.ndarray:
+    if start + (n - 1) * stride >= (1 << 32) - 1:
+        raise ValueError("progression_u32 overflows")
+    return (np.arange(n, dtype=np.uint64) * _U64(stride) + _U64(start)).astype(np.uint32)
+
+
+def progression_f64(n: int, stride: float = 0.25, start: float = 1.0) -> np.ndarray:
+    return start + np.arange(n, dtype=np.float64) * stride
+
+
+def progression_outlier_u64(n: int, stride: int = 1 << 20) -> np.ndarray:
+    """A progression with one far outlier at the end (a root that fits everything but one key)."""
+    k = progression_u64(n, stride, 1)
+    k[-1] = _U64((1 << 63) + 12345)
+    return k
+
+
+def around_2_53(n: int) -> np.ndarray:
+    """Keys straddling 2^53, where key -> f64 starts to round (stride 3: odd and even keys)."""
+    return progression_u64(n, 3, (1 << 53) - 3 * (n // 2))
+
+
+def around_2_63(n: int) -> np.ndarray:
+    """Stride-1025 keys straddling 2^63 (f64 spacing 1024 below, 2048 above)."""
+    return progression_u64(n, 1025, (1 << 63) - 1025 * (n // 2))
+
+
 GENERATORS = {
     "uniform_u64": uniform_u64,
     "books_u64": books_u64,
@@ -108,6 +144,17 @@ GENERATORS = {
     "dups_u32": dups_u32,
     "clustered_u64": clustered_u64,
     "uniform_f64": uniform_f64,
+}
+ADVERSARIAL = {
+    "prog1_u64": lambda n: progression_u64(n, 1),
+    "prog10_u64": lambda n: progression_u64(n, 10),
+    "prog2p20_u64": lambda n: progression_u64(n, 1 << 20),
+    "prog2p44_u64": lambda n: progression_u64(n, 1 << 44) if n < (1 << 19) else progression_u64(n, (1 << 63) // n),
+    "prog2_u32": lambda n: progression_u32(n, 2),
+    "prog_f64": lambda n: progression_f64(n, 0.25),
+    "prog_outlier_u64": progression_outlier_u64,
+    "around_2_53": around_2_53,
+    "around_2_63": around_2_63,
 }
 
 

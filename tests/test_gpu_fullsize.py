@@ -186,6 +186,11 @@ def test_more_than_2_pow_32_keys(oracle):
     rows1 = g.rows                                                          # (lives in the context until the next train call)
     g2 = tr.train_leaves(root, "linear", L)
     assert np.array_equal(g2.rows, rows1)
+    # a one-pass mode requested beyond 2^32 - 2^16 keys: the 32-bit-index kernels are not used, and the result says so
+    tr.set_fit_mode("onepass_guarded")
+    g3 = tr.train_leaves(root, "linear", L)
+    assert g3.fit_mode_used == 0 and np.array_equal(g3.rows, rows1)
+    tr.set_fit_mode("exact")
     with pytest.raises(RuntimeError):
         _ = g.leaf_counts.sum() if "counts" not in g._cache else g._trainer._download("counts", g)   # stale result: refused, not another training's arrays
     tr.close()
