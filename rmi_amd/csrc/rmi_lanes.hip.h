@@ -77,28 +77,28 @@ template <> struct LnBits<uint32_t> { using type = unsigned int; };
 
 // ---------------------------------------------------------------------------------------------
 // k_leaf_search (linear-like roots with slope >= 0; the host checks).  leaf_start[j] = lower bound of "target >= j"
-// in the sorted keys, one thread per leaf, a block of 256 threads for 256 consecutive leaves, in two levels:
-//   anchors   every 16th leaf of the block (and the block's end).  The root model IS an approximation of the keys'
-//             distribution function scaled to L, good to about a leaf: two independent loads 1.5 leaves below and above
-//             the global guess j n / L bracket the boundary, the (unfloored) root values at the two keys place the
-//             first probe by interpolation (keys are locally uniform at that scale), gallop + bisection finish;
-//   leaves    interpolate between their two anchors (good to a few keys), then the same search: two or three probes.
-// A probe is ONE 16-byte load (two neighbouring keys).  What limits this kernel is the number of scattered line requests
-// and the length of the dependent chain: 64-byte sector probes (four loads per lane) took 0.17 ms for 2^20 leaves,
-// every leaf on its own from the global guess (chains of ~12) 0.21 ms, anchors by gallop from the global guess 0.08 ms.
+// in the sorted keys, one thread per leaf, a dependent chain of ~4 loads:
+//   1. two INDEPENDENT loads 1.5 leaves below and above the global guess j n / L -- the root model IS an approximation
+//      of the keys' distribution function scaled to L, good to about a leaf, so they bracket the boundary;
+//   2. interpolate between the (unfloored) root values at the two keys: keys are locally uniform at the scale of a few
+//      leaves, so this lands within a few keys; PAIR probes (one 16-byte load = two neighbouring keys) gallop and
+//      bisect from there.  No bracket (a root that is off by more): gallop from the global guess.
+// What limits this kernel is the length of the dependent chain (~2-3 us per scattered load under load) and the number of
+// scattered line requests.  Measured for 2^20 leaves: 64-byte sector probes (four loads per lane) 171 us; bracket of
+// +-0.5 leaf (fails too often, chains of ~12) 212 us; anchors every 16th leaf + interpolation between anchors (chains of
+// 9 with a block barrier) 61-78 us; this form: see DESIGN.md section 4.
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ keys, Span sp, RootP r,
                                                           unsigned long long* __restrict__ leaf_start,
                                                           DevState* __restrict__ st) {
-  __shared__ unsigned long long anch[LS_BLOCK / 16 + 1];
   const double Lm1f = (double)(r.L - 1);
-  const int t = threadIdx.x;
-  const uint64_t jb = sp.leaf_lo + (uint64_t)blockIdx.x * LS_BLOCK;
+  const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * LS_BLOCK + threadIdx.x;
   const uint64_t A = sp.it_lo, Bn = sp.it_hi, L_own = sp.leaf_hi - sp.leaf_lo;
   auto tgt = [&](uint64_t i) -> double { bool oob; return root_target_f<K_LINEAR, K>(r, Lm1f, keys[i], oob); };
-  // lower bound of "target >= jf" in [lo, hi] (the answer lies between them), first probe at g, first gallop step d
-  auto search = [&](double jf, uint64_t lo, uint64_t hi, uint64_t g, uint64_t d) -> uint64_t {
+  if (j < sp.leaf_hi) {
+    const double jf = (double)j;
+    uint64_t lo = A, hi = Bn;                                        // the answer lies in [lo, hi]
     // pair probe at i (lo <= i < hi): narrows [lo, hi] by the keys i and i + 1
     auto probe = [&](uint64_t i) {
       typedef typename LnBits<K>::type BT;
@@ -115,79 +115,66 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
       else if (!b1 || i + 1 >= hi) { lo = i + 1; if (!b1) hi = i + 1; }
       else lo = i + 2 < hi ? i + 2 : hi;
     };
-    if (!(lo < hi)) return lo;
-    if (g < lo) g = lo;
-    if (g >= hi) g = hi - 1;
-    probe(g);
-    if (lo < hi) {
-      if (lo > g) {                                                  // the keys at the guess are below: gallop upwards
-        while (lo < hi) {
-          const uint64_t q = lo + d - 1;
-          if (q >= hi) break;
-          const uint64_t before = lo;
-          probe(q);
-          if (!(lo > q && lo > before)) break;                       // not "both below": bracketed
-          d <<= 1;
+    auto search_from = [&](uint64_t g, uint64_t d) {                 // first probe at g, first gallop step d
+      if (!(lo < hi)) return;
+      if (g < lo) g = lo;
+      if (g >= hi) g = hi - 1;
+      probe(g);
+      if (lo < hi) {
+        if (lo > g) {                                                // the keys at the guess are below: gallop upwards
+          while (lo < hi) {
+            const uint64_t q = lo + d - 1;
+            if (q >= hi) break;
+            const uint64_t before = lo;
+            probe(q);
+            if (!(lo > q && lo > before)) break;                     // not "both below": bracketed
+            d <<= 1;
+          }
+        } else {                                                     // downwards
+          while (lo < hi) {
+            if (hi - lo <= d) break;
+            const uint64_t q = hi - d;
+            const uint64_t before = hi;
+            probe(q);
+            if (!(hi == q && hi < before)) break;                    // not "none below"
+            d <<= 1;
+          }
         }
-      } else {                                                       // downwards
-        while (lo < hi) {
-          if (hi - lo <= d) break;
-          const uint64_t q = hi - d;
-          const uint64_t before = hi;
-          probe(q);
-          if (!(hi == q && hi < before)) break;                      // not "none below"
-          d <<= 1;
-        }
+        while (lo < hi) probe(lo + ((hi - lo) >> 1));
       }
-      while (lo < hi) probe(lo + ((hi - lo) >> 1));
-    }
-    return lo;
-  };
-  if (jb < sp.leaf_hi) {
-    // ---- anchors: leaf jb + 16 a for a = 0 .. 16 (threads 0, 16, .. and, for the last one, thread 8)
-    const double per_leaf = (double)(Bn - A) / (double)L_own;
-    if ((t & 15) == 0 || t == 8) {
-      const int a = t == 8 ? LS_BLOCK / 16 : t / 16;
-      const uint64_t ja = jb + 16ull * (uint64_t)a;
-      const double jf = (double)ja;
-      uint64_t pos = Bn;                                             // leaves from leaf_hi on: the end of the launch's keys
-      if (ja <= sp.leaf_lo) pos = (Bn > A && tgt(A) < jf) ? search(jf, A + 1, Bn, A + 1, 2) : A;
-      else if (ja < sp.leaf_hi && Bn > A) {
-        uint64_t w = (uint64_t)(per_leaf * 1.5);
-        if (w < 4) w = 4;
-        const uint64_t g = A + (uint64_t)((double)(ja - sp.leaf_lo) * per_leaf);
-        const uint64_t i1 = g > A + w ? (g - w < Bn ? g - w : Bn - 1) : A;
-        const uint64_t i2 = g + w < Bn ? g + w : Bn - 1;
-        const double f1 = root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(keys[i1]));
-        const double f2 = root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(keys[i2]));
-        // (for the integer 1 <= ja <= L - 1:  target(i) < ja  <=>  f(i) < ja;  the probes decide, f1 and f2 only place the first)
-        if (i1 < i2 && f1 < jf && f2 >= jf) pos = search(jf, i1 + 1, i2, i1 + (uint64_t)((jf - f1) / (f2 - f1) * (double)(i2 - i1)), 4);
-        else {
-          uint64_t d = w >> 3;
-          if (d < 2) d = 2;
-          pos = search(jf, A, Bn, g < Bn ? g : Bn - 1, d);
-        }
-      } else if (ja < sp.leaf_hi) pos = A;
-      anch[a] = (unsigned long long)pos;
-    }
-    __syncthreads();
-    const uint64_t j = jb + (uint64_t)t;
-    if (j < sp.leaf_hi) {
-      const uint64_t p0 = anch[t / 16], p1 = anch[t / 16 + 1];
-      uint64_t lo = p0;
-      if ((t & 15) != 0) lo = search((double)j, p0, p1, p0 + (uint64_t)(t & 15) * (p1 - p0) / 16, 2);
-      leaf_start[j] = (unsigned long long)lo;
-      if (j == r.L / 2 && lo < sp.it_hi) {                            // two_layer.rs:131-136, 152-156
-        if (lo == 0) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);   // split_idx == 0 -> :27
-        else if (lo > sp.rd_lo) {
-          st->split_idx = (unsigned long long)lo;
-          st->split_target = (unsigned long long)tgt(lo);
-          if (lo + 1 >= sp.n) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);   // second half empty -> :27
-        }
+    };
+    if (j <= sp.leaf_lo) {                                           // the launch's first leaf: A, unless it has no key at all
+      if (Bn > A && tgt(A) < jf) { lo = A + 1; search_from(A + 1, 2); } else hi = lo;
+    } else if (Bn > A) {
+      const double per_leaf = (double)(Bn - A) / (double)L_own;
+      uint64_t w = (uint64_t)(per_leaf * 1.5);
+      if (w < 4) w = 4;
+      const uint64_t g = A + (uint64_t)((double)(j - sp.leaf_lo) * per_leaf);
+      const uint64_t i1 = g > A + w ? (g - w < Bn ? g - w : Bn - 1) : A;
+      const uint64_t i2 = g + w < Bn ? g + w : Bn - 1;
+      const double f1 = root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(keys[i1]));
+      const double f2 = root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(keys[i2]));
+      // (for the integer 1 <= j <= L - 1:  target(i) < j  <=>  f(i) < j;  the probes decide, f1 and f2 only place the first)
+      if (i1 < i2 && f1 < jf && f2 >= jf) {
+        lo = i1 + 1; hi = i2;
+        search_from(i1 + (uint64_t)((jf - f1) / (f2 - f1) * (double)(i2 - i1)), 2);
+      } else {
+        uint64_t d = w >> 3;
+        if (d < 2) d = 2;
+        search_from(g < Bn ? g : Bn - 1, d);
+      }
+    } else hi = lo;
+    leaf_start[j] = (unsigned long long)lo;
+    if (j == r.L / 2 && lo < sp.it_hi) {                              // two_layer.rs:131-136, 152-156
+      if (lo == 0) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);     // split_idx == 0 -> :27
+      else if (lo > sp.rd_lo) {
+        st->split_idx = (unsigned long long)lo;
+        st->split_target = (unsigned long long)tgt(lo);
+        if (lo + 1 >= sp.n) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);   // second half empty -> :27
       }
     }
   }
-  if (blockIdx.x == 0 && t == 0 && sp.n - 1 >= sp.it_lo && sp.n - 1 < sp.it_hi) st->last_target = (unsigned long long)tgt(sp.n - 1);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sp.n - 1 >= sp.it_lo && sp.n - 1 < sp.it_hi) st->last_target = (unsigned long long)tgt(sp.n - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -568,9 +555,12 @@ __global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ k
   // `flat` (the giant-leaf epilogue): the leaves of that array, fitted by the host meanwhile; else the regions of the
   // list, without the leaves k_list left to the host (the same test as there)
   const int nreg = flat ? 1 : SG_REGIONS;
+  __shared__ unsigned long long s_cnt[SG_REGIONS];                   // (one load per region, not a chain of 64 dependent ones per thread)
+  if (threadIdx.x < SG_REGIONS) s_cnt[threadIdx.x] = flat ? 0ull : (fl.cnt[threadIdx.x] < fl.cap ? fl.cnt[threadIdx.x] : fl.cap);
+  __syncthreads();
   for (int rg = 0; rg < nreg; rg++) {
-    const unsigned long long cnt = flat ? (st->giant_count < st->giant_cap ? st->giant_count : st->giant_cap)
-                                        : (fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap);
+    const unsigned long long cnt = flat ? (st->giant_count < st->giant_cap ? st->giant_count : st->giant_cap) : s_cnt[rg];
+    if (cnt == 0) continue;
     for (unsigned long long t = gid; t < cnt; t += gsz) {
       const uint64_t j = flat ? flat[t].j : (uint64_t)(fl.ids[(unsigned long long)rg * fl.cap + t] & ~SG_TAG);
       const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
