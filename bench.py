@@ -322,7 +322,7 @@ def main():
 
     if rank == 0:
         used = int(getattr(res, "fit_mode_used", 0))
-        lanes_path = used == 0 and leaf_kind == 0 and os.environ.get("RMI_HIP_PIPELINE", "3") not in ("1", "2") and n_local >= 1024
+        lanes_path = used == 0 and leaf_kind in (0, 1) and os.environ.get("RMI_HIP_PIPELINE", "3") not in ("1", "2") and n_local >= 1024
         names = KERNELS_ONEPASS if used else (KERNELS_LANES if lanes_path else KERNELS_EXACT)
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global / (elapsed / args.steps)

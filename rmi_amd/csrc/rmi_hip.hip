@@ -76,6 +76,9 @@ struct rmi_hip_ctx {
   double* d_lntab = nullptr;                    // RN(1 / k) for the running count of the leaf-lane walk (k_lane_table)
   bool lanes_fuse = true;                       // error pass fused behind the fit in k_leaf_lanes (else k_err_range)
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
+  bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes (RMI_HIP_SPLINE_LANES=0: k_sigma2's spline variant)
+  uint64_t edge_epoch = 0;                      // first / last resident key of the key set `keys_epoch` (radix roots: is the prefix common?)
+  uint64_t edge_first = 0, edge_last = 0;
   bool last_lanes = false;
   // giant leaves (containers of more than host_min points): recorded by k_list, fitted on host cores after the device
   // pipeline, their error pass and finalize in a short epilogue (giant_epilogue).  Plain single-context trainings only.
@@ -260,7 +263,8 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* lf = std::getenv("RMI_HIP_LANES_FUSE"); if (lf && *lf) c->lanes_fuse = std::atoi(lf) != 0; }
   { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
   { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
-  if (hipMalloc(&c->d_lntab, sizeof(double) * 3 * LN_TMAX) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
+  { const char* sl = std::getenv("RMI_HIP_SPLINE_LANES"); if (sl && *sl) c->spline_lanes = std::atoi(sl) != 0; }
+  if (hipMalloc(&c->d_lntab, sizeof(double) * (3 * LN_TMAX + 2 * (LS_SAMPLES + 1))) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   hipLaunchKernelGGL(k_lane_table, dim3((LN_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_lntab, LN_TMAX);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
@@ -1024,18 +1028,35 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     for (int h = 0; h < c->hint_n && h < 8; h++) hinted = hinted || c->hint_L[h] == L_own;
   // linear_spline leaves (the line through a container's two end points) need no sums and no guard: the one-pass kernel
   // reproduces them bit for bit, so it serves EVERY fit mode (RMI_HIP_SPLINE_ONEPASS=0: the per-pass kernels)
-  const bool spline1 = (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_onepass;
+  // ... and, in front of it, the leaf-lane kernel (two end points per leaf, then its error pass with duplicates handled natively)
+  const bool spline_l = c->pipeline >= 3 && (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_lanes && n_it >= 1024 &&
+                        sp.n < (1ull << 32) - (1ull << 16);
+  const bool spline1 = (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_onepass && !spline_l;
   const bool sigma = ((stream_fit && c->fit_mode != 0) || spline1) && !hinted && sp.n < (1ull << 32) - (1ull << 16) &&
                      n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
   c->last_sigma = sigma;
   c->last_spline = sigma && LEAF == K_LINEAR_SPLINE;
   // exact linear leaves, pipeline 3: the leaf-lane kernels (rmi_lanes.hip.h)
-  const bool lanes = c->pipeline >= 3 && stream_fit && !sigma && n_it >= 1024;   // (tiny key sets: the streaming passes)
+  const bool lanes = (c->pipeline >= 3 && stream_fit && !sigma && n_it >= 1024) || spline_l;   // (tiny key sets: the streaming passes)
   c->last_lanes = lanes;
   // the fused error pass of k_leaf_lanes needs 32-bit indices; with it and the search, k_init has no array to prepare
   const bool lanes_fused_plan = lanes && c->lanes_fuse && sp.n < (1ull << 32) - (1ull << 16);
   bool lanes_search_plan = false;
   if constexpr (ROOT == K_LINEAR) lanes_search_plan = lanes && c->lanes_search && rp.p1 >= 0.0 && std::isfinite(rp.p0) && std::isfinite(rp.p1);
+  if constexpr (ROOT == K_RADIX) {
+    // (key << prefix) >> (64 - bits) is monotone in the key exactly when no key loses a distinguishing bit to the
+    // shift: all resident keys share their top `prefix` bits.  First and last key of the sorted set decide; fetched once per key set.
+    if (lanes && c->lanes_search) {
+      if (c->edge_epoch != c->keys_epoch) {
+        K k0{}, k1{};
+        HIPCHK(c, hipMemcpy(&k0, c->d_keys, sizeof(K), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&k1, (const K*)c->d_keys + (c->n - 1), sizeof(K), hipMemcpyDeviceToHost));
+        c->edge_first = rmi_host::as_uint(k0); c->edge_last = rmi_host::as_uint(k1); c->edge_epoch = c->keys_epoch;
+      }
+      const unsigned pfx = rp.prefix & 63u;
+      lanes_search_plan = pfx == 0u || ((c->edge_first ^ c->edge_last) >> (64u - pfx)) == 0ull;
+    }
+  }
   const bool init_arrays = !(lanes_fused_plan && lanes_search_plan);
   if (!c->stream_mode || c->stream_slot == 0) HIPCHK(c, hipEventRecord(c->ev[8], s));   // start of the device work of this call
   {
@@ -1063,14 +1084,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   };
   bool lanes_fused = false;
   if (lanes) {
-    if constexpr (LEAF == K_LINEAR) {
+    if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
       { const int lrc = ensure_lists(); if (lrc != RMI_OK) return lrc; }
       // --- leaf boundaries: lower bounds by search where the root is monotone by arithmetic, else the bucketing scan + fill ---
       bool searched = false;
-      if constexpr (ROOT == K_LINEAR) {
+      if constexpr (ROOT == K_LINEAR || ROOT == K_RADIX) {
         if (lanes_search_plan) {
           const uint64_t sb = (L_own + LS_BLOCK - 1) / LS_BLOCK;
-          hipLaunchKernelGGL((k_leaf_search<K>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state);
+          double* smp = c->d_lntab + 3 * LN_TMAX;                       // 2 (LS_SAMPLES + 1) doubles behind the step tables
+          hipLaunchKernelGGL((k_leaf_samples<ROOT, K>), dim3((LS_SAMPLES + 256) / 256), dim3(256), 0, s, keys, sp, rp, smp);
+          hipLaunchKernelGGL((k_leaf_search<ROOT, K>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state, (const double*)smp);
           searched = true;
         }
       }
@@ -1089,7 +1112,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       lanes_fused = lanes_fused_plan;
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
       // giant leaves go to the host when this call ends with its own synchronisation (not inside a streamed or a sharded training)
-      const bool giants = lanes_fused_plan && c->host_min > 0 && !c->stream_mode && !c->defer_sync;
+      const bool giants = LEAF == K_LINEAR && lanes_fused_plan && c->host_min > 0 && !c->stream_mode && !c->defer_sync;
       if (giants) {
         const uint64_t gcap = n_it / c->host_min + 64;
         if (c->giant_cap < gcap) {
@@ -1105,10 +1128,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
       const uint64_t wb = (L_own + 63) / 64;
       if (lanes_fused)
-        hipLaunchKernelGGL((k_leaf_lanes<K, true>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
+        hipLaunchKernelGGL((k_leaf_lanes<K, true, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
                            L, err, count, rows, c->d_partials);
       else
-        hipLaunchKernelGGL((k_leaf_lanes<K, false>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
+        hipLaunchKernelGGL((k_leaf_lanes<K, false, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
                            L, err, count, rows, c->d_partials);
       mark();
       // --- the leaves handed over (containers too long for the lockstep walk): one wave each, fit + error pass ---
@@ -1116,7 +1139,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       sgp.flist = fl; sgp.segs = c->d_segs; sgp.mode = 0; sgp.guard_k = c->guard_k;
       c->last_sg = sgp;
       // (one wave per listed leaf wherever possible: on skewed keys thousands of leaves are listed and each is a sequential chain)
-      hipLaunchKernelGGL((k_list<K, K_LINEAR>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run,
+      hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run,
                          giants ? c->d_giant : (GiantLeaf*)nullptr, giants ? (unsigned long long)c->host_min : ~0ull);
       mark();
       hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);

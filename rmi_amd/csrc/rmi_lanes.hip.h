@@ -76,26 +76,53 @@ template <typename K> struct LnBits { using type = unsigned long long; };   // t
 template <> struct LnBits<uint32_t> { using type = unsigned int; };
 
 // ---------------------------------------------------------------------------------------------
-// k_leaf_search (linear-like roots with slope >= 0; the host checks).  leaf_start[j] = lower bound of "target >= j"
-// in the sorted keys, one thread per leaf, a dependent chain of ~4 loads:
-//   1. two INDEPENDENT loads 1.5 leaves below and above the global guess j n / L -- the root model IS an approximation
-//      of the keys' distribution function scaled to L, good to about a leaf, so they bracket the boundary;
-//   2. interpolate between the (unfloored) root values at the two keys: keys are locally uniform at the scale of a few
-//      leaves, so this lands within a few keys; PAIR probes (one 16-byte load = two neighbouring keys) gallop and
-//      bisect from there.  No bracket (a root that is off by more): gallop from the global guess.
-// What limits this kernel is the length of the dependent chain (~2-3 us per scattered load under load) and the number of
-// scattered line requests.  Measured for 2^20 leaves: 64-byte sector probes (four loads per lane) 171 us; bracket of
-// +-0.5 leaf (fails too often, chains of ~12) 212 us; anchors every 16th leaf + interpolation between anchors (chains of
-// 9 with a block barrier) 61-78 us; this form: see DESIGN.md section 4.
+// k_leaf_search (roots whose targets are monotone BY ARITHMETIC: linear-like with a slope >= 0, radix when every key
+// shares the prefix -- the host checks both).  leaf_start[j] = lower bound of "target >= j" in the sorted keys, one
+// thread per leaf: bracket from the sample table (k_leaf_samples; a binary search in a cache-resident table), interpolate
+// on the unfloored root values (keys are locally uniform at that scale: within a few keys), then PAIR probes (one 16-byte
+// load = two neighbouring keys) gallop and bisect: a chain of ~3 scattered loads.  What limits this kernel is that chain
+// (~2-3 us per scattered load under load) and the number of scattered line requests.  History for 2^20 leaves: sector
+// probes (four loads per lane) 171 us; bracket of +-0.5 leaf around j n / L (fails often: chains of 12) 212 us; anchors
+// every 16th leaf 61-78 us; bracket of +-1.5 leaves 58 us -- and 3.4 ms on a radix root whose leaves are not evenly filled.
 // ---------------------------------------------------------------------------------------------
-template <typename K>
+// the root's value before flooring and clamping, as a double: only places the first probe of a search
+template <int ROOT, typename K>
+__device__ __forceinline__ double ls_root_value(const RootP& r, K k) {
+  if constexpr (ROOT == K_RADIX) {
+    // radix.rs:43-50 keeps the `bits` bits behind the common prefix; the bits behind those give the position inside the bin
+    const uint64_t v = KeyTraits<K>::as_uint(k) << (r.prefix & 63u);
+    return ldexp(KeyTraits<uint64_t>::as_float(v), -(int)((64u - r.bits) & 63u));
+  } else return root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(k));
+}
+
+// Level 0 of the search: the root's target (exact: floored, clamped) and value (unfloored) at LS_SAMPLES + 1 evenly spaced
+// keys of the launch.  A root need not spread the keys evenly over its leaves (a radix root over keys that do not fill
+// their 2^k range, a linear root on skewed data), so "leaf j starts near j n / L" can be off by millions of keys; the
+// sample table brackets every leaf to n / 1024 keys whatever the root does, and the values interpolate inside the bracket.
+constexpr int LS_SAMPLES = 1024;
+__device__ __forceinline__ uint64_t ls_sample_index(uint64_t A, uint64_t Bn, int t) {
+  const uint64_t stride = (Bn - A - 1) / (uint64_t)LS_SAMPLES > 0 ? (Bn - A - 1) / (uint64_t)LS_SAMPLES : 1;
+  const uint64_t i = A + (uint64_t)t * stride;
+  return (t >= LS_SAMPLES || i >= Bn) ? Bn - 1 : i;
+}
+template <int ROOT, typename K>
+__global__ void __launch_bounds__(256) k_leaf_samples(const K* __restrict__ keys, Span sp, RootP r, double* __restrict__ smp) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t > LS_SAMPLES || !(sp.it_hi > sp.it_lo)) return;
+  const K k = keys[ls_sample_index(sp.it_lo, sp.it_hi, t)];
+  bool oob;
+  smp[t] = root_target_f<ROOT, K>(r, (double)(r.L - 1), k, oob);
+  smp[LS_SAMPLES + 1 + t] = ls_root_value<ROOT, K>(r, k);
+}
+
+template <int ROOT, typename K>
 __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ keys, Span sp, RootP r,
                                                           unsigned long long* __restrict__ leaf_start,
-                                                          DevState* __restrict__ st) {
+                                                          DevState* __restrict__ st, const double* __restrict__ smp) {
   const double Lm1f = (double)(r.L - 1);
   const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * LS_BLOCK + threadIdx.x;
-  const uint64_t A = sp.it_lo, Bn = sp.it_hi, L_own = sp.leaf_hi - sp.leaf_lo;
-  auto tgt = [&](uint64_t i) -> double { bool oob; return root_target_f<K_LINEAR, K>(r, Lm1f, keys[i], oob); };
+  const uint64_t A = sp.it_lo, Bn = sp.it_hi;
+  auto tgt = [&](uint64_t i) -> double { bool oob; return root_target_f<ROOT, K>(r, Lm1f, keys[i], oob); };
   if (j < sp.leaf_hi) {
     const double jf = (double)j;
     uint64_t lo = A, hi = Bn;                                        // the answer lies in [lo, hi]
@@ -109,8 +136,8 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
         k0 = bits_to_key<K>(v.x); k1 = bits_to_key<K>(v.y);
       } else { k0 = keys[i]; k1 = k0; }
       bool oob;
-      const bool b0 = root_target_f<K_LINEAR, K>(r, Lm1f, k0, oob) < jf;
-      const bool b1 = root_target_f<K_LINEAR, K>(r, Lm1f, k1, oob) < jf;
+      const bool b0 = root_target_f<ROOT, K>(r, Lm1f, k0, oob) < jf;
+      const bool b1 = root_target_f<ROOT, K>(r, Lm1f, k1, oob) < jf;
       if (!b0) hi = i;
       else if (!b1 || i + 1 >= hi) { lo = i + 1; if (!b1) hi = i + 1; }
       else lo = i + 2 < hi ? i + 2 : hi;
@@ -143,25 +170,19 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
         while (lo < hi) probe(lo + ((hi - lo) >> 1));
       }
     };
-    if (j <= sp.leaf_lo) {                                           // the launch's first leaf: A, unless it has no key at all
-      if (Bn > A && tgt(A) < jf) { lo = A + 1; search_from(A + 1, 2); } else hi = lo;
-    } else if (Bn > A) {
-      const double per_leaf = (double)(Bn - A) / (double)L_own;
-      uint64_t w = (uint64_t)(per_leaf * 1.5);
-      if (w < 4) w = 4;
-      const uint64_t g = A + (uint64_t)((double)(j - sp.leaf_lo) * per_leaf);
-      const uint64_t i1 = g > A + w ? (g - w < Bn ? g - w : Bn - 1) : A;
-      const uint64_t i2 = g + w < Bn ? g + w : Bn - 1;
-      const double f1 = root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(keys[i1]));
-      const double f2 = root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(keys[i2]));
-      // (for the integer 1 <= j <= L - 1:  target(i) < j  <=>  f(i) < j;  the probes decide, f1 and f2 only place the first)
-      if (i1 < i2 && f1 < jf && f2 >= jf) {
-        lo = i1 + 1; hi = i2;
-        search_from(i1 + (uint64_t)((jf - f1) / (f2 - f1) * (double)(i2 - i1)), 2);
-      } else {
-        uint64_t d = w >> 3;
-        if (d < 2) d = 2;
-        search_from(g < Bn ? g : Bn - 1, d);
+    if (Bn > A) {
+      // first sample whose target is >= j (the table is a few KB, read by every thread: cache resident)
+      int a = 0, b = LS_SAMPLES + 1;
+      while (a < b) { const int m = (a + b) >> 1; if (smp[m] < jf) a = m + 1; else b = m; }
+      if (a == 0) hi = lo;                                           // the launch's first key is already in leaf j or behind it
+      else if (a > LS_SAMPLES) lo = hi;                              // even the last key is below: no key reaches leaf j
+      else {
+        const uint64_t i1 = ls_sample_index(A, Bn, a - 1), i2 = ls_sample_index(A, Bn, a);
+        lo = i1 + 1; hi = i2;                                        // key i1 is below, key i2 is not
+        const double f1 = smp[LS_SAMPLES + 1 + a - 1], f2 = smp[LS_SAMPLES + 1 + a];
+        double tq = (f2 > f1) ? (jf - f1) / (f2 - f1) : 0.5;
+        tq = tq < 0.0 ? 0.0 : (tq > 1.0 ? 1.0 : tq);
+        search_from(i1 + (uint64_t)(tq * (double)(i2 - i1)), 2);
       }
     } else hi = lo;
     leaf_start[j] = (unsigned long long)lo;
@@ -180,7 +201,7 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // k_leaf_lanes
 // ---------------------------------------------------------------------------------------------
-template <typename K, bool ERR>
+template <typename K, bool ERR, int LEAFK = K_LINEAR>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_WPE, RMI_LN_WPE))) k_leaf_lanes(const K* __restrict__ keys, Span sp,
                                                    const unsigned long long* __restrict__ leaf_start,
                                                    DevState* __restrict__ st, double* __restrict__ params,
@@ -222,7 +243,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   // leaves for the list kernels (one wave per leaf: exact fit + its error pass): containers longer than the lockstep
   // walk takes, and whatever lies beyond 32-bit offsets from the wave base
   constexpr uint64_t FAR = 1ull << 30;
-  const bool handed = valid && ((ck == 2 && (npts + 1u > long_min || hi - wb >= FAR)) || (e > s && e - wb >= FAR));
+  // (linear_spline leaves: no walk for the fit, but a leaf far longer than its neighbours would hold the wave's error pass)
+  const bool handed = valid && ((ck == 2 && (npts + 1u > long_min || hi - wb >= FAR)) || (e > s && e - wb >= FAR) ||
+                                (LEAFK != K_LINEAR && e - s > (uint64_t)long_min));
   if (handed) fl.push((unsigned int)j);
   const bool act = ck == 2 && !handed;
 
@@ -290,8 +313,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   unsigned int flags = 0;
   double pa = 0.0, pb = 0.0;                                          // this lane's leaf: (alpha, beta)
   bool wave_dups = true;                                              // some container of this wave holds a duplicate key
-  // =========================== the fit: lockstep walk of the containers ===========================
-  {
+  // =========================== the fit ===========================
+  if constexpr (LEAFK == K_LINEAR_SPLINE) {
+    // linear_spline.rs:13-35: the line through the first and the last point of the container -- two keys, their FixDups
+    // offsets, the reference's two operations (IEEE division, plain multiply-subtract): the same bits, no walk
+    if (valid && !handed && ck == 2) {
+      const K k0 = keys[lo], k1 = keys[hi];
+      const double y0 = (double)first_occurrence(keys, lo, sp.rd_lo);
+      if (lo == hi || k0 == k1) { pa = y0; pb = 0.0; }
+      else {
+        const double y1 = (double)first_occurrence(keys, hi, sp.rd_lo);
+        const double x0 = KeyTraits<K>::as_float(k0), x1 = KeyTraits<K>::as_float(k1);
+        pb = (y0 - y1) / (x0 - x1);
+        pa = y0 - pb * x0;
+      }
+    } else if (ck == 1) { pa = (double)lo; pb = 0.0; }
+    if (valid && !handed) { params[2 * j] = pa; params[2 * j + 1] = pb; }
+  } else {
+    // ---- linear leaves: lockstep walk of the containers
     make_rows(act ? (unsigned int)(lo - wb) : 0u, act ? npts : 0u);
     const unsigned int a0 = act ? (unsigned int)(lo - wb) & 15u : 0u;   // ring slot of the container's first point
 #pragma unroll

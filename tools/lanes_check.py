@@ -41,25 +41,30 @@ def check():
              ("dups_u64", 200_000, 40_000, "linear"), ("uniform_u64", 1_000_000, 64, "linear"), ("uniform_u64", 300_000, 4096, "radix"),
              ("dups_u64", 300_000, 64, "linear"), ("books_u64", 300_000, 100, "linear"), ("uniform_u64", 2_000_000, 8, "linear"),
              ("dups_u32", 300_000, 32, "linear"), ("clustered_u64", 300_000, 16, "linear")]
+    spl = [(g, n, L, r, "linear_spline") for g, n, L, r in
+           [("uniform_u32", 300_000, 4096, "radix"), ("dups_u32", 300_000, 4096, "radix"), ("dups_u64", 300_000, 1024, "linear"),
+            ("books_u64", 300_000, 256, "radix"), ("uniform_u64", 1_000_000, 16, "radix"), ("uniform_f64", 200_000, 512, "radix"),
+            ("clustered_u64", 300_000, 1024, "radix"), ("dups_u32", 200_000, 60_000, "radix")]]
+    cases = [c + ("linear",) for c in cases] + spl
     for name, env in VARIANTS.items():
-        for gen, n, L, root in cases:
+        for gen, n, L, root, leaf in cases:
             keys = dg.GENERATORS[gen](n)
             tr = mk(env)
             tr.set_keys(keys)
             g_root = tr.fit_root(root, L)
             try:
-                o = orc.train_two_layer(root, "linear", keys, L)
+                o = orc.train_two_layer(root, leaf, keys, L)
             except orc.OracleError as oe:
                 try:
-                    tr.train_leaves(g_root, "linear", L)
-                    print(f"[{name}] {gen} n={n} L={L} {root}: oracle error {oe.code}, GPU none  BAD")
+                    tr.train_leaves(g_root, leaf, L)
+                    print(f"[{name}] {gen} n={n} L={L} {root},{leaf}: oracle error {oe.code}, GPU none  BAD")
                     bad_total += 1
                 except train.RMIError as ge:
                     print(f"[{name}] {gen} n={n} L={L} {root}: both error {oe.code}/{ge.code}", "ok" if oe.code == ge.code else "BAD")
                 tr.close()
                 continue
             try:
-                g = tr.train_leaves(g_root, "linear", L)
+                g = tr.train_leaves(g_root, leaf, L)
             except train.RMIError as ge:
                 print(f"[{name}] {gen} n={n} L={L} {root}: GPU error {ge.code} {ge}  BAD")
                 bad_total += 1
@@ -71,7 +76,7 @@ def check():
             cc = np.nonzero(g.leaf_counts != o.leaf_count)[0]
             ok = not (len(ls) or len(pp) or len(ee) or len(cc))
             bad_total += 0 if ok else 1
-            print(f"[{name}] {gen} n={n} L={L} {root}: starts {len(ls)} params {len(pp)} errs {len(ee)} counts {len(cc)} long {g.long_leaves}", "ok" if ok else "BAD")
+            print(f"[{name}] {gen} n={n} L={L} {root},{leaf}: starts {len(ls)} params {len(pp)} errs {len(ee)} counts {len(cc)} long {g.long_leaves}", "ok" if ok else "BAD")
             if len(ls):
                 print("    starts:", [(int(j), int(g.leaf_starts[j]), int(o.leaf_start[j])) for j in ls[:6]])
             if len(pp):
