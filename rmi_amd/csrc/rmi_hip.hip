@@ -1043,6 +1043,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   const bool lanes_fused_plan = lanes && c->lanes_fuse && sp.n < (1ull << 32) - (1ull << 16);
   bool lanes_search_plan = false;
   if constexpr (ROOT == K_LINEAR) lanes_search_plan = lanes && c->lanes_search && rp.p1 >= 0.0 && std::isfinite(rp.p0) && std::isfinite(rp.p1);
+  // cubic roots: not monotone by arithmetic, but the search may assume it when k_leaf_lanes verifies every key's target
+  // during its (fused) error pass -- no bucketing scan, no fill
+  if constexpr (ROOT == K_CUBIC) lanes_search_plan = lanes && c->lanes_search && lanes_fused_plan && LEAF == K_LINEAR && std::isfinite(rp.p0) && std::isfinite(rp.p1) && std::isfinite(rp.p2) && std::isfinite(rp.p3);
   if constexpr (ROOT == K_RADIX) {
     // (key << prefix) >> (64 - bits) is monotone in the key exactly when no key loses a distinguishing bit to the
     // shift: all resident keys share their top `prefix` bits.  First and last key of the sorted set decide; fetched once per key set.
@@ -1088,7 +1091,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       { const int lrc = ensure_lists(); if (lrc != RMI_OK) return lrc; }
       // --- leaf boundaries: lower bounds by search where the root is monotone by arithmetic, else the bucketing scan + fill ---
       bool searched = false;
-      if constexpr (ROOT == K_LINEAR || ROOT == K_RADIX) {
+      if constexpr (ROOT == K_LINEAR || ROOT == K_RADIX || ROOT == K_CUBIC) {
         if (lanes_search_plan) {
           const uint64_t sb = (L_own + LS_BLOCK - 1) / LS_BLOCK;
           double* smp = c->d_lntab + 3 * LN_TMAX;                       // 2 (LS_SAMPLES + 1) doubles behind the step tables
@@ -1127,12 +1130,22 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       }
       const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
       const uint64_t wb = (L_own + 63) / 64;
-      if (lanes_fused)
+      bool launched = false;
+      if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR) {
+        if (searched) {                                                 // (searched implies fused: the verification rides on the error pass)
+          hipLaunchKernelGGL((k_leaf_lanes<K, true, K_LINEAR, K_CUBIC>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
+                             L, err, count, rows, c->d_partials, rp);
+          hipLaunchKernelGGL((k_verify_listed<K_CUBIC, K>), dim3(1024), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state, fl);
+          launched = true;
+        }
+      }
+      if (launched) {
+      } else if (lanes_fused)
         hipLaunchKernelGGL((k_leaf_lanes<K, true, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                           L, err, count, rows, c->d_partials);
+                           L, err, count, rows, c->d_partials, rp);
       else
         hipLaunchKernelGGL((k_leaf_lanes<K, false, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                           L, err, count, rows, c->d_partials);
+                           L, err, count, rows, c->d_partials, rp);
       mark();
       // --- the leaves handed over (containers too long for the lockstep walk): one wave each, fit + error pass ---
       SgParams sgp; std::memset(&sgp, 0, sizeof sgp);

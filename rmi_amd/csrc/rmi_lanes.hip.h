@@ -92,7 +92,7 @@ __device__ __forceinline__ double ls_root_value(const RootP& r, K k) {
     // radix.rs:43-50 keeps the `bits` bits behind the common prefix; the bits behind those give the position inside the bin
     const uint64_t v = KeyTraits<K>::as_uint(k) << (r.prefix & 63u);
     return ldexp(KeyTraits<uint64_t>::as_float(v), -(int)((64u - r.bits) & 63u));
-  } else return root_eval_f<K_LINEAR>(r, KeyTraits<K>::as_float(k));
+  } else return root_eval_f<ROOT>(r, KeyTraits<K>::as_float(k));
 }
 
 // Level 0 of the search: the root's target (exact: floored, clamped) and value (unfloored) at LS_SAMPLES + 1 evenly spaced
@@ -201,7 +201,11 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // k_leaf_lanes
 // ---------------------------------------------------------------------------------------------
-template <typename K, bool ERR, int LEAFK = K_LINEAR>
+// VROOT >= 0: a root whose targets are NOT monotone by arithmetic (cubic: three nested fmas round independently).  The
+// search then rests on an assumption, and this kernel verifies it key by key during the error pass: every key of the
+// partition of leaf j must have target j -- which holds for all leaves exactly when the targets are non-decreasing
+// (two_layer.rs:50, the reference's panic) -- and, for roots without a bounds check, stay below L (two_layer.rs:45-48).
+template <typename K, bool ERR, int LEAFK = K_LINEAR, int VROOT = -1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_WPE, RMI_LN_WPE))) k_leaf_lanes(const K* __restrict__ keys, Span sp,
                                                    const unsigned long long* __restrict__ leaf_start,
                                                    DevState* __restrict__ st, double* __restrict__ params,
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
                                                    unsigned long long* __restrict__ leaf_run, uint64_t L,
                                                    unsigned long long* __restrict__ leaf_err,
                                                    unsigned long long* __restrict__ leaf_count,
-                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials) {
+                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr) {
   using B = typename LnBits<K>::type;
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
   constexpr int LPR = 8;                                              // lanes per row (2 keys each)
@@ -503,6 +507,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
               const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[q]));
               const double f = __builtin_fma(pb, x, pa);                // linear.rs:87-90
               const unsigned int pr = min(sg_cvt_u32(f), n32);         // models/mod.rs:735-737, two_layer.rs:14-18
+              if constexpr (VROOT >= 0) {
+                const unsigned int rt = sg_cvt_u32(root_eval_f<VROOT>(vr, x));      // max(0, floor(.)), saturating
+                const unsigned int Lm1 = (unsigned int)(vr.L - 1);
+                if constexpr (!root_needs_bounds_check<VROOT>()) { if (rt > Lm1) flags |= EF_ROOT_OOB; }
+                if ((rt < Lm1 ? rt : Lm1) != (unsigned int)j) flags |= EF_NON_MONOTONE;
+              }
               const unsigned int idx = i0 + (unsigned int)q;
               if constexpr (GEN) {
                 const bool dup = (dmask >> q) & 1u;
@@ -651,6 +661,28 @@ __global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ k
     stw->max_err = mx; stw->max_err_idx = mi; stw->sum_n_err = sm; stw->sum_l2 = l2; stw->sum_log2 = lg;
     if (host_copy) *host_copy = *stw;                                // pinned host memory: visible to the host once the stream is synchronised
   }
+}
+
+// The verification of k_leaf_lanes<.., VROOT> for the leaves it handed to the list kernels: every key of the partition
+// of a listed leaf must have that leaf as its target (a block per listed leaf, its threads stride over the keys).
+template <int ROOT, typename K>
+__global__ void __launch_bounds__(256) k_verify_listed(const K* __restrict__ keys, Span sp, RootP r,
+                                                       const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st, SgList fl) {
+  unsigned int flags = 0;
+  const unsigned int Lm1 = (unsigned int)(r.L - 1);
+  for (int rg = 0; rg < SG_REGIONS; rg++) {
+    const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
+    for (unsigned long long t = blockIdx.x; t < cnt; t += gridDim.x) {
+      const uint64_t j = fl.ids[(unsigned long long)rg * fl.cap + t] & ~SG_TAG;
+      const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+      for (uint64_t i = s + threadIdx.x; i < e; i += 256) {
+        const unsigned int rt = sg_cvt_u32(root_eval_f<ROOT>(r, KeyTraits<K>::as_float(keys[i])));
+        if constexpr (!root_needs_bounds_check<ROOT>()) { if (rt > Lm1) flags |= EF_ROOT_OOB; }
+        if ((rt < Lm1 ? rt : Lm1) != (unsigned int)j) flags |= EF_NON_MONOTONE;
+      }
+    }
+  }
+  if (flags) atomicOr(&st->err_flags, flags);
 }
 
 // the error pass of the giant leaves, once the host has written their coefficients: stretches for k_list_tail

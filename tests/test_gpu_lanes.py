@@ -115,3 +115,30 @@ def test_one_pass_request_beyond_32_bit_indices_reports_exact(monkeypatch):
     g = tr.train_leaves(root, "linear", 4096)
     assert g.fit_mode_used == 1                  # below the limit the request is honoured
     tr.close()
+
+
+@pytest.mark.parametrize("params,what", [((0.0, 0.0, -1e-15, 3000.0), "decreasing"), ((0.0, 0.0, 1e-13, 0.0), "out of bounds"),
+                                         ((1e-50, -3e-32, 2e-14, 5.0), "wiggle")])
+def test_cubic_root_verified_by_the_error_pass(monkeypatch, oracle, params, what):
+    """A cubic root is not monotone by arithmetic: the search assumes it and k_leaf_lanes verifies every key's target during
+    its error pass (two_layer.rs:45-50).  Caller-provided roots that are decreasing / out of bounds / wiggling must give the
+    reference's panic as the same error code as the scan-based pipelines and the oracle -- or the same result."""
+    from rmi_amd import train
+    keys = dg.uniform_u64(300_000)
+    L = 4096
+    root = train.Model(2, params, (0, 0, 0, 0))
+    outs = []
+    for pl in ("3", "2"):
+        monkeypatch.setenv("RMI_HIP_PIPELINE", pl)
+        tr = train.Trainer(keys)
+        try:
+            g = tr.train_leaves(root, "linear", L).materialize()
+            outs.append(("ok", g.last_layer_max_l1s.copy(), g.leaf_params.copy()))
+        except train.RMIError as e:
+            outs.append(("err", e.code, None))
+        tr.close()
+    assert outs[0][0] == outs[1][0], (what, outs[0][:2], outs[1][:2])
+    if outs[0][0] == "err":
+        assert outs[0][1] == outs[1][1], what
+    else:
+        assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2].view(np.uint64), outs[1][2].view(np.uint64))
