@@ -154,16 +154,21 @@ const char* rmi_hip_strerror(int code);
  * ~5 us of idle device time, so the detail is not free.  RMI_HIP_PROFILE_KERNELS=1 selects 2 at creation. */
 int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
 /* How linear leaves (linear.rs:12-59) are fitted:
- *   RMI_FIT_EXACT (default): the reference's recurrence in the reference's order; coefficients, error
- *     integers and counts bit-identical to the reference; two streaming passes over the keys.
- *   RMI_FIT_ONEPASS_GUARDED: ONE pass over the keys; a leaf's line from shifted sums (n, S dx, S dx^2,
+ *   RMI_FIT_EXACT (default, and the fastest mode since the leaf-lane kernels of rmi_lanes.hip.h): the reference's
+ *     recurrence in the reference's order; coefficients, error integers and counts bit-identical to the reference.  Leaf
+ *     boundaries by search, 64 leaves per wave in lockstep, error pass and finalize fused behind the fit; containers of
+ *     more than 4 096 points one wave each, of more than 262 144 points on a host core (RMI_HIP_HOST_MIN).  The keys are
+ *     read twice (the second read largely from the Infinity Cache).  This is the mode every figure of merit is quoted in.
+ *   RMI_FIT_ONEPASS_GUARDED (an opt-in FAST mode: its coefficients do NOT meet a 1e-9 relative tolerance on every
+ *     leaf): ONE pass over the keys; a leaf's line from shifted sums (n, S dx, S dx^2,
  *     S dx dy) reduced in parallel, the error pass from LDS.  Bucket ids, per-leaf error integers and
  *     counts stay bit-identical: a leaf with any prediction closer to an integer than a bound on the
  *     distance between the two lines (guard_k times a first-order rounding bound, see rmi_sigma.hip.h),
  *     or that the sums do not describe (duplicate keys, the leaves at the split of two_layer.rs:130-175,
  *     first / last leaf, leaves longer than a tile), is re-fitted by the exact kernels.  Coefficients of
- *     the other leaves agree with the reference's to its own rounding noise (~1e-9 relative on 200M u64
- *     keys), not bit for bit.
+ *     the other leaves agree with the reference's to its own rounding noise (up to 2.3e-9 relative on 200M u64
+ *     keys), not bit for bit.  The guard is a first-order bound with an empirical factor, not a proof: the integers are
+ *     bit-identical on every key set tested (tests/test_gpu_sigma.py, test_gpu_lanes.py::test_adversarial_guard).
  *   RMI_FIT_ONEPASS: the least-squares line of the sums wherever the sums are defined.  No re-fit of guard-flagged
  *     leaves (counted in rmi_hip_result.guard_leaves); leaves longer than a wave's LDS ring, or cut at the border
  *     of two waves' chunks, are summed piecewise and merged (rmi_hip_result.merged_leaves) -- also the first leaf,
@@ -182,9 +187,9 @@ int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
  * uniform / heavy-tailed / clustered key sets of 200 M keys, is 0.46 of the bound with factor 1).  Leaf kinds other
  * than `linear` ignore the mode. */
 enum rmi_hip_fit_mode { RMI_FIT_EXACT = 0, RMI_FIT_ONEPASS_GUARDED = 1, RMI_FIT_ONEPASS = 2 };
-/* linear_spline leaves (the line through the two end points of a container, linear_spline.rs:13-35) need no sums: the
- * one-pass kernel reproduces them bit for bit and serves them in EVERY mode; rmi_hip_result.fit_mode_used then reads
- * RMI_FIT_USED_ONEPASS_EXACT. */
+/* linear_spline leaves (the line through the two end points of a container, linear_spline.rs:13-35) are exact in every
+ * mode: through the leaf-lane kernels (fit_mode_used 0), or -- RMI_HIP_SPLINE_LANES=0 -- through the one-pass kernel,
+ * which reproduces them bit for bit as well; rmi_hip_result.fit_mode_used then reads RMI_FIT_USED_ONEPASS_EXACT. */
 enum { RMI_FIT_USED_ONEPASS_EXACT = 3 };
 int rmi_hip_set_fit_mode(rmi_hip_ctx* ctx, int mode, double guard_k);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = context's own. */
