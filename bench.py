@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures (fast mode, other configurations, PCIe-inclusive, fast root)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side figures of the other BASELINE configurations")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo for functional tests)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "direct", "auto"],
+                    help="N>1: how the rows reach every rank -- ncclAllGather (default), direct peer stores over xGMI (rmi_hip_peer_*), "
+                         "or an A/B at start-up that takes the direct form only if its table equals RCCL's and it is faster")
     a = ap.parse_args()
     keys, leaves, spec, dataset, dtype, scaling = CONFIGS[a.config or "M"]
     a.keys = a.keys or keys
@@ -269,7 +272,7 @@ def main():
         from rmi_amd import sharded
         if args.dataset == "books":
             raise SystemExit("books-shaped keys are generated on the host: single GPU only")
-        sh = sharded.ShardedTrainer(tr, dist, rank, world, args.dataset, np_dtype, n_global, L_global, args.spec, fit_mode=mode)
+        sh = sharded.ShardedTrainer(tr, dist, rank, world, args.dataset, np_dtype, n_global, L_global, args.spec, fit_mode=mode, exchange=args.exchange)
         root_s = sh.root_seconds
         run_step = sh.step
         n_local, L_local = sh.plan.key_hi - sh.plan.key_lo, sh.plan.leaf_hi - sh.plan.leaf_lo
@@ -380,6 +383,8 @@ def main():
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
+            if getattr(sh, "auto_report", None):
+                out["exchange_ab"] = sh.auto_report
         tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
         if os.path.exists(tpath) and world == 1 and args.config == "M":
             try:

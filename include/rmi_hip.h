@@ -285,11 +285,26 @@ int rmi_hip_fit_root_from_source(int root_kind, int dtype, uint64_t n_global, ui
                                  void* user, rmi_hip_model_params* out);
 int rmi_hip_comm_unique_id(void* id_out /* RMI_HIP_COMM_ID_BYTES */);
 int rmi_hip_comm_init(rmi_hip_ctx* ctx, int rank, int world, const void* id /* RMI_HIP_COMM_ID_BYTES; NULL with world == 1 */);
+int rmi_hip_comm_info(rmi_hip_ctx* ctx, int* world, int* rank);   /* ncclCommCount / ncclCommUserRank of the context's communicator */
 int rmi_hip_comm_destroy(rmi_hip_ctx* ctx);
 int rmi_hip_train_sharded(rmi_hip_ctx* ctx, const rmi_hip_model_params* root, int leaf_kind, uint64_t num_leaves,
                           rmi_hip_result* out);
 void* rmi_hip_device_rows_full(rmi_hip_ctx* ctx);
 int rmi_hip_download_rows_full(rmi_hip_ctx* ctx, void* host_out, uint64_t capacity_bytes);
+/* ---- the exchange as direct peer stores over xGMI, next to the RCCL all-gather ----
+ * xGMI is a full mesh: a rank can store its 24 L / G bytes into all G - 1 peers at once (~ slice / 153 GB/s per link),
+ * where a ring all-gather takes G - 1 dependent steps.  Every rank exports its (double-buffered) full row table and a
+ * mailbox as IPC handles, imports its peers' (any channel carries the RMI_HIP_PEER_HANDLE_BYTES), and with
+ * rmi_hip_set_exchange(ctx, RMI_EXCHANGE_DIRECT) rmi_hip_train_sharded ends with: one kernel that stores this rank's
+ * slice into every peer's table, one that publishes the aggregates and an epoch flag in every peer's mailbox (system
+ * scope), one that waits for the G flags of this epoch (bounded: 5 s, then RMI_ERR_HIP).  No RCCL needed.
+ * Works across processes on ONE device too (how it is tested here); across devices it has NOT run yet -- it is opt-in,
+ * and bench.py --exchange auto validates its table against the RCCL exchange before preferring it. */
+#define RMI_HIP_PEER_HANDLE_BYTES 256
+enum { RMI_EXCHANGE_RCCL = 0, RMI_EXCHANGE_DIRECT = 1 };
+int rmi_hip_peer_export(rmi_hip_ctx* ctx, int rank, int world, int leaf_kind, uint64_t num_leaves, void* handle_out);
+int rmi_hip_peer_import(rmi_hip_ctx* ctx, int peer_rank, const void* handle);
+int rmi_hip_set_exchange(rmi_hip_ctx* ctx, int mode);
 
 /* ---- root model ---- */
 /* Fit the root exactly as the reference does.  `host_keys` may be NULL, in which case the keys

@@ -93,14 +93,19 @@ SYMBOLS = [
     ("rmi_hip_fit_root_from_source", C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(ModelParams)]),
     ("rmi_hip_comm_unique_id", C.c_int, [C.c_void_p]),
     ("rmi_hip_comm_init", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    ("rmi_hip_comm_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("rmi_hip_comm_destroy", C.c_int, [C.c_void_p]),
     ("rmi_hip_train_sharded", C.c_int, [C.c_void_p, C.POINTER(ModelParams), C.c_int, C.c_uint64, C.POINTER(Result)]),
     ("rmi_hip_device_rows_full", C.c_void_p, [C.c_void_p]),
+    ("rmi_hip_peer_export", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p]),
+    ("rmi_hip_peer_import", C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    ("rmi_hip_set_exchange", C.c_int, [C.c_void_p, C.c_int]),
     ("rmi_hip_download_rows_full", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
 ]
 
 KEY_AT_FN = C.CFUNCTYPE(C.c_uint64, C.c_void_p, C.c_uint64)
 COMM_ID_BYTES = 128
+PEER_HANDLE_BYTES = 256
 
 _lib = None
 

@@ -24,6 +24,7 @@ enum : uint32_t {
   EF_ROBUST_TOO_SMALL = 1u << 5,   // linear.rs:248: assert!(bnd*2+1 < data.len()) on a leaf container
   EF_CUBIC_DEGENERATE = 1u << 4,   // cubic_spline.rs:46-65: `.unwrap()` on an empty search (distinct keys, one f64)
   EF_LIST_OVERFLOW = 1u << 6,      // internal: a hand-over list (leaves for the list kernels, their stretches) was full
+  EF_PEER_TIMEOUT = 1u << 7,       // direct exchange: a peer's flag of this epoch did not arrive in time
 };
 
 // Root model parameters + branching factor, passed by value to kernels.

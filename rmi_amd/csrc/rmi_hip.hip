@@ -1562,6 +1562,15 @@ static void free_multi(rmi_hip_ctx* c) {
   if (!m) return;
   if (m->comm && rmi_multi::api().CommDestroy) (void)rmi_multi::api().CommDestroy(m->comm);
   if (m->d_rows_full) (void)hipFree(m->d_rows_full);
+  for (int r = 0; r < 64; r++) {
+    if (!m->peer_open[r] || r == m->rank) continue;
+    if (m->peer_rows[r]) (void)hipIpcCloseMemHandle(m->peer_rows[r]);
+    if (m->peer_mail[r]) (void)hipIpcCloseMemHandle(m->peer_mail[r]);
+  }
+  if (m->d_rows2) (void)hipFree(m->d_rows2);
+  if (m->d_mail) (void)hipFree(m->d_mail);
+  if (m->d_peer_rows) (void)hipFree(m->d_peer_rows);
+  if (m->d_peer_mail) (void)hipFree(m->d_peer_mail);
   if (m->d_stats_all) (void)hipFree(m->d_stats_all);
   if (m->h_stats_all) (void)hipHostFree(m->h_stats_all);
   delete m;

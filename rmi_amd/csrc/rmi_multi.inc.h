@@ -24,6 +24,8 @@ struct Api {
   int (*CommDestroy)(NcclComm) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(NcclComm, int*) = nullptr;
+  int (*CommUserRank)(NcclComm, int*) = nullptr;
   bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather; }
 };
 
@@ -44,6 +46,8 @@ static Api& api() {
       a.CommDestroy = (int (*)(NcclComm))dlsym(a.handle, "ncclCommDestroy");
       a.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))dlsym(a.handle, "ncclAllGather");
       a.GetErrorString = (const char* (*)(int))dlsym(a.handle, "ncclGetErrorString");
+      a.CommCount = (int (*)(NcclComm, int*))dlsym(a.handle, "ncclCommCount");
+      a.CommUserRank = (int (*)(NcclComm, int*))dlsym(a.handle, "ncclCommUserRank");
     }
   });
   return a;
@@ -67,7 +71,55 @@ struct rmi_hip_multi {
   uint64_t rows_last_bytes = 0;                 // num_leaves * row_bytes of the last sharded training
   unsigned char* d_stats_all = nullptr;     // world * 40 bytes
   unsigned char* h_stats_all = nullptr;     // pinned
+  // direct exchange (peer stores): the row table double-buffered by the parity of the epoch, a mailbox (64 flags + 64 x 40 bytes)
+  int exchange = 0;                         // RMI_EXCHANGE_*
+  unsigned char* d_rows2 = nullptr;         // 2 x slot_bytes (exported)
+  uint64_t rows2_slot = 0;
+  unsigned char* d_mail = nullptr;          // fine-grained device memory (exported)
+  unsigned char* peer_rows[64] = {};        // [rank]: that rank's d_rows2 as mapped here (own rank: local)
+  unsigned char* peer_mail[64] = {};
+  bool peer_open[64] = {};
+  int peers = 0;
+  unsigned char** d_peer_rows = nullptr;    // the two tables above for the kernels
+  unsigned char** d_peer_mail = nullptr;
+  unsigned long long epoch = 0;
 };
+constexpr size_t RMI_MAIL_BYTES = 64 * 8 + 64 * 40;
+struct rmi_peer_handle { hipIpcMemHandle_t rows, mail; uint64_t slot_bytes; int rank, world; };
+static_assert(sizeof(rmi_peer_handle) <= RMI_HIP_PEER_HANDLE_BYTES, "handle size");
+
+// this rank's slice into every peer's table (16-byte stores; a block reads its piece once and writes it G - 1 times)
+__global__ void __launch_bounds__(256) k_peer_push(const uint4* __restrict__ src, uint64_t n16, unsigned char* const* __restrict__ peer_rows,
+                                                   uint64_t byte_off, int rank, int world) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    for (int r = 0; r < world; r++)
+      if (r != rank) reinterpret_cast<uint4*>(peer_rows[r] + byte_off)[i] = v;
+  }
+}
+// the aggregates and the epoch flag into every mailbox (the kernel boundary before this launch has made the slice visible)
+__global__ void __launch_bounds__(64) k_peer_signal(unsigned char* const* __restrict__ peer_mail, const unsigned long long* __restrict__ my_stats,
+                                                    int rank, int world, unsigned long long epoch) {
+  const int r = threadIdx.x;
+  if (r >= world) return;
+  unsigned long long* mail = reinterpret_cast<unsigned long long*>(peer_mail[r]);
+  for (int q = 0; q < 5; q++) __hip_atomic_store(&mail[64 + rank * 5 + q], my_stats[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&mail[rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// wait for the `world` flags of this epoch in the own mailbox, then hand the aggregates to the host copy
+__global__ void __launch_bounds__(64) k_peer_wait(unsigned long long* __restrict__ mail, int world, unsigned long long epoch,
+                                                  unsigned long long* __restrict__ stats_all, rmi::DevState* __restrict__ st) {
+  const int r = threadIdx.x;
+  if (r >= world) return;
+  const unsigned long long t0 = wall_clock64();                      // 100 MHz
+  bool ok = true;
+  while (__hip_atomic_load(&mail[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > 500000000ull) { ok = false; break; }  // 5 s
+  }
+  if (!ok) { atomicOr(&st->err_flags, rmi::EF_PEER_TIMEOUT); return; }
+  for (int q = 0; q < 5; q++) stats_all[r * 5 + q] = __hip_atomic_load(&mail[64 + r * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 static rmi_hip_multi* multi_of(rmi_hip_ctx* c);    // (accessor defined in rmi_hip.hip)
 
@@ -194,11 +246,69 @@ int rmi_hip_comm_init(rmi_hip_ctx* c, int rank, int world, const void* id_bytes)
   return RMI_OK;
 }
 
+// what the communicator itself says (ncclCommCount / ncclCommUserRank): the proof that a collective spans `world` ranks
+int rmi_hip_comm_info(rmi_hip_ctx* c, int* world, int* rank) {
+  if (!c || !world || !rank) return RMI_ERR_BAD_ARG;
+  rmi_hip_multi* m = multi_of(c);
+  *world = m->world; *rank = m->rank;
+  if (!m->comm) return RMI_OK;
+  rmi_multi::Api& a = rmi_multi::api();
+  if (!a.CommCount || !a.CommUserRank) return RMI_ERR_NO_RCCL;
+  if (a.CommCount(m->comm, world) != 0 || a.CommUserRank(m->comm, rank) != 0) return RMI_ERR_RCCL;
+  return RMI_OK;
+}
+
 int rmi_hip_comm_destroy(rmi_hip_ctx* c) {
   if (!c) return RMI_ERR_BAD_ARG;
   rmi_hip_multi* m = multi_of(c);
   if (m->comm) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)rmi_multi::api().CommDestroy(m->comm); m->comm = nullptr; }
   m->world = 1; m->rank = 0;
+  return RMI_OK;
+}
+
+// The exchange as peer stores (include/rmi_hip.h).  Epoch e uses half e & 1 of every rank's table: a rank that runs ahead
+// stores into the half its peers are not reading.
+static int train_sharded_direct(rmi_hip_ctx* c, rmi_hip_multi* m, const rmi_hip_model_params* root, int leaf_kind, uint64_t num_leaves,
+                                uint64_t rowb, uint64_t L_own, rmi_hip_result* out) {
+  const unsigned long long epoch = ++m->epoch;
+  unsigned char* table = m->d_rows2 + (epoch & 1ull) * m->rows2_slot;
+  const uint64_t off = (uint64_t)m->rank * L_own * rowb;
+  m->rows_last_bytes = num_leaves * rowb;
+  void* const saved_ext = c->d_rows_ext;
+  c->d_rows_ext = table + off;
+  c->defer_sync = true;
+  int rc = rmi_hip_train_two_layer(c, root, leaf_kind, num_leaves, out);
+  c->defer_sync = false;
+  if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
+  HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+  // (peer pointers of this epoch's half: the tables hold the bases, the half is part of the byte offset)
+  const uint64_t n16 = L_own * rowb / 16;
+  const uint64_t byte_off = (epoch & 1ull) * m->rows2_slot + off;
+  hipLaunchKernelGGL(k_peer_push, dim3(512), dim3(256), 0, c->stream, (const uint4*)(table + off), n16, (unsigned char* const*)m->d_peer_rows, byte_off, m->rank, m->world);
+  hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, c->stream, (unsigned char* const*)m->d_peer_mail, (const unsigned long long*)&c->d_state->max_err, m->rank, m->world, epoch);
+  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, (unsigned long long*)m->d_mail, m->world, epoch, (unsigned long long*)m->d_stats_all, c->d_state);
+  HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, 40 * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
+  unsigned int* eflags = nullptr; (void)eflags;
+  HIPCHK(c, hipMemcpyAsync(&c->h_state->err_flags, &c->d_state->err_flags, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));   // (k_peer_wait may have raised the timeout)
+  HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->d_rows_ext = saved_ext;
+  if (c->h_state->err_flags & EF_PEER_TIMEOUT) { set_err(c, "direct exchange: a peer's flag of epoch %llu did not arrive within 5 s", epoch); return RMI_ERR_HIP; }
+  rc = finish_train(c, leaf_kind, num_leaves, out);
+  if (rc != RMI_OK) return rc;
+  { float xms = 0.f; if (hipEventElapsedTime(&xms, c->ev[7], c->ev[9]) == hipSuccess) out->kernel_ns[7] = (uint64_t)((double)xms * 1e6); }
+  unsigned long long mx = 0, mi = 0, sn = 0; double l2 = 0.0, lg = 0.0;
+  for (int r = 0; r < m->world; r++) {
+    unsigned long long v[3]; double d[2];
+    std::memcpy(v, m->h_stats_all + 40 * r, 24); std::memcpy(d, m->h_stats_all + 40 * r + 24, 16);
+    if (v[0] > mx || (v[0] == mx && v[1] >= mi)) { mx = v[0]; mi = v[1]; }
+    sn += v[2]; l2 += d[0]; lg += d[1];
+  }
+  const double ng = (double)c->shard.n;
+  out->model_max_error = mx; out->model_max_error_idx = mi;
+  out->model_avg_error = (double)sn / ng; out->model_avg_l2_error = l2; out->model_avg_log2_error = lg / ng;
+  out->model_max_log2_error = std::log2((double)mx);
   return RMI_OK;
 }
 
@@ -213,6 +323,10 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
   const uint64_t L_own = c->shard.leaf_hi - c->shard.leaf_lo;
   if (L_own * (uint64_t)m->world != num_leaves || c->shard.leaf_lo != (uint64_t)m->rank * L_own) return RMI_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  const bool direct = m->exchange == RMI_EXCHANGE_DIRECT && m->world > 1 && m->peers == m->world && m->rows2_slot >= num_leaves * rowb &&
+                      (L_own * rowb) % 16 == 0;
+  if (m->exchange == RMI_EXCHANGE_DIRECT && m->world > 1 && !direct) { set_err(c, "direct exchange: peers not imported (or another table size than exported)"); return RMI_ERR_BAD_ARG; }
+  if (direct) return train_sharded_direct(c, m, root, leaf_kind, num_leaves, rowb, L_own, out);
   if (m->rows_full_bytes < num_leaves * rowb) {
     if (m->d_rows_full) (void)hipFree(m->d_rows_full);
     m->d_rows_full = nullptr; m->rows_full_bytes = 0;
@@ -370,14 +484,76 @@ int rmi_hip_train_streamed(rmi_hip_ctx* c, const void* host_keys, uint64_t n, in
   return finish_train(c, leaf_kind, num_leaves, out);
 }
 
-void* rmi_hip_device_rows_full(rmi_hip_ctx* c) { return c ? multi_of(c)->d_rows_full : nullptr; }
+void* rmi_hip_device_rows_full(rmi_hip_ctx* c) {
+  if (!c) return nullptr;
+  rmi_hip_multi* m = multi_of(c);
+  if (m->exchange == RMI_EXCHANGE_DIRECT && m->d_rows2 && m->epoch) return m->d_rows2 + (m->epoch & 1ull) * m->rows2_slot;
+  return m->d_rows_full;
+}
+
+int rmi_hip_peer_export(rmi_hip_ctx* c, int rank, int world, int leaf_kind, uint64_t num_leaves, void* handle_out) {
+  if (!c || !handle_out || world < 1 || world > 64 || rank < 0 || rank >= world || num_leaves == 0) return RMI_ERR_BAD_ARG;
+  rmi_hip_multi* m = multi_of(c);
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t rowb = (leaf_kind == RMI_MODEL_CUBIC ? 4 : 2) * 8 + 8;
+  const uint64_t slot = ((num_leaves * rowb + 255) / 256) * 256;
+  if (m->d_rows2 && m->rows2_slot != slot) return RMI_ERR_BAD_ARG;     // (one table size per context: the peers hold mappings of it)
+  if (!m->d_rows2) {
+    HIPCHK(c, hipMalloc(&m->d_rows2, 2 * slot));
+    m->rows2_slot = slot;
+    HIPCHK(c, hipExtMallocWithFlags((void**)&m->d_mail, RMI_MAIL_BYTES, hipDeviceMallocFinegrained));
+    HIPCHK(c, hipMemset(m->d_mail, 0, RMI_MAIL_BYTES));
+    HIPCHK(c, hipMalloc(&m->d_peer_rows, 64 * sizeof(void*)));
+    HIPCHK(c, hipMalloc(&m->d_peer_mail, 64 * sizeof(void*)));
+    if (!m->d_stats_all) {
+      HIPCHK(c, hipMalloc(&m->d_stats_all, 40 * 64));
+      HIPCHK(c, hipHostMalloc((void**)&m->h_stats_all, 40 * 64, hipHostMallocDefault));
+    }
+  }
+  m->rank = rank; m->world = world;
+  m->peer_rows[rank] = m->d_rows2; m->peer_mail[rank] = m->d_mail;
+  if (!m->peer_open[rank]) { m->peer_open[rank] = true; m->peers++; }
+  rmi_peer_handle h; std::memset(&h, 0, sizeof h);
+  HIPCHK(c, hipIpcGetMemHandle(&h.rows, m->d_rows2));
+  HIPCHK(c, hipIpcGetMemHandle(&h.mail, m->d_mail));
+  h.slot_bytes = slot; h.rank = rank; h.world = world;
+  std::memset(handle_out, 0, RMI_HIP_PEER_HANDLE_BYTES);
+  std::memcpy(handle_out, &h, sizeof h);
+  return RMI_OK;
+}
+
+int rmi_hip_peer_import(rmi_hip_ctx* c, int peer_rank, const void* handle) {
+  if (!c || !handle) return RMI_ERR_BAD_ARG;
+  rmi_hip_multi* m = multi_of(c);
+  rmi_peer_handle h; std::memcpy(&h, handle, sizeof h);
+  if (!m->d_rows2 || peer_rank < 0 || peer_rank >= m->world || h.rank != peer_rank || h.world != m->world || h.slot_bytes != m->rows2_slot) return RMI_ERR_BAD_ARG;
+  if (peer_rank == m->rank || m->peer_open[peer_rank]) return RMI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  void* pr = nullptr; void* pm = nullptr;
+  HIPCHK(c, hipIpcOpenMemHandle(&pr, h.rows, hipIpcMemLazyEnablePeerAccess));
+  HIPCHK(c, hipIpcOpenMemHandle(&pm, h.mail, hipIpcMemLazyEnablePeerAccess));
+  m->peer_rows[peer_rank] = (unsigned char*)pr; m->peer_mail[peer_rank] = (unsigned char*)pm;
+  m->peer_open[peer_rank] = true; m->peers++;
+  if (m->peers == m->world) {
+    HIPCHK(c, hipMemcpy(m->d_peer_rows, m->peer_rows, 64 * sizeof(void*), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(m->d_peer_mail, m->peer_mail, 64 * sizeof(void*), hipMemcpyHostToDevice));
+  }
+  return RMI_OK;
+}
+
+int rmi_hip_set_exchange(rmi_hip_ctx* c, int mode) {
+  if (!c || (mode != RMI_EXCHANGE_RCCL && mode != RMI_EXCHANGE_DIRECT)) return RMI_ERR_BAD_ARG;
+  multi_of(c)->exchange = mode;
+  return RMI_OK;
+}
 
 int rmi_hip_download_rows_full(rmi_hip_ctx* c, void* host_out, uint64_t capacity_bytes) {
   if (!c || !host_out) return RMI_ERR_BAD_ARG;
   rmi_hip_multi* m = multi_of(c);
-  if (!m->d_rows_full || !m->rows_last_bytes || capacity_bytes < m->rows_last_bytes) return RMI_ERR_BAD_ARG;   // (the table of the LAST training, not the high-water allocation)
+  const unsigned char* table = (const unsigned char*)rmi_hip_device_rows_full(c);
+  if (!table || !m->rows_last_bytes || capacity_bytes < m->rows_last_bytes) return RMI_ERR_BAD_ARG;   // (the table of the LAST training, not the high-water allocation)
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(host_out, m->d_rows_full, m->rows_last_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host_out, table, m->rows_last_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return RMI_OK;
 }

@@ -184,7 +184,7 @@ class ShardedTrainer:
     (functional tests without RCCL) the rows are exchanged through torch instead."""
 
     def __init__(self, tr: T.Trainer, dist, rank: int, world: int, dataset: str, np_dtype,
-                 n_global: int, num_leaves: int, spec: str, chunk: int = 50_000_000, fit_mode: int = 0):
+                 n_global: int, num_leaves: int, spec: str, chunk: int = 50_000_000, fit_mode: int = 0, exchange: str = "rccl"):
         import torch
         self.tr, self.dist, self.rank, self.world = tr, dist, rank, world
         self.n_global, self.L = n_global, num_leaves
@@ -250,7 +250,29 @@ class ShardedTrainer:
         self.row_bytes = 24 if self.leaf_kind != 2 else 40
         # ---- communicator: rank 0 makes the id, torch carries the 128 bytes ----
         self.exchange = "library (ncclAllGather in rmi_hip_train_sharded)"
-        if self.on_gpu:
+        self.auto_report = None
+        self._torch = torch
+
+        def setup_direct():
+            # peer stores over xGMI (rmi_hip_peer_export / _import): needs no RCCL; torch.distributed carries the handles
+            hb = (C.c_ubyte * _lib.PEER_HANDLE_BYTES)()
+            T._check(lib.rmi_hip_peer_export(tr._h, rank, world, self.leaf_kind, num_leaves, hb), tr._h)
+            mine = torch.tensor(list(hb), dtype=torch.uint8, device=dev)
+            allh = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allh, mine)
+            for r in range(world):
+                pb = (C.c_ubyte * _lib.PEER_HANDLE_BYTES)(*allh[r].cpu().tolist())
+                T._check(lib.rmi_hip_peer_import(tr._h, r, pb), tr._h)
+
+        if exchange == "direct":
+            setup_direct()
+            T._check(lib.rmi_hip_set_exchange(tr._h, 1), tr._h)
+            self._shard_c = self.plan.c_struct()
+            T._check(lib.rmi_hip_set_shard(tr._h, C.byref(self._shard_c)), tr._h)
+            dist.barrier()
+            self.on_gpu = True
+            self.exchange = "library (direct peer stores into every rank's table + epoch flags: rmi_hip_peer_*)"
+        elif self.on_gpu:
             # the library's own communicator; should RCCL not be loadable or the communicator not come up on some rank, EVERY
             # rank falls back to torch.distributed's all-gather of device tensors (the kernels are the same)
             ok = torch.ones(1, dtype=torch.int32, device=dev)
@@ -274,12 +296,43 @@ class ShardedTrainer:
                 lib.rmi_hip_comm_destroy(tr._h)
                 self.on_gpu = False
                 self.exchange = "torch.distributed all_gather_into_tensor (the library's communicator did not come up)"
+        if exchange == "auto" and self.on_gpu and world > 1:
+            # A/B on the machine itself: the direct exchange is taken only if it completes, gives the SAME table as the
+            # RCCL exchange on every rank, and is faster (max over ranks of the median step)
+            rep = {"rccl_ms": None, "direct_ms": None, "same_table": None, "chosen": "rccl"}
+            try:
+                setup_direct()
+
+                def med(k=12):
+                    ts = []
+                    for _ in range(k):
+                        dist.barrier(); torch.cuda.synchronize()
+                        t1 = time.perf_counter(); self.step(); torch.cuda.synchronize()
+                        ts.append(time.perf_counter() - t1)
+                    v = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=dev)
+                    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+                    return float(v.item())
+                rep["rccl_ms"] = med() * 1e3
+                ref_rows = self.full_rows().copy()
+                T._check(lib.rmi_hip_set_exchange(tr._h, 1), tr._h)
+                rep["direct_ms"] = med() * 1e3
+                same = torch.tensor([1 if np.array_equal(ref_rows, self.full_rows()) else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                rep["same_table"] = bool(int(same.item()))
+                if rep["same_table"] and rep["direct_ms"] < rep["rccl_ms"]:
+                    rep["chosen"] = "direct"
+                    self.exchange = "library (direct peer stores: chosen by the A/B at start-up)"
+                else:
+                    T._check(lib.rmi_hip_set_exchange(tr._h, 0), tr._h)
+            except Exception as ex:                     # (a failure of the experimental path must not take the run down)
+                rep["error"] = str(ex)
+                lib.rmi_hip_set_exchange(tr._h, 0)
+            self.auto_report = rep
         if not self.on_gpu:
             per = (self.plan.leaf_hi - self.plan.leaf_lo) * self.row_bytes
             self._full = torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda")
             self._mine = torch.empty(per, dtype=torch.uint8, device="cuda")
             self._host = (torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8), torch.empty(per, dtype=torch.uint8))
-        self._torch = torch
 
     def step(self):
         """One training: when it returns, every rank holds the full row table (the step of SURVEY 8d for N > 1)."""

@@ -93,7 +93,7 @@ def test_sharded_matches_oracle(oracle):
     assert np.array_equal(full.last_layer_max_l1s, o.leaf_err)
 
 
-def _sharded_trainer_worker(rank, world, port, n_global, L, q):
+def _sharded_trainer_worker(rank, world, port, n_global, L, q, exchange="rccl"):
     import os
     import torch
     import torch.distributed as dist
@@ -103,12 +103,15 @@ def _sharded_trainer_worker(rank, world, port, n_global, L, q):
     torch.cuda.set_device(0)                                      # both ranks share the one GPU of the box
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tr = train.Trainer(device=0)
-    sh = sharded.ShardedTrainer(tr, dist, rank, world, "uniform", np.uint64, n_global, L, "linear,linear", chunk=700_000)
+    sh = sharded.ShardedTrainer(tr, dist, rank, world, "uniform", np.uint64, n_global, L, "linear,linear", chunk=700_000, exchange=exchange)
     sh.step()
     sh.step()                                                     # (a second step re-uses every buffer)
+    if exchange == "direct":
+        sh.step()                                                 # (direct exchange: both halves of the double-buffered table)
+        dist.barrier()
     rows = sh.full_rows().copy()
     ok = True
-    if rank == 0:                                                 # against the unsharded result on the same keys
+    if rank == 0 or exchange == "direct":                         # against the unsharded result on the same keys
         t1 = train.Trainer(device=0)
         t1.generate_keys("uniform", np.uint64, n_global)
         ref = t1.train("linear,linear", L)
@@ -137,7 +140,26 @@ def test_sharded_trainer_two_ranks_one_gpu():
     assert sorted(res) == [(0, True), (1, True)]
 
 
-def _rccl_worker(rank, world, port, n_global, L, mode, q):
+def test_sharded_direct_exchange_two_ranks_one_gpu():
+    """The exchange as peer stores (rmi_hip_peer_export / _import, RMI_EXCHANGE_DIRECT): two processes on the one GPU of the
+    box map each other's row table and mailbox through IPC handles, every rank stores its slice into the other's table,
+    publishes aggregates + epoch flag, waits for the peers' flags.  Every rank ends with the byte-identical table of the
+    unsharded run (three steps: both halves of the double buffer).  Across devices this path has not run yet."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_trainer_worker, args=(r, 2, port, 2_000_000, 8192, q, "direct")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def _rccl_worker(rank, world, port, n_global, L, mode, q, exchange="rccl"):
     """The N>1 path through the C ABI only: rmi_hip_plan_shards, rmi_hip_comm_init, rmi_hip_train_sharded (kernels +
     ncclAllGather on the library's stream).  torch.distributed carries the communicator id and the root parameters."""
     import os
@@ -146,11 +168,20 @@ def _rccl_worker(rank, world, port, n_global, L, mode, q):
     from rmi_amd import sharded, train
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        os.environ.setdefault("NCCL_DEBUG", "INFO")               # (the first multi-GPU run logs which algorithm RCCL picks)
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL")
     dev = rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
     tr = train.Trainer(device=dev)
-    sh = sharded.ShardedTrainer(tr, dist, rank, world, "uniform", np.uint64, n_global, L, "linear,linear", chunk=700_000, fit_mode=mode)
+    sh = sharded.ShardedTrainer(tr, dist, rank, world, "uniform", np.uint64, n_global, L, "linear,linear", chunk=700_000, fit_mode=mode, exchange=exchange)
+    import ctypes as C
+    cw, cr = C.c_int(), C.c_int()
+    assert tr._lib.rmi_hip_comm_info(tr._h, C.byref(cw), C.byref(cr)) == 0
+    info_ok = (cw.value, cr.value) == (world, rank) or exchange == "direct"     # the communicator itself counts `world` ranks
+    if sh.auto_report is not None:
+        print(f"[rank {rank}] exchange A/B: {sh.auto_report}", flush=True)
     res = None
     for _ in range(3):                                            # (later steps re-use every buffer)
         res = sh.step()
@@ -160,7 +191,7 @@ def _rccl_worker(rank, world, port, n_global, L, mode, q):
     ref = t1.train("linear,linear", L)
     ref_rows = ref.rows.view(np.uint64).reshape(L, 3)
     got = rows.view(np.uint64).reshape(L, 3)
-    ok = bool(np.array_equal(got[:, 2], ref_rows[:, 2])) and ref.root.p == sh.root.p        # error integers: always
+    ok = info_ok and bool(np.array_equal(got[:, 2], ref_rows[:, 2])) and ref.root.p == sh.root.p        # error integers: always
     if mode == 0:
         ok = ok and bool(np.array_equal(got, ref_rows))                                     # exact mode: byte-identical table
     ok = ok and int(res.model_max_error) == ref.model_max_error and int(res.model_max_error_idx) == ref.model_max_error_idx
@@ -171,13 +202,13 @@ def _rccl_worker(rank, world, port, n_global, L, mode, q):
     dist.destroy_process_group()
 
 
-def _spawn(world, n_global, L, mode):
+def _spawn(world, n_global, L, mode, exchange="rccl"):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n_global, L, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n_global, L, mode, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -208,6 +239,16 @@ def test_train_sharded_rccl_two_ranks(mode):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     assert _spawn(2, 6_000_000, 8192, mode) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("exchange", ["direct", "auto"])
+def test_train_sharded_peer_stores_two_gpus(exchange):
+    """The direct exchange across two DEVICES (stores over xGMI into the peer's table, system-scope flags), and the A/B
+    against ncclAllGather that bench.py --exchange auto runs: wherever the box has two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    assert _spawn(2, 6_000_000, 8192, 0, exchange) == [(0, True), (1, True)]
 
 
 def test_upload_overlaps_the_host_root_fit(oracle):
