@@ -941,7 +941,7 @@ static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   HIPCHK(c, hipMalloc(&c->d_count, L * 8));
   HIPCHK(c, hipMalloc(&c->d_rows, L * (ppl * 8 + 8)));
   HIPCHK(c, hipMalloc(&c->d_tilemin, ((L + 1 + FILL_TILE - 1) / FILL_TILE + 1) * 8));
-  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 63) / 64 + 2 * FL_BLOCKS + 1)));   // (per block of k_finalize, or per wave of k_leaf_lanes + per block of k_finalize_listed)
+  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 63) / 64 + SG_REGIONS + 2 * FL_BLOCKS + 1)));   // (per block of k_finalize, or per wave of k_leaf_lanes + per block of k_finalize_listed)
   c->cap_leaves = L; c->cap_ppl = ppl;
   return RMI_OK;
 }
@@ -1155,12 +1155,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run,
                          giants ? c->d_giant : (GiantLeaf*)nullptr, giants ? (unsigned long long)c->host_min : ~0ull);
       mark();
-      hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
+      // (waves' aggregate records: [0, wb); their 64 slice sums, by k_list_tail: [wb, wb + 64); the records of k_finalize_listed behind)
+      hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run,
+                         lanes_fused ? (const StatsPartial*)c->d_partials : (const StatsPartial*)nullptr, (unsigned int)wb, c->d_partials + wb);
       mark();
       if (lanes_fused) {
         // --- the listed leaves' share of the finalize, the first level of the aggregates, then the result record ---
-        hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, params, maxerr, run, err, count, rows,
-                           fl, c->d_partials, (unsigned int)wb, c->d_partials + wb, c->d_flist_cnt + 2 * SG_REGIONS, c->d_state,
+        hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(FL_THREADS), 0, s, keys, sp, L, leaf_start, c->d_state, params, maxerr, run, err, count, rows,
+                           fl, c->d_partials + wb, (unsigned int)SG_REGIONS, c->d_partials + wb + SG_REGIONS, c->d_flist_cnt + 2 * SG_REGIONS, c->d_state,
                            c->h_state_dev + (c->stream_mode ? c->stream_slot : 0), (const GiantLeaf*)nullptr, giants ? (unsigned long long)c->host_min : ~0ull);
       }
     }
@@ -1364,8 +1366,8 @@ static int giant_epilogue(rmi_hip_ctx* c) {
   SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
   hipLaunchKernelGGL(k_giant_segments, dim3(16), dim3(64), 0, s, c->d_giant, c->lp.leaf_start, c->d_state, c->d_segs, c->lp.maxerr, c->lp.run);
   hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, c->lp.sp, c->lp.leaf_start, c->d_state, c->lp.params, fl, c->d_segs, c->lp.maxerr, c->lp.run);
-  StatsPartial* first = c->d_partials + c->lp.waves;                 // the records of the launch's own k_finalize_listed
-  hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(256), 0, s, keys, c->lp.sp, c->lp.L, c->lp.leaf_start, c->d_state, c->lp.params,
+  StatsPartial* first = c->d_partials + c->lp.waves + SG_REGIONS;    // the records of the launch's own k_finalize_listed
+  hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(FL_THREADS), 0, s, keys, c->lp.sp, c->lp.L, c->lp.leaf_start, c->d_state, c->lp.params,
                      c->lp.maxerr, c->lp.run, c->lp.err, c->lp.count, c->lp.rows, fl, first, (unsigned int)FL_BLOCKS, first + FL_BLOCKS,
                      c->d_flist_cnt + 2 * SG_REGIONS, c->d_state, c->h_state_dev, (const GiantLeaf*)c->d_giant, ~0ull);
   HIPCHK(c, hipEventRecord(c->ev[9], s));                            // (the device time of the call covers the epilogue, host fit included)

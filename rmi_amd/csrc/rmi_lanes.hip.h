@@ -584,9 +584,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
 // kernels (fitted and measured by k_list / k_list_tail) -- and the first level of the aggregates: block b also
 // combines its slice of the waves' partial records, so that k_stats_reduce reads FL_BLOCKS records.
 // ---------------------------------------------------------------------------------------------
-constexpr int FL_BLOCKS = 64;
+constexpr int FL_BLOCKS = 1;        // one block of 1024 threads: no arrival counter, no device-scope fence (64 blocks + ticket: 15 us)
+constexpr int FL_THREADS = 1024;
 template <typename K>
-__global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ keys, Span sp, uint64_t L,
+__global__ void __launch_bounds__(FL_THREADS) k_finalize_listed(const K* __restrict__ keys, Span sp, uint64_t L,
                                                          const unsigned long long* __restrict__ leaf_start,
                                                          const DevState* __restrict__ st, double* __restrict__ params,
                                                          const unsigned long long* __restrict__ leaf_maxerr,
@@ -600,7 +601,7 @@ __global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ k
                                                          const GiantLeaf* __restrict__ flat, unsigned long long host_min) {
   unsigned long long mx = 0, mi = 0, sm = 0;
   double l2 = 0.0, lg = 0.0;
-  const unsigned int gid = blockIdx.x * 256u + threadIdx.x, gsz = gridDim.x * 256u;
+  const unsigned int gid = blockIdx.x * (unsigned int)FL_THREADS + threadIdx.x, gsz = gridDim.x * (unsigned int)FL_THREADS;
   // `flat` (the giant-leaf epilogue): the leaves of that array, fitted by the host meanwhile; else the regions of the
   // list, without the leaves k_list left to the host (the same test as there)
   const int nreg = flat ? 1 : SG_REGIONS;
@@ -639,24 +640,26 @@ __global__ void __launch_bounds__(256) k_finalize_listed(const K* __restrict__ k
     if (p.mx > mx || (p.mx == mx && p.mi > mi)) { mx = p.mx; mi = p.mi; }
     sm += p.sum; l2 += p.l2; lg += p.lg;
   }
-  stats_block_reduce(mx, mi, sm, l2, lg);
-  // the last block to arrive combines the FL_BLOCKS records (64 arrivals on one counter: ~2 us; a launch of its own: ~5)
-  __shared__ bool last;
-  if (threadIdx.x == 0) {
-    out[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
+  stats_block_reduce<FL_THREADS>(mx, mi, sm, l2, lg);
+  if (threadIdx.x == 0) out[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};   // (read again by the giant-leaf epilogue)
+  if (gridDim.x > 1) {
+    // several blocks: the last one to arrive combines their records
+    __shared__ bool last;
+    if (threadIdx.x == 0) {
+      __threadfence();
+      last = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull;
+    }
+    __syncthreads();
+    if (!last) return;
     __threadfence();
-    last = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull;
+    mx = 0; mi = 0; sm = 0; l2 = 0.0; lg = 0.0;
+    if (threadIdx.x < gridDim.x) {
+      const volatile StatsPartial* vo = out;
+      mx = vo[threadIdx.x].mx; mi = vo[threadIdx.x].mi; sm = vo[threadIdx.x].sum; l2 = vo[threadIdx.x].l2; lg = vo[threadIdx.x].lg;
+    }
+    __syncthreads();                                                 // (stats_block_reduce reuses its LDS arrays)
+    stats_block_reduce<FL_THREADS>(mx, mi, sm, l2, lg);
   }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  mx = 0; mi = 0; sm = 0; l2 = 0.0; lg = 0.0;
-  if (threadIdx.x < gridDim.x) {
-    const volatile StatsPartial* vo = out;
-    mx = vo[threadIdx.x].mx; mi = vo[threadIdx.x].mi; sm = vo[threadIdx.x].sum; l2 = vo[threadIdx.x].l2; lg = vo[threadIdx.x].lg;
-  }
-  __syncthreads();                                                   // (stats_block_reduce reuses its LDS arrays)
-  stats_block_reduce(mx, mi, sm, l2, lg);
   if (threadIdx.x == 0) {
     stw->max_err = mx; stw->max_err_idx = mi; stw->sum_n_err = sm; stw->sum_l2 = l2; stw->sum_log2 = lg;
     if (host_copy) *host_copy = *stw;                                // pinned host memory: visible to the host once the stream is synchronised

@@ -254,9 +254,33 @@ template <typename K>
 __global__ void __launch_bounds__(64) k_list_tail(const K* __restrict__ keys, Span sp,
                                                   const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
                                                   const double* __restrict__ params, SgList fl, const unsigned long long* __restrict__ segs,
-                                                  unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
+                                                  unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run,
+                                                  const StatsPartial* __restrict__ wave_partials = nullptr, unsigned int nwave = 0,
+                                                  StatsPartial* __restrict__ slice_out = nullptr) {
   constexpr int U = 8;
   const int lane = threadIdx.x;
+  // (leaf-lane pipeline: this launch exists anyway -- its first SG_REGIONS blocks also combine the aggregate records of
+  //  k_leaf_lanes' waves, a slice each, so that the single block of k_finalize_listed reads 64 records instead of L / 64)
+  if (wave_partials != nullptr && blockIdx.x < (unsigned)SG_REGIONS) {
+    const unsigned int per = (nwave + SG_REGIONS - 1) / SG_REGIONS;
+    const unsigned int a = blockIdx.x * per, b = a + per < nwave ? a + per : nwave;
+    unsigned long long mx = 0, mi = 0, sm = 0;
+    double l2 = 0.0, lg = 0.0;
+    for (unsigned int q = a + (unsigned int)lane; q < b; q += 64u) {
+      const StatsPartial p = wave_partials[q];
+      if (p.mx > mx || (p.mx == mx && p.mi > mi)) { mx = p.mx; mi = p.mi; }
+      sm += p.sum; l2 += p.l2; lg += p.lg;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const unsigned long long omx = shfl_down_u64(mx, d), omi = shfl_down_u64(mi, d);
+      if (omx > mx || (omx == mx && omi > mi)) { mx = omx; mi = omi; }
+      sm += shfl_down_u64(sm, d);
+      l2 += __shfl_down(l2, d);
+      lg += __shfl_down(lg, d);
+    }
+    if (lane == 0) slice_out[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
+  }
   if (blockIdx.x == 0) {
     unsigned long long a = fl.cnt[lane] < fl.cap ? fl.cnt[lane] : fl.cap, m = fl.cnt[SG_REGIONS + lane];
 #pragma unroll
