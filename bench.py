@@ -385,14 +385,14 @@ def main():
             out["per_rank"] = per_rank
             if getattr(sh, "auto_report", None):
                 out["exchange_ab"] = sh.auto_report
-        tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_r03_%s.json" % ("exact" if not used else "onepass_guarded"))
         if os.path.exists(tpath) and world == 1 and args.config == "M":
             try:
                 tj = json.load(open(tpath))
                 ent = tj.get(names[dom], {})
                 out["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
                 out["roofline"]["traffic_note"] = "NOT measured in this run: rocprofv3 FETCH_SIZE/WRITE_SIZE of the same command, from " \
-                                                  "profiles/traffic_r03.json (" + str(tj.get("note", "")) + ")"
+                                                  + os.path.relpath(tpath, ROOT) + " (" + str(tj.get("note", "")) + ")"
             except Exception:
                 pass
 
@@ -429,6 +429,36 @@ def main():
                                      "frac": frac_of(n_global, key_bytes, L_global, row_bytes, d_s),
                                      "note": "the same step with rmi_hip_set_fit_mode(RMI_FIT_EXACT): coefficients bit-identical"}
                 tr.set_fit_mode(mode)
+            # two trainings in flight on the one resident key set (two contexts / streams, one host thread each -- how the
+            # optimizer issues its configurations, optimizer.rs:220-231): the host's turn-around between trainings and the
+            # short kernels at both ends of one training hide behind the other's
+            try:
+                import threading
+                views = [tr.view(), tr.view()]
+                for v in views:
+                    v.set_fit_mode(mode)
+                    v.train_leaves(root, leaf_kind, L_global)
+                torch.cuda.synchronize()
+                per = 50
+
+                def work(v):
+                    for _ in range(per):
+                        v.train_leaves(root, leaf_kind, L_global)
+                th = [threading.Thread(target=work, args=(v,)) for v in views]
+                t0 = time.perf_counter()
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / (2 * per)
+                out["two_in_flight"] = {"value": n_global / dt, "unit": "keys/s", "ms_per_training": dt * 1e3,
+                                        "note": "throughput with two independent trainings in flight on the same resident keys; a side figure, "
+                                                "not `value` (a step of `value` is one training at a time)"}
+                for v in views:
+                    v.close()
+            except Exception as ex:
+                out["two_in_flight"] = {"error": str(ex)}
             # The boundary also takes host buffers: the PCIe-inclusive rate of "pageable host keys -> HBM -> the leaf path",
             # (a) plain: rmi_hip_upload_keys (one hipMemcpy) then one step; (b) rmi_hip_train_streamed: chunked upload
             # through pinned staging buffers, every leaf-aligned shard trained behind the upload of the following ones.

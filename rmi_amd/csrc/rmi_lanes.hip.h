@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
 // combines its slice of the waves' partial records, so that k_stats_reduce reads FL_BLOCKS records.
 // ---------------------------------------------------------------------------------------------
 constexpr int FL_BLOCKS = 1;        // one block of 1024 threads: no arrival counter, no device-scope fence (64 blocks + ticket: 15 us)
-constexpr int FL_THREADS = 1024;
+constexpr int FL_THREADS = 256;
 template <typename K>
 __global__ void __launch_bounds__(FL_THREADS) k_finalize_listed(const K* __restrict__ keys, Span sp, uint64_t L,
                                                          const unsigned long long* __restrict__ leaf_start,
