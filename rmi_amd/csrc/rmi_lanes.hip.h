@@ -56,10 +56,16 @@
 
 namespace rmi {
 
-constexpr int LN_ROW = 16;        // keys per panel row = lockstep steps per panel = one aligned 128-byte line of 8-byte keys
-constexpr int LN_RING = 32;       // LDS slots per row: two aligned panels (a lane's 16 steps straddle two of them)
-constexpr int LN_MIRROR = 7;      // the first slots once more behind the ring: 8 consecutive reads never wrap
-constexpr int LN_STRIDE = LN_RING + LN_MIRROR;   // 39, odd: lane-per-row reads spread over the banks
+#ifndef RMI_LN_ROW
+#define RMI_LN_ROW 16
+#endif
+constexpr int LN_ROW = RMI_LN_ROW;               // keys per panel row = lockstep steps per panel: 16 = one aligned 128-byte line of 8-byte keys; 8 = half a line
+constexpr int LN_RING = 2 * LN_ROW;              // LDS slots per row: two aligned panels (a lane's steps straddle two of them)
+constexpr int LN_MIRROR = 7;                     // the first slots once more behind the ring: 8 consecutive reads never wrap
+constexpr int LN_STRIDE = LN_RING + LN_MIRROR;   // 39 (23), odd: lane-per-row reads spread over the banks
+constexpr int LN_LPR = LN_ROW / 2;               // lanes per row and load (2 keys each) == loads per panel
+constexpr int LN_RPI = 64 / LN_LPR;              // rows per load instruction
+static_assert(LN_ROW == 16 || LN_ROW == 8, "panel geometry");
 constexpr int LN_LONG_MAX = 8192; // longest container the lockstep walk takes (longer: the list kernels, one wave per leaf)
 constexpr int LN_TMAX = LN_LONG_MAX + 64;   // entries of the reciprocal table
 constexpr int LS_BLOCK = 256;     // leaves per block of k_leaf_search
@@ -217,7 +223,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
                                                    unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr) {
   using B = typename LnBits<K>::type;
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
-  constexpr int LPR = 8;                                              // lanes per row (2 keys each)
+  constexpr int LPR = LN_LPR, NLD = LN_LPR, RPI = LN_RPI;            // lanes per row (2 keys each), loads per panel, rows per load
+  constexpr unsigned int ROWK = (unsigned int)LN_ROW;
   __shared__ B panel[64 * LN_STRIDE];                                 // 19 968 B for 8-byte keys: 8 waves per CU
   unsigned int* const s_off = reinterpret_cast<unsigned int*>(panel);   // (row descriptors of a phase: exchanged before its first panel is staged)
   unsigned int* const s_end = s_off + 64;
@@ -265,15 +272,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   // issue of its loads -- 57 % of the wave time -- at 4.4 TB/s.)  A lane's key k then sits at ring slot (a + k) mod 32,
   // a = its row's offset inside its first chunk.  Every load is unconditional (the compiler counts them: NBUF panels
   // are in flight); a finished row keeps re-reading its last chunk.
-  unsigned int roff[8], rlim[8];
+  unsigned int roff[NLD], rlim[NLD];
   auto make_rows = [&](unsigned int my_off, unsigned int my_len) {   // my_off: relative to wb
     wave_sync();
-    s_off[lane] = my_off & ~15u;
-    s_end[lane] = (my_len ? my_off + my_len - 1u : my_off) & ~15u;
+    s_off[lane] = my_off & ~(ROWK - 1u);
+    s_end[lane] = (my_len ? my_off + my_len - 1u : my_off) & ~(ROWK - 1u);
     wave_sync();
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int row = i * 8 + lane / LPR;
+    for (int i = 0; i < NLD; i++) {
+      const int row = i * RPI + lane / LPR;
       const unsigned int piece = 2u * (unsigned int)(lane % LPR);
       roff[i] = (s_off[row] + piece) * (unsigned int)sizeof(K);       // byte offsets from kb: a scalar base + a 32-bit lane offset per load
       rlim[i] = (s_end[row] + piece) * (unsigned int)sizeof(K);
@@ -281,10 +288,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     wave_sync();                                                      // (the descriptors alias the panel)
   };
   constexpr int NBUF = RMI_LN_NBUF;
-  B bufs[NBUF][8][2];
-  auto load_panel = [&](B (&buf)[8][2], unsigned int p16, bool nt) {
+  B bufs[NBUF][NLD][2];
+  auto load_panel = [&](B (&buf)[NLD][2], unsigned int p16, bool nt) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < NLD; i++) {
       unsigned int off = roff[i] + p16 * (unsigned int)sizeof(K);
       off = off < rlim[i] ? off : rlim[i];
       typedef B vec_t __attribute__((ext_vector_type(2)));
@@ -294,19 +301,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     }
   };
   // aligned panel p goes to the ring slots [16 (p & 1), +16); an even panel's first slots once more behind the ring
-  auto stage = [&](B (&buf)[8][2], unsigned int p) {
-    const unsigned int sb = (p & 1u) * 16u;
+  auto stage = [&](B (&buf)[NLD][2], unsigned int p) {
+    const unsigned int sb = (p & 1u) * ROWK;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const unsigned int base = (unsigned int)(i * 8 + lane / LPR) * LN_STRIDE + sb + 2u * (unsigned int)(lane % LPR);
+    for (int i = 0; i < NLD; i++) {
+      const unsigned int base = (unsigned int)(i * RPI + lane / LPR) * LN_STRIDE + sb + 2u * (unsigned int)(lane % LPR);
       panel[base] = buf[i][0]; panel[base + 1] = buf[i][1];
     }
     if (sb == 0u) {
       const unsigned int piece = (unsigned int)(lane % LPR);
       if (piece < 4u) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const unsigned int base = (unsigned int)(i * 8 + lane / LPR) * LN_STRIDE + LN_RING + 2u * piece;
+        for (int i = 0; i < NLD; i++) {
+          const unsigned int base = (unsigned int)(i * RPI + lane / LPR) * LN_STRIDE + LN_RING + 2u * piece;
           panel[base] = buf[i][0];
           if (piece < 3u) panel[base + 1] = buf[i][1];
         }
@@ -336,9 +343,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   } else {
     // ---- linear leaves: lockstep walk of the containers
     make_rows(act ? (unsigned int)(lo - wb) : 0u, act ? npts : 0u);
-    const unsigned int a0 = act ? (unsigned int)(lo - wb) & 15u : 0u;   // ring slot of the container's first point
+    const unsigned int a0 = act ? (unsigned int)(lo - wb) & (ROWK - 1u) : 0u;   // ring slot of the container's first point
 #pragma unroll
-    for (int u = 0; u < NBUF; u++) load_panel(bufs[u], 16u * (unsigned int)u, RMI_LN_NT_FIT != 0);
+    for (int u = 0; u < NBUF; u++) load_panel(bufs[u], ROWK * (unsigned int)u, RMI_LN_NT_FIT != 0);
     uint64_t y0 = lo;
     if (act) y0 = first_occurrence(keys, lo, sp.rd_lo);               // FixDups offset of the container's first point
     const double y0f = (double)y0, lof = (double)lo;
@@ -347,13 +354,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     bool gen = false;                                                 // explicit my-chain (a duplicate key was met)
     // the 16 steps [p16, p16 + 16) of every lane: they read the aligned panels p16 / 16 (staged one trip ago) and
     // p16 / 16 + 1 (staged now, from `buf`, which is refilled with the panel NBUF further on)
-    auto fit_panel = [&](B (&buf)[8][2], unsigned int p16) {
+    auto fit_panel = [&](B (&buf)[NLD][2], unsigned int p16) {
       wave_sync();
-      stage(buf, p16 / 16u + 1u);
-      load_panel(buf, p16 + 16u * (unsigned int)(NBUF + 1), RMI_LN_NT_FIT != 0);
+      stage(buf, p16 / ROWK + 1u);
+      load_panel(buf, p16 + ROWK * (unsigned int)(NBUF + 1), RMI_LN_NT_FIT != 0);
       wave_sync();
 #pragma unroll
-      for (int hb = 0; hb < 2; hb++) {
+      for (int hb = 0; hb < LN_ROW / 8; hb++) {
         const unsigned int b0 = p16 + 8u * (unsigned int)hb;
         // wave-uniform operands of the 8 steps, through the scalar cache: RN(1 / k), k, (k - 1) / 2
         double rr[8], kq[8], hq[8];
@@ -361,7 +368,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
         for (int q = 0; q < 8; q++) { rr[q] = rtab[b0 + (unsigned int)q]; kq[q] = rtab[LN_TMAX + b0 + (unsigned int)q]; hq[q] = rtab[2 * LN_TMAX + b0 + (unsigned int)q]; }
         B kk[8];
         {
-          const unsigned int rb = (unsigned int)lane * LN_STRIDE + ((a0 + b0) & 31u);
+          const unsigned int rb = (unsigned int)lane * LN_STRIDE + ((a0 + b0) & (2u * ROWK - 1u));
 #pragma unroll
           for (int q = 0; q < 8; q++) kk[q] = panel[rb + (unsigned int)q];
         }
@@ -428,10 +435,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     //  in flight and waits for ALL of them at every panel -- vmcnt(7..0) instead of vmcnt(23..16) -- i.e. no prefetch)
     wave_sync();
     stage(bufs[0], 0u);
-    load_panel(bufs[0], 16u * (unsigned int)NBUF, RMI_LN_NT_FIT != 0);
-    for (unsigned int p16 = 0; __any(act && p16 < npts); p16 += 16u * (unsigned int)NBUF) {
+    load_panel(bufs[0], ROWK * (unsigned int)NBUF, RMI_LN_NT_FIT != 0);
+    for (unsigned int p16 = 0; __any(act && p16 < npts); p16 += ROWK * (unsigned int)NBUF) {
 #pragma unroll
-      for (int u = 0; u < NBUF; u++) fit_panel(bufs[(u + 1) % NBUF], p16 + 16u * (unsigned int)u);
+      for (int u = 0; u < NBUF; u++) fit_panel(bufs[(u + 1) % NBUF], p16 + ROWK * (unsigned int)u);
     }
     // ---- the container's last item once more (Q1, models/mod.rs:180), then linear.rs:36-58
     if (act) {
@@ -457,24 +464,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     const bool eact = valid && !handed && e > s;
     const unsigned int len = eact ? (unsigned int)(e - s) : 0u;
     make_rows(eact ? (unsigned int)(s - wb) : 0u, len);
-    const unsigned int a0 = eact ? (unsigned int)(s - wb) & 15u : 0u;
+    const unsigned int a0 = eact ? (unsigned int)(s - wb) & (ROWK - 1u) : 0u;
 #pragma unroll
-    for (int u = 0; u < NBUF; u++) load_panel(bufs[u], 16u * (unsigned int)u, RMI_LN_NT_ERR != 0);
+    for (int u = 0; u < NBUF; u++) load_panel(bufs[u], ROWK * (unsigned int)u, RMI_LN_NT_ERR != 0);
     const unsigned int n32 = (unsigned int)sp.n, s32 = (unsigned int)s;
     unsigned int emax = 0u, run = 0u, yprev = s32;
     bool tr = false;                                                   // yprev is being tracked (a run of equal keys is open)
     B kprev = 0;
-    auto err_panel = [&](B (&buf)[8][2], unsigned int p16) {
+    auto err_panel = [&](B (&buf)[NLD][2], unsigned int p16) {
       wave_sync();
-      stage(buf, p16 / 16u + 1u);
-      load_panel(buf, p16 + 16u * (unsigned int)(NBUF + 1), RMI_LN_NT_ERR != 0);
+      stage(buf, p16 / ROWK + 1u);
+      load_panel(buf, p16 + ROWK * (unsigned int)(NBUF + 1), RMI_LN_NT_ERR != 0);
       wave_sync();
 #pragma unroll
-      for (int hb = 0; hb < 2; hb++) {
+      for (int hb = 0; hb < LN_ROW / 8; hb++) {
         const unsigned int b0 = p16 + 8u * (unsigned int)hb;
         B kk[8];
         {
-          const unsigned int rb = (unsigned int)lane * LN_STRIDE + ((a0 + b0) & 31u);
+          const unsigned int rb = (unsigned int)lane * LN_STRIDE + ((a0 + b0) & (2u * ROWK - 1u));
 #pragma unroll
           for (int q = 0; q < 8; q++) kk[q] = panel[rb + (unsigned int)q];
         }
@@ -538,10 +545,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     };
     wave_sync();
     stage(bufs[0], 0u);
-    load_panel(bufs[0], 16u * (unsigned int)NBUF, RMI_LN_NT_ERR != 0);
-    for (unsigned int p16 = 0; __any(p16 < len); p16 += 16u * (unsigned int)NBUF) {
+    load_panel(bufs[0], ROWK * (unsigned int)NBUF, RMI_LN_NT_ERR != 0);
+    for (unsigned int p16 = 0; __any(p16 < len); p16 += ROWK * (unsigned int)NBUF) {
 #pragma unroll
-      for (int u = 0; u < NBUF; u++) err_panel(bufs[(u + 1) % NBUF], p16 + 16u * (unsigned int)u);
+      for (int u = 0; u < NBUF; u++) err_panel(bufs[(u + 1) % NBUF], p16 + ROWK * (unsigned int)u);
     }
     // the key behind the leaf is a different one: it ends the run of the leaf's last key (the globally last run is
     // never recorded, Q5)
