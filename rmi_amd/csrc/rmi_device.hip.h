@@ -77,6 +77,9 @@ struct DevState {
   unsigned long long sum_n_err;     // sum(n*err) wrapping u64
   double sum_l2;                    // sum((n*err)^2 / N)
   double sum_log2;                  // sum(n * log2(2 err + 2))
+  // leaves k_leaf_lanes handed to the list kernels while the record was published WITHOUT them (k_lane_reduce): the host
+  // runs them behind its synchronisation (listed_epilogue); part of the record the ranks of a sharded training exchange
+  unsigned long long pending;
   // leaves too long for the lockstep pass (see k_fit_long): number of entries in the long list
   unsigned long long long_count;
   unsigned long long long_cap;

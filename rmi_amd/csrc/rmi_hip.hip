@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -68,6 +69,10 @@ struct rmi_hip_ctx {
   int stream_slot = 0;
   void* h_stage[2] = {nullptr, nullptr};        // pinned staging buffers of the chunked upload
   hipStream_t copy_stream = nullptr;
+  bool opt_tail = true;                         // k_lane_reduce publishes the result behind k_leaf_lanes; the list kernels run behind the synchronisation, and only if a leaf was handed over
+  bool tail_armed = false;
+  std::function<int()> tail_fn;                 // the list kernels + k_finalize_listed of the last launch (listed_epilogue)
+  unsigned int* d_tickets = nullptr;            // arrival counter of k_lane_reduce's blocks
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   hipEvent_t ev[10] = {};
   int profile_level = 0;                        // 0: whole call only; 1: + the first (dominant) kernel; 2: every kernel group
@@ -262,6 +267,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (pl && *pl) c->pipeline = std::atoi(pl);
   { const char* lf = std::getenv("RMI_HIP_LANES_FUSE"); if (lf && *lf) c->lanes_fuse = std::atoi(lf) != 0; }
   { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
+  { const char* otl = std::getenv("RMI_HIP_OPT_TAIL"); if (otl && *otl) c->opt_tail = std::atoi(otl) != 0; }
   { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
   { const char* sl = std::getenv("RMI_HIP_SPLINE_LANES"); if (sl && *sl) c->spline_lanes = std::atoi(sl) != 0; }
   if (hipMalloc(&c->d_lntab, sizeof(double) * (3 * LN_TMAX + 2 * (LS_SAMPLES + 1))) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
@@ -290,6 +296,7 @@ static void free_outputs(rmi_hip_ctx* c) {
   (void)hipFree(c->d_leaf_start); (void)hipFree(c->d_params); (void)hipFree(c->d_maxerr); (void)hipFree(c->d_run);
   (void)hipFree(c->d_err); (void)hipFree(c->d_count); (void)hipFree(c->d_rows); (void)hipFree(c->d_tilemin);
   (void)hipFree(c->d_partials); c->d_partials = nullptr;
+  (void)hipFree(c->d_tickets); c->d_tickets = nullptr;
   if (c->d_long) { (void)hipFree(c->d_long); c->d_long = nullptr; c->long_cap = 0; }
   if (c->d_cube) { (void)hipFree(c->d_cube); c->d_cube = nullptr; c->cube_cap = 0; }
   if (c->d_flist) { (void)hipFree(c->d_flist); c->d_flist = nullptr; c->flist_cap = 0; }
@@ -930,6 +937,7 @@ int rmi_hip_root_stream_finish(rmi_hip_root_stream* r, rmi_hip_model_params* out
 
 }  // extern "C"
 
+static inline uint64_t lane_slices(uint64_t leaves) { return ((leaves + 63) / 64 + LF_SLICE - 1) / LF_SLICE; }
 static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   if (L <= c->cap_leaves && ppl <= c->cap_ppl) return RMI_OK;
   free_outputs(c);
@@ -941,7 +949,10 @@ static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   HIPCHK(c, hipMalloc(&c->d_count, L * 8));
   HIPCHK(c, hipMalloc(&c->d_rows, L * (ppl * 8 + 8)));
   HIPCHK(c, hipMalloc(&c->d_tilemin, ((L + 1 + FILL_TILE - 1) / FILL_TILE + 1) * 8));
-  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 63) / 64 + SG_REGIONS + 2 * FL_BLOCKS + 1)));   // (per block of k_finalize, or per wave of k_leaf_lanes + per block of k_finalize_listed)
+  // (per block of k_finalize, or: per wave of k_leaf_lanes, the slice records of k_list_tail, the blocks of
+  //  k_finalize_listed, then the slice records of k_leaf_lanes' own reduction)
+  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 63) / 64 + SG_REGIONS + 2 * FL_BLOCKS + 1 + lane_slices(L) + 1)));
+  HIPCHK(c, hipMalloc(&c->d_tickets, 64));
   c->cap_leaves = L; c->cap_ppl = ppl;
   return RMI_OK;
 }
@@ -1062,11 +1073,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   }
   const bool init_arrays = !(lanes_fused_plan && lanes_search_plan);
   if (!c->stream_mode || c->stream_slot == 0) HIPCHK(c, hipEventRecord(c->ev[8], s));   // start of the device work of this call
-  {
+  // (the leaf-lane pipeline with its search and its fused error pass: the launch of k_leaf_samples carries the init)
+  const bool init_folded = !init_arrays && (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE);
+  if (!init_folded) {
     const uint64_t ib = init_arrays ? (L_own + 1 + 255) / 256 : 1;
     hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
                        L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS + 8, init_arrays);
   }
+  c->tail_armed = false; c->tail_fn = nullptr;
 
   auto ensure_lists = [&]() -> int {
     const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
@@ -1091,15 +1105,25 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       { const int lrc = ensure_lists(); if (lrc != RMI_OK) return lrc; }
       // --- leaf boundaries: lower bounds by search where the root is monotone by arithmetic, else the bucketing scan + fill ---
       bool searched = false;
+      const uint64_t wb = (L_own + 63) / 64;
+      const unsigned int nsl = (unsigned int)lane_slices(L_own);
+      // the result published by k_lane_reduce right behind k_leaf_lanes; the list kernels behind the synchronisation, if a leaf was handed over
+      const bool optimistic = lanes_fused_plan && c->opt_tail && !c->stream_mode;
       if constexpr (ROOT == K_LINEAR || ROOT == K_RADIX || ROOT == K_CUBIC) {
         if (lanes_search_plan) {
           const uint64_t sb = (L_own + LS_BLOCK - 1) / LS_BLOCK;
           double* smp = c->d_lntab + 3 * LN_TMAX;                       // 2 (LS_SAMPLES + 1) doubles behind the step tables
-          hipLaunchKernelGGL((k_leaf_samples<ROOT, K>), dim3((LS_SAMPLES + 256) / 256), dim3(256), 0, s, keys, sp, rp, smp);
+          LaneInit li; std::memset(&li, 0, sizeof li);
+          if (init_folded) {
+            li.st = c->d_state; li.init = init; li.leaf_start = a_leaf_start; li.L_own = L_own; li.sentinel = (unsigned long long)sp.it_hi;
+            li.list_cnt = c->d_flist_cnt; li.n_list_cnt = 2 * SG_REGIONS + 8; li.tickets = c->d_tickets; li.n_tickets = 1;
+          }
+          hipLaunchKernelGGL((k_leaf_samples<ROOT, K>), dim3((LS_SAMPLES + 256) / 256), dim3(256), 0, s, keys, sp, rp, smp, li);
           hipLaunchKernelGGL((k_leaf_search<ROOT, K>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state, (const double*)smp);
           searched = true;
         }
       }
+      if (optimistic && !(searched && init_folded)) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 4, s));
       if (!searched) {
         constexpr uint64_t V = 16 / sizeof(K);
         const uint64_t blocks = ((n_it + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
@@ -1129,42 +1153,57 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         c->lp.err = err; c->lp.count = count; c->lp.rows = rows; c->lp.waves = (L_own + 63) / 64;
       }
       const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
-      const uint64_t wb = (L_own + 63) / 64;
-      bool launched = false;
+      StatsPartial* const part = c->d_partials;
+      bool verify = false;
       if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR) {
         if (searched) {                                                 // (searched implies fused: the verification rides on the error pass)
           hipLaunchKernelGGL((k_leaf_lanes<K, true, K_LINEAR, K_CUBIC>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                             L, err, count, rows, c->d_partials, rp);
-          hipLaunchKernelGGL((k_verify_listed<K_CUBIC, K>), dim3(1024), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state, fl);
-          launched = true;
+                             L, err, count, rows, part, rp);
+          verify = true;
         }
       }
-      if (launched) {
+      if (verify) {
       } else if (lanes_fused)
         hipLaunchKernelGGL((k_leaf_lanes<K, true, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                           L, err, count, rows, c->d_partials, rp);
+                           L, err, count, rows, part, rp);
       else
         hipLaunchKernelGGL((k_leaf_lanes<K, false, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                           L, err, count, rows, c->d_partials, rp);
+                           L, err, count, rows, part, rp);
       mark();
-      // --- the leaves handed over (containers too long for the lockstep walk): one wave each, fit + error pass ---
+      // --- the leaves handed over (containers too long for the lockstep walk): one wave each, fit + error pass; the
+      //     listed leaves' share of the finalize, the aggregates, the result record ---
       SgParams sgp; std::memset(&sgp, 0, sizeof sgp);
       sgp.flist = fl; sgp.segs = c->d_segs; sgp.mode = 0; sgp.guard_k = c->guard_k;
       c->last_sg = sgp;
-      // (one wave per listed leaf wherever possible: on skewed keys thousands of leaves are listed and each is a sequential chain)
-      hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, sgp, maxerr, run,
-                         giants ? c->d_giant : (GiantLeaf*)nullptr, giants ? (unsigned long long)c->host_min : ~0ull);
-      mark();
-      // (waves' aggregate records: [0, wb); their 64 slice sums, by k_list_tail: [wb, wb + 64); the records of k_finalize_listed behind)
-      hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run,
-                         lanes_fused ? (const StatsPartial*)c->d_partials : (const StatsPartial*)nullptr, (unsigned int)wb, c->d_partials + wb);
-      mark();
-      if (lanes_fused) {
-        // --- the listed leaves' share of the finalize, the first level of the aggregates, then the result record ---
-        hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(FL_THREADS), 0, s, keys, sp, L, leaf_start, c->d_state, params, maxerr, run, err, count, rows,
-                           fl, c->d_partials + wb, (unsigned int)SG_REGIONS, c->d_partials + wb + SG_REGIONS, c->d_flist_cnt + 2 * SG_REGIONS, c->d_state,
-                           c->h_state_dev + (c->stream_mode ? c->stream_slot : 0), (const GiantLeaf*)nullptr, giants ? (unsigned long long)c->host_min : ~0ull);
-      }
+      unsigned long long* const segs = c->d_segs;
+      DevState* const dst = c->d_state;
+      unsigned long long* const fticket = c->d_flist_cnt + 2 * SG_REGIONS;
+      DevState* const hcopy = c->h_state_dev + (c->stream_mode ? c->stream_slot : 0);
+      GiantLeaf* const dgiant = giants ? c->d_giant : (GiantLeaf*)nullptr;
+      const unsigned long long hmin = giants ? (unsigned long long)c->host_min : ~0ull;
+      const bool fused = lanes_fused;
+      auto tail = [=](auto&& mk) {
+        if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR) {
+          if (verify) hipLaunchKernelGGL((k_verify_listed<K_CUBIC, K>), dim3(1024), dim3(256), 0, s, keys, sp, rp, leaf_start, dst, fl);
+        }
+        // (one wave per listed leaf wherever possible: on skewed keys thousands of leaves are listed and each is a sequential chain)
+        hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, dst, params, fl, sgp, maxerr, run, dgiant, hmin);
+        mk();
+        // (waves' aggregate records: [0, wb); their 64 slice sums, by k_list_tail: [wb, wb + 64); the records of k_finalize_listed behind)
+        hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, dst, params, fl, segs, maxerr, run,
+                           fused ? (const StatsPartial*)part : (const StatsPartial*)nullptr, (unsigned int)wb, part + wb);
+        mk();
+        if (fused)
+          hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(FL_THREADS), 0, s, keys, sp, L, leaf_start, dst, params, maxerr, run, err, count, rows,
+                             fl, part + wb, (unsigned int)SG_REGIONS, part + wb + SG_REGIONS, fticket, dst, hcopy, (const GiantLeaf*)nullptr, hmin);
+      };
+      if (optimistic) {
+        hipLaunchKernelGGL(k_lane_reduce, dim3(nsl), dim3(LF_SLICE), 0, s, (const StatsPartial*)part, (unsigned int)wb, part + wb + SG_REGIONS + 2 * FL_BLOCKS + 1,
+                           c->d_tickets, fl, dst, hcopy);
+        mark(); mark();
+        c->tail_armed = true;
+        c->tail_fn = [tail]() -> int { tail([]() {}); return RMI_OK; };
+      } else tail(mark);
     }
   } else if (pl >= 1) HIPCHK(c, hipEventRecord(c->ev[0], s));
   if (lanes) {
@@ -1456,6 +1495,18 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (rc) return rc;
   if (c->defer_sync) return RMI_OK;                            // (rmi_hip_train_sharded goes on from here)
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->tail_armed) {
+    // k_lane_reduce has published the result: final unless k_leaf_lanes handed leaves to the list kernels
+    c->tail_armed = false;
+    if (c->h_state->pending > 0) {
+      rc = c->tail_fn();
+      c->tail_fn = nullptr;
+      if (rc) return rc;
+      HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->tail_fn = nullptr;
+  }
   if (c->giant_armed && c->h_state->giant_count > 0 && !c->h_state->err_flags) {
     switch (c->dtype) {
       case RMI_KEY_U64: rc = giant_epilogue<uint64_t>(c); break;

@@ -111,9 +111,22 @@ __device__ __forceinline__ uint64_t ls_sample_index(uint64_t A, uint64_t Bn, int
   const uint64_t i = A + (uint64_t)t * stride;
   return (t >= LS_SAMPLES || i >= Bn) ? Bn - 1 : i;
 }
+// What k_init does for this pipeline (state, sentinel, list counters), and the arrival counters of k_leaf_lanes' waves:
+// carried by the launch of k_leaf_samples (one launch and one gap fewer in front of the search).
+struct LaneInit {
+  DevState* st; DevState init;
+  unsigned long long* leaf_start; uint64_t L_own; unsigned long long sentinel;
+  unsigned long long* list_cnt; int n_list_cnt;
+  unsigned int* tickets; unsigned int n_tickets;
+};
 template <int ROOT, typename K>
-__global__ void __launch_bounds__(256) k_leaf_samples(const K* __restrict__ keys, Span sp, RootP r, double* __restrict__ smp) {
+__global__ void __launch_bounds__(256) k_leaf_samples(const K* __restrict__ keys, Span sp, RootP r, double* __restrict__ smp, LaneInit li) {
   const int t = blockIdx.x * 256 + threadIdx.x;
+  if (li.st != nullptr && blockIdx.x == gridDim.x - 1) {
+    for (int q = threadIdx.x; q < li.n_list_cnt; q += 256) li.list_cnt[q] = 0ull;
+    for (unsigned int q = threadIdx.x; q < li.n_tickets; q += 256u) li.tickets[q] = 0u;
+    if (threadIdx.x == 0) { *li.st = li.init; li.leaf_start[li.L_own] = li.sentinel; }
+  }
   if (t > LS_SAMPLES || !(sp.it_hi > sp.it_lo)) return;
   const K k = keys[ls_sample_index(sp.it_lo, sp.it_hi, t)];
   bool oob;
@@ -129,9 +142,15 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
   const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * LS_BLOCK + threadIdx.x;
   const uint64_t A = sp.it_lo, Bn = sp.it_hi;
   auto tgt = [&](uint64_t i) -> double { bool oob; return root_target_f<ROOT, K>(r, Lm1f, keys[i], oob); };
+  // the sample table into LDS (16 KB: the occupancy stays at 8 waves per SIMD): the bracket search is 11 dependent reads,
+  // and the scattered probes of 8 192 resident waves keep evicting the table from the vector L1
+  __shared__ double t_tgt[LS_SAMPLES + 1], t_val[LS_SAMPLES + 1];
+  for (int t = threadIdx.x; t <= LS_SAMPLES; t += LS_BLOCK) { t_tgt[t] = smp[t]; t_val[t] = smp[LS_SAMPLES + 1 + t]; }
+  __syncthreads();
   if (j < sp.leaf_hi) {
     const double jf = (double)j;
     uint64_t lo = A, hi = Bn;                                        // the answer lies in [lo, hi]
+    double pv = 0.0;                                                 // unfloored root value of the first key of the last probe
     // pair probe at i (lo <= i < hi): narrows [lo, hi] by the keys i and i + 1
     auto probe = [&](uint64_t i) {
       typedef typename LnBits<K>::type BT;
@@ -144,9 +163,17 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
       bool oob;
       const bool b0 = root_target_f<ROOT, K>(r, Lm1f, k0, oob) < jf;
       const bool b1 = root_target_f<ROOT, K>(r, Lm1f, k1, oob) < jf;
+      pv = ls_root_value<ROOT, K>(r, k0);
       if (!b0) hi = i;
       else if (!b1 || i + 1 >= hi) { lo = i + 1; if (!b1) hi = i + 1; }
       else lo = i + 2 < hi ? i + 2 : hi;
+    };
+    // the pair (g - 1, g) around a guess g of the answer, kept inside the bracket
+    auto pair_at = [&](double gf) -> uint64_t {
+      uint64_t g = gf >= 1.0 ? (gf < 1.8e19 ? (uint64_t)gf - 1 : ~0ull - 1) : 0;
+      if (g < lo) g = lo;
+      if (g >= hi) g = hi - 1;
+      return g;
     };
     auto search_from = [&](uint64_t g, uint64_t d) {                 // first probe at g, first gallop step d
       if (!(lo < hi)) return;
@@ -177,18 +204,36 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
       }
     };
     if (Bn > A) {
-      // first sample whose target is >= j (the table is a few KB, read by every thread: cache resident)
+      // first sample whose target is >= j
       int a = 0, b = LS_SAMPLES + 1;
-      while (a < b) { const int m = (a + b) >> 1; if (smp[m] < jf) a = m + 1; else b = m; }
+      while (a < b) { const int m = (a + b) >> 1; if (t_tgt[m] < jf) a = m + 1; else b = m; }
       if (a == 0) hi = lo;                                           // the launch's first key is already in leaf j or behind it
       else if (a > LS_SAMPLES) lo = hi;                              // even the last key is below: no key reaches leaf j
       else {
         const uint64_t i1 = ls_sample_index(A, Bn, a - 1), i2 = ls_sample_index(A, Bn, a);
         lo = i1 + 1; hi = i2;                                        // key i1 is below, key i2 is not
-        const double f1 = smp[LS_SAMPLES + 1 + a - 1], f2 = smp[LS_SAMPLES + 1 + a];
-        double tq = (f2 > f1) ? (jf - f1) / (f2 - f1) : 0.5;
-        tq = tq < 0.0 ? 0.0 : (tq > 1.0 ? 1.0 : tq);
-        search_from(i1 + (uint64_t)(tq * (double)(i2 - i1)), 2);
+        // Interpolation on the unfloored values: from the table (off by ~sqrt(bracket) / 2 keys where the keys are locally
+        // uniform), then two secant steps from the values the probes see themselves (a few keys, then ~1), then gallop and
+        // bisect from there.  Only the comparisons of exact targets narrow [lo, hi]: the guesses place the probes.
+        const double f1 = t_val[a - 1], f2 = t_val[a];
+        const double slope = (f2 > f1) ? (double)(i2 - i1) / (f2 - f1) : 0.0;      // keys per unit of root value
+        double g1 = (f2 > f1) ? (double)i1 + (jf - f1) * slope : (double)i1 + 0.5 * (double)(i2 - i1);
+        if (lo < hi) {
+          const uint64_t q1 = pair_at(g1);
+          probe(q1);
+          if (lo < hi && slope > 0.0) {
+            const double v1 = pv;
+            const double g2 = (double)q1 + (jf - v1) * slope;
+            const uint64_t q2 = pair_at(g2 + 1.0);
+            probe(q2);
+            if (lo < hi) {
+              const double v2 = pv;
+              const double s2 = (q2 != q1 && v2 != v1) ? ((double)q2 - (double)q1) / (v2 - v1) : slope;
+              const double g3 = (double)q2 + (jf - v2) * ((s2 > 0.0 && s2 < 64.0 * slope) ? s2 : slope);
+              search_from(pair_at(g3 + 1.0), 2);
+            }
+          } else search_from(lo + ((hi - lo) >> 1), 2);
+        }
       }
     } else hi = lo;
     leaf_start[j] = (unsigned long long)lo;
@@ -230,7 +275,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   unsigned int* const s_end = s_off + 64;
 
   const int lane = threadIdx.x;
-  const uint64_t j0 = sp.leaf_lo + (uint64_t)blockIdx.x * 64;
+  const unsigned int wid = blockIdx.x;
+  const uint64_t j0 = sp.leaf_lo + (uint64_t)wid * 64;
   const uint64_t j = j0 + (uint64_t)lane;
   const bool valid = j < sp.leaf_hi;
   uint64_t s = 0, e = 0;
@@ -581,9 +627,90 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
       st_l2 += __shfl_down(st_l2, d);
       st_lg += __shfl_down(st_lg, d);
     }
-    if (lane == 0) partials[blockIdx.x] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
+    if (lane == 0) partials[wid] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
   }
   if (flags) atomicOr(&st->err_flags, flags);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lane_reduce: the aggregates of a training whose leaves were all finished by k_leaf_lanes, in ONE launch behind it
+// (instead of k_list + k_list_tail + k_finalize_listed: ~20 us + two gaps when nothing is listed).  Block b combines
+// the records of the waves [LF_SLICE b, LF_SLICE (b + 1)); the last block to arrive combines the slices and publishes
+// the result record -- FINAL when no leaf was handed to the list kernels (pending == 0; otherwise the host runs them
+// behind its synchronisation: listed_epilogue in rmi_hip.hip).
+// (Tried: every wave of k_leaf_lanes counts itself in and the last one reduces -- no launch at all, but a wave must
+//  wait for the acknowledgement of its stores before it may count itself in, ~3-4 us with its LDS still allocated:
+//  k_leaf_lanes 507 -> 540 us.)
+// Coherence across the XCDs' L2s: the slice records are written and read with agent-scope accesses (sc1: write-through
+// / miss-always), a block waits for its stores' acknowledgement (vmcnt) before its agent-scope ticket increment, and
+// the last block reads only behind its own increment.  The order of the sums is fixed by the indices: same bits every run.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned int LF_SLICE = 128;
+__device__ __forceinline__ void lf_store(StatsPartial* p, const StatsPartial& v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  __hip_atomic_store(q + 0, v.mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, v.mi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 2, v.sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 3, (unsigned long long)__double_as_longlong(v.l2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 4, (unsigned long long)__double_as_longlong(v.lg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ StatsPartial lf_load(const StatsPartial* p) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<StatsPartial*>(p));
+  StatsPartial v;
+  v.mx = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.mi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.sum = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.l2 = __longlong_as_double((long long)__hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  v.lg = __longlong_as_double((long long)__hip_atomic_load(q + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return v;
+}
+__device__ __forceinline__ void lf_combine(StatsPartial& a, const StatsPartial& p) {
+  if (p.mx > a.mx || (p.mx == a.mx && p.mi > a.mi)) { a.mx = p.mx; a.mi = p.mi; }
+  a.sum += p.sum; a.l2 += p.l2; a.lg += p.lg;
+}
+// the LF_SLICE threads' records combined in thread order (two waves: lanes by shuffles, then wave 1 behind wave 0)
+__device__ __forceinline__ void lf_block_reduce(StatsPartial& a, StatsPartial* s_w) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    StatsPartial o;
+    o.mx = shfl_down_u64(a.mx, d); o.mi = shfl_down_u64(a.mi, d); o.sum = shfl_down_u64(a.sum, d);
+    o.l2 = __shfl_down(a.l2, d); o.lg = __shfl_down(a.lg, d);
+    lf_combine(a, o);
+  }
+  __syncthreads();
+  if (threadIdx.x == 64) *s_w = a;
+  __syncthreads();
+  if (threadIdx.x == 0) lf_combine(a, *s_w);
+}
+__global__ void __launch_bounds__(LF_SLICE) k_lane_reduce(const StatsPartial* __restrict__ partials, unsigned int nwaves,
+                                                          StatsPartial* __restrict__ slices, unsigned int* __restrict__ ticket,
+                                                          SgList fl, DevState* __restrict__ st, DevState* __restrict__ host_copy) {
+  static_assert(LF_SLICE == 128 && SG_REGIONS == 64, "two waves per block; one hand-over counter per lane");
+  __shared__ StatsPartial s_w;
+  __shared__ bool s_last;
+  const unsigned int q = blockIdx.x * LF_SLICE + threadIdx.x;
+  StatsPartial a{0ull, 0ull, 0ull, 0.0, 0.0};
+  if (q < nwaves) a = partials[q];
+  lf_block_reduce(a, &s_w);
+  if (threadIdx.x == 0) {
+    lf_store(slices + blockIdx.x, a);
+    s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  StatsPartial b{0ull, 0ull, 0ull, 0.0, 0.0};
+  for (unsigned int t = threadIdx.x; t < gridDim.x; t += LF_SLICE) lf_combine(b, lf_load(slices + t));
+  lf_block_reduce(b, &s_w);
+  unsigned long long fc = threadIdx.x < (unsigned int)SG_REGIONS ? fl.cnt[threadIdx.x] : 0ull;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) fc += shfl_down_u64(fc, d);
+  if (threadIdx.x == 0) {
+    *ticket = 0u;                                                      // (for the next training; the init of k_leaf_samples zeroes it as well)
+    st->max_err = b.mx; st->max_err_idx = b.mi; st->sum_n_err = b.sum; st->sum_l2 = b.l2; st->sum_log2 = b.lg;
+    st->flag_count = fc; st->merged_count = 0; st->pending = fc;
+    *host_copy = *st;                                                  // pinned host memory: visible to the host once the stream is synchronised
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -668,7 +795,7 @@ __global__ void __launch_bounds__(FL_THREADS) k_finalize_listed(const K* __restr
     stats_block_reduce<FL_THREADS>(mx, mi, sm, l2, lg);
   }
   if (threadIdx.x == 0) {
-    stw->max_err = mx; stw->max_err_idx = mi; stw->sum_n_err = sm; stw->sum_l2 = l2; stw->sum_log2 = lg;
+    stw->max_err = mx; stw->max_err_idx = mi; stw->sum_n_err = sm; stw->sum_l2 = l2; stw->sum_log2 = lg; stw->pending = 0;
     if (host_copy) *host_copy = *stw;                                // pinned host memory: visible to the host once the stream is synchronised
   }
 }

@@ -84,7 +84,11 @@ struct rmi_hip_multi {
   unsigned char** d_peer_mail = nullptr;
   unsigned long long epoch = 0;
 };
-constexpr size_t RMI_MAIL_BYTES = 64 * 8 + 64 * 40;
+// A rank's record in the exchange of the aggregates: the 6 words of DevState from max_err on (max_err, max_err_idx, sum_n_err,
+// sum_l2, sum_log2, pending): the last one tells every rank whether SOME rank still has listed leaves to finish.
+constexpr int RMI_STATS_WORDS = 6;
+constexpr size_t RMI_STATS_BYTES = 8 * RMI_STATS_WORDS;
+constexpr size_t RMI_MAIL_BYTES = 64 * 8 + 64 * RMI_STATS_BYTES;
 struct rmi_peer_handle { hipIpcMemHandle_t rows, mail; uint64_t slot_bytes; int rank, world; };
 static_assert(sizeof(rmi_peer_handle) <= RMI_HIP_PEER_HANDLE_BYTES, "handle size");
 
@@ -103,7 +107,7 @@ __global__ void __launch_bounds__(64) k_peer_signal(unsigned char* const* __rest
   const int r = threadIdx.x;
   if (r >= world) return;
   unsigned long long* mail = reinterpret_cast<unsigned long long*>(peer_mail[r]);
-  for (int q = 0; q < 5; q++) __hip_atomic_store(&mail[64 + rank * 5 + q], my_stats[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int q = 0; q < RMI_STATS_WORDS; q++) __hip_atomic_store(&mail[64 + rank * RMI_STATS_WORDS + q], my_stats[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&mail[rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // wait for the `world` flags of this epoch in the own mailbox, then hand the aggregates to the host copy
@@ -118,7 +122,7 @@ __global__ void __launch_bounds__(64) k_peer_wait(unsigned long long* __restrict
     if (wall_clock64() - t0 > 500000000ull) { ok = false; break; }  // 5 s
   }
   if (!ok) { atomicOr(&st->err_flags, rmi::EF_PEER_TIMEOUT); return; }
-  for (int q = 0; q < 5; q++) stats_all[r * 5 + q] = __hip_atomic_load(&mail[64 + r * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int q = 0; q < RMI_STATS_WORDS; q++) stats_all[r * RMI_STATS_WORDS + q] = __hip_atomic_load(&mail[64 + r * RMI_STATS_WORDS + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static rmi_hip_multi* multi_of(rmi_hip_ctx* c);    // (accessor defined in rmi_hip.hip)
@@ -266,11 +270,49 @@ int rmi_hip_comm_destroy(rmi_hip_ctx* c) {
   return RMI_OK;
 }
 
+// the aggregates of the whole model from the ranks' records (two_layer.rs:267-287 over all shards: lexicographic maximum, the
+// last maximum wins; exact integer sum; f64 sums); true if some rank still has listed leaves to finish
+static bool sharded_totals(rmi_hip_ctx* c, rmi_hip_multi* m, rmi_hip_result* out) {
+  unsigned long long mx = 0, mi = 0, sn = 0; double l2 = 0.0, lg = 0.0;
+  bool listed = false;
+  for (int r = 0; r < m->world; r++) {
+    unsigned long long v[RMI_STATS_WORDS]; double d[2];
+    std::memcpy(v, m->h_stats_all + RMI_STATS_BYTES * r, sizeof v); std::memcpy(d, m->h_stats_all + RMI_STATS_BYTES * r + 24, 16);
+    if (v[0] > mx || (v[0] == mx && v[1] >= mi)) { mx = v[0]; mi = v[1]; }
+    sn += v[2]; l2 += d[0]; lg += d[1];
+    listed = listed || v[RMI_STATS_WORDS - 1] != 0;
+  }
+  if (out) {
+    const double ng = (double)c->shard.n;
+    out->model_max_error = mx; out->model_max_error_idx = mi;
+    out->model_avg_error = (double)sn / ng; out->model_avg_l2_error = l2; out->model_avg_log2_error = lg / ng;
+    out->model_max_log2_error = std::log2((double)mx);
+  }
+  return listed;
+}
+
 // The exchange as peer stores (include/rmi_hip.h).  Epoch e uses half e & 1 of every rank's table: a rank that runs ahead
 // stores into the half its peers are not reading.
+static int direct_exchange(rmi_hip_ctx* c, rmi_hip_multi* m, unsigned long long epoch, uint64_t off, uint64_t bytes) {
+  unsigned char* table = m->d_rows2 + (epoch & 1ull) * m->rows2_slot;
+  // (peer pointers of this epoch's half: the tables hold the bases, the half is part of the byte offset)
+  const uint64_t n16 = bytes / 16;
+  const uint64_t byte_off = (epoch & 1ull) * m->rows2_slot + off;
+  hipLaunchKernelGGL(k_peer_push, dim3(512), dim3(256), 0, c->stream, (const uint4*)(table + off), n16, (unsigned char* const*)m->d_peer_rows, byte_off, m->rank, m->world);
+  hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, c->stream, (unsigned char* const*)m->d_peer_mail, (const unsigned long long*)&c->d_state->max_err, m->rank, m->world, epoch);
+  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, (unsigned long long*)m->d_mail, m->world, epoch, (unsigned long long*)m->d_stats_all, c->d_state);
+  HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, RMI_STATS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->h_state->err_flags, &c->d_state->err_flags, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));   // (k_peer_wait may have raised the timeout)
+  HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->h_state->err_flags & EF_PEER_TIMEOUT) { set_err(c, "direct exchange: a peer's flag of epoch %llu did not arrive within 5 s", epoch); return RMI_ERR_HIP; }
+  return RMI_OK;
+}
+
 static int train_sharded_direct(rmi_hip_ctx* c, rmi_hip_multi* m, const rmi_hip_model_params* root, int leaf_kind, uint64_t num_leaves,
                                 uint64_t rowb, uint64_t L_own, rmi_hip_result* out) {
-  const unsigned long long epoch = ++m->epoch;
+  unsigned long long epoch = ++m->epoch;
   unsigned char* table = m->d_rows2 + (epoch & 1ull) * m->rows2_slot;
   const uint64_t off = (uint64_t)m->rank * L_own * rowb;
   m->rows_last_bytes = num_leaves * rowb;
@@ -279,36 +321,30 @@ static int train_sharded_direct(rmi_hip_ctx* c, rmi_hip_multi* m, const rmi_hip_
   c->defer_sync = true;
   int rc = rmi_hip_train_two_layer(c, root, leaf_kind, num_leaves, out);
   c->defer_sync = false;
-  if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
-  HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-  // (peer pointers of this epoch's half: the tables hold the bases, the half is part of the byte offset)
-  const uint64_t n16 = L_own * rowb / 16;
-  const uint64_t byte_off = (epoch & 1ull) * m->rows2_slot + off;
-  hipLaunchKernelGGL(k_peer_push, dim3(512), dim3(256), 0, c->stream, (const uint4*)(table + off), n16, (unsigned char* const*)m->d_peer_rows, byte_off, m->rank, m->world);
-  hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, c->stream, (unsigned char* const*)m->d_peer_mail, (const unsigned long long*)&c->d_state->max_err, m->rank, m->world, epoch);
-  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, (unsigned long long*)m->d_mail, m->world, epoch, (unsigned long long*)m->d_stats_all, c->d_state);
-  HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, 40 * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
-  unsigned int* eflags = nullptr; (void)eflags;
-  HIPCHK(c, hipMemcpyAsync(&c->h_state->err_flags, &c->d_state->err_flags, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));   // (k_peer_wait may have raised the timeout)
-  HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->d_rows_ext = saved_ext;
-  if (c->h_state->err_flags & EF_PEER_TIMEOUT) { set_err(c, "direct exchange: a peer's flag of epoch %llu did not arrive within 5 s", epoch); return RMI_ERR_HIP; }
+  if (rc != RMI_OK) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+  rc = direct_exchange(c, m, epoch, off, L_own * rowb);
+  if (rc != RMI_OK) return rc;
+  {
+    // the ranks' results may have been published without their list kernels (launch_pipeline): if SOME rank handed leaves
+    // over, every rank learns it from the records, the ranks concerned finish theirs, and all exchange once more -- in the
+    // next epoch, i.e. the other half of the tables (this rank's rows move there first)
+    const bool listed = sharded_totals(c, m, nullptr);
+    if (listed) {
+      if (c->tail_armed && c->h_state->pending > 0) { rc = c->tail_fn(); if (rc != RMI_OK) { c->tail_armed = false; c->tail_fn = nullptr; return rc; } }
+      epoch = ++m->epoch;
+      unsigned char* table2 = m->d_rows2 + (epoch & 1ull) * m->rows2_slot;
+      HIPCHK(c, hipMemcpyAsync(table2 + off, table + off, L_own * rowb, hipMemcpyDeviceToDevice, c->stream));
+      rc = direct_exchange(c, m, epoch, off, L_own * rowb);
+    }
+    c->tail_armed = false; c->tail_fn = nullptr;
+    if (rc != RMI_OK) return rc;
+  }
   rc = finish_train(c, leaf_kind, num_leaves, out);
   if (rc != RMI_OK) return rc;
   { float xms = 0.f; if (hipEventElapsedTime(&xms, c->ev[7], c->ev[9]) == hipSuccess) out->kernel_ns[7] = (uint64_t)((double)xms * 1e6); }
-  unsigned long long mx = 0, mi = 0, sn = 0; double l2 = 0.0, lg = 0.0;
-  for (int r = 0; r < m->world; r++) {
-    unsigned long long v[3]; double d[2];
-    std::memcpy(v, m->h_stats_all + 40 * r, 24); std::memcpy(d, m->h_stats_all + 40 * r + 24, 16);
-    if (v[0] > mx || (v[0] == mx && v[1] >= mi)) { mx = v[0]; mi = v[1]; }
-    sn += v[2]; l2 += d[0]; lg += d[1];
-  }
-  const double ng = (double)c->shard.n;
-  out->model_max_error = mx; out->model_max_error_idx = mi;
-  out->model_avg_error = (double)sn / ng; out->model_avg_l2_error = l2; out->model_avg_log2_error = lg / ng;
-  out->model_max_log2_error = std::log2((double)mx);
+  (void)sharded_totals(c, m, out);
   return RMI_OK;
 }
 
@@ -334,8 +370,8 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
     m->rows_full_bytes = num_leaves * rowb;
   }
   if (!m->d_stats_all) {
-    HIPCHK(c, hipMalloc(&m->d_stats_all, 40 * 64));
-    HIPCHK(c, hipHostMalloc((void**)&m->h_stats_all, 40 * 64, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc(&m->d_stats_all, RMI_STATS_BYTES * 64));
+    HIPCHK(c, hipHostMalloc((void**)&m->h_stats_all, RMI_STATS_BYTES * 64, hipHostMallocDefault));
   }
   if (m->world > 64) return RMI_ERR_BAD_ARG;
   m->rows_last_bytes = num_leaves * rowb;
@@ -349,28 +385,29 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
   if (m->comm) {
     rmi_multi::Api& a = rmi_multi::api();
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));                       // (kernel_ns[7] of the result: the exchange alone)
-    // rows: in place (this rank's piece already sits in its slot); aggregates: the 40 bytes of DevState from max_err on
-    int n1 = a.AllGather(c->d_rows_ext, m->d_rows_full, (size_t)(L_own * rowb), 1 /* ncclUint8 */, m->comm, c->stream);
-    int n2 = a.AllGather(&c->d_state->max_err, m->d_stats_all, 40, 1, m->comm, c->stream);
-    if (n1 != 0 || n2 != 0) { c->d_rows_ext = saved_ext; set_err(c, "ncclAllGather: %s", a.GetErrorString ? a.GetErrorString(n1 ? n1 : n2) : "error"); return RMI_ERR_RCCL; }
-    HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, 40 * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[9], c->stream));                       // device time of the call now includes the exchange
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto exchange = [&]() -> int {
+      // rows: in place (this rank's piece already sits in its slot); aggregates: the record of RMI_STATS_WORDS words
+      int n1 = a.AllGather(c->d_rows_ext, m->d_rows_full, (size_t)(L_own * rowb), 1 /* ncclUint8 */, m->comm, c->stream);
+      int n2 = a.AllGather(&c->d_state->max_err, m->d_stats_all, RMI_STATS_BYTES, 1, m->comm, c->stream);
+      if (n1 != 0 || n2 != 0) { set_err(c, "ncclAllGather: %s", a.GetErrorString ? a.GetErrorString(n1 ? n1 : n2) : "error"); return RMI_ERR_RCCL; }
+      HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, RMI_STATS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipEventRecord(c->ev[9], c->stream));                     // device time of the call now includes the exchange
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      return RMI_OK;
+    };
+    rc = exchange();
+    if (rc == RMI_OK && sharded_totals(c, m, nullptr)) {
+      // the ranks' results may have been published without their list kernels (launch_pipeline): if SOME rank handed leaves
+      // over, every rank learns it from the records, the ranks concerned finish theirs, and all gather once more
+      if (c->tail_armed && c->h_state->pending > 0) rc = c->tail_fn();
+      if (rc == RMI_OK) rc = exchange();
+    }
+    c->tail_armed = false; c->tail_fn = nullptr;
+    if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
     rc = finish_train(c, leaf_kind, num_leaves, out);                     // error flags, per-shard result, timings
     if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
     { float xms = 0.f; if (hipEventElapsedTime(&xms, c->ev[7], c->ev[9]) == hipSuccess) out->kernel_ns[7] = (uint64_t)((double)xms * 1e6); }
-    // two_layer.rs:267-287 over all shards: lexicographic maximum (last maximum wins), exact integer sum, f64 sums
-    unsigned long long mx = 0, mi = 0, sn = 0; double l2 = 0.0, lg = 0.0;
-    for (int r = 0; r < m->world; r++) {
-      unsigned long long v[3]; double d[2];
-      std::memcpy(v, m->h_stats_all + 40 * r, 24); std::memcpy(d, m->h_stats_all + 40 * r + 24, 16);
-      if (v[0] > mx || (v[0] == mx && v[1] >= mi)) { mx = v[0]; mi = v[1]; }
-      sn += v[2]; l2 += d[0]; lg += d[1];
-    }
-    const double ng = (double)c->shard.n;
-    out->model_max_error = mx; out->model_max_error_idx = mi;
-    out->model_avg_error = (double)sn / ng; out->model_avg_l2_error = l2; out->model_avg_log2_error = lg / ng;
-    out->model_max_log2_error = std::log2((double)mx);
+    (void)sharded_totals(c, m, out);
   }
   c->d_rows_ext = saved_ext;
   return RMI_OK;
@@ -506,8 +543,8 @@ int rmi_hip_peer_export(rmi_hip_ctx* c, int rank, int world, int leaf_kind, uint
     HIPCHK(c, hipMalloc(&m->d_peer_rows, 64 * sizeof(void*)));
     HIPCHK(c, hipMalloc(&m->d_peer_mail, 64 * sizeof(void*)));
     if (!m->d_stats_all) {
-      HIPCHK(c, hipMalloc(&m->d_stats_all, 40 * 64));
-      HIPCHK(c, hipHostMalloc((void**)&m->h_stats_all, 40 * 64, hipHostMallocDefault));
+      HIPCHK(c, hipMalloc(&m->d_stats_all, RMI_STATS_BYTES * 64));
+      HIPCHK(c, hipHostMalloc((void**)&m->h_stats_all, RMI_STATS_BYTES * 64, hipHostMallocDefault));
     }
   }
   m->rank = rank; m->world = world;

@@ -15,6 +15,10 @@ VARIANTS = {
     "fused_scan": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_FUSE": "1", "RMI_HIP_LANES_SEARCH": "0"},
     # leaves of more than 512 points go to the list kernels, of more than 2000 to the host
     "lists_and_host": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_HOST_MIN": "2000", "RMI_HIP_LONG_MIN": "512"},
+    # the list kernels and k_finalize_listed inside the stream of every training (default: k_lane_reduce publishes, the list
+    # kernels run behind the synchronisation, and only when a leaf was handed over)
+    "in_stream_tail": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_OPT_TAIL": "0"},
+    "in_stream_lists": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_OPT_TAIL": "0", "RMI_HIP_HOST_MIN": "2000", "RMI_HIP_LONG_MIN": "512"},
 }
 
 

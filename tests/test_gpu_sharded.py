@@ -93,29 +93,33 @@ def test_sharded_matches_oracle(oracle):
     assert np.array_equal(full.last_layer_max_l1s, o.leaf_err)
 
 
-def _sharded_trainer_worker(rank, world, port, n_global, L, q, exchange="rccl"):
+def _sharded_trainer_worker(rank, world, port, n_global, L, q, exchange="rccl", listed_rank=-1):
     import os
     import torch
     import torch.distributed as dist
     from rmi_amd import sharded, train
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if rank == listed_rank:
+        os.environ["RMI_HIP_LONG_MIN"] = "64"                     # this rank hands (nearly) every leaf to the list kernels
     torch.cuda.set_device(0)                                      # both ranks share the one GPU of the box
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tr = train.Trainer(device=0)
     sh = sharded.ShardedTrainer(tr, dist, rank, world, "uniform", np.uint64, n_global, L, "linear,linear", chunk=700_000, exchange=exchange)
     sh.step()
-    sh.step()                                                     # (a second step re-uses every buffer)
+    res = sh.step()                                               # (a second step re-uses every buffer)
     if exchange == "direct":
-        sh.step()                                                 # (direct exchange: both halves of the double-buffered table)
+        res = sh.step()                                           # (direct exchange: both halves of the double-buffered table)
         dist.barrier()
     rows = sh.full_rows().copy()
     ok = True
+    if listed_rank >= 0:                                          # (the rank concerned really took the list kernels, the other none)
+        ok = (int(res.long_leaves) > 1000) == (rank == listed_rank)
     if rank == 0 or exchange == "direct":                         # against the unsharded result on the same keys
         t1 = train.Trainer(device=0)
         t1.generate_keys("uniform", np.uint64, n_global)
         ref = t1.train("linear,linear", L)
-        ok = bool(np.array_equal(rows, ref.rows)) and ref.root.p == sh.root.p
+        ok = ok and bool(np.array_equal(rows, ref.rows)) and ref.root.p == sh.root.p
         t1.close()
     q.put((rank, ok))
     tr.close()
@@ -159,7 +163,25 @@ def test_sharded_direct_exchange_two_ranks_one_gpu():
     assert sorted(res) == [(0, True), (1, True)]
 
 
-def _rccl_worker(rank, world, port, n_global, L, mode, q, exchange="rccl"):
+def test_sharded_direct_exchange_listed_leaves_on_one_rank():
+    """A training publishes its result without the list kernels; if SOME rank handed leaves to them, every rank reads it
+    from the exchanged records, the rank concerned finishes its leaves and all exchange once more (the next epoch of the
+    peer-store tables).  Rank 1 lists nearly every leaf here, rank 0 none: same table as the unsharded run on both."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_trainer_worker, args=(r, 2, port, 2_000_000, 8192, q, "direct", 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def _rccl_worker(rank, world, port, n_global, L, mode, q, exchange="rccl", listed_rank=-1):
     """The N>1 path through the C ABI only: rmi_hip_plan_shards, rmi_hip_comm_init, rmi_hip_train_sharded (kernels +
     ncclAllGather on the library's stream).  torch.distributed carries the communicator id and the root parameters."""
     import os
@@ -168,6 +190,8 @@ def _rccl_worker(rank, world, port, n_global, L, mode, q, exchange="rccl"):
     from rmi_amd import sharded, train
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if rank == listed_rank:
+        os.environ["RMI_HIP_LONG_MIN"] = "64"                     # this rank hands (nearly) every leaf to the list kernels
     if world > 1:
         os.environ.setdefault("NCCL_DEBUG", "INFO")               # (the first multi-GPU run logs which algorithm RCCL picks)
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL")
@@ -192,6 +216,8 @@ def _rccl_worker(rank, world, port, n_global, L, mode, q, exchange="rccl"):
     ref_rows = ref.rows.view(np.uint64).reshape(L, 3)
     got = rows.view(np.uint64).reshape(L, 3)
     ok = info_ok and bool(np.array_equal(got[:, 2], ref_rows[:, 2])) and ref.root.p == sh.root.p        # error integers: always
+    if listed_rank >= 0:
+        ok = ok and (int(res.long_leaves) > 1000) == (rank == listed_rank)
     if mode == 0:
         ok = ok and bool(np.array_equal(got, ref_rows))                                     # exact mode: byte-identical table
     ok = ok and int(res.model_max_error) == ref.model_max_error and int(res.model_max_error_idx) == ref.model_max_error_idx
@@ -202,13 +228,13 @@ def _rccl_worker(rank, world, port, n_global, L, mode, q, exchange="rccl"):
     dist.destroy_process_group()
 
 
-def _spawn(world, n_global, L, mode, exchange="rccl"):
+def _spawn(world, n_global, L, mode, exchange="rccl", listed_rank=-1):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n_global, L, mode, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n_global, L, mode, q, exchange, listed_rank)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -222,6 +248,12 @@ def test_train_sharded_rccl_single_rank(mode):
     """The library's own RCCL path (communicator from a real unique id, in-place ncclAllGather of the rows and of the
     aggregates on the context's stream) with the one rank a 1-GPU box allows."""
     assert _spawn(1, 3_000_000, 4096, mode) == [(0, True)]
+
+
+def test_train_sharded_rccl_single_rank_listed_leaves():
+    """... and with leaves handed to the list kernels: the result is published without them, the rank reads its own `pending`
+    from the gathered records, runs them and gathers once more."""
+    assert _spawn(1, 3_000_000, 4096, 0, listed_rank=0) == [(0, True)]
 
 
 def test_sharded_trainer_falls_back_to_torch_all_gather(monkeypatch):
