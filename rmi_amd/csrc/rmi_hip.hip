@@ -75,7 +75,7 @@ struct rmi_hip_ctx {
   unsigned int* d_tickets = nullptr;            // arrival counter of k_lane_reduce's blocks
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   hipEvent_t ev[10] = {};
-  int profile_level = 0;                        // 0: whole call only; 1: + the first (dominant) kernel; 2: every kernel group
+  int profile_level = 0;                        // -1: no events at all (device_ns = 0); 0: whole call only; 1: + the first (dominant) kernel; 2: every kernel group
   DevState* h_state_dev = nullptr;              // device address of the pinned h_state (written by the last kernel)
   int pipeline = 3;                             // 1 = one kernel per reference pass; 2 = streaming passes A/B; 3 = leaf-lane kernels (rmi_lanes.hip.h)
   double* d_lntab = nullptr;                    // RN(1 / k) for the running count of the leaf-lane walk (k_lane_table)
@@ -334,7 +334,7 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
 const char* rmi_hip_last_error(const rmi_hip_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int rmi_hip_set_profile_level(rmi_hip_ctx* c, int level) {
-  if (!c || level < 0 || level > 2) return RMI_ERR_BAD_ARG;
+  if (!c || level < -1 || level > 2) return RMI_ERR_BAD_ARG;
   c->profile_level = level;
   return RMI_OK;
 }
@@ -1072,7 +1072,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     }
   }
   const bool init_arrays = !(lanes_fused_plan && lanes_search_plan);
-  if (!c->stream_mode || c->stream_slot == 0) HIPCHK(c, hipEventRecord(c->ev[8], s));   // start of the device work of this call
+  if ((!c->stream_mode || c->stream_slot == 0) && pl >= 0) HIPCHK(c, hipEventRecord(c->ev[8], s));   // start of the device work of this call
   // (the leaf-lane pipeline with its search and its fused error pass: the launch of k_leaf_samples carries the init)
   const bool init_folded = !init_arrays && (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE);
   if (!init_folded) {
@@ -1364,7 +1364,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials, (int)blocks, c->d_state, c->h_state_dev + (c->stream_mode ? c->stream_slot : 0));
   }
   mark();
-  HIPCHK(c, hipEventRecord(c->ev[9], s));
+  if (pl >= 0) HIPCHK(c, hipEventRecord(c->ev[9], s));
   HIPCHK(c, hipGetLastError());
   return RMI_OK;
 }
@@ -1409,7 +1409,7 @@ static int giant_epilogue(rmi_hip_ctx* c) {
   hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(FL_THREADS), 0, s, keys, c->lp.sp, c->lp.L, c->lp.leaf_start, c->d_state, c->lp.params,
                      c->lp.maxerr, c->lp.run, c->lp.err, c->lp.count, c->lp.rows, fl, first, (unsigned int)FL_BLOCKS, first + FL_BLOCKS,
                      c->d_flist_cnt + 2 * SG_REGIONS, c->d_state, c->h_state_dev, (const GiantLeaf*)c->d_giant, ~0ull);
-  HIPCHK(c, hipEventRecord(c->ev[9], s));                            // (the device time of the call covers the epilogue, host fit included)
+  if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], s)); // (the device time of the call covers the epilogue, host fit included)
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(s));
   return RMI_OK;
@@ -1502,7 +1502,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
       rc = c->tail_fn();
       c->tail_fn = nullptr;
       if (rc) return rc;
-      HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+      if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->tail_fn = nullptr;
@@ -1561,7 +1561,7 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   out->merged_leaves = c->last_sigma ? (int32_t)(st.merged_count < 0x7fffffffull ? st.merged_count : 0x7fffffffull) : 0;
   out->guard_leaves = c->last_sigma ? st.guard_count : 0;
   float ms = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[8], c->ev[9]));
+  if (c->profile_level >= 0) HIPCHK(c, hipEventElapsedTime(&ms, c->ev[8], c->ev[9]));
   out->device_ns = (uint64_t)((double)ms * 1e6);
   for (int k = 0; k < (c->profile_level >= 2 ? 5 : c->profile_level); k++) {
     float m2 = 0.f;

@@ -303,7 +303,7 @@ static int direct_exchange(rmi_hip_ctx* c, rmi_hip_multi* m, unsigned long long 
   hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, (unsigned long long*)m->d_mail, m->world, epoch, (unsigned long long*)m->d_stats_all, c->d_state);
   HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, RMI_STATS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&c->h_state->err_flags, &c->d_state->err_flags, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));   // (k_peer_wait may have raised the timeout)
-  HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+  if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->h_state->err_flags & EF_PEER_TIMEOUT) { set_err(c, "direct exchange: a peer's flag of epoch %llu did not arrive within 5 s", epoch); return RMI_ERR_HIP; }
@@ -323,7 +323,7 @@ static int train_sharded_direct(rmi_hip_ctx* c, rmi_hip_multi* m, const rmi_hip_
   c->defer_sync = false;
   c->d_rows_ext = saved_ext;
   if (rc != RMI_OK) return rc;
-  HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+  if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
   rc = direct_exchange(c, m, epoch, off, L_own * rowb);
   if (rc != RMI_OK) return rc;
   {
@@ -343,7 +343,7 @@ static int train_sharded_direct(rmi_hip_ctx* c, rmi_hip_multi* m, const rmi_hip_
   }
   rc = finish_train(c, leaf_kind, num_leaves, out);
   if (rc != RMI_OK) return rc;
-  { float xms = 0.f; if (hipEventElapsedTime(&xms, c->ev[7], c->ev[9]) == hipSuccess) out->kernel_ns[7] = (uint64_t)((double)xms * 1e6); }
+  { float xms = 0.f; if (c->profile_level >= 0 && hipEventElapsedTime(&xms, c->ev[7], c->ev[9]) == hipSuccess) out->kernel_ns[7] = (uint64_t)((double)xms * 1e6); }
   (void)sharded_totals(c, m, out);
   return RMI_OK;
 }
@@ -384,14 +384,14 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
   if (m->world > 1 && !m->comm) { c->d_rows_ext = saved_ext; return RMI_ERR_BAD_ARG; }
   if (m->comm) {
     rmi_multi::Api& a = rmi_multi::api();
-    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));                       // (kernel_ns[7] of the result: the exchange alone)
+    if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[7], c->stream));   // (kernel_ns[7] of the result: the exchange alone)
     auto exchange = [&]() -> int {
       // rows: in place (this rank's piece already sits in its slot); aggregates: the record of RMI_STATS_WORDS words
       int n1 = a.AllGather(c->d_rows_ext, m->d_rows_full, (size_t)(L_own * rowb), 1 /* ncclUint8 */, m->comm, c->stream);
       int n2 = a.AllGather(&c->d_state->max_err, m->d_stats_all, RMI_STATS_BYTES, 1, m->comm, c->stream);
       if (n1 != 0 || n2 != 0) { set_err(c, "ncclAllGather: %s", a.GetErrorString ? a.GetErrorString(n1 ? n1 : n2) : "error"); return RMI_ERR_RCCL; }
       HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, RMI_STATS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipEventRecord(c->ev[9], c->stream));                     // device time of the call now includes the exchange
+      if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));   // device time of the call now includes the exchange
       HIPCHK(c, hipStreamSynchronize(c->stream));
       return RMI_OK;
     };
@@ -406,7 +406,7 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
     if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
     rc = finish_train(c, leaf_kind, num_leaves, out);                     // error flags, per-shard result, timings
     if (rc != RMI_OK) { c->d_rows_ext = saved_ext; return rc; }
-    { float xms = 0.f; if (hipEventElapsedTime(&xms, c->ev[7], c->ev[9]) == hipSuccess) out->kernel_ns[7] = (uint64_t)((double)xms * 1e6); }
+    { float xms = 0.f; if (c->profile_level >= 0 && hipEventElapsedTime(&xms, c->ev[7], c->ev[9]) == hipSuccess) out->kernel_ns[7] = (uint64_t)((double)xms * 1e6); }
     (void)sharded_totals(c, m, out);
   }
   c->d_rows_ext = saved_ext;

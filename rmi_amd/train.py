@@ -271,7 +271,7 @@ class Trainer:
         return float(v.value)
 
     def set_profile_level(self, level: int):
-        """0: device_ns only; 1: + kernel_ns[0] (the first, dominant kernel); 2: every kernel group."""
+        """-1: no events (device_ns = 0); 0: device_ns only; 1: + kernel_ns[0] (the first, dominant kernel); 2: every kernel group."""
         _check(self._lib.rmi_hip_set_profile_level(self._h, int(level)), self._h)
 
     def set_fit_mode(self, mode: int | str, guard_k: float = 0.0):

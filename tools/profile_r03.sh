@@ -6,7 +6,7 @@ set -u
 OUT=gpurun_out/prof_r03; mkdir -p $OUT; export TMPDIR=/tmp
 B="python bench.py --no-cpu-baseline --no-extras"
 timeout 200 rocprofv3 --kernel-trace --stats -T -d $OUT/kt -o kt -f csv -- $B --steps 200 --warmup 50 > $OUT/kt.log 2>&1
-INC='k_leaf_lanes|k_leaf_search|k_leaf_samples|k_list|k_finalize|k_init'
+INC='k_leaf_lanes|k_leaf_search|k_leaf_samples|k_lane_reduce|k_list|k_finalize|k_init'
 timeout 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
    --kernel-include-regex "$INC" -d $OUT/pmc1 -o p -f csv -- $B --steps 2 --warmup 0 > $OUT/pmc1.log 2>&1
 timeout 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS \
@@ -17,8 +17,8 @@ cp $OUT/kt/*kernel_stats.csv $OUT/r03_kernel_stats.csv 2>/dev/null
 # ---- traffic: FETCH_SIZE / WRITE_SIZE per kernel and mode, reads calibrated on k_read_bw (reads every key byte exactly once)
 for MODE in exact onepass_guarded; do
   M=0; [ $MODE = onepass_guarded ] && M=1
-  timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_read_bw|k_leaf_lanes|k_leaf_search|k_sigma2|k_finalize|k_list' -d $OUT/tf_$MODE -o p -f csv -- python tools/traffic_r03.py $M > $OUT/tf_$MODE.log 2>&1
-  timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex 'k_read_bw|k_leaf_lanes|k_leaf_search|k_sigma2|k_finalize|k_list' -d $OUT/tw_$MODE -o p -f csv -- python tools/traffic_r03.py $M > $OUT/tw_$MODE.log 2>&1
+  timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_read_bw|k_leaf_lanes|k_leaf_search|k_leaf_samples|k_lane_reduce|k_sigma2|k_finalize|k_list' -d $OUT/tf_$MODE -o p -f csv -- python tools/traffic_r03.py $M > $OUT/tf_$MODE.log 2>&1
+  timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex 'k_read_bw|k_leaf_lanes|k_leaf_search|k_leaf_samples|k_lane_reduce|k_sigma2|k_finalize|k_list' -d $OUT/tw_$MODE -o p -f csv -- python tools/traffic_r03.py $M > $OUT/tw_$MODE.log 2>&1
   python tools/traffic_r03_json.py $OUT $MODE > $OUT/traffic_r03_$MODE.json
 done
 head -30 $OUT/r03_rocprofv3_summary.txt

@@ -2,7 +2,7 @@
 import csv, glob, json, sys
 from collections import defaultdict
 out_dir, mode = sys.argv[1], sys.argv[2]
-names = ["k_read_bw", "k_leaf_lanes", "k_leaf_search", "k_sigma2", "k_finalize", "k_list_tail", "k_list"]
+names = ["k_read_bw", "k_leaf_lanes", "k_leaf_search", "k_leaf_samples", "k_lane_reduce", "k_sigma2", "k_finalize", "k_list_tail", "k_list"]
 acc = defaultdict(lambda: defaultdict(list))
 for d in (f"{out_dir}/tf_{mode}", f"{out_dir}/tw_{mode}"):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
