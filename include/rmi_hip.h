@@ -140,6 +140,9 @@ typedef struct {
   uint64_t generation;            /* number of this train call on the context, for rmi_hip_download_checked */
 } rmi_hip_result;
 
+/* kernel_ns slots of the round-1/2 pipelines (RMI_HIP_PIPELINE=1|2).  The default leaf-lane pipeline fills slot 0 with
+ * k_leaf_lanes (bracketed behind the search), slot 1 with k_lane_reduce (or k_list when RMI_HIP_OPT_TAIL=0, then k_list_tail
+ * and k_finalize_listed in 2 and 3); kernel_ns[7] is the exchange of rmi_hip_train_sharded. */
 enum { RMI_K_BOUNDARIES = 0, RMI_K_FILL = 1, RMI_K_FIT = 2, RMI_K_ERR = 3, RMI_K_FINALIZE = 4 };
 
 /* ---- lifetime ---- */
