@@ -92,6 +92,15 @@ struct rmi_hip_ctx {
   uint64_t host_min = 262144;                   // RMI_HIP_HOST_MIN; 0: never.  (A wave walks 262 144 points in ~7 ms, a host core in ~1: below that the
                                                 //  leaves of a skewed key set are many and run side by side on the device)
   bool giant_armed = false;                     // the last launch recorded giant leaves for the host
+  // the giant list early (k_giant_scan in front of k_list, read through pinned memory): the host walks the chains while
+  // the device fits the other listed leaves
+  static constexpr uint64_t GIANT_EARLY_MAX = 256;
+  unsigned long long* h_giant = nullptr;        // pinned: [0] count, then GIANT_EARLY_MAX entries of 4 words
+  hipEvent_t ev_giant = nullptr;
+  bool giant_early = false;                     // the running tail carries the early list
+  bool giant_fitted = false;                    // ... and the host has fitted it (giant_list / giant_ab)
+  std::vector<GiantLeaf> giant_list;
+  std::vector<double> giant_ab;
   struct { const void* keys; Span sp; uint64_t L; unsigned long long* leaf_start; double* params; unsigned long long* maxerr; unsigned long long* run;
            unsigned long long* err; unsigned long long* count; unsigned char* rows; uint64_t waves; } lp = {};
   uint64_t fit_threads = 131072;                // lanes of pass A (256 CUs x 8 waves x 64)
@@ -326,6 +335,8 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->h_sentinel) (void)hipHostFree(c->h_sentinel);
   for (int b = 0; b < 2; b++) { if (c->h_stage[b]) (void)hipHostFree(c->h_stage[b]); if (c->ev_stage[b]) (void)hipEventDestroy(c->ev_stage[b]); }
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->h_giant) (void)hipHostFree(c->h_giant);
+  if (c->ev_giant) (void)hipEventDestroy(c->ev_giant);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1080,7 +1091,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
                        L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS + 8, init_arrays);
   }
-  c->tail_armed = false; c->tail_fn = nullptr;
+  c->tail_armed = false; c->tail_fn = nullptr; c->giant_early = false; c->giant_fitted = false;
 
   auto ensure_lists = [&]() -> int {
     const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
@@ -1149,6 +1160,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           c->giant_cap = gcap;
         }
         c->giant_armed = true;
+        if (!c->h_giant) HIPCHK(c, hipHostMalloc((void**)&c->h_giant, 8 + rmi_hip_ctx::GIANT_EARLY_MAX * sizeof(GiantLeaf), hipHostMallocDefault));
+        if (!c->ev_giant) HIPCHK(c, hipEventCreateWithFlags(&c->ev_giant, hipEventDisableTiming));
         c->lp.keys = keys; c->lp.sp = sp; c->lp.L = L; c->lp.leaf_start = leaf_start; c->lp.params = params; c->lp.maxerr = maxerr; c->lp.run = run;
         c->lp.err = err; c->lp.count = count; c->lp.rows = rows; c->lp.waves = (L_own + 63) / 64;
       }
@@ -1182,12 +1195,23 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       GiantLeaf* const dgiant = giants ? c->d_giant : (GiantLeaf*)nullptr;
       const unsigned long long hmin = giants ? (unsigned long long)c->host_min : ~0ull;
       const bool fused = lanes_fused;
+      // (the early giant list only where the host runs the tail itself, behind its synchronisation)
+      const bool early = optimistic && giants && !c->defer_sync && c->h_giant != nullptr;
+      unsigned long long* const hg = c->h_giant;
+      hipEvent_t const evg = c->ev_giant;
+      const uint64_t hgn = c->giant_cap < rmi_hip_ctx::GIANT_EARLY_MAX ? c->giant_cap : rmi_hip_ctx::GIANT_EARLY_MAX;
       auto tail = [=](auto&& mk) {
         if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR) {
           if (verify) hipLaunchKernelGGL((k_verify_listed<K_CUBIC, K>), dim3(1024), dim3(256), 0, s, keys, sp, rp, leaf_start, dst, fl);
         }
         // (one wave per listed leaf wherever possible: on skewed keys thousands of leaves are listed and each is a sequential chain)
-        hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, dst, params, fl, sgp, maxerr, run, dgiant, hmin);
+        if (early) {
+          hipLaunchKernelGGL((k_giant_scan<K>), dim3(SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, dst, fl, dgiant, hmin);
+          (void)hipMemcpyAsync(hg, &dst->giant_count, 8, hipMemcpyDeviceToHost, s);
+          (void)hipMemcpyAsync(hg + 1, dgiant, hgn * sizeof(GiantLeaf), hipMemcpyDeviceToHost, s);
+          (void)hipEventRecord(evg, s);
+        }
+        hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, dst, params, fl, sgp, maxerr, run, dgiant, hmin, !early);
         mk();
         // (waves' aggregate records: [0, wb); their 64 slice sums, by k_list_tail: [wb, wb + 64); the records of k_finalize_listed behind)
         hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, dst, params, fl, segs, maxerr, run,
@@ -1202,6 +1226,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
                            c->d_tickets, fl, dst, hcopy);
         mark(); mark();
         c->tail_armed = true;
+        c->giant_early = early;
         c->tail_fn = [tail]() -> int { tail([]() {}); return RMI_OK; };
       } else tail(mark);
     }
@@ -1375,31 +1400,48 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
 // reference order, the coefficients go back, and a short device epilogue runs their error pass (k_list_tail in
 // stretches), their finalize and the aggregates again.  books-shaped 200 M keys / 262 144 leaves (one leaf of 2.5 M
 // keys): 78 ms -> ~13 ms per training, same bits.
+// (the chains on host threads, given the list: the keys come over on `cs` -- the context's stream, or a stream of its own
+//  while that one is still busy with k_list)
+template <typename K>
+static int giant_host_fit(rmi_hip_ctx* c, const GiantLeaf* list, uint64_t cnt, hipStream_t cs) {
+  c->giant_list.assign(list, list + cnt);
+  c->giant_ab.assign(2 * cnt, 0.0);
+  const std::vector<GiantLeaf>& g = c->giant_list;
+  std::vector<double>& ab = c->giant_ab;
+  const K* keys = (const K*)c->lp.keys;
+  std::vector<std::vector<K>> bufs(cnt);
+  std::vector<int> rcs(cnt, RMI_OK);
+  std::vector<std::thread> th;
+  for (uint64_t i = 0; i < cnt; i++) {
+    const uint64_t npts = g[i].hi - g[i].lo + 1;
+    bufs[i].resize(npts);
+    HIPCHK(c, hipMemcpyAsync(bufs[i].data(), keys + g[i].lo, npts * sizeof(K), hipMemcpyDeviceToHost, cs));
+    HIPCHK(c, hipStreamSynchronize(cs));
+    th.emplace_back([&, i, npts]() { rcs[i] = rmi_host::leaf_slr<K>(bufs[i].data(), npts, g[i].lo, g[i].y0, &ab[2 * i], &ab[2 * i + 1]); });
+    if (th.size() >= 16) { for (auto& t : th) t.join(); th.clear(); }
+  }
+  for (auto& t : th) t.join();
+  for (uint64_t i = 0; i < cnt; i++)
+    if (rcs[i] != RMI_OK) { set_err(c, "%s", rmi_hip_strerror(rcs[i])); return rcs[i]; }
+  return RMI_OK;
+}
+
 template <typename K>
 static int giant_epilogue(rmi_hip_ctx* c) {
   hipStream_t s = c->stream;
   const DevState& st0 = *c->h_state;
   if (st0.giant_count > c->giant_cap) { set_err(c, "internal: giant-leaf list overflow"); return RMI_ERR_HIP; }
   const uint64_t cnt = st0.giant_count;
-  std::vector<GiantLeaf> g(cnt);
-  HIPCHK(c, hipMemcpy(g.data(), c->d_giant, cnt * sizeof(GiantLeaf), hipMemcpyDeviceToHost));
   const K* keys = (const K*)c->lp.keys;
-  std::vector<std::vector<K>> bufs(cnt);
-  std::vector<double> ab(2 * cnt);
-  std::vector<int> rcs(cnt, RMI_OK);
-  std::vector<std::thread> th;
-  for (uint64_t i = 0; i < cnt; i++) {
-    const uint64_t npts = g[i].hi - g[i].lo + 1;
-    bufs[i].resize(npts);
-    HIPCHK(c, hipMemcpy(bufs[i].data(), keys + g[i].lo, npts * sizeof(K), hipMemcpyDeviceToHost));
-    th.emplace_back([&, i, npts]() { rcs[i] = rmi_host::leaf_slr<K>(bufs[i].data(), npts, g[i].lo, g[i].y0, &ab[2 * i], &ab[2 * i + 1]); });
-    if (th.size() >= 16) { for (auto& t : th) t.join(); th.clear(); }
+  if (!(c->giant_fitted && c->giant_list.size() == cnt)) {           // (not fitted beside k_list: now)
+    std::vector<GiantLeaf> g(cnt);
+    HIPCHK(c, hipMemcpy(g.data(), c->d_giant, cnt * sizeof(GiantLeaf), hipMemcpyDeviceToHost));
+    const int frc = giant_host_fit<K>(c, g.data(), cnt, s);
+    if (frc != RMI_OK) return frc;
   }
-  for (auto& t : th) t.join();
-  for (uint64_t i = 0; i < cnt; i++) {
-    if (rcs[i] != RMI_OK) { set_err(c, "%s", rmi_hip_strerror(rcs[i])); return rcs[i]; }
-    HIPCHK(c, hipMemcpyAsync(c->lp.params + 2 * g[i].j, &ab[2 * i], 16, hipMemcpyHostToDevice, s));
-  }
+  const std::vector<GiantLeaf>& g = c->giant_list;
+  for (uint64_t i = 0; i < cnt; i++)
+    HIPCHK(c, hipMemcpyAsync(c->lp.params + 2 * g[i].j, &c->giant_ab[2 * i], 16, hipMemcpyHostToDevice, s));
   HIPCHK(c, hipMemsetAsync(&c->d_state->seg_count, 0, 8, s));
   HIPCHK(c, hipMemsetAsync(c->d_flist_cnt + 2 * SG_REGIONS, 0, 8, s));
   SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
@@ -1503,6 +1545,22 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
       c->tail_fn = nullptr;
       if (rc) return rc;
       if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+      if (c->giant_early) {
+        // the giant list is out before k_list starts: the host walks those chains while the device fits the other listed leaves
+        HIPCHK(c, hipEventSynchronize(c->ev_giant));
+        const uint64_t gc = c->h_giant[0];
+        if (gc > 0 && gc <= rmi_hip_ctx::GIANT_EARLY_MAX && gc <= c->giant_cap) {
+          if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+          const GiantLeaf* gl = reinterpret_cast<const GiantLeaf*>(c->h_giant + 1);
+          switch (c->dtype) {
+            case RMI_KEY_U64: rc = giant_host_fit<uint64_t>(c, gl, gc, c->copy_stream); break;
+            case RMI_KEY_U32: rc = giant_host_fit<uint32_t>(c, gl, gc, c->copy_stream); break;
+            default: rc = giant_host_fit<double>(c, gl, gc, c->copy_stream); break;
+          }
+          if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+          c->giant_fitted = true;
+        }
+      }
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->tail_fn = nullptr;

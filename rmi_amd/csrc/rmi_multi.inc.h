@@ -26,6 +26,8 @@ struct Api {
   const char* (*GetErrorString)(int) = nullptr;
   int (*CommCount)(NcclComm, int*) = nullptr;
   int (*CommUserRank)(NcclComm, int*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   bool ok() const { return GetUniqueId && CommInitRank && CommDestroy && AllGather; }
 };
 
@@ -48,6 +50,8 @@ static Api& api() {
       a.GetErrorString = (const char* (*)(int))dlsym(a.handle, "ncclGetErrorString");
       a.CommCount = (int (*)(NcclComm, int*))dlsym(a.handle, "ncclCommCount");
       a.CommUserRank = (int (*)(NcclComm, int*))dlsym(a.handle, "ncclCommUserRank");
+      a.GroupStart = (int (*)())dlsym(a.handle, "ncclGroupStart");
+      a.GroupEnd = (int (*)())dlsym(a.handle, "ncclGroupEnd");
     }
   });
   return a;
@@ -386,9 +390,14 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
     rmi_multi::Api& a = rmi_multi::api();
     if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[7], c->stream));   // (kernel_ns[7] of the result: the exchange alone)
     auto exchange = [&]() -> int {
-      // rows: in place (this rank's piece already sits in its slot); aggregates: the record of RMI_STATS_WORDS words
+      // rows: in place (this rank's piece already sits in its slot); aggregates: the record of RMI_STATS_WORDS words.
+      // One group: RCCL launches the two gathers as one kernel (one launch latency instead of two on a ~0.1 ms step)
+      const bool grouped = a.GroupStart && a.GroupEnd && !std::getenv("RMI_HIP_NO_NCCL_GROUP");
+      int n0 = grouped ? a.GroupStart() : 0;
       int n1 = a.AllGather(c->d_rows_ext, m->d_rows_full, (size_t)(L_own * rowb), 1 /* ncclUint8 */, m->comm, c->stream);
       int n2 = a.AllGather(&c->d_state->max_err, m->d_stats_all, RMI_STATS_BYTES, 1, m->comm, c->stream);
+      int n3 = grouped ? a.GroupEnd() : 0;
+      if (n1 == 0 && n2 == 0) n1 = n0 ? n0 : n3;
       if (n1 != 0 || n2 != 0) { set_err(c, "ncclAllGather: %s", a.GetErrorString ? a.GetErrorString(n1 ? n1 : n2) : "error"); return RMI_ERR_RCCL; }
       HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, RMI_STATS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
       if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));   // device time of the call now includes the exchange

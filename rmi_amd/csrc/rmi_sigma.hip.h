@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp
                                              const unsigned long long* __restrict__ leaf_start, DevState* __restrict__ st,
                                              double* __restrict__ params, SgList fl, SgParams sg,
                                              unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run,
-                                             GiantLeaf* __restrict__ giant = nullptr, unsigned long long host_min = ~0ull) {
+                                             GiantLeaf* __restrict__ giant = nullptr, unsigned long long host_min = ~0ull,
+                                             bool record_giants = true) {
   __shared__ FitLongLds lds;
   const unsigned int rg = blockIdx.x % SG_REGIONS;
   const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp
     // a container of more than host_min points: its fit is a sequential chain of that length, ~28 ns per point on a wave
     // and ~4 on a host core -- recorded for the host (rmi_hip.hip: the giant-leaf epilogue), nothing else done here
     if (LEAFK == K_LINEAR && giant != nullptr && !tagged && ck == 2 && hi - lo + 1 > host_min) {
-      if (lane == 0) {
+      if (lane == 0 && record_giants) {                              // (else k_giant_scan has recorded it before this launch)
         const unsigned long long pos = atomicAdd(&st->giant_count, 1ull);
         if (pos < st->giant_cap) giant[pos] = GiantLeaf{j, lo, hi, first_occurrence(keys, lo, sp.rd_lo)};
       }
@@ -246,6 +247,27 @@ __global__ void __launch_bounds__(64) k_list(const K* __restrict__ keys, Span sp
     if (lane == 0) { leaf_maxerr[j] = err; leaf_run[j] = run; }
   }
   if (lane == 0 && merged_here) atomicAdd(&fl.cnt[SG_REGIONS + rg], (unsigned long long)merged_here);
+}
+
+// The giant leaves of the list, recorded BEFORE k_list runs (a launch of SG_REGIONS waves): the host reads the short list
+// through pinned memory and walks their chains while k_list is still fitting the other listed leaves (rmi_hip.hip).
+// Same condition as in k_list, which then only skips them.
+template <typename K>
+__global__ void __launch_bounds__(64) k_giant_scan(const K* __restrict__ keys, Span sp, const unsigned long long* __restrict__ leaf_start,
+                                                   DevState* __restrict__ st, SgList fl, GiantLeaf* __restrict__ giant, unsigned long long host_min) {
+  const unsigned int rg = blockIdx.x;
+  const unsigned long long cnt = fl.cnt[rg] < fl.cap ? fl.cnt[rg] : fl.cap;
+  const unsigned int* ids = fl.ids + (unsigned long long)rg * fl.cap;
+  for (unsigned long long t = threadIdx.x; t < cnt; t += 64) {
+    if (ids[t] & SG_TAG) continue;
+    const uint64_t j = ids[t];
+    uint64_t lo, hi;
+    const int ck = leaf_container(j, leaf_start[j], leaf_start[j + 1], sp.n, st->split_idx, st->split_target, lo, hi);
+    if (ck == 2 && hi - lo + 1 > host_min) {
+      const unsigned long long pos = atomicAdd(&st->giant_count, 1ull);
+      if (pos < st->giant_cap) giant[pos] = GiantLeaf{j, lo, hi, first_occurrence(keys, lo, sp.rd_lo)};
+    }
+  }
 }
 
 // k_list_tail: the error pass of the long listed leaves, one wave per stretch of SG_SEG keys, eight independent loads
