@@ -56,16 +56,20 @@
 
 namespace rmi {
 
-#ifndef RMI_LN_ROW
-#define RMI_LN_ROW 16
-#endif
-constexpr int LN_ROW = RMI_LN_ROW;               // keys per panel row = lockstep steps per panel: 16 = one aligned 128-byte line of 8-byte keys; 8 = half a line
-constexpr int LN_RING = 2 * LN_ROW;              // LDS slots per row: two aligned panels (a lane's steps straddle two of them)
-constexpr int LN_MIRROR = 7;                     // the first slots once more behind the ring: 8 consecutive reads never wrap
-constexpr int LN_STRIDE = LN_RING + LN_MIRROR;   // 39 (23), odd: lane-per-row reads spread over the banks
-constexpr int LN_LPR = LN_ROW / 2;               // lanes per row and load (2 keys each) == loads per panel
-constexpr int LN_RPI = 64 / LN_LPR;              // rows per load instruction
-static_assert(LN_ROW == 16 || LN_ROW == 8, "panel geometry");
+// Panel geometry: a load instruction is 64 lanes x 16 bytes = 8 rows x one aligned 128-byte line; a panel is 8 such loads
+// (64 rows), i.e. LnGeom<K>::KPL keys per lane and load and ROW = 8 KPL keys per row: 16 keys of 8 bytes, 32 of 4.
+// (Tried for 8-byte keys: half lines per row -- 8 keys, a ring of 11.8 KB, 3 waves per SIMD: 0.71-0.74 ms against 0.60.
+//  4-byte keys in 16-key panels, i.e. half lines and 8-byte loads: C5 0.82 ms against 0.68 with whole lines.)
+template <typename K> struct LnGeom {
+  static constexpr int KPL = 16 / (int)sizeof(K);   // keys per lane and load
+  static constexpr int ROW = 8 * KPL;               // keys per panel row = lockstep steps per panel
+  static constexpr int RING = 2 * ROW;              // LDS slots per row: two aligned panels (a lane's steps straddle two of them)
+  static constexpr int MIRROR = 7;                  // the first slots once more behind the ring: 8 consecutive reads never wrap
+  static constexpr int STRIDE = RING + MIRROR;      // 39 / 71, odd: lane-per-row reads spread over the banks
+};
+constexpr int LN_LPR = 8;                           // lanes per row and load
+constexpr int LN_RPI = 8;                           // rows per load instruction
+constexpr int LN_NLD = 8;                           // loads per panel
 constexpr int LN_LONG_MAX = 8192; // longest container the lockstep walk takes (longer: the list kernels, one wave per leaf)
 constexpr int LN_TMAX = LN_LONG_MAX + 64;   // entries of the reciprocal table
 constexpr int LS_BLOCK = 256;     // leaves per block of k_leaf_search
@@ -268,9 +272,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
                                                    unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr) {
   using B = typename LnBits<K>::type;
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
-  constexpr int LPR = LN_LPR, NLD = LN_LPR, RPI = LN_RPI;            // lanes per row (2 keys each), loads per panel, rows per load
+  constexpr int LPR = LN_LPR, NLD = LN_NLD, RPI = LN_RPI;            // lanes per row, loads per panel, rows per load
+  constexpr int KPL = LnGeom<K>::KPL, LN_STRIDE = LnGeom<K>::STRIDE, LN_RING = LnGeom<K>::RING, LN_ROW = LnGeom<K>::ROW;
   constexpr unsigned int ROWK = (unsigned int)LN_ROW;
-  __shared__ B panel[64 * LN_STRIDE];                                 // 19 968 B for 8-byte keys: 8 waves per CU
+  __shared__ B panel[64 * LN_STRIDE];                                 // 19 968 B for 8-byte keys, 18 176 for 4-byte keys: 8 waves per CU
   unsigned int* const s_off = reinterpret_cast<unsigned int*>(panel);   // (row descriptors of a phase: exchanged before its first panel is staged)
   unsigned int* const s_end = s_off + 64;
 
@@ -294,7 +299,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   }
   // ... moved down to the start of the 16-key line it lies in (by ADDRESS: whole aligned lines are fetched; the keys
   // of a line in front of the first / behind the last readable key share its page and are never used)
-  wb -= (uint64_t)((reinterpret_cast<uintptr_t>(keys + wb) / sizeof(K)) % (uintptr_t)LN_ROW);
+  wb -= (uint64_t)((reinterpret_cast<uintptr_t>(keys + wb) / sizeof(K)) % (uintptr_t)LnGeom<K>::ROW);
   const K* __restrict__ kb = keys + wb;
   const unsigned int npts = ck == 2 ? (unsigned int)((hi - lo + 1 < 0xFFFFFFFFull) ? hi - lo + 1 : 0xFFFFFFFFull) : 0u;
   // leaves for the list kernels (one wave per leaf: exact fit + its error pass): containers longer than the lockstep
@@ -327,41 +332,44 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       const int row = i * RPI + lane / LPR;
-      const unsigned int piece = 2u * (unsigned int)(lane % LPR);
+      const unsigned int piece = (unsigned int)KPL * (unsigned int)(lane % LPR);
       roff[i] = (s_off[row] + piece) * (unsigned int)sizeof(K);       // byte offsets from kb: a scalar base + a 32-bit lane offset per load
       rlim[i] = (s_end[row] + piece) * (unsigned int)sizeof(K);
     }
     wave_sync();                                                      // (the descriptors alias the panel)
   };
   constexpr int NBUF = RMI_LN_NBUF;
-  B bufs[NBUF][NLD][2];
-  auto load_panel = [&](B (&buf)[NLD][2], unsigned int p16, bool nt) {
+  B bufs[NBUF][NLD][KPL];
+  auto load_panel = [&](B (&buf)[NLD][KPL], unsigned int p16, bool nt) {
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       unsigned int off = roff[i] + p16 * (unsigned int)sizeof(K);
       off = off < rlim[i] ? off : rlim[i];
-      typedef B vec_t __attribute__((ext_vector_type(2)));
-      const vec_t* pv = reinterpret_cast<const vec_t*>(reinterpret_cast<const char*>(kb) + off);   // (16-byte aligned: wb is line aligned, the piece even)
+      typedef B vec_t __attribute__((ext_vector_type(KPL)));
+      const vec_t* pv = reinterpret_cast<const vec_t*>(reinterpret_cast<const char*>(kb) + off);   // (16-byte aligned: wb is line aligned, the piece a multiple of KPL)
       const vec_t v = nt ? __builtin_nontemporal_load(pv) : *pv;
-      buf[i][0] = v.x; buf[i][1] = v.y;
+#pragma unroll
+      for (int q = 0; q < KPL; q++) buf[i][q] = v[q];
     }
   };
   // aligned panel p goes to the ring slots [16 (p & 1), +16); an even panel's first slots once more behind the ring
-  auto stage = [&](B (&buf)[NLD][2], unsigned int p) {
+  auto stage = [&](B (&buf)[NLD][KPL], unsigned int p) {
     const unsigned int sb = (p & 1u) * ROWK;
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
-      const unsigned int base = (unsigned int)(i * RPI + lane / LPR) * LN_STRIDE + sb + 2u * (unsigned int)(lane % LPR);
-      panel[base] = buf[i][0]; panel[base + 1] = buf[i][1];
+      const unsigned int base = (unsigned int)(i * RPI + lane / LPR) * LN_STRIDE + sb + (unsigned int)KPL * (unsigned int)(lane % LPR);
+#pragma unroll
+      for (int q = 0; q < KPL; q++) panel[base + q] = buf[i][q];
     }
     if (sb == 0u) {
-      const unsigned int piece = (unsigned int)(lane % LPR);
-      if (piece < 4u) {
+      const unsigned int slot0 = (unsigned int)KPL * (unsigned int)(lane % LPR);    // (the slots 0 .. 6 once more behind the ring)
+      if (slot0 < (unsigned int)LnGeom<K>::MIRROR) {
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
-          const unsigned int base = (unsigned int)(i * RPI + lane / LPR) * LN_STRIDE + LN_RING + 2u * piece;
-          panel[base] = buf[i][0];
-          if (piece < 3u) panel[base + 1] = buf[i][1];
+          const unsigned int base = (unsigned int)(i * RPI + lane / LPR) * LN_STRIDE + LN_RING + slot0;
+#pragma unroll
+          for (int q = 0; q < KPL; q++)
+            if (slot0 + (unsigned int)q < (unsigned int)LnGeom<K>::MIRROR) panel[base + q] = buf[i][q];
         }
       }
     }
@@ -400,7 +408,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     bool gen = false;                                                 // explicit my-chain (a duplicate key was met)
     // the 16 steps [p16, p16 + 16) of every lane: they read the aligned panels p16 / 16 (staged one trip ago) and
     // p16 / 16 + 1 (staged now, from `buf`, which is refilled with the panel NBUF further on)
-    auto fit_panel = [&](B (&buf)[NLD][2], unsigned int p16) {
+    auto fit_panel = [&](B (&buf)[NLD][KPL], unsigned int p16) {
       wave_sync();
       stage(buf, p16 / ROWK + 1u);
       load_panel(buf, p16 + ROWK * (unsigned int)(NBUF + 1), RMI_LN_NT_FIT != 0);
@@ -517,7 +525,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     unsigned int emax = 0u, run = 0u, yprev = s32;
     bool tr = false;                                                   // yprev is being tracked (a run of equal keys is open)
     B kprev = 0;
-    auto err_panel = [&](B (&buf)[NLD][2], unsigned int p16) {
+    auto err_panel = [&](B (&buf)[NLD][KPL], unsigned int p16) {
       wave_sync();
       stage(buf, p16 / ROWK + 1u);
       load_panel(buf, p16 + ROWK * (unsigned int)(NBUF + 1), RMI_LN_NT_ERR != 0);
