@@ -736,21 +736,22 @@ __device__ __forceinline__ void stats_block_reduce(unsigned long long& mx, unsig
 // and the Q7 count, from its fitted parameters `p`, its raw maximum `curr` and longest run `run` (runs of 1 reported
 // as 0, see k_err_range): what k_finalize does per thread, for the kernels that finish a leaf where they fit it.
 // ---------------------------------------------------------------------------------------------
+// (finalize_one_pre: with the two boundary keys already in registers -- key_next = keys[e] or the type's maximum behind the
+//  last key, key_prev = keys[s - 1] or zero in front of the first: k_leaf_lanes fetches them when the wave starts, so that
+//  their round trip does not stand alone at the wave's end)
 template <int LEAF, typename K>
-__device__ __forceinline__ void finalize_one(uint64_t j, uint64_t s, uint64_t e, const Span& sp, uint64_t L, const K* __restrict__ keys,
-                                             double* p, uint64_t curr, uint64_t run, uint64_t last_target,
-                                             uint64_t& final_err, uint64_t& cnt_j) {
+__device__ __forceinline__ void finalize_one_pre(uint64_t j, uint64_t s, uint64_t e, const Span& sp, uint64_t L, const K* __restrict__ keys,
+                                                 double* p, uint64_t curr, uint64_t run, uint64_t last_target, K key_next, K key_prev,
+                                                 uint64_t& final_err, uint64_t& cnt_j) {
   const uint64_t n = sp.n;
   if (!(s < e)) {
     if constexpr (LEAF == K_CUBIC) { p[0] = 0.0; p[1] = 0.0; p[2] = (j + 1 < L) ? 0.0 : 1.0; p[3] = (j + 1 < L) ? (double)e : 0.0; }
     else { p[0] = (j + 1 < L) ? (double)e : 0.0; p[1] = 0.0; }
   }
-  const K key_next = e < n ? keys[e] : KeyTraits<K>::max_value();            // lower_bound_correction.rs:47-49
-  const uint64_t up_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::minus_eps(key_next));
+  const uint64_t up_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::minus_eps(key_next));   // lower_bound_correction.rs:47-49
   const uint64_t upper = error_between(up_pred, e + 1, n);                   // two_layer.rs:229-235
-  const K key_prev = s > 0 ? keys[s - 1] : KeyTraits<K>::zero_value();       // lower_bound_correction.rs:62-63
   const uint64_t first_idx = (j == 0) ? e : s;                               // next_index(max(j-1,0))
-  const uint64_t lo_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::plus_eps(key_prev));
+  const uint64_t lo_pred = leaf_predict<LEAF, K>(p, KeyTraits<K>::plus_eps(key_prev));    // lower_bound_correction.rs:62-63
   const uint64_t lower = error_between(lo_pred, first_idx, n);               // two_layer.rs:237-247
   uint64_t m = curr;
   m = upper > m ? upper : m;
@@ -758,6 +759,14 @@ __device__ __forceinline__ void finalize_one(uint64_t j, uint64_t s, uint64_t e,
   if (run == 0 && s < e && !(e == n && keys[s] == keys[n - 1])) run = 1;    // (Q5: the globally last run is never recorded)
   final_err = m + run;                                                       // two_layer.rs:250-251
   cnt_j = (e - s) + (last_target == j ? 1ull : 0ull);                        // Q7: tail duplicate
+}
+template <int LEAF, typename K>
+__device__ __forceinline__ void finalize_one(uint64_t j, uint64_t s, uint64_t e, const Span& sp, uint64_t L, const K* __restrict__ keys,
+                                             double* p, uint64_t curr, uint64_t run, uint64_t last_target,
+                                             uint64_t& final_err, uint64_t& cnt_j) {
+  const K key_next = e < sp.n ? keys[e] : KeyTraits<K>::max_value();
+  const K key_prev = s > 0 ? keys[s - 1] : KeyTraits<K>::zero_value();
+  finalize_one_pre<LEAF, K>(j, s, e, sp, L, keys, p, curr, run, last_target, key_next, key_prev, final_err, cnt_j);
 }
 
 // ---------------------------------------------------------------------------------------------

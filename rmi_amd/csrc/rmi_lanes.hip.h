@@ -310,6 +310,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
                                 (LEAFK != K_LINEAR && e - s > (uint64_t)long_min));
   if (handed) fl.push((unsigned int)j);
   const bool act = ck == 2 && !handed;
+  // Single keys this wave needs much later -- the container's last key (the Q1 point, models/mod.rs:180), the keys on either
+  // side of the leaf (the widening of finalize_one) -- and the pair that decides the FixDups offset of the container's first
+  // point: fetched NOW, in front of the first panels, so that none of their round trips stands alone later (a wave lives
+  // ~60 us; an exposed round trip under load is 2-4 us, and the LDS ring allows only two waves per SIMD to cover it).
+  const bool own = valid && !handed;
+  K k_hi = KeyTraits<K>::zero_value(), k_lo = KeyTraits<K>::zero_value(), k_lom1 = KeyTraits<K>::zero_value();
+  K k_him1 = KeyTraits<K>::zero_value();
+  K k_next = KeyTraits<K>::max_value(), k_prev = KeyTraits<K>::zero_value();
+  if (act) {
+    k_hi = keys[hi]; k_lo = keys[lo];
+    if (lo > sp.rd_lo) k_lom1 = keys[lo - 1];
+    if constexpr (LEAFK == K_LINEAR_SPLINE) { if (hi > sp.rd_lo) k_him1 = keys[hi - 1]; }
+  }
+  if (own) { if (e < sp.n) k_next = keys[e]; if (s > 0) k_prev = keys[s - 1]; }
+  // FixDups offset of point i given its key and the key in front of it (the search of first_occurrence only for a duplicate)
+  auto first_occ = [&](uint64_t i, K ki, K kim1) -> uint64_t {
+    return (i <= sp.rd_lo || kim1 != ki) ? i : first_occurrence(keys, i, sp.rd_lo);
+  };
 
   auto wave_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -375,6 +393,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     }
   };
 
+  // the rows of the error pass (the leaves' own keys) and its first panels on their way
+  const bool eact = own && e > s;
+  const unsigned int elen = eact ? (unsigned int)(e - s) : 0u;
+  auto err_prime = [&]() {
+    make_rows(eact ? (unsigned int)(s - wb) : 0u, elen);
+#pragma unroll
+    for (int u = 0; u < RMI_LN_NBUF; u++) load_panel(bufs[u], ROWK * (unsigned int)u, RMI_LN_NT_ERR != 0);
+  };
+
   unsigned int flags = 0;
   double pa = 0.0, pb = 0.0;                                          // this lane's leaf: (alpha, beta)
   bool wave_dups = true;                                              // some container of this wave holds a duplicate key
@@ -382,12 +409,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   if constexpr (LEAFK == K_LINEAR_SPLINE) {
     // linear_spline.rs:13-35: the line through the first and the last point of the container -- two keys, their FixDups
     // offsets, the reference's two operations (IEEE division, plain multiply-subtract): the same bits, no walk
+    if constexpr (ERR) err_prime();                                    // (the first panels of the error pass: on their way meanwhile)
     if (valid && !handed && ck == 2) {
-      const K k0 = keys[lo], k1 = keys[hi];
-      const double y0 = (double)first_occurrence(keys, lo, sp.rd_lo);
+      const K k0 = k_lo, k1 = k_hi;
+      const double y0 = (double)first_occ(lo, k_lo, k_lom1);
       if (lo == hi || k0 == k1) { pa = y0; pb = 0.0; }
       else {
-        const double y1 = (double)first_occurrence(keys, hi, sp.rd_lo);
+        const double y1 = (double)first_occ(hi, k_hi, k_him1);
         const double x0 = KeyTraits<K>::as_float(k0), x1 = KeyTraits<K>::as_float(k1);
         pb = (y0 - y1) / (x0 - x1);
         pa = y0 - pb * x0;
@@ -401,7 +429,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
 #pragma unroll
     for (int u = 0; u < NBUF; u++) load_panel(bufs[u], ROWK * (unsigned int)u, RMI_LN_NT_FIT != 0);
     uint64_t y0 = lo;
-    if (act) y0 = first_occurrence(keys, lo, sp.rd_lo);               // FixDups offset of the container's first point
+    if (act) y0 = first_occ(lo, k_lo, k_lom1);                        // FixDups offset of the container's first point
     const double y0f = (double)y0, lof = (double)lo;
     double mx = 0.0, cc = 0.0, m2 = 0.0, my = 0.0, yprev = y0f;
     B kprev = 0;
@@ -494,9 +522,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
 #pragma unroll
       for (int u = 0; u < NBUF; u++) fit_panel(bufs[(u + 1) % NBUF], p16 + ROWK * (unsigned int)u);
     }
+    // (the first panels of the error pass are asked for before the arithmetic that ends the fit)
+    if constexpr (ERR) err_prime();
     // ---- the container's last item once more (Q1, models/mod.rs:180), then linear.rs:36-58
     if (act) {
-      const double x = KeyTraits<K>::as_float(keys[hi]);
+      const double x = KeyTraits<K>::as_float(k_hi);
       const double nn = (double)npts;
       if (!gen) { my = y0f + (nn - 1.0) * 0.5; yprev = y0f + (nn - 1.0); }
       const double nf = nn + 1.0;
@@ -515,12 +545,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
   }
   // =========================== the error pass over the leaves' own keys ===========================
   if constexpr (ERR) {
-    const bool eact = valid && !handed && e > s;
-    const unsigned int len = eact ? (unsigned int)(e - s) : 0u;
-    make_rows(eact ? (unsigned int)(s - wb) : 0u, len);
+    const unsigned int len = elen;                                     // (err_prime() has run: the first panels are on their way)
     const unsigned int a0 = eact ? (unsigned int)(s - wb) & (ROWK - 1u) : 0u;
-#pragma unroll
-    for (int u = 0; u < NBUF; u++) load_panel(bufs[u], ROWK * (unsigned int)u, RMI_LN_NT_ERR != 0);
     const unsigned int n32 = (unsigned int)sp.n, s32 = (unsigned int)s;
     unsigned int emax = 0u, run = 0u, yprev = s32;
     bool tr = false;                                                   // yprev is being tracked (a run of equal keys is open)
@@ -614,7 +640,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     if (valid && !handed) {
       double pp[2] = {pa, pb};
       uint64_t final_err, cnt_j;
-      finalize_one<K_LINEAR, K>(j, s, e, sp, L, keys, pp, (uint64_t)emax, run > 1u ? (uint64_t)run : 0ull, st->last_target, final_err, cnt_j);
+      finalize_one_pre<K_LINEAR, K>(j, s, e, sp, L, keys, pp, (uint64_t)emax, run > 1u ? (uint64_t)run : 0ull, st->last_target, k_next, k_prev, final_err, cnt_j);
       if (!(s < e)) { params[2 * j] = pp[0]; params[2 * j + 1] = pp[1]; }
       leaf_err[j] = final_err;
       leaf_count[j] = cnt_j;
