@@ -26,6 +26,12 @@ def run_case(rng, c=0):
     waves = [None, "64", "1000", "100000"][rng.integers(4)]
     if waves: os.environ["RMI_HIP_SIGMA_WAVES"] = waves
     else: os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
+    # the leaf-lane pipeline's own switches (exact mode): leaves handed to the list kernels / to the host, the tail in-stream
+    knobs = {"RMI_HIP_LONG_MIN": [None, "64", "512"][rng.integers(3)], "RMI_HIP_HOST_MIN": [None, "2000"][rng.integers(2)],
+             "RMI_HIP_OPT_TAIL": [None, "0"][rng.integers(2)], "RMI_HIP_LANES_SEARCH": [None, "0"][rng.integers(2)]}
+    for k, v in knobs.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
     keys = dg.GENERATORS[gen](n, seed=int(rng.integers(1, 1 << 30)))
     try:
         o = orc.train_two_layer(root, leaf, keys, L, threads=2)
@@ -70,7 +76,9 @@ def run_case(rng, c=0):
         over = mx - ge
         ok = ok and int(np.count_nonzero(over > 0)) <= 2 and (over.max() <= 1)
     os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
-    return ok, (f"{c:3d} {gen:14s} {root:13s} n={n:8d} L={L:7d} leaf={leaf} mode={mode} streamed={chunks if streamed else 0} waves={waves} used={g.fit_mode_used} exact={g.exact_leaves} "
+    for k in knobs: os.environ.pop(k, None)
+    kn = ",".join(f"{k[8:].lower()}={v}" for k, v in knobs.items() if v is not None)
+    return ok, (f"[{kn}] " + f"{c:3d} {gen:14s} {root:13s} n={n:8d} L={L:7d} leaf={leaf} mode={mode} streamed={chunks if streamed else 0} waves={waves} used={g.fit_mode_used} exact={g.exact_leaves} "
                 f"merged={g.merged_leaves} guard={g.guard_leaves} diff={nd}")
 
 
