@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
       unsigned int off = roff[i] + p16 * (unsigned int)sizeof(K);
-      off = off < rlim[i] ? off : rlim[i];
+      off = off < rlim[i] ? off : rlim[i];                            // (tried: finished rows all read ONE shared line -- 0.582 against 0.577 ms)
       typedef B vec_t __attribute__((ext_vector_type(KPL)));
       const vec_t* pv = reinterpret_cast<const vec_t*>(reinterpret_cast<const char*>(kb) + off);   // (16-byte aligned: wb is line aligned, the piece a multiple of KPL)
       const vec_t v = nt ? __builtin_nontemporal_load(pv) : *pv;
