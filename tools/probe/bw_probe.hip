@@ -41,6 +41,34 @@ __global__ void __launch_bounds__(256) k_chunk(const u4* __restrict__ src, uint6
 }
 // C: 64 row streams per wave like k_leaf_lanes: lane group of 8 lanes reads one 128-byte line of its row per load, rows are
 // contiguous pieces of `rowlen` lines, 8 loads (64 rows) per step, U steps in flight
+// D dependent scattered loads in front of the streaming (what a wave of k_leaf_lanes does before its first panel: the
+// entries of leaf_start, then single keys, then the panels): each is a round trip with nothing else in flight
+template <int U, int D>
+__global__ void __launch_bounds__(64) k_rows_dep(const u4* __restrict__ src, uint64_t n16, unsigned int rowlines, unsigned int* sink) {
+  extern __shared__ unsigned int lds_pad[];
+  if (rowlines == 0xFFFFFFFFu) lds_pad[threadIdx.x] = 1;
+  const uint64_t wave = blockIdx.x;
+  const int lane = threadIdx.x;
+  uint64_t base = wave * 64ull * rowlines * 8ull;
+  if (base + 64ull * rowlines * 8ull > n16) return;
+  unsigned int acc = 0;
+  uint64_t chase = (wave * 2654435761ull + lane * 40503ull) % (n16 - 1);
+#pragma unroll
+  for (int d = 0; d < D; d++) { const u4 v = src[chase]; acc ^= v.x; chase = (chase * 31ull + (v.y & 1u) + 977ull * (d + 1)) % (n16 - 1); }
+  base += (acc == 0x7fffffffu) ? 1 : 0;                            // (the streaming waits for the chain)
+  for (unsigned int l = 0; l + U <= rowlines; l += U) {
+    u4 v[U][8];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[u][i] = src[base + (uint64_t)(i * 8 + lane / 8) * rowlines * 8ull + (uint64_t)(l + u) * 8ull + (lane % 8)];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc ^= v[u][i].x ^ v[u][i].y ^ v[u][i].z ^ v[u][i].w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
 template <int U, bool NT = false>
 __global__ void __launch_bounds__(64) k_rows(const u4* __restrict__ src, uint64_t n16, unsigned int rowlines, unsigned int* sink) {
   extern __shared__ unsigned int lds_pad[];                      // (dynamic LDS only to set the occupancy like k_leaf_lanes' ring does)
@@ -88,6 +116,14 @@ int main() {
     snprintf(nm, sizeof nm, "chunk U=8 grid=%d", g); timeit(nm, [&]() { hipLaunchKernelGGL((k_chunk<8, false>), dim3(g), dim3(256), 0, 0, d, n16, sink); });
     snprintf(nm, sizeof nm, "chunk U=8 nt grid=%d", g); timeit(nm, [&]() { hipLaunchKernelGGL((k_chunk<8, true>), dim3(g), dim3(256), 0, 0, d, n16, sink); });
     snprintf(nm, sizeof nm, "chunk U=16 grid=%d", g); timeit(nm, [&]() { hipLaunchKernelGGL((k_chunk<16, false>), dim3(g), dim3(256), 0, 0, d, n16, sink); });
+  }
+  {
+    const unsigned int rl = 12u, lds = 20000u;
+    const unsigned int waves = (unsigned int)(n16 / (64ull * rl * 8ull));
+    timeit("64 rows x 12 lines, 8 waves/CU, 0 dependent loads first", [&]() { hipLaunchKernelGGL((k_rows<2>), dim3(waves), dim3(64), lds, 0, d, n16, rl, sink); });
+    timeit("64 rows x 12 lines, 8 waves/CU, 1 dependent load first", [&]() { hipLaunchKernelGGL((k_rows_dep<2, 1>), dim3(waves), dim3(64), lds, 0, d, n16, rl, sink); });
+    timeit("64 rows x 12 lines, 8 waves/CU, 2 dependent loads first", [&]() { hipLaunchKernelGGL((k_rows_dep<2, 2>), dim3(waves), dim3(64), lds, 0, d, n16, rl, sink); });
+    timeit("64 rows x 12 lines, 8 waves/CU, 3 dependent loads first", [&]() { hipLaunchKernelGGL((k_rows_dep<2, 3>), dim3(waves), dim3(64), lds, 0, d, n16, rl, sink); });
   }
   // row streams: rows of 12 lines (190 keys of 8 bytes); LDS per wave sets the waves per CU (20 000 B: 8 like k_leaf_lanes)
   for (unsigned int lds : {0u, 20000u, 13000u}) {
