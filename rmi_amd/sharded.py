@@ -329,6 +329,8 @@ class ShardedTrainer:
                 lib.rmi_hip_set_exchange(tr._h, 0)
             self.auto_report = rep
         if not self.on_gpu:
+            if dist.get_backend() == "gloo":
+                self.exchange = "torch.distributed all_gather through host memory (gloo: functional runs only)"
             per = (self.plan.leaf_hi - self.plan.leaf_lo) * self.row_bytes
             self._full = torch.empty(num_leaves * self.row_bytes, dtype=torch.uint8, device="cuda")
             self._mine = torch.empty(per, dtype=torch.uint8, device="cuda")
