@@ -73,6 +73,15 @@ def test_lanes_variants(monkeypatch, oracle, variant, gen, n, L, root):
     _check(monkeypatch, oracle, VARIANTS[variant], dg.GENERATORS[gen](n), root, L)
 
 
+@pytest.mark.parametrize("gen,n,L", [("uniform_u64", 300_000, 1024), ("dups_u64", 300_000, 1024), ("books_u64", 400_000, 512)])
+def test_more_giant_leaves_than_the_early_list_holds(monkeypatch, oracle, gen, n, L):
+    """Every leaf a 'giant' (host threshold 150 points): more of them than the early list carries to the host beside k_list
+    (256) -- the host then fits them all behind the list kernels, from the complete list.  Same bits."""
+    env = {"RMI_HIP_PIPELINE": "3", "RMI_HIP_HOST_MIN": "150", "RMI_HIP_LONG_MIN": "64"}
+    g = _check(monkeypatch, oracle, env, dg.GENERATORS[gen](n), "linear", L)
+    assert g is not None and g.long_leaves > 256
+
+
 @pytest.mark.parametrize("gen", sorted(dg.ADVERSARIAL))
 @pytest.mark.parametrize("n,L", [(200_000, 1024), (199_999, 1000), (65_536, 4096)])
 def test_adversarial_exact(monkeypatch, oracle, gen, n, L):
