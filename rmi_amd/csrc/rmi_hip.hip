@@ -72,6 +72,7 @@ struct rmi_hip_ctx {
   bool opt_tail = true;                         // k_lane_reduce publishes the result behind k_leaf_lanes; the list kernels run behind the synchronisation, and only if a leaf was handed over
   bool tail_armed = false;
   std::function<int()> tail_fn;                 // the list kernels + k_finalize_listed of the last launch (listed_epilogue)
+  std::function<void()> refinalize_fn;          // one-pass modes: k_finalize + k_stats_reduce once more, behind the host fit of giant leaves
   unsigned int* d_tickets = nullptr;            // arrival counter of k_lane_reduce's blocks
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   hipEvent_t ev[10] = {};
@@ -1110,6 +1111,23 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     }
     return RMI_OK;
   };
+  // giant leaves go to the host when this call ends with its own synchronisation (not inside a streamed or a sharded training)
+  auto arm_giants = [&]() -> int {
+    const uint64_t gcap = n_it / c->host_min + 64;
+    if (c->giant_cap < gcap) {
+      if (c->d_giant) (void)hipFree(c->d_giant);
+      c->d_giant = nullptr; c->giant_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_giant, gcap * sizeof(GiantLeaf)));
+      c->giant_cap = gcap;
+    }
+    c->giant_armed = true;
+    if (!c->h_giant) HIPCHK(c, hipHostMalloc((void**)&c->h_giant, 8 + rmi_hip_ctx::GIANT_EARLY_MAX * sizeof(GiantLeaf), hipHostMallocDefault));
+    if (!c->ev_giant) HIPCHK(c, hipEventCreateWithFlags(&c->ev_giant, hipEventDisableTiming));
+    c->lp.keys = keys; c->lp.sp = sp; c->lp.L = L; c->lp.leaf_start = leaf_start; c->lp.params = params; c->lp.maxerr = maxerr; c->lp.run = run;
+    c->lp.err = err; c->lp.count = count; c->lp.rows = rows; c->lp.waves = (L_own + 63) / 64;
+    return RMI_OK;
+  };
+  c->refinalize_fn = nullptr;
   bool lanes_fused = false;
   if (lanes) {
     if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
@@ -1149,22 +1167,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // --- exact fit of 64 leaves per wave in lockstep, and their error pass behind it ---
       lanes_fused = lanes_fused_plan;
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
-      // giant leaves go to the host when this call ends with its own synchronisation (not inside a streamed or a sharded training)
       const bool giants = LEAF == K_LINEAR && lanes_fused_plan && c->host_min > 0 && !c->stream_mode && !c->defer_sync;
-      if (giants) {
-        const uint64_t gcap = n_it / c->host_min + 64;
-        if (c->giant_cap < gcap) {
-          if (c->d_giant) (void)hipFree(c->d_giant);
-          c->d_giant = nullptr; c->giant_cap = 0;
-          HIPCHK(c, hipMalloc(&c->d_giant, gcap * sizeof(GiantLeaf)));
-          c->giant_cap = gcap;
-        }
-        c->giant_armed = true;
-        if (!c->h_giant) HIPCHK(c, hipHostMalloc((void**)&c->h_giant, 8 + rmi_hip_ctx::GIANT_EARLY_MAX * sizeof(GiantLeaf), hipHostMallocDefault));
-        if (!c->ev_giant) HIPCHK(c, hipEventCreateWithFlags(&c->ev_giant, hipEventDisableTiming));
-        c->lp.keys = keys; c->lp.sp = sp; c->lp.L = L; c->lp.leaf_start = leaf_start; c->lp.params = params; c->lp.maxerr = maxerr; c->lp.run = run;
-        c->lp.err = err; c->lp.count = count; c->lp.rows = rows; c->lp.waves = (L_own + 63) / 64;
-      }
+      if (giants) { const int grc = arm_giants(); if (grc != RMI_OK) return grc; }
       const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
       StatsPartial* const part = c->d_partials;
       bool verify = false;
@@ -1318,13 +1322,27 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     hipLaunchKernelGGL(k_fill_apply, dim3((unsigned)ntiles), dim3(256), 0, s, a_leaf_start, count_e, c->d_tilemin);
   }
   if (!lanes) mark();
+  bool sigma_giants = false;
   if (lanes) {
   } else if (sigma) {
     if constexpr (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE) {
       // --- the leaves the one-pass kernel handed over: fit (or merge) + error pass, one wave per leaf; long ones in stretches ---
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
+      // (the guarded mode re-fits its long leaves exactly: a giant one is a chain for a host core, as on the exact path;
+      //  RMI_FIT_ONEPASS merges their partial sums instead -- tagged entries, never handed to the host)
+      sigma_giants = LEAF == K_LINEAR && c->host_min > 0 && !c->stream_mode && !c->defer_sync;
+      if (sigma_giants) {
+        const int grc = arm_giants(); if (grc != RMI_OK) return grc;
+        // (their list first, through pinned memory: the host walks those chains while k_list fits the other listed leaves)
+        const uint64_t hgn = c->giant_cap < rmi_hip_ctx::GIANT_EARLY_MAX ? c->giant_cap : rmi_hip_ctx::GIANT_EARLY_MAX;
+        hipLaunchKernelGGL((k_giant_scan<K>), dim3(SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, fl, c->d_giant, (unsigned long long)c->host_min);
+        HIPCHK(c, hipMemcpyAsync(c->h_giant, &c->d_state->giant_count, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_giant + 1, c->d_giant, hgn * sizeof(GiantLeaf), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->ev_giant, s));
+        c->giant_early = true;
+      }
       hipLaunchKernelGGL((k_list<K, LEAF>), dim3(128 * SG_REGIONS), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->last_sg, maxerr, run,
-                         (GiantLeaf*)nullptr, ~0ull);
+                         sigma_giants ? c->d_giant : (GiantLeaf*)nullptr, sigma_giants ? (unsigned long long)c->host_min : ~0ull, !sigma_giants);
       mark();
       hipLaunchKernelGGL((k_list_tail<K>), dim3(8192), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, fl, c->d_segs, maxerr, run);
     }
@@ -1387,6 +1405,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     // (the last kernel also copies the device state into the pinned host copy: a separate 100-byte
     // copy command would cost ~15 us of the call)
     hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, c->d_partials, (int)blocks, c->d_state, c->h_state_dev + (c->stream_mode ? c->stream_slot : 0));
+    if (sigma_giants) {
+      // (behind the host fit of giant leaves, giant_epilogue: every leaf finalized once more -- ~25 us -- and the aggregates)
+      StatsPartial* const part = c->d_partials;
+      DevState* const dst = c->d_state;
+      DevState* const hcopy = c->h_state_dev;
+      c->refinalize_fn = [=]() {
+        hipLaunchKernelGGL((k_finalize<LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, L, leaf_start, dst, params, maxerr, run, err, count, rows, part, bn, bp);
+        hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, s, part, (int)blocks, dst, hcopy);
+      };
+    }
   }
   mark();
   if (pl >= 0) HIPCHK(c, hipEventRecord(c->ev[9], s));
@@ -1447,6 +1475,14 @@ static int giant_epilogue(rmi_hip_ctx* c) {
   SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
   hipLaunchKernelGGL(k_giant_segments, dim3(16), dim3(64), 0, s, c->d_giant, c->lp.leaf_start, c->d_state, c->d_segs, c->lp.maxerr, c->lp.run);
   hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, c->lp.sp, c->lp.leaf_start, c->d_state, c->lp.params, fl, c->d_segs, c->lp.maxerr, c->lp.run);
+  if (c->refinalize_fn) {                                           // one-pass modes: k_finalize over all leaves + the aggregates again
+    c->refinalize_fn();
+    c->refinalize_fn = nullptr;
+    if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], s));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(s));
+    return RMI_OK;
+  }
   StatsPartial* first = c->d_partials + c->lp.waves + SG_REGIONS;    // the records of the launch's own k_finalize_listed
   hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(FL_THREADS), 0, s, keys, c->lp.sp, c->lp.L, c->lp.leaf_start, c->d_state, c->lp.params,
                      c->lp.maxerr, c->lp.run, c->lp.err, c->lp.count, c->lp.rows, fl, first, (unsigned int)FL_BLOCKS, first + FL_BLOCKS,
@@ -1454,6 +1490,25 @@ static int giant_epilogue(rmi_hip_ctx* c) {
   if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], s)); // (the device time of the call covers the epilogue, host fit included)
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(s));
+  return RMI_OK;
+}
+
+// The giant list is out before k_list starts (k_giant_scan + a copy into pinned memory + an event): the host walks those
+// chains while the device fits the other listed leaves.
+static int giant_early_fit(rmi_hip_ctx* c) {
+  HIPCHK(c, hipEventSynchronize(c->ev_giant));
+  const uint64_t gc = c->h_giant[0];
+  if (gc == 0 || gc > rmi_hip_ctx::GIANT_EARLY_MAX || gc > c->giant_cap) return RMI_OK;   // (none, or more than the early list holds: giant_epilogue)
+  if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  const GiantLeaf* gl = reinterpret_cast<const GiantLeaf*>(c->h_giant + 1);
+  int rc;
+  switch (c->dtype) {
+    case RMI_KEY_U64: rc = giant_host_fit<uint64_t>(c, gl, gc, c->copy_stream); break;
+    case RMI_KEY_U32: rc = giant_host_fit<uint32_t>(c, gl, gc, c->copy_stream); break;
+    default: rc = giant_host_fit<double>(c, gl, gc, c->copy_stream); break;
+  }
+  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+  c->giant_fitted = true;
   return RMI_OK;
 }
 
@@ -1536,6 +1591,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   }
   if (rc) return rc;
   if (c->defer_sync) return RMI_OK;                            // (rmi_hip_train_sharded goes on from here)
+  if (c->giant_early && !c->tail_armed) { rc = giant_early_fit(c); if (rc) return rc; }   // (one-pass modes: k_list is already running)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->tail_armed) {
     // k_lane_reduce has published the result: final unless k_leaf_lanes handed leaves to the list kernels
@@ -1545,22 +1601,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
       c->tail_fn = nullptr;
       if (rc) return rc;
       if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
-      if (c->giant_early) {
-        // the giant list is out before k_list starts: the host walks those chains while the device fits the other listed leaves
-        HIPCHK(c, hipEventSynchronize(c->ev_giant));
-        const uint64_t gc = c->h_giant[0];
-        if (gc > 0 && gc <= rmi_hip_ctx::GIANT_EARLY_MAX && gc <= c->giant_cap) {
-          if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-          const GiantLeaf* gl = reinterpret_cast<const GiantLeaf*>(c->h_giant + 1);
-          switch (c->dtype) {
-            case RMI_KEY_U64: rc = giant_host_fit<uint64_t>(c, gl, gc, c->copy_stream); break;
-            case RMI_KEY_U32: rc = giant_host_fit<uint32_t>(c, gl, gc, c->copy_stream); break;
-            default: rc = giant_host_fit<double>(c, gl, gc, c->copy_stream); break;
-          }
-          if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-          c->giant_fitted = true;
-        }
-      }
+      if (c->giant_early) { rc = giant_early_fit(c); if (rc) return rc; }
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->tail_fn = nullptr;

@@ -82,6 +82,16 @@ def test_more_giant_leaves_than_the_early_list_holds(monkeypatch, oracle, gen, n
     assert g is not None and g.long_leaves > 256
 
 
+@pytest.mark.parametrize("gen,n,L", [("books_u64", 600_000, 64), ("clustered_u64", 600_000, 32), ("uniform_u64", 1_000_000, 16)])
+def test_guarded_mode_hands_its_giant_leaves_to_the_host(monkeypatch, oracle, gen, n, L):
+    """The guarded one-pass mode re-fits its long leaves exactly; those beyond the host threshold (2 000 points here) are
+    chains for host cores, like on the exact path, with every leaf finalized once more behind them: error integers, counts
+    and aggregates the oracle's."""
+    env = {"RMI_HIP_HOST_MIN": "2000"}
+    g = _check(monkeypatch, oracle, env, dg.GENERATORS[gen](n), "linear", L, mode=1, coef_exact=False)
+    assert g is not None and g.fit_mode_used == 1
+
+
 @pytest.mark.parametrize("gen", sorted(dg.ADVERSARIAL))
 @pytest.mark.parametrize("n,L", [(200_000, 1024), (199_999, 1000), (65_536, 4096)])
 def test_adversarial_exact(monkeypatch, oracle, gen, n, L):
