@@ -7,6 +7,7 @@ sys.path.insert(0, ".")
 from rmi_amd import datagen as dg, train
 from oracle import binding as orc
 
+BIG_LOG2N = 0.0        # python tests/devtools/fuzz.py cases seed big: keys up to 2^24.5
 GENS = ["uniform_u64", "books_u64", "uniform_u32", "uniform_f64", "dups_u64", "dups_u32", "clustered_u64"]
 ROOTS = ["linear", "linear_spline", "radix", "cubic"]
 
@@ -16,7 +17,7 @@ def run_case(rng, c=0):
     import os
     gen = GENS[rng.integers(len(GENS))]
     root = ROOTS[rng.integers(len(ROOTS))]
-    n = int(2 ** rng.uniform(12.1, 21.5))
+    n = int(2 ** rng.uniform(12.1, BIG_LOG2N if BIG_LOG2N else 21.5))
     L = int(2 ** rng.uniform(3, np.log2(n / 32)))
     if root == "radix":
         L = 1 << max(3, int(np.log2(L)))
@@ -85,6 +86,8 @@ def run_case(rng, c=0):
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    if len(sys.argv) > 3 and sys.argv[3] == "big":
+        BIG_LOG2N = 24.5
     bad = 0
     t_start = time.time()
     for c in range(cases):
