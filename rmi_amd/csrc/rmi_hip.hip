@@ -74,6 +74,9 @@ struct rmi_hip_ctx {
   std::function<int()> tail_fn;                 // the list kernels + k_finalize_listed of the last launch (listed_epilogue)
   std::function<void()> refinalize_fn;          // one-pass modes: k_finalize + k_stats_reduce once more, behind the host fit of giant leaves
   unsigned int* d_tickets = nullptr;            // arrival counter of k_lane_reduce's blocks
+  int peer_fuse_n = 0;                          // direct exchange, <= 8 ranks: the peers' tables of the running epoch (k_leaf_lanes stores its rows there too)
+  unsigned char* peer_fuse_tab[7] = {};
+  bool rows_pushed = false;                     // ... and whether the last launch did
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   hipEvent_t ev[10] = {};
   int profile_level = 0;                        // -1: no events at all (device_ns = 0); 0: whole call only; 1: + the first (dominant) kernel; 2: every kernel group
@@ -1171,21 +1174,31 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       if (giants) { const int grc = arm_giants(); if (grc != RMI_OK) return grc; }
       const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
       StatsPartial* const part = c->d_partials;
+      // sharded training with the direct exchange: the rows of the leaves k_leaf_lanes finishes go to every peer's table from
+      // the kernel itself (train_sharded_direct has set the tables of this epoch); leaves handed to the list kernels follow
+      // with the whole slot in the second exchange of the `pending` protocol
+      PeerRows peers; std::memset(&peers, 0, sizeof peers);
+      c->rows_pushed = false;
+      if (lanes_fused_plan && c->peer_fuse_n > 0) {                 // (linear and linear_spline leaves: rows of 24 bytes)
+        peers.n = c->peer_fuse_n;
+        for (int p = 0; p < peers.n; p++) peers.tab[p] = c->peer_fuse_tab[p];
+        c->rows_pushed = true;
+      }
       bool verify = false;
       if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR) {
         if (searched) {                                                 // (searched implies fused: the verification rides on the error pass)
           hipLaunchKernelGGL((k_leaf_lanes<K, true, K_LINEAR, K_CUBIC>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                             L, err, count, rows, part, rp);
+                             L, err, count, rows, part, rp, peers);
           verify = true;
         }
       }
       if (verify) {
       } else if (lanes_fused)
         hipLaunchKernelGGL((k_leaf_lanes<K, true, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                           L, err, count, rows, part, rp);
+                           L, err, count, rows, part, rp, peers);
       else
         hipLaunchKernelGGL((k_leaf_lanes<K, false, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                           L, err, count, rows, part, rp);
+                           L, err, count, rows, part, rp, peers);
       mark();
       // --- the leaves handed over (containers too long for the lockstep walk): one wave each, fit + error pass; the
       //     listed leaves' share of the finalize, the aggregates, the result record ---

@@ -253,6 +253,12 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x == 0 && sp.n - 1 >= sp.it_lo && sp.n - 1 < sp.it_hi) st->last_target = (unsigned long long)tgt(sp.n - 1);
 }
 
+// The direct exchange of a sharded training (rmi_multi.inc.h) inside k_leaf_lanes: a finished leaf's row goes not only to this
+// rank's table but to every peer's (IPC-mapped, this epoch's half) -- SURVEY H8's "peer stores from the kernel epilogue":
+// the exchange runs under the compute instead of behind it (22 MB per rank at 8 ranks: ~60 us as a step of its own against
+// ~100 us of kernels).  tab[p] + 24 j is row j of peer p's table (j global); n == 0: no peers.
+struct PeerRows { int n; unsigned char* tab[7]; };
+
 // ---------------------------------------------------------------------------------------------
 // k_leaf_lanes
 // ---------------------------------------------------------------------------------------------
@@ -269,7 +275,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
                                                    unsigned long long* __restrict__ leaf_run, uint64_t L,
                                                    unsigned long long* __restrict__ leaf_err,
                                                    unsigned long long* __restrict__ leaf_count,
-                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr) {
+                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr,
+                                                   PeerRows peers) {
   using B = typename LnBits<K>::type;
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
   constexpr int LPR = LN_LPR, NLD = LN_NLD, RPI = LN_RPI;            // lanes per row, loads per panel, rows per load
@@ -647,6 +654,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
       double* rp = reinterpret_cast<double*>(rows + j * 24);
       rp[0] = pp[0]; rp[1] = pp[1];
       *reinterpret_cast<unsigned long long*>(rows + j * 24 + 16) = final_err;
+      for (int p = 0; p < peers.n; p++) {                              // (wave-uniform trip count; 24-byte rows: three 8-byte stores)
+        double* pr = reinterpret_cast<double*>(peers.tab[p] + j * 24);
+        pr[0] = pp[0]; pr[1] = pp[1];
+        *reinterpret_cast<unsigned long long*>(peers.tab[p] + j * 24 + 16) = final_err;
+      }
       st_mx = final_err; st_mi = j;
       st_sum = cnt_j * final_err;                                      // wrapping u64, like the reference's sum
       const double v = (double)st_sum;

@@ -87,6 +87,7 @@ struct rmi_hip_multi {
   unsigned char** d_peer_rows = nullptr;    // the two tables above for the kernels
   unsigned char** d_peer_mail = nullptr;
   unsigned long long epoch = 0;
+  bool fuse_peer_stores = true;             // direct exchange: rows to the peers from k_leaf_lanes itself (RMI_HIP_PEER_FUSE=0: k_peer_push behind the kernels)
 };
 // A rank's record in the exchange of the aggregates: the 6 words of DevState from max_err on (max_err, max_err_idx, sum_n_err,
 // sum_l2, sum_log2, pending): the last one tells every rank whether SOME rank still has listed leaves to finish.
@@ -297,12 +298,13 @@ static bool sharded_totals(rmi_hip_ctx* c, rmi_hip_multi* m, rmi_hip_result* out
 
 // The exchange as peer stores (include/rmi_hip.h).  Epoch e uses half e & 1 of every rank's table: a rank that runs ahead
 // stores into the half its peers are not reading.
-static int direct_exchange(rmi_hip_ctx* c, rmi_hip_multi* m, unsigned long long epoch, uint64_t off, uint64_t bytes) {
+static int direct_exchange(rmi_hip_ctx* c, rmi_hip_multi* m, unsigned long long epoch, uint64_t off, uint64_t bytes, bool rows_there) {
   unsigned char* table = m->d_rows2 + (epoch & 1ull) * m->rows2_slot;
   // (peer pointers of this epoch's half: the tables hold the bases, the half is part of the byte offset)
   const uint64_t n16 = bytes / 16;
   const uint64_t byte_off = (epoch & 1ull) * m->rows2_slot + off;
-  hipLaunchKernelGGL(k_peer_push, dim3(512), dim3(256), 0, c->stream, (const uint4*)(table + off), n16, (unsigned char* const*)m->d_peer_rows, byte_off, m->rank, m->world);
+  // (rows_there: k_leaf_lanes has stored its rows into the peers' tables itself)
+  if (!rows_there) hipLaunchKernelGGL(k_peer_push, dim3(512), dim3(256), 0, c->stream, (const uint4*)(table + off), n16, (unsigned char* const*)m->d_peer_rows, byte_off, m->rank, m->world);
   hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, c->stream, (unsigned char* const*)m->d_peer_mail, (const unsigned long long*)&c->d_state->max_err, m->rank, m->world, epoch);
   hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, (unsigned long long*)m->d_mail, m->world, epoch, (unsigned long long*)m->d_stats_all, c->d_state);
   HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, RMI_STATS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
@@ -323,12 +325,19 @@ static int train_sharded_direct(rmi_hip_ctx* c, rmi_hip_multi* m, const rmi_hip_
   void* const saved_ext = c->d_rows_ext;
   c->d_rows_ext = table + off;
   c->defer_sync = true;
+  // (<= 8 ranks: the peers' tables of this epoch go to k_leaf_lanes, which stores every row it finishes there as well)
+  c->peer_fuse_n = 0;
+  if (m->world <= 8 && m->fuse_peer_stores) {
+    for (int r = 0; r < m->world; r++)
+      if (r != m->rank) c->peer_fuse_tab[c->peer_fuse_n++] = m->peer_rows[r] + (epoch & 1ull) * m->rows2_slot;
+  }
   int rc = rmi_hip_train_two_layer(c, root, leaf_kind, num_leaves, out);
   c->defer_sync = false;
+  c->peer_fuse_n = 0;
   c->d_rows_ext = saved_ext;
   if (rc != RMI_OK) return rc;
   if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-  rc = direct_exchange(c, m, epoch, off, L_own * rowb);
+  rc = direct_exchange(c, m, epoch, off, L_own * rowb, c->rows_pushed);
   if (rc != RMI_OK) return rc;
   {
     // the ranks' results may have been published without their list kernels (launch_pipeline): if SOME rank handed leaves
@@ -340,7 +349,7 @@ static int train_sharded_direct(rmi_hip_ctx* c, rmi_hip_multi* m, const rmi_hip_
       epoch = ++m->epoch;
       unsigned char* table2 = m->d_rows2 + (epoch & 1ull) * m->rows2_slot;
       HIPCHK(c, hipMemcpyAsync(table2 + off, table + off, L_own * rowb, hipMemcpyDeviceToDevice, c->stream));
-      rc = direct_exchange(c, m, epoch, off, L_own * rowb);
+      rc = direct_exchange(c, m, epoch, off, L_own * rowb, false);
     }
     c->tail_armed = false; c->tail_fn = nullptr;
     if (rc != RMI_OK) return rc;
@@ -590,6 +599,7 @@ int rmi_hip_peer_import(rmi_hip_ctx* c, int peer_rank, const void* handle) {
 int rmi_hip_set_exchange(rmi_hip_ctx* c, int mode) {
   if (!c || (mode != RMI_EXCHANGE_RCCL && mode != RMI_EXCHANGE_DIRECT)) return RMI_ERR_BAD_ARG;
   multi_of(c)->exchange = mode;
+  { const char* pf = std::getenv("RMI_HIP_PEER_FUSE"); if (pf && *pf) multi_of(c)->fuse_peer_stores = std::atoi(pf) != 0; }
   return RMI_OK;
 }
 
