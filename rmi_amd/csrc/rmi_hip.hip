@@ -19,6 +19,7 @@
 #include "rmi_stream.hip.h"
 #include "rmi_sigma.hip.h"
 #include "rmi_lanes.hip.h"
+#include "rmi_regs.hip.h"
 #include "rmi_root_host.h"
 
 using namespace rmi;
@@ -84,6 +85,19 @@ struct rmi_hip_ctx {
   int pipeline = 3;                             // 1 = one kernel per reference pass; 2 = streaming passes A/B; 3 = leaf-lane kernels (rmi_lanes.hip.h)
   double* d_lntab = nullptr;                    // RN(1 / k) for the running count of the leaf-lane walk (k_lane_table)
   bool lanes_fuse = true;                       // error pass fused behind the fit in k_leaf_lanes (else k_err_range)
+  // pipeline 4 (rmi_regs.hip.h): k_leaf_regs -- one read of the keys, a leaf's keys stay in registers between its fit and its error pass --
+  // in place of k_leaf_lanes where the leaves are short enough on average; the groups it does not take go through k_leaf_lanes_listed
+  bool regs = false;                            // RMI_HIP_REGS=1: k_leaf_regs where it applies (measured slower than k_leaf_lanes so far: DESIGN section 4)
+  bool regs_nt = true;                          // non-temporal LDS-DMA loads (the keys are read once)
+  unsigned int regs_grid = 0;                   // persistent waves of k_leaf_regs (0: 4 per CU)
+  unsigned int regs_max_avg = 208;              // average keys per leaf above which most groups would not fit (RG_MAXPTS = 240 per container)
+  unsigned int regs_slow = 0;                   // debugging: every group on the list
+  double* d_regtab = nullptr;                   // the interleaved step table of k_leaf_regs
+  unsigned long long* d_regprof = nullptr;      // RG_PROF builds: cycles per phase, summed over the waves
+  unsigned int* d_slow_list = nullptr;          // groups of 64 leaves left to k_leaf_lanes_listed (counter: d_tickets[1])
+  uint64_t slow_cap = 0;
+  int n_cu = 256;
+  bool last_regs = false;
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
   bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes (RMI_HIP_SPLINE_LANES=0: k_sigma2's spline variant)
   uint64_t edge_epoch = 0;                      // first / last resident key of the key set `keys_epoch` (radix roots: is the prefix common?)
@@ -283,8 +297,17 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* otl = std::getenv("RMI_HIP_OPT_TAIL"); if (otl && *otl) c->opt_tail = std::atoi(otl) != 0; }
   { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
   { const char* sl = std::getenv("RMI_HIP_SPLINE_LANES"); if (sl && *sl) c->spline_lanes = std::atoi(sl) != 0; }
+  { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) c->regs = std::atoi(rg) != 0; }
+  { const char* rg = std::getenv("RMI_HIP_REGS_NT"); if (rg && *rg) c->regs_nt = std::atoi(rg) != 0; }
+  { const char* rg = std::getenv("RMI_HIP_REGS_GRID"); if (rg && *rg) c->regs_grid = (unsigned int)std::atoi(rg); }
+  { const char* rg = std::getenv("RMI_HIP_REGS_MAX_AVG"); if (rg && *rg) c->regs_max_avg = (unsigned int)std::atoi(rg); }
+  { const char* rg = std::getenv("RMI_HIP_REGS_SLOW"); if (rg && *rg) c->regs_slow = (unsigned int)std::atoi(rg); }
+  { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) c->n_cu = cu; }
   if (hipMalloc(&c->d_lntab, sizeof(double) * (3 * LN_TMAX + 2 * (LS_SAMPLES + 1))) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   hipLaunchKernelGGL(k_lane_table, dim3((LN_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_lntab, LN_TMAX);
+  if (hipMalloc(&c->d_regtab, sizeof(double) * 4 * RG_TMAX) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
+  if (RG_PROF) { if (hipMalloc(&c->d_regprof, 128) != hipSuccess || hipMemset(c->d_regprof, 0, 128) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; } }
+  hipLaunchKernelGGL(k_regs_table, dim3((RG_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_regtab, RG_TMAX);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
   if (ft && *ft) c->fit_threads = std::strtoull(ft, nullptr, 10);
@@ -334,6 +357,14 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->d_keys_owned) (void)hipFree(c->d_keys_owned);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_lntab) (void)hipFree(c->d_lntab);
+  if (c->d_regtab) (void)hipFree(c->d_regtab);
+  if (c->d_regprof) {
+    unsigned long long h[16] = {};
+    if (hipMemcpy(h, c->d_regprof, 128, hipMemcpyDeviceToHost) == hipSuccess)
+      std::fprintf(stderr, "k_leaf_regs cycles (sum over waves and trainings): fit %llu, epilogue+tail %llu, hand-over %llu, error pass %llu, finalize %llu; in the fit: panel requests %llu, constants + key reads %llu, stash copies %llu, waits for panels %llu, arithmetic %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+    (void)hipFree(c->d_regprof);
+  }
+  if (c->d_slow_list) (void)hipFree(c->d_slow_list);
   if (c->d_giant) (void)hipFree(c->d_giant);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_sentinel) (void)hipHostFree(c->h_sentinel);
@@ -1148,14 +1179,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           LaneInit li; std::memset(&li, 0, sizeof li);
           if (init_folded) {
             li.st = c->d_state; li.init = init; li.leaf_start = a_leaf_start; li.L_own = L_own; li.sentinel = (unsigned long long)sp.it_hi;
-            li.list_cnt = c->d_flist_cnt; li.n_list_cnt = 2 * SG_REGIONS + 8; li.tickets = c->d_tickets; li.n_tickets = 1;
+            li.list_cnt = c->d_flist_cnt; li.n_list_cnt = 2 * SG_REGIONS + 8; li.tickets = c->d_tickets; li.n_tickets = 2;
           }
           hipLaunchKernelGGL((k_leaf_samples<ROOT, K>), dim3((LS_SAMPLES + 256) / 256), dim3(256), 0, s, keys, sp, rp, smp, li);
           hipLaunchKernelGGL((k_leaf_search<ROOT, K>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state, (const double*)smp);
           searched = true;
         }
       }
-      if (optimistic && !(searched && init_folded)) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 4, s));
+      if (!(searched && init_folded)) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 8, s));   // (k_lane_reduce's arrival counter, k_leaf_regs' list counter)
       if (!searched) {
         constexpr uint64_t V = 16 / sizeof(K);
         const uint64_t blocks = ((n_it + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
@@ -1192,7 +1223,32 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           verify = true;
         }
       }
-      if (verify) {
+      // pipeline 4: one read of the keys (8-byte keys, linear leaves, leaves short enough on average that most groups of 64 qualify)
+      bool regs = false;
+      if constexpr (LEAF == K_LINEAR && sizeof(K) == 8) {
+        regs = !verify && lanes_fused && c->regs && c->pipeline >= 3 && n_it <= (uint64_t)c->regs_max_avg * L_own;
+        if (regs) {
+          if (c->slow_cap < wb) {
+            if (c->d_slow_list) (void)hipFree(c->d_slow_list);
+            c->d_slow_list = nullptr; c->slow_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_slow_list, wb * 4));
+            c->slow_cap = wb;
+          }
+          unsigned int grid = c->regs_grid ? c->regs_grid : 4u * (unsigned int)c->n_cu;
+          if ((uint64_t)grid > wb) grid = (unsigned int)wb;
+          if (c->regs_nt)
+            hipLaunchKernelGGL((k_leaf_regs<K, true>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
+                               L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof);
+          else
+            hipLaunchKernelGGL((k_leaf_regs<K, false>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
+                               L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof);
+          const unsigned int lgrid = wb < 2048 ? (unsigned int)wb : 2048u;
+          hipLaunchKernelGGL((k_leaf_lanes_listed<K>), dim3(lgrid), dim3(64), 0, s, c->d_slow_list, c->d_tickets + 1, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin,
+                             maxerr, run, L, err, count, rows, part, rp, peers);
+        }
+      }
+      c->last_regs = regs;
+      if (verify || regs) {
       } else if (lanes_fused)
         hipLaunchKernelGGL((k_leaf_lanes<K, true, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
                            L, err, count, rows, part, rp, peers);

@@ -269,28 +269,29 @@ struct PeerRows { int n; unsigned char* tab[7]; };
 // search then rests on an assumption, and this kernel verifies it key by key during the error pass: every key of the
 // partition of leaf j must have target j -- which holds for all leaves exactly when the targets are non-decreasing
 // (two_layer.rs:50, the reference's panic) -- and, for roots without a bounds check, stay below L (two_layer.rs:45-48).
-template <typename K, bool ERR, int LEAFK = K_LINEAR, int VROOT = -1>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_WPE, RMI_LN_WPE))) k_leaf_lanes(const K* __restrict__ keys, Span sp,
-                                                   const unsigned long long* __restrict__ leaf_start,
-                                                   DevState* __restrict__ st, double* __restrict__ params,
-                                                   const double* __restrict__ rtab, SgList fl, unsigned int long_min,
-                                                   unsigned long long* __restrict__ leaf_maxerr,
-                                                   unsigned long long* __restrict__ leaf_run, uint64_t L,
-                                                   unsigned long long* __restrict__ leaf_err,
-                                                   unsigned long long* __restrict__ leaf_count,
-                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr,
-                                                   PeerRows peers) {
+// The body of k_leaf_lanes for the 64 leaves of wave `wid`, on `panel` (64 * LnGeom<K>::STRIDE key slots of LDS): a function,
+// because k_leaf_regs (rmi_regs.hip.h) runs it for the groups of leaves its register-resident path does not take.
+template <typename K, bool ERR, int LEAFK, int VROOT>
+__device__ __forceinline__ void leaf_lanes_body(const unsigned int wid, typename LnBits<K>::type* const panel,
+                                                const K* __restrict__ keys, const Span& sp,
+                                                const unsigned long long* __restrict__ leaf_start,
+                                                DevState* __restrict__ st, double* __restrict__ params,
+                                                const double* __restrict__ rtab, const SgList& fl, unsigned int long_min,
+                                                unsigned long long* __restrict__ leaf_maxerr,
+                                                unsigned long long* __restrict__ leaf_run, uint64_t L,
+                                                unsigned long long* __restrict__ leaf_err,
+                                                unsigned long long* __restrict__ leaf_count,
+                                                unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, const RootP& vr,
+                                                const PeerRows& peers) {
   using B = typename LnBits<K>::type;
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
   constexpr int LPR = LN_LPR, NLD = LN_NLD, RPI = LN_RPI;            // lanes per row, loads per panel, rows per load
   constexpr int KPL = LnGeom<K>::KPL, LN_STRIDE = LnGeom<K>::STRIDE, LN_RING = LnGeom<K>::RING, LN_ROW = LnGeom<K>::ROW;
   constexpr unsigned int ROWK = (unsigned int)LN_ROW;
-  __shared__ B panel[64 * LN_STRIDE];                                 // 19 968 B for 8-byte keys, 18 176 for 4-byte keys: 8 waves per CU
   unsigned int* const s_off = reinterpret_cast<unsigned int*>(panel);   // (row descriptors of a phase: exchanged before its first panel is staged)
   unsigned int* const s_end = s_off + 64;
 
   const int lane = threadIdx.x;
-  const unsigned int wid = blockIdx.x;
   const uint64_t j0 = sp.leaf_lo + (uint64_t)wid * 64;
   const uint64_t j = j0 + (uint64_t)lane;
   const bool valid = j < sp.leaf_hi;
@@ -679,6 +680,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_
     if (lane == 0) partials[wid] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
   }
   if (flags) atomicOr(&st->err_flags, flags);
+}
+
+template <typename K, bool ERR, int LEAFK = K_LINEAR, int VROOT = -1>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_WPE, RMI_LN_WPE))) k_leaf_lanes(const K* __restrict__ keys, Span sp,
+                                                   const unsigned long long* __restrict__ leaf_start,
+                                                   DevState* __restrict__ st, double* __restrict__ params,
+                                                   const double* __restrict__ rtab, SgList fl, unsigned int long_min,
+                                                   unsigned long long* __restrict__ leaf_maxerr,
+                                                   unsigned long long* __restrict__ leaf_run, uint64_t L,
+                                                   unsigned long long* __restrict__ leaf_err,
+                                                   unsigned long long* __restrict__ leaf_count,
+                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr,
+                                                   PeerRows peers) {
+  __shared__ typename LnBits<K>::type panel[64 * LnGeom<K>::STRIDE];   // 19 968 B for 8-byte keys, 18 176 for 4-byte keys: 8 waves per CU
+  leaf_lanes_body<K, ERR, LEAFK, VROOT>(blockIdx.x, panel, keys, sp, leaf_start, st, params, rtab, fl, long_min, leaf_maxerr, leaf_run, L, leaf_err, leaf_count,
+                                        rows, partials, vr, peers);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,638 @@
+// rmi_regs.hip.h -- the REGISTER-RESIDENT leaf kernel of the exact leaf path (gfx950, wave64): pipeline 4.
+//
+//   k_leaf_regs    what k_leaf_lanes does (exact per-leaf SLR, linear.rs:12-59 on the container of two_layer.rs:52-90, then
+//                  the last-level error pass, two_layer.rs:207-217, lower_bound_correction.rs:104-119, then the leaf's row)
+//                  with ONE read of the keys.
+//
+// Why registers.  The error of a key needs the final (alpha, beta) of its leaf, known only behind the leaf's last key, and
+// bit-identical (alpha, beta) need the order-dependent recurrence: one sequential chain per leaf, 64 chains per wave in
+// lockstep (rmi_lanes.hip.h).  The keys of a wave's 64 leaves (64 x ~191 x 8 B = 98 KB) must therefore stay on chip between
+// the two phases, for every wave in flight: with all 1 024 SIMDs busy that is 100 MB.  The chip has 40 MB of LDS and 32 MB of
+// L2 -- and 128 MB of vector registers.  So: ONE wave per SIMD with the full 512-register budget; a lane keeps the keys of its
+// leaf (as the doubles the recurrence consumed: `key as f64`, models/mod.rs:83) in registers while it walks them -- the first
+// RG_STASH = 192 steps in registers, the following <= 48 in the LDS ring the keys arrive through, which is simply not
+// refilled at the end of a group of leaves -- and replays them for the error pass.  Nothing is read twice.
+//
+// Data movement.  The keys arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, the register file belongs to the
+// stash): as in k_leaf_lanes a row (= a leaf's container) is fetched in aligned 128-byte lines, 8 rows per instruction, a
+// panel = 16 steps of all 64 rows = 8 instructions = 8 KB; the ring holds 4 panels (32 KB per wave, 4 waves per CU).  The
+// destination of an LDS-DMA instruction is linear in the lane, so a panel is stored row-major as fetched ([8 rows][128 B]
+// per instruction) and lane r reads slot (a0_r + k) of its row: the panel that slot lies in differs between lanes that have
+// and have not crossed a line boundary (one select per step).  The wave is PERSISTENT: it takes every gridDim.x-th group of
+// 64 leaves, and the first panels of the next group are requested before the register part of this group's error pass.
+//
+// What takes this path: groups of 64 consecutive leaves whose containers hold at most RG_MAXPTS = 240 points, cover their
+// leaves (every leaf but the one behind the split, two_layer.rs:166-169) and hold no duplicate key (found while walking:
+// compared as doubles, a superset of key equality); 8-byte keys; linear leaves.  Every other group is put on a list and runs
+// the body of k_leaf_lanes in k_leaf_lanes_listed, launched behind this kernel: the same bits either way.
+#pragma once
+#include <type_traits>
+
+#include "rmi_lanes.hip.h"
+
+namespace rmi {
+
+#ifndef RG_STASH_N
+#define RG_STASH_N 192
+#endif
+constexpr int RG_ROW = 16;                          // steps (keys) per row and panel: one aligned 128-byte line
+constexpr int RG_RING = 4;                          // panels in the LDS ring
+constexpr int RG_PANEL_B = 64 * RG_ROW * 8;         // bytes of a panel: 64 rows x 128 B
+constexpr int RG_STASH = RG_STASH_N;                       // steps whose keys stay in registers
+constexpr int RG_MAXPTS = RG_STASH_N + 48;                      // longest container of a group that takes the register path
+constexpr int RG_NBLK = RG_MAXPTS / RG_ROW;         // 15 blocks of 16 steps
+constexpr int RG_SBLK = RG_STASH / RG_ROW;          // 12 of them stashed in registers
+static_assert(RG_NBLK - RG_SBLK <= RG_RING - 1, "the tail of a group must still be in the ring when its fit ends");
+static_assert(RG_MAXPTS + 64 <= LN_TMAX, "the step tables cover the walk");
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void rg_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); rg_static_for<I + 1, N>(f); }
+}
+
+// Timing experiments (results wrong), compiled in by macro: RG_KO & 1 no recurrence arithmetic, & 2 no error pass, & 4 no loads.
+#ifndef RG_KO
+#define RG_KO 0
+#endif
+#ifndef RG_PROF
+#define RG_PROF 0                // 1: cycles per phase of a group, summed over the waves into prof[] (printed by the host at destroy)
+#endif
+#ifndef RG_DIAG
+#define RG_DIAG 0                // & 1 the constants of the first half block for all, & 2 no duplicate test, & 8 no lane ever tests, & 16 only bank 0 stashed
+#endif
+
+// The step tables of this kernel, four arrays of RG_TMAX doubles for the running count k = i + 1: RN(1 / k), the tail of the
+// reciprocal (1 / k = r + rl to 2^-105: div_by_count2 of rmi_stream.hip.h, one FMA fewer than div_by_count -- an FMA costs 7.3
+// cycles on this chip, an addition or a multiplication 4), (k - 1) / 2, k.  A half block of 8 steps takes its constants with
+// one 64-byte scalar load per array.
+__global__ void __launch_bounds__(256) k_regs_table(double* __restrict__ tab, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) {
+    const double nf = (double)(i + 1), r = 1.0 / nf;
+    tab[i] = r; tab[count + i] = recip_tail(nf, r); tab[2 * count + i] = (double)i * 0.5; tab[3 * count + i] = nf;
+  }
+}
+constexpr int RG_TMAX = 256;                        // entries of the interleaved table
+
+// One panel: 8 LDS-DMA instructions, instruction i = rows 8 i + lane / 8, 128 bytes each; off[i] = this lane's byte offset
+// from `kb` (a wave-uniform pointer) of its 16-byte piece.  The destination is M0 + 16 lane.  M0 is not the compiler's to
+// keep around an asm statement (cdna_hip_programming.md section 5): saved and restored here.
+#define RG_DMA8(NTS)                                                                                                   \
+  asm volatile("s_mov_b32 %[keep], m0\n\t"                                                                             \
+               "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[kb]" NTS "\n\t"                     \
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[kb]" NTS "\n\t"                  \
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o2], %[kb]" NTS "\n\t"                  \
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o3], %[kb]" NTS "\n\t"                  \
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o4], %[kb]" NTS "\n\t"                  \
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o5], %[kb]" NTS "\n\t"                  \
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o6], %[kb]" NTS "\n\t"                  \
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o7], %[kb]" NTS "\n\t"                  \
+               "s_mov_b32 m0, %[keep]"                                                                                 \
+               : [keep] "=&s"(keep)                                                                                    \
+               : [lds] "s"(lds), [kb] "s"(kb), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), \
+                 [o4] "v"(off[4]), [o5] "v"(off[5]), [o6] "v"(off[6]), [o7] "v"(off[7])                                \
+               : "memory", "scc")
+template <bool NT>
+__device__ __forceinline__ void rg_dma_panel(const void* kb, unsigned int lds, const unsigned int (&off)[8]) {
+  unsigned int keep;
+  if constexpr (NT) RG_DMA8(" nt"); else RG_DMA8("");
+}
+// one dword per lane to LDS (M0 + 4 lane): the single keys and the leaf boundaries a group needs late are parked in LDS this way --
+// no register holds them meanwhile and, more important, no wait of the compiler's stands behind a panel request for them
+__device__ __forceinline__ void rg_dma_dword(const void* base, unsigned int lds, unsigned int voff) {
+  unsigned int keep;
+  asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dword %[o], %[kb]\n\ts_mov_b32 m0, %[keep]"
+               : [keep] "=&s"(keep)
+               : [lds] "s"(lds), [kb] "s"(base), [o] "v"(voff)
+               : "memory");
+}
+// the loads of rg_dma_panel are not in the compiler's count: waits for them are written here (at most N VMEM operations
+// outstanding; operations complete in order, so whatever else the compiler has in flight only makes a wait longer)
+__device__ __forceinline__ unsigned long long rg_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+template <int N> __device__ __forceinline__ void rg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ unsigned int rg_wave_max(unsigned int v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { const unsigned int o = (unsigned int)__shfl_xor((int)v, d); v = o > v ? o : v; }
+  return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// `key as f64` from the two halves of the key as they lie in LDS (models/mod.rs:83; see KeyTraits<uint64_t>::as_float -- written
+// on the halves because the compiler turns (double)(uint32_t)(k >> 32) back into a 64-bit conversion with one addition more)
+template <typename K> __device__ __forceinline__ double rg_as_float(uint2 v) {
+  if constexpr (std::is_same<K, double>::value) return __hiloint2double((int)v.y, (int)v.x);
+  else return __builtin_fma((double)v.y, 4294967296.0, (double)v.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_leaf_regs
+// ---------------------------------------------------------------------------------------------
+template <typename K, bool NT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_leaf_regs(const K* __restrict__ keys, Span sp,
+                                                   const unsigned long long* __restrict__ leaf_start,
+                                                   DevState* __restrict__ st, double* __restrict__ params,
+                                                   const double* __restrict__ rtab, const double* __restrict__ rtab4, SgList fl, unsigned int long_min,
+                                                   unsigned long long* __restrict__ leaf_maxerr,
+                                                   unsigned long long* __restrict__ leaf_run, uint64_t L,
+                                                   unsigned long long* __restrict__ leaf_err,
+                                                   unsigned long long* __restrict__ leaf_count,
+                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr,
+                                                   PeerRows peers, unsigned int ntiles, unsigned int slow,
+                                                   unsigned int* __restrict__ slow_list, unsigned int* __restrict__ slow_count,
+                                                   unsigned long long* __restrict__ prof) {
+  static_assert(sizeof(K) == 8, "8-byte keys");
+  using B = unsigned long long;
+  constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
+  __shared__ __attribute__((aligned(1024))) unsigned char ringc[RG_RING * RG_PANEL_B];   // 32 KB: 4 waves per CU
+  __shared__ unsigned int s_off[64], s_lim[64];
+  __shared__ unsigned int park[10][64];                              // k_hi, k_lom1, k_next, k_prev (two words each), next group's s, e
+  static_assert(RG_RING * RG_PANEL_B >= 64 * LnGeom<K>::STRIDE * 8, "the ring holds the LDS image of k_leaf_lanes");
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const unsigned int ring_lds = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(lds_byte*)ringc);
+  const unsigned int park_lds = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(lds_byte*)&park[0][0]);
+
+  const int lane = threadIdx.x;
+  const unsigned int rowpart = (unsigned int)(lane >> 3) * 1024u + (unsigned int)(lane & 7) * 128u;   // this lane's row inside a panel
+  const unsigned int piece = (unsigned int)(lane & 7) * 16u;         // its 16-byte piece of a line as a loader
+  const unsigned int n32 = (unsigned int)sp.n;
+  const uint64_t split_idx = st->split_idx, split_target = st->split_target;
+
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // ---- a group of 64 leaves ("tile"): per-lane view and what is wave-uniform
+  struct Tile {
+    bool fast;                          // uniform: the register path takes it
+    bool valid, act;                    // leaf exists / container walked here
+    int ck;
+    unsigned int s, e, lo, npts;        // leaf [s, e), container [lo, lo + npts)
+    unsigned int a0;                    // slot of the container's first point in its first line
+    unsigned int maxlen, lastp;         // uniform: longest walk, last panel any row needs
+    const K* kb;                        // uniform: keys + wave base (line aligned)
+  };
+  // (all lanes: a loader lane serves the rows 8 i + lane / 8, whatever its own leaf does)
+  auto issue_panel = [&](const K* kb, unsigned int p) {
+    unsigned int off[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int row = i * 8 + (lane >> 3);
+      const unsigned int o = s_off[row] + p * 128u, l = s_lim[row];
+      off[i] = (o < l ? o : l) + piece;                               // (a finished row keeps re-reading its last line)
+    }
+    rg_dma_panel<NT>(kb, ring_lds + (p & (unsigned int)(RG_RING - 1)) * (unsigned int)RG_PANEL_B, off);
+  };
+  unsigned int nxt_off = 0u, nxt_lim = 0u;                             // row descriptors of the group requested last (this lane's row)
+  // descriptor of tile `tl` from its leaves' boundaries; a fast tile's first panels are requested at once
+  auto make_tile = [&](unsigned int tl, uint64_t s, uint64_t e) -> Tile {
+    Tile t;
+    const uint64_t j = sp.leaf_lo + (uint64_t)tl * 64 + (uint64_t)lane;
+    t.valid = j < sp.leaf_hi;
+    uint64_t lo = 0, hi = 0;
+    t.ck = t.valid ? leaf_container(j, s, e, sp.n, split_idx, split_target, lo, hi) : 0;
+    uint64_t wb;
+    {
+      const unsigned int s0l = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)s);
+      const unsigned int s0h = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(s >> 32));
+      const uint64_t s0 = ((uint64_t)s0h << 32) | s0l;
+      wb = s0 > sp.rd_lo ? s0 - 1 : sp.rd_lo;
+    }
+    wb -= (uint64_t)((reinterpret_cast<uintptr_t>(keys + wb) / sizeof(K)) % (uintptr_t)RG_ROW);
+    t.kb = keys + wb;
+    const uint64_t np64 = t.ck == 2 ? hi - lo + 1 : 0;
+    const bool handed = t.valid && t.ck == 2 && np64 + 1 > (uint64_t)long_min;
+    const bool ok = !t.valid || (!handed && (t.ck == 2 ? (np64 <= (uint64_t)RG_MAXPTS && lo <= s && e <= hi + 1) : e == s));
+    t.fast = __all(ok) && !slow;
+    t.act = t.valid && t.ck == 2;
+    t.s = (unsigned int)s; t.e = (unsigned int)e; t.lo = (unsigned int)lo; t.npts = t.act ? (unsigned int)np64 : 0u;
+    const unsigned int rel = t.act ? (unsigned int)(lo - wb) : 0u;
+    t.a0 = rel & (unsigned int)(RG_ROW - 1);
+    t.maxlen = rg_wave_max(t.npts);
+    t.lastp = rg_wave_max(t.act ? (t.a0 + t.npts - 1u) >> 4 : 0u);
+    if (t.fast) {
+      wave_sync();
+      nxt_off = (rel & ~(unsigned int)(RG_ROW - 1)) * 8u;
+      nxt_lim = t.act ? ((rel + t.npts - 1u) & ~(unsigned int)(RG_ROW - 1)) * 8u : 0u;
+      s_off[lane] = nxt_off; s_lim[lane] = nxt_lim;
+      wave_sync();
+      if (!(RG_KO & 4)) {
+        // the single keys of this group's end -- the container's last key (Q1), the key in front of the container (FixDups offset
+        // of its first point), the keys on either side of the leaf (finalize_one) -- in FRONT of the panels: landed before them
+        const K* const kbm = t.kb - RG_ROW;                              // (offsets from one line in front of the wave base: never negative)
+        const unsigned int o_hi = t.act ? (rel + t.npts - 1u + (unsigned int)RG_ROW) * 8u : (unsigned int)RG_ROW * 8u;
+        const unsigned int o_lom1 = (t.act && lo > sp.rd_lo) ? (rel - 1u + (unsigned int)RG_ROW) * 8u : (unsigned int)RG_ROW * 8u;
+        const unsigned int o_next = (t.valid && e < sp.n) ? ((unsigned int)(e - wb) + (unsigned int)RG_ROW) * 8u : (unsigned int)RG_ROW * 8u;
+        const unsigned int o_prev = (t.valid && s > 0) ? ((unsigned int)(s - wb) - 1u + (unsigned int)RG_ROW) * 8u : (unsigned int)RG_ROW * 8u;
+        rg_dma_dword(kbm, park_lds + 0u * 256u, o_hi); rg_dma_dword(kbm, park_lds + 1u * 256u, o_hi + 4u);
+        rg_dma_dword(kbm, park_lds + 2u * 256u, o_lom1); rg_dma_dword(kbm, park_lds + 3u * 256u, o_lom1 + 4u);
+        rg_dma_dword(kbm, park_lds + 4u * 256u, o_next); rg_dma_dword(kbm, park_lds + 5u * 256u, o_next + 4u);
+        rg_dma_dword(kbm, park_lds + 6u * 256u, o_prev); rg_dma_dword(kbm, park_lds + 7u * 256u, o_prev + 4u);
+#pragma unroll
+        for (unsigned int p = 0; p < (unsigned int)RG_RING; p++)
+          if (p <= t.lastp) issue_panel(t.kb, p);
+      }
+    }
+    return t;
+  };
+  // the boundaries of tile `tl`'s leaves to the parking rows 8, 9 (low words: the fused path has n < 2^32)
+  auto request_bounds = [&](unsigned int tl) {
+    const uint64_t j0 = sp.leaf_lo + (uint64_t)tl * 64;
+    const uint64_t left = sp.leaf_hi - j0;                               // > 0
+    const unsigned int jl = (uint64_t)lane < left ? (unsigned int)lane : (unsigned int)(left - 1);
+    const unsigned long long* const base = leaf_start + j0;
+    if (!(RG_KO & 4)) { rg_dma_dword(base, park_lds + 8u * 256u, jl * 8u); rg_dma_dword(base, park_lds + 9u * 256u, jl * 8u + 8u); }
+  };
+  auto parked_key = [&](int row) -> K {
+    const unsigned long long v = ((unsigned long long)park[row + 1][lane] << 32) | (unsigned long long)park[row][lane];
+    return bits_to_key<K>(v);
+  };
+  auto load_bounds = [&](unsigned int tl, uint64_t& s, uint64_t& e) {
+    const uint64_t j = sp.leaf_lo + (uint64_t)tl * 64 + (uint64_t)lane;
+    s = 0; e = 0;
+    if (j < sp.leaf_hi) { s = leaf_start[j]; e = leaf_start[j + 1]; }
+  };
+
+  // The loop is skewed by the hand-over: iteration i finishes tile i - 1 around the descriptor (and first panels) of tile i,
+  // so that there is ONE copy of everything in the code.
+  unsigned int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  unsigned long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                   // (RG_PROF)
+  unsigned long long pt = 0;
+  auto mark = [&](int i) { if (RG_PROF) { const unsigned long long t = rg_now(); pf[i] += t - pt; pt = t; } };
+  uint64_t sn, en;
+  load_bounds(tile, sn, en);
+  Tile cur;                                                            // (set at the first hand-over)
+  bool have = false;
+  for (;;) {
+    const unsigned int done_tile = tile - gridDim.x;                   // the tile `cur` describes (when `have`)
+    if (RG_PROF) pt = rg_now();
+    const bool more = tile < ntiles;
+    unsigned int flags = 0;
+    double pa = 0.0, pb = 0.0;
+    const bool fast = have && cur.fast;
+    unsigned int lane_j = (unsigned int)lane;
+    asm volatile("" : "+v"(lane_j));                                   // (the addresses of this group's results are formed when they are stored: not kept, not spilled)
+    const uint64_t j = sp.leaf_lo + (uint64_t)done_tile * 64 + (uint64_t)lane_j;
+    const unsigned int a8 = cur.a0 * 8u;
+    // LDS address of step 16 b + qq of this lane's row: slot a0 + qq of the two-panel window that starts at panel b -- in panel
+    // b (ring slot b mod 4) for the lanes that have not crossed their line's end yet, in panel b + 1 for the others
+    const unsigned int cross = (unsigned int)RG_ROW - cur.a0;           // first qq behind the crossing (16: never)
+    auto block_base = [&](unsigned int b, unsigned int& in_b, unsigned int& in_b1) {
+      const unsigned int sb = b & (unsigned int)(RG_RING - 1), sb1 = (b + 1u) & (unsigned int)(RG_RING - 1);
+      in_b = rowpart + a8 + sb * (unsigned int)RG_PANEL_B;
+      in_b1 = rowpart + a8 + sb1 * (unsigned int)RG_PANEL_B - 128u;
+      asm volatile("" : "+v"(in_b), "+v"(in_b1));                       // (two registers to select between; the step's offset goes into the read)
+    };
+    auto slot_key = [&](unsigned int in_b, unsigned int in_b1, int qq) -> uint2 {
+      unsigned int cr = cross;
+      asm volatile("" : "+v"(cr));                                       // (else the 16 comparisons live in 32 SGPRs across the whole walk)
+      const unsigned int addr = ((unsigned int)qq >= cr ? in_b1 : in_b) + (unsigned int)(qq * 8);
+      return *reinterpret_cast<const uint2*>(ringc + addr);
+    };
+    K k_hi = KeyTraits<K>::zero_value(), k_lom1 = KeyTraits<K>::zero_value();
+    K k_next = KeyTraits<K>::max_value(), k_prev = KeyTraits<K>::zero_value();    // the two boundary keys of finalize_one
+    // =========================== the error pass over the leaves' own keys ===========================
+    // the leaf's keys are the steps [es, eend) of its container's walk: es = s - lo is 0 or 1
+    const unsigned int es = cur.s - cur.lo;
+    unsigned int eend = (have && cur.act) ? cur.e - cur.lo : 0u;
+    unsigned int emax = 0u, femax = 0u;                                  // femax: the maximum as it stands behind the leaf's last key
+    auto err_step = [&](double x, unsigned int k) {
+      const double f = __builtin_fma(pb, x, pa);                            // linear.rs:87-90
+      const unsigned int pr = min(sg_cvt_u32(f), n32);                      // models/mod.rs:735-737, two_layer.rs:14-18
+      emax = max(emax, sg_absdiff(pr, cur.lo + k));
+    };
+    // ---- hand-over: the ring is free -- the next group's descriptor and its first panels, under the rest of this group's work
+    Tile nxt = cur;
+    auto hand_over = [&]() {
+      if (more) {
+        uint64_t s_nx = sn, e_nx = en;                                   // (the first group's: loaded in front of the loop)
+        if (have && !(RG_KO & 4)) { s_nx = park[8][lane]; e_nx = park[9][lane]; }
+        else if (have) load_bounds(tile, s_nx, e_nx);
+        nxt = make_tile(tile, s_nx, e_nx);
+        if (tile + gridDim.x < ntiles) request_bounds(tile + gridDim.x);  // (for the hand-over after this one)
+      }
+    };
+    bool done = false;
+    if (fast) {
+      double xs[RG_STASH];                                             // the stash: the doubles of this lane's first 192 points
+      // =========================== the fit ===========================
+      // Rolled over the blocks of 16 steps (the code of a block is ~3 KB; unrolled over the whole walk it would be 60 KB, and two
+      // CUs share 64 KB of instruction cache): a block leaves its 16 doubles in T[], and a switch on the block index copies
+      // them to their places in the stash (static register names in every case: xs[] never becomes memory).
+      double mx = 0.0, cc = 0.0, m2 = 0.0;
+      double fmx = 0.0, fcc = 0.0, fm2 = 0.0;                            // ... as they stand behind the lane's last point
+      // Duplicates.  8-byte integer keys: the minimum over the walk of lo(key_k) ^ lo(key_k-1) -- zero where two keys in a row share
+      // their low word, a superset of "equal" that costs two 32-bit operations per step (false alarms: 2^-32 per pair);
+      // f64 keys (low words of round numbers ARE equal): cleared by a comparison of the doubles.
+      unsigned int dmin = 0xFFFFFFFFu, fdmin = 0xFFFFFFFFu;
+      unsigned int plo = 0u;
+      double xp = 0.0;
+      const unsigned int npts = cur.npts;
+      uint2 rawA[8], rawB[8];                                            // the keys of the half block in work / of the next one
+      // panel 1 has landed once at most the panels behind it are outstanding (requested at the hand-over: up to panel 3)
+      if (cur.maxlen > 0u) {
+        if (!(RG_KO & 4)) {
+          if (cur.lastp >= 3u) rg_wait_vm<16>();
+          else if (cur.lastp == 2u) rg_wait_vm<8>();
+          else rg_wait_vm<0>();
+        }
+        unsigned int in_b, in_b1;
+        block_base(0u, in_b, in_b1);
+#pragma unroll
+        for (int q = 0; q < 8; q++) rawA[q] = slot_key(in_b, in_b1, q);
+      }
+#pragma nounroll
+      for (unsigned int b = 0; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
+        unsigned int in_b, in_b1;
+        block_base(b, in_b, in_b1);
+        double T[8];
+        // Masking: a lane is finished behind its container's last point, and stays finished.  Its sums are put aside at the end
+        // of the half block (8 steps) in which it finishes; from then on it may compute what it likes.  So a half block in
+        // which every lane is either alive for all 8 steps or finished before the first -- the rule while the walk is younger
+        // than the shortest container -- runs WITHOUT any test; else every step tests.  (Tried: narrowing EXEC once per step
+        // by v_cmpx behind the compiler's back -- cheap, but every copy or spill the register allocator places inside such a
+        // region moves only the lanes still alive, and at 500 registers it places them.)
+        // The constants of a half block come through the scalar cache, and scalar loads share their counter with the LDS reads
+        // without returning in order: a wait for them is a wait for every LDS read in flight.  So they are asked for FIRST and
+        // waited for at once (a hit in the scalar cache: tens of cycles), together with this half's keys, asked for a half block
+        // ago; only then are the next half's keys requested, and those land under the arithmetic.
+        double r8[8], rl8[8], hh8[8], kf8[8];
+        auto constants = [&](int hb) {
+          const unsigned int k0 = (RG_DIAG & 1) ? 0u : b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            r8[q] = rtab4[k0 + q]; hh8[q] = rtab4[2 * RG_TMAX + k0 + q];
+            if constexpr (DIVK) kf8[q] = rtab4[3 * RG_TMAX + k0 + q]; else rl8[q] = rtab4[RG_TMAX + k0 + q];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        auto half = [&](int hb, const uint2 (&raw)[8], auto full_tag) {
+          constexpr bool FULL = decltype(full_tag)::value;
+          const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const unsigned int k = k0 + (unsigned int)q;
+            const double x = rg_as_float<K>(raw[q]);
+            T[q] = x;
+            if (FULL || k < npts) {
+              if (!(RG_DIAG & 2)) {
+                if constexpr (DIVK) { if (x == xp && k != 0u) dmin = 0u; }
+                else { const unsigned int d = raw[q].x ^ plo; if (k != 0u) dmin = dmin < d ? dmin : d; }
+              }
+              if (!(RG_KO & 1)) {
+                const double dx = x - mx;                                 // linear.rs:26
+                if constexpr (DIVK) mx += dx / kf8[q]; else mx += div_by_count2(dx, r8[q], rl8[q]);   // :27
+                cc += dx * hh8[q];                                        // :28-29 in closed form (head of rmi_lanes.hip.h)
+                m2 += dx * (x - mx);                                      // :30-31
+              }
+            }
+            xp = x; plo = raw[q].x;
+          }
+        };
+        // a half block's doubles to their registers of the stash
+        auto stash_half = [&](int hb) {
+          // (a chain of tests in three groups of four: as a `switch` the cases meet in one block of phis, and the register
+          //  allocator then shuffles the whole stash around in every case)
+          auto group = [&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            rg_static_for<4 * g, 4 * g + 4>([&](auto i_tag) {
+              constexpr int i = decltype(i_tag)::value;
+              if (b == (unsigned int)i && !((RG_DIAG & 16) && i > 0)) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) xs[i * RG_ROW + hb * 8 + q] = T[q];
+                asm volatile("; stash bank %0" ::"n"(i));                 // (keeps the cases apart: merged, xs[] would be indexed by b, i.e. memory)
+              }
+            });
+          };
+          static_assert(RG_SBLK == 12, "three groups of four banks");
+          if (b < 4u) group(std::integral_constant<int, 0>{});
+          if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
+          if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
+        };
+        auto run_half = [&](int hb, const uint2 (&raw)[8]) {
+          const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
+          if ((RG_DIAG & 8) || __all(npts >= k0 + 8u || npts <= k0)) half(hb, raw, std::true_type{});
+          else half(hb, raw, std::false_type{});
+          const bool ends = npts > k0 && npts <= k0 + 8u;
+          if (__any(ends)) { if (ends) { fmx = mx; fcc = cc; fm2 = m2; fdmin = dmin; } }
+          stash_half(hb);
+        };
+        // first half: its keys were asked for a half block ago; the second half's are asked for now
+        unsigned long long q0 = 0, q1 = 0;
+        if (RG_PROF) q0 = rg_now();
+        constants(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) rawB[q] = slot_key(in_b, in_b1, 8 + q);
+        if (RG_PROF) { q1 = rg_now(); pf[6] += q1 - q0; }
+        run_half(0, rawA);
+        if (RG_PROF) { q0 = rg_now(); pf[9] += q0 - q1; }
+        // second half.  Every read of panel b is behind us: its ring slot takes panel b + 4 -- but nothing behind the walk's
+        // last panel, so that at the end of the fit the ring still holds the tail of every row (the steps >= RG_STASH of the
+        // error pass).  Then the first keys of the next block: panel b + 2 has landed once at most the panels behind it are
+        // outstanding.
+        constants(1);
+        if (RG_PROF) { q1 = rg_now(); pf[6] += q1 - q0; }
+        if (!(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING);
+        if (RG_PROF) { q0 = rg_now(); pf[5] += q0 - q1; }
+        if ((b + 1u) * (unsigned int)RG_ROW < cur.maxlen) {
+          if (!(RG_KO & 4)) {
+            if (cur.lastp >= b + 4u) rg_wait_vm<16>();
+            else if (cur.lastp == b + 3u) rg_wait_vm<8>();
+            else rg_wait_vm<0>();
+          }
+          if (RG_PROF) { q1 = rg_now(); pf[8] += q1 - q0; q0 = q1; }
+          unsigned int nx_b, nx_b1;
+          block_base(b + 1u, nx_b, nx_b1);
+#pragma unroll
+          for (int q = 0; q < 8; q++) rawA[q] = slot_key(nx_b, nx_b1, q);
+        }
+        if (RG_PROF) { q1 = rg_now(); pf[6] += q1 - q0; }
+        run_half(1, rawB);
+        if (RG_PROF) { q0 = rg_now(); pf[9] += q0 - q1; }
+        if (RG_PROF) pf[7] += rg_now() - q0;
+      }
+      mark(0);
+      if (!(RG_KO & 4)) { k_hi = parked_key(0); k_lom1 = parked_key(2); k_next = parked_key(4); k_prev = parked_key(6); }
+      if (!cur.valid || !((uint64_t)cur.e < sp.n)) k_next = KeyTraits<K>::max_value();
+      if (!cur.valid || !(cur.s > 0u)) k_prev = KeyTraits<K>::zero_value();
+      // a duplicate key somewhere in the group, or in front of a container's first point (compared as doubles: a superset
+      // of key equality): the closed form of the y half does not hold -- the whole group goes through the general walk
+      const bool dup0 = cur.act && (uint64_t)cur.lo > sp.rd_lo && KeyTraits<K>::as_float(k_lom1) == xs[0];
+      if (!__any(dup0 || (cur.act && fdmin == 0u))) {
+        // ---- the container's last item once more (Q1, models/mod.rs:180), then linear.rs:36-58
+        if (cur.act) {
+          const double x = KeyTraits<K>::as_float(k_hi);
+          const double nn = (double)npts;
+          const double y0f = (double)cur.lo;
+          const double my0 = y0f + (nn - 1.0) * 0.5, yprev = y0f + (nn - 1.0);   // the y half in closed form (no duplicate)
+          const double nf = nn + 1.0;
+          mx = fmx; cc = fcc; m2 = fm2;
+          const double dx = x - mx;
+          mx += dx / nf;
+          const double my = my0 + (yprev - my0) / nf;
+          cc += dx * (yprev - my);
+          m2 += dx * (x - mx);
+          const double cov = cc / (nf - 1.0), var = m2 / (nf - 1.0);
+          if (!(var >= 0.0)) flags |= EF_NEG_VARIANCE;                     // linear.rs:48
+          if (var == 0.0) { pa = my; pb = 0.0; }                           // linear.rs:50-53
+          else { pb = cov / var; pa = my - pb * mx; }                      // no fma: linear.rs:56
+        } else if (cur.ck == 1) { pa = (double)cur.lo; pb = 0.0; }         // Q4: one borrowed point (two identical items)
+        if (cur.valid) { params[2 * j] = pa; params[2 * j + 1] = pb; }
+      if (!(RG_KO & 2)) {
+        // the steps behind the stash: still in the ring (masked the plain way: a few blocks)
+#pragma nounroll
+        for (unsigned int b = (unsigned int)RG_SBLK; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
+          unsigned int in_b, in_b1;
+          block_base(b, in_b, in_b1);
+#pragma unroll
+          for (int qq = 0; qq < RG_ROW; qq++) {
+            const unsigned int k = b * (unsigned int)RG_ROW + (unsigned int)qq;
+            const double x = rg_as_float<K>(slot_key(in_b, in_b1, qq));
+            if (k < eend) err_step(x, k);
+          }
+        }
+      }
+      mark(1);
+      asm volatile("" : "+v"(k_next), "+v"(k_prev));                   // (read from their parking rows before the next group's keys are sent there)
+      hand_over();
+      mark(2);
+      if (!(RG_KO & 2)) {
+        if (es == 0u && eend > 0u) err_step(xs[0], 0u);                  // (step 0 belongs to the leaf only where the container starts with it)
+        const unsigned int sl = cur.maxlen < (unsigned int)RG_STASH ? cur.maxlen : (unsigned int)RG_STASH;
+#pragma nounroll
+        for (unsigned int b = 0; b * (unsigned int)RG_ROW < sl; b++) {
+          const unsigned int kb0 = b * (unsigned int)RG_ROW;
+          // a block without an end in it and without step 0: straight from the bank's registers (one copy of the 16 steps per bank:
+          // 6 instructions a step); else through T[] with the tests
+          if (b != 0u && __all(eend >= kb0 + 16u || eend <= kb0)) {
+            auto group = [&](auto g_tag) {
+              constexpr int g = decltype(g_tag)::value;
+              rg_static_for<(g == 0 ? 1 : 4 * g), 4 * g + 4>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                if (b == (unsigned int)i) {
+#pragma unroll
+                  for (int qq = 0; qq < RG_ROW; qq++) err_step(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq));
+                  asm volatile("; stash bank %0" ::"n"(i));
+                }
+              });
+            };
+            if (b < 4u) group(std::integral_constant<int, 0>{});
+            if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
+            if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
+            continue;
+          }
+          double T[RG_ROW];
+          {
+            auto group = [&](auto g_tag) {
+              constexpr int g = decltype(g_tag)::value;
+              rg_static_for<4 * g, 4 * g + 4>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                if (b == (unsigned int)i) {
+#pragma unroll
+                  for (int qq = 0; qq < RG_ROW; qq++) T[qq] = xs[i * RG_ROW + qq];
+                  asm volatile("; stash bank %0" ::"n"(i));
+                }
+              });
+            };
+            if (b < 4u) group(std::integral_constant<int, 0>{});
+            if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
+            if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
+          }
+          // (as in the fit: a leaf's maximum is put aside behind its last key)
+#pragma unroll
+          for (int hb = 0; hb < 2; hb++) {
+            const unsigned int k0 = kb0 + (unsigned int)(hb * 8);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const unsigned int k = k0 + (unsigned int)q;
+              if (k < eend && k != 0u) err_step(T[hb * 8 + q], k);          // (step 0: above)
+            }
+            if (eend > k0 && eend <= k0 + 8u) femax = emax;
+          }
+        }
+        if (eend <= (unsigned int)RG_STASH) emax = femax;                 // (a leaf that ends behind the stash was alive to the end here)
+      }
+      mark(3);
+      // ---- finish the leaf (two_layer.rs:185-197, 226-259, the row of codegen.rs:288-315, the terms of :267-287)
+      unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;
+      double st_l2 = 0.0, st_lg = 0.0;
+      if (cur.valid) {
+        double pp[2] = {pa, pb};
+        uint64_t final_err, cnt_j;
+        const uint64_t s = cur.s, e = cur.e;
+        finalize_one_pre<K_LINEAR, K>(j, s, e, sp, L, keys, pp, (uint64_t)emax, 0ull, st->last_target, k_next, k_prev, final_err, cnt_j);
+        if (!(s < e)) { params[2 * j] = pp[0]; params[2 * j + 1] = pp[1]; }
+        leaf_err[j] = final_err;
+        leaf_count[j] = cnt_j;
+        double* rp = reinterpret_cast<double*>(rows + j * 24);
+        rp[0] = pp[0]; rp[1] = pp[1];
+        *reinterpret_cast<unsigned long long*>(rows + j * 24 + 16) = final_err;
+        for (int p = 0; p < peers.n; p++) {                              // (wave-uniform trip count; 24-byte rows: three 8-byte stores)
+          double* pr = reinterpret_cast<double*>(peers.tab[p] + j * 24);
+          pr[0] = pp[0]; pr[1] = pp[1];
+          *reinterpret_cast<unsigned long long*>(peers.tab[p] + j * 24 + 16) = final_err;
+        }
+        st_mx = final_err; st_mi = j;
+        st_sum = cnt_j * final_err;                                      // wrapping u64, like the reference's sum
+        const double v = (double)st_sum;
+        st_l2 = (v * v) / (double)sp.n;
+        st_lg = (double)cnt_j * log2((double)(2 * final_err + 2));
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {                                 // (lexicographic maximum and sums: any order combines)
+        const unsigned long long omx = shfl_down_u64(st_mx, d), omi = shfl_down_u64(st_mi, d);
+        if (omx > st_mx || (omx == st_mx && omi > st_mi)) { st_mx = omx; st_mi = omi; }
+        st_sum += shfl_down_u64(st_sum, d);
+        st_l2 += __shfl_down(st_l2, d);
+        st_lg += __shfl_down(st_lg, d);
+      }
+      if (lane == 0) partials[done_tile] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
+      if (flags) atomicOr(&st->err_flags, flags);
+      mark(4);
+      done = true;
+      }
+    }
+    if (!done) {
+      // not taken here: the group goes on the list of k_leaf_lanes_listed, launched behind this kernel (the general walk inside
+      // this kernel would share its registers with the stash: the compiler then keeps a third of the stash in scratch memory)
+      if (have && lane == 0) slow_list[atomicAdd(slow_count, 1u)] = done_tile;
+      hand_over();
+    }
+    if (!more) break;
+    cur = nxt;
+    have = true;
+    tile += gridDim.x;
+  }
+  if (RG_PROF && prof != nullptr && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) atomicAdd(prof + i, pf[i]);
+  }
+}
+
+// The groups k_leaf_regs did not take: the body of k_leaf_lanes per listed group (a fixed grid; nothing listed: the blocks leave).
+template <typename K>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_LN_WPE, RMI_LN_WPE))) k_leaf_lanes_listed(const unsigned int* __restrict__ slow_list,
+                                                   const unsigned int* __restrict__ slow_count, const K* __restrict__ keys, Span sp,
+                                                   const unsigned long long* __restrict__ leaf_start,
+                                                   DevState* __restrict__ st, double* __restrict__ params,
+                                                   const double* __restrict__ rtab, SgList fl, unsigned int long_min,
+                                                   unsigned long long* __restrict__ leaf_maxerr,
+                                                   unsigned long long* __restrict__ leaf_run, uint64_t L,
+                                                   unsigned long long* __restrict__ leaf_err,
+                                                   unsigned long long* __restrict__ leaf_count,
+                                                   unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr,
+                                                   PeerRows peers) {
+  __shared__ typename LnBits<K>::type panel[64 * LnGeom<K>::STRIDE];
+  const unsigned int n = *slow_count;
+  for (unsigned int i = blockIdx.x; i < n; i += gridDim.x)
+    leaf_lanes_body<K, true, K_LINEAR, -1>(slow_list[i], panel, keys, sp, leaf_start, st, params, rtab, fl, long_min, leaf_maxerr, leaf_run, L, leaf_err, leaf_count,
+                                           rows, partials, vr, peers);
+}
+
+}  // namespace rmi
