@@ -87,13 +87,16 @@ struct rmi_hip_ctx {
   bool lanes_fuse = true;                       // error pass fused behind the fit in k_leaf_lanes (else k_err_range)
   // pipeline 4 (rmi_regs.hip.h): k_leaf_regs -- one read of the keys, a leaf's keys stay in registers between its fit and its error pass --
   // in place of k_leaf_lanes where the leaves are short enough on average; the groups it does not take go through k_leaf_lanes_listed
-  bool regs = false;                            // RMI_HIP_REGS=1: k_leaf_regs where it applies (measured slower than k_leaf_lanes so far: DESIGN section 4)
+  bool regs = true;                             // RMI_HIP_REGS=0: k_leaf_lanes for everything
   bool regs_nt = true;                          // non-temporal LDS-DMA loads (the keys are read once)
   unsigned int regs_grid = 0;                   // persistent waves of k_leaf_regs (0: 4 per CU)
   unsigned int regs_max_avg = 208;              // average keys per leaf above which most groups would not fit (RG_MAXPTS = 240 per container)
   unsigned int regs_slow = 0;                   // debugging: every group on the list
+  bool regs_queue = false;                      // RMI_HIP_REGS_QUEUE=1: groups dealt to the waves from a counter instead of by wave number (measured: 473 against 460 us)
   double* d_regtab = nullptr;                   // the interleaved step table of k_leaf_regs
   unsigned long long* d_regprof = nullptr;      // RG_PROF builds: cycles per phase, summed over the waves
+  void* d_bnext = nullptr;                      // the keys on either side of every leaf, for k_regs_finalize: [2][64 groups]
+  unsigned char* d_tile_slow = nullptr;         // per group: finished by k_leaf_lanes_listed
   unsigned int* d_slow_list = nullptr;          // groups of 64 leaves left to k_leaf_lanes_listed (counter: d_tickets[1])
   uint64_t slow_cap = 0;
   int n_cu = 256;
@@ -301,6 +304,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* rg = std::getenv("RMI_HIP_REGS_NT"); if (rg && *rg) c->regs_nt = std::atoi(rg) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS_GRID"); if (rg && *rg) c->regs_grid = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_MAX_AVG"); if (rg && *rg) c->regs_max_avg = (unsigned int)std::atoi(rg); }
+  { const char* rg = std::getenv("RMI_HIP_REGS_QUEUE"); if (rg && *rg) c->regs_queue = std::atoi(rg) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS_SLOW"); if (rg && *rg) c->regs_slow = (unsigned int)std::atoi(rg); }
   { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) c->n_cu = cu; }
   if (hipMalloc(&c->d_lntab, sizeof(double) * (3 * LN_TMAX + 2 * (LS_SAMPLES + 1))) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
@@ -361,10 +365,12 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->d_regprof) {
     unsigned long long h[16] = {};
     if (hipMemcpy(h, c->d_regprof, 128, hipMemcpyDeviceToHost) == hipSuccess)
-      std::fprintf(stderr, "k_leaf_regs cycles (sum over waves and trainings): fit %llu, epilogue+tail %llu, hand-over %llu, error pass %llu, finalize %llu; in the fit: panel requests %llu, constants + key reads %llu, stash copies %llu, waits for panels %llu, arithmetic %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+      std::fprintf(stderr, "k_leaf_regs cycles (sum over waves and trainings): fit %llu, epilogue+tail %llu, hand-over %llu, error pass %llu, finalize %llu; (unused %llu) hand-over requests %llu, (unused %llu), finalize stores %llu, finalize up to the shuffles' end %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
     (void)hipFree(c->d_regprof);
   }
   if (c->d_slow_list) (void)hipFree(c->d_slow_list);
+  if (c->d_tile_slow) (void)hipFree(c->d_tile_slow);
+  if (c->d_bnext) (void)hipFree(c->d_bnext);
   if (c->d_giant) (void)hipFree(c->d_giant);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_sentinel) (void)hipHostFree(c->h_sentinel);
@@ -1179,14 +1185,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           LaneInit li; std::memset(&li, 0, sizeof li);
           if (init_folded) {
             li.st = c->d_state; li.init = init; li.leaf_start = a_leaf_start; li.L_own = L_own; li.sentinel = (unsigned long long)sp.it_hi;
-            li.list_cnt = c->d_flist_cnt; li.n_list_cnt = 2 * SG_REGIONS + 8; li.tickets = c->d_tickets; li.n_tickets = 2;
+            li.list_cnt = c->d_flist_cnt; li.n_list_cnt = 2 * SG_REGIONS + 8; li.tickets = c->d_tickets; li.n_tickets = 3;
           }
           hipLaunchKernelGGL((k_leaf_samples<ROOT, K>), dim3((LS_SAMPLES + 256) / 256), dim3(256), 0, s, keys, sp, rp, smp, li);
           hipLaunchKernelGGL((k_leaf_search<ROOT, K>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state, (const double*)smp);
           searched = true;
         }
       }
-      if (!(searched && init_folded)) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 8, s));   // (k_lane_reduce's arrival counter, k_leaf_regs' list counter)
+      if (!(searched && init_folded)) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 12, s));   // (k_lane_reduce's arrival counter, k_leaf_regs' list counter and group counter)
       if (!searched) {
         constexpr uint64_t V = 16 / sizeof(K);
         const uint64_t blocks = ((n_it + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
@@ -1230,21 +1236,30 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         if (regs) {
           if (c->slow_cap < wb) {
             if (c->d_slow_list) (void)hipFree(c->d_slow_list);
-            c->d_slow_list = nullptr; c->slow_cap = 0;
+            if (c->d_tile_slow) (void)hipFree(c->d_tile_slow);
+            if (c->d_bnext) (void)hipFree(c->d_bnext);
+            c->d_slow_list = nullptr; c->d_tile_slow = nullptr; c->d_bnext = nullptr; c->slow_cap = 0;
             HIPCHK(c, hipMalloc(&c->d_slow_list, wb * 4));
+            HIPCHK(c, hipMalloc(&c->d_tile_slow, wb));
+            HIPCHK(c, hipMalloc(&c->d_bnext, wb * 64 * 16));                // (the keys on either side of every leaf: 2 x 8 bytes)
             c->slow_cap = wb;
           }
+          HIPCHK(c, hipGetLastError());
           unsigned int grid = c->regs_grid ? c->regs_grid : 4u * (unsigned int)c->n_cu;
           if ((uint64_t)grid > wb) grid = (unsigned int)wb;
           if (c->regs_nt)
             hipLaunchKernelGGL((k_leaf_regs<K, true>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
-                               L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof);
+                               L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
           else
             hipLaunchKernelGGL((k_leaf_regs<K, false>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
-                               L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof);
-          const unsigned int lgrid = wb < 2048 ? (unsigned int)wb : 2048u;
+                               L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
+          const unsigned int lgrid = wb < 512 ? (unsigned int)wb : 512u;    // (as a rule nothing is listed: few blocks to start and to leave)
           hipLaunchKernelGGL((k_leaf_lanes_listed<K>), dim3(lgrid), dim3(64), 0, s, c->d_slow_list, c->d_tickets + 1, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin,
                              maxerr, run, L, err, count, rows, part, rp, peers);
+          hipLaunchKernelGGL((k_regs_finalize<K>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, (const DevState*)c->d_state, params,
+                             (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
+                             err, count, rows, part, peers);
+          HIPCHK(c, hipGetLastError());
         }
       }
       c->last_regs = regs;

@@ -39,11 +39,12 @@ constexpr int RG_ROW = 16;                          // steps (keys) per row and 
 constexpr int RG_RING = 4;                          // panels in the LDS ring
 constexpr int RG_PANEL_B = 64 * RG_ROW * 8;         // bytes of a panel: 64 rows x 128 B
 constexpr int RG_STASH = RG_STASH_N;                       // steps whose keys stay in registers
-constexpr int RG_MAXPTS = RG_STASH_N + 48;                      // longest container of a group that takes the register path
+constexpr int RG_MAXPTS = RG_STASH_N + 48;                      // longest container whose steps behind the stash are still in the ring at the end
+constexpr int RG_FARPTS = 1008;                                 // longest container of a group that takes the register path at all
 constexpr int RG_NBLK = RG_MAXPTS / RG_ROW;         // 15 blocks of 16 steps
 constexpr int RG_SBLK = RG_STASH / RG_ROW;          // 12 of them stashed in registers
 static_assert(RG_NBLK - RG_SBLK <= RG_RING - 1, "the tail of a group must still be in the ring when its fit ends");
-static_assert(RG_MAXPTS + 64 <= LN_TMAX, "the step tables cover the walk");
+static_assert(RG_FARPTS + 16 <= 1024, "the step table (RG_TMAX) covers the walk");
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void rg_static_for(F&& f) {
@@ -69,10 +70,11 @@ __global__ void __launch_bounds__(256) k_regs_table(double* __restrict__ tab, in
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) {
     const double nf = (double)(i + 1), r = 1.0 / nf;
-    tab[i] = r; tab[count + i] = recip_tail(nf, r); tab[2 * count + i] = (double)i * 0.5; tab[3 * count + i] = nf;
+    double* const t = tab + (i >> 3) * 32 + (i & 7);                     // (the 32 doubles of a half block lie together: one address per half)
+    t[0] = r; t[8] = recip_tail(nf, r); t[16] = (double)i * 0.5; t[24] = nf;
   }
 }
-constexpr int RG_TMAX = 256;                        // entries of the interleaved table
+constexpr int RG_TMAX = 1024;                       // steps the table covers
 
 // One panel: 8 LDS-DMA instructions, instruction i = rows 8 i + lane / 8, 128 bytes each; off[i] = this lane's byte offset
 // from `kb` (a wave-uniform pointer) of its 16-byte piece.  The destination is M0 + 16 lane.  M0 is not the compiler's to
@@ -123,6 +125,9 @@ __device__ __forceinline__ unsigned int rg_wave_max(unsigned int v) {
 
 // `key as f64` from the two halves of the key as they lie in LDS (models/mod.rs:83; see KeyTraits<uint64_t>::as_float -- written
 // on the halves because the compiler turns (double)(uint32_t)(k >> 32) back into a 64-bit conversion with one addition more)
+template <typename K> __device__ __forceinline__ unsigned long long key_to_bits_rg(K k) {
+  if constexpr (std::is_same<K, double>::value) return (unsigned long long)__double_as_longlong(k); else return (unsigned long long)k;
+}
 template <typename K> __device__ __forceinline__ double rg_as_float(uint2 v) {
   if constexpr (std::is_same<K, double>::value) return __hiloint2double((int)v.y, (int)v.x);
   else return __builtin_fma((double)v.y, 4294967296.0, (double)v.x);
@@ -143,7 +148,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                                                    unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, RootP vr,
                                                    PeerRows peers, unsigned int ntiles, unsigned int slow,
                                                    unsigned int* __restrict__ slow_list, unsigned int* __restrict__ slow_count,
-                                                   unsigned long long* __restrict__ prof) {
+                                                   unsigned long long* __restrict__ prof,
+                                                   K* __restrict__ bnext, K* __restrict__ bprev, unsigned char* __restrict__ tile_slow,
+                                                   unsigned int* __restrict__ tile_queue) {
   static_assert(sizeof(K) == 8, "8-byte keys");
   using B = unsigned long long;
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
@@ -160,13 +167,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const unsigned int piece = (unsigned int)(lane & 7) * 16u;         // its 16-byte piece of a line as a loader
   const unsigned int n32 = (unsigned int)sp.n;
   const uint64_t split_idx = st->split_idx, split_target = st->split_target;
-
   auto wave_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
 
+  unsigned long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                   // (RG_PROF)
+  unsigned long long pt = 0;
+  auto mark = [&](int i) { if (RG_PROF) { const unsigned long long t = rg_now(); pf[i] += t - pt; pt = t; } };
   // ---- a group of 64 leaves ("tile"): per-lane view and what is wave-uniform
   struct Tile {
     bool fast;                          // uniform: the register path takes it
@@ -174,7 +183,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     int ck;
     unsigned int s, e, lo, npts;        // leaf [s, e), container [lo, lo + npts)
     unsigned int a0;                    // slot of the container's first point in its first line
-    unsigned int maxlen, lastp;         // uniform: longest walk, last panel any row needs
+    unsigned int maxlen, lastp;         // uniform: longest walk through the ring (<= RG_MAXPTS steps), last panel any row needs
+    unsigned int maxfar;                // uniform: longest container (> RG_MAXPTS: those lanes go on from the key array)
     const K* kb;                        // uniform: keys + wave base (line aligned)
   };
   // (all lanes: a loader lane serves the rows 8 i + lane / 8, whatever its own leaf does)
@@ -207,20 +217,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     t.kb = keys + wb;
     const uint64_t np64 = t.ck == 2 ? hi - lo + 1 : 0;
     const bool handed = t.valid && t.ck == 2 && np64 + 1 > (uint64_t)long_min;
-    const bool ok = !t.valid || (!handed && (t.ck == 2 ? (np64 <= (uint64_t)RG_MAXPTS && lo <= s && e <= hi + 1) : e == s));
+    const bool ok = !t.valid || (!handed && (t.ck == 2 ? (np64 <= (uint64_t)RG_FARPTS && lo <= s + 1 && e <= hi + 1) : e == s));
     t.fast = __all(ok) && !slow;
     t.act = t.valid && t.ck == 2;
     t.s = (unsigned int)s; t.e = (unsigned int)e; t.lo = (unsigned int)lo; t.npts = t.act ? (unsigned int)np64 : 0u;
     const unsigned int rel = t.act ? (unsigned int)(lo - wb) : 0u;
     t.a0 = rel & (unsigned int)(RG_ROW - 1);
-    t.maxlen = rg_wave_max(t.npts);
-    t.lastp = rg_wave_max(t.act ? (t.a0 + t.npts - 1u) >> 4 : 0u);
+    // the walk through the ring covers RG_MAXPTS = 240 steps (panels 0 .. 15: the ring then still holds the panels behind the
+    // stash); the few lanes with more points go on from there by themselves (far_fit below)
+    const unsigned int wl = t.npts < (unsigned int)RG_MAXPTS ? t.npts : (unsigned int)RG_MAXPTS;
+    t.maxfar = rg_wave_max(t.npts);
+    t.maxlen = t.maxfar < (unsigned int)RG_MAXPTS ? t.maxfar : (unsigned int)RG_MAXPTS;
+    t.lastp = rg_wave_max(t.act ? (t.a0 + wl - 1u) >> 4 : 0u);
     if (t.fast) {
       wave_sync();
       nxt_off = (rel & ~(unsigned int)(RG_ROW - 1)) * 8u;
-      nxt_lim = t.act ? ((rel + t.npts - 1u) & ~(unsigned int)(RG_ROW - 1)) * 8u : 0u;
+      nxt_lim = t.act ? ((rel + wl - 1u) & ~(unsigned int)(RG_ROW - 1)) * 8u : 0u;
       s_off[lane] = nxt_off; s_lim[lane] = nxt_lim;
       wave_sync();
+      unsigned long long m0t = 0;
+      if (RG_PROF) m0t = rg_now();
       if (!(RG_KO & 4)) {
         // the single keys of this group's end -- the container's last key (Q1), the key in front of the container (FixDups offset
         // of its first point), the keys on either side of the leaf (finalize_one) -- in FRONT of the panels: landed before them
@@ -237,6 +253,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         for (unsigned int p = 0; p < (unsigned int)RG_RING; p++)
           if (p <= t.lastp) issue_panel(t.kb, p);
       }
+      if (RG_PROF) pf[6] += rg_now() - m0t;
     }
     return t;
   };
@@ -260,19 +277,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
   // The loop is skewed by the hand-over: iteration i finishes tile i - 1 around the descriptor (and first panels) of tile i,
   // so that there is ONE copy of everything in the code.
-  unsigned int tile = blockIdx.x;
+  // Which groups a wave takes: its first two by its number, the others from a counter (a group with a long leaf, 2 % of them on
+  // the metric configuration, takes its wave 20 us longer: dealt out statically, the waves with two or three of those end 40-60 us
+  // behind the others).  A group's number is needed two hand-overs ahead (its leaves' boundaries are requested one ahead).
+  unsigned int tile = blockIdx.x;                                      // the group the NEXT hand-over describes
   if (tile >= ntiles) return;
-  unsigned long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                   // (RG_PROF)
-  unsigned long long pt = 0;
-  auto mark = [&](int i) { if (RG_PROF) { const unsigned long long t = rg_now(); pf[i] += t - pt; pt = t; } };
+  unsigned int tile2 = tile + gridDim.x;                               // ... and the one behind it
+  unsigned int done_tile = 0u;                                         // the group `cur` describes (when `have`)
   uint64_t sn, en;
   load_bounds(tile, sn, en);
   Tile cur;                                                            // (set at the first hand-over)
   bool have = false;
   for (;;) {
-    const unsigned int done_tile = tile - gridDim.x;                   // the tile `cur` describes (when `have`)
     if (RG_PROF) pt = rg_now();
     const bool more = tile < ntiles;
+    // (asked for at the top of the iteration, looked at behind the walk: no wait of the compiler's for it stands behind a panel request)
+    unsigned int tile3 = 0xFFFFFFFFu;
+    if (tile_queue == nullptr) tile3 = tile2 + gridDim.x;               // (static dealing: RMI_HIP_REGS_QUEUE=0)
+    else if (lane == 0 && tile2 < ntiles) tile3 = 2u * gridDim.x + atomicAdd(tile_queue, 1u);
     unsigned int flags = 0;
     double pa = 0.0, pb = 0.0;
     const bool fast = have && cur.fast;
@@ -282,26 +304,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     const unsigned int a8 = cur.a0 * 8u;
     // LDS address of step 16 b + qq of this lane's row: slot a0 + qq of the two-panel window that starts at panel b -- in panel
     // b (ring slot b mod 4) for the lanes that have not crossed their line's end yet, in panel b + 1 for the others
-    const unsigned int cross = (unsigned int)RG_ROW - cur.a0;           // first qq behind the crossing (16: never)
-    auto block_base = [&](unsigned int b, unsigned int& in_b, unsigned int& in_b1) {
+    // (the select: bit qq of `cm` says "crossed"; times the distance between the two places: two VOP3 operations, no VCC)
+    const unsigned int cm = 0xFFFFu << ((unsigned int)RG_ROW - cur.a0);  // crossed at qq >= 16 - a0 (a0 = 0: never)
+    auto block_base = [&](unsigned int b, unsigned int& in_b, unsigned int& delta) {
       const unsigned int sb = b & (unsigned int)(RG_RING - 1), sb1 = (b + 1u) & (unsigned int)(RG_RING - 1);
       in_b = rowpart + a8 + sb * (unsigned int)RG_PANEL_B;
-      in_b1 = rowpart + a8 + sb1 * (unsigned int)RG_PANEL_B - 128u;
-      asm volatile("" : "+v"(in_b), "+v"(in_b1));                       // (two registers to select between; the step's offset goes into the read)
+      delta = (sb1 - sb) * (unsigned int)RG_PANEL_B - 128u;              // (wrapping: the ring's last slot is followed by its first)
     };
-    auto slot_key = [&](unsigned int in_b, unsigned int in_b1, int qq) -> uint2 {
-      unsigned int cr = cross;
-      asm volatile("" : "+v"(cr));                                       // (else the 16 comparisons live in 32 SGPRs across the whole walk)
-      const unsigned int addr = ((unsigned int)qq >= cr ? in_b1 : in_b) + (unsigned int)(qq * 8);
+    auto slot_key = [&](unsigned int in_b, unsigned int delta, int qq) -> uint2 {
+      // (written out: from C the compiler makes 16 comparisons of it, kept in 32 SGPRs across the whole walk)
+      unsigned int crossed, addr0;
+      asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(crossed) : "v"(cm), "n"(qq));
+      asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr0) : "v"(crossed), "s"(delta), "v"(in_b));   // (signed: the ring wraps backwards)
+      const unsigned int addr = addr0 + (unsigned int)(qq * 8);
       return *reinterpret_cast<const uint2*>(ringc + addr);
     };
     K k_hi = KeyTraits<K>::zero_value(), k_lom1 = KeyTraits<K>::zero_value();
     K k_next = KeyTraits<K>::max_value(), k_prev = KeyTraits<K>::zero_value();    // the two boundary keys of finalize_one
     // =========================== the error pass over the leaves' own keys ===========================
-    // the leaf's keys are the steps [es, eend) of its container's walk: es = s - lo is 0 or 1
+    // the leaf's keys are the steps [es, eend) of its container's walk: es = s - lo is 0 or 1 -- or -1 for the leaf behind the split
+    // (two_layer.rs:166-169: its container starts behind its first key, which is the parked key in front of the container)
     const unsigned int es = cur.s - cur.lo;
     unsigned int eend = (have && cur.act) ? cur.e - cur.lo : 0u;
-    unsigned int emax = 0u, femax = 0u;                                  // femax: the maximum as it stands behind the leaf's last key
+    unsigned int emax = 0u;
     auto err_step = [&](double x, unsigned int k) {
       const double f = __builtin_fma(pb, x, pa);                            // linear.rs:87-90
       const unsigned int pr = min(sg_cvt_u32(f), n32);                      // models/mod.rs:735-737, two_layer.rs:14-18
@@ -310,12 +335,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // ---- hand-over: the ring is free -- the next group's descriptor and its first panels, under the rest of this group's work
     Tile nxt = cur;
     auto hand_over = [&]() {
+      asm volatile("" : "+v"(tile3));                                   // (the counter's answer is waited for HERE, in front of the panel requests)
       if (more) {
         uint64_t s_nx = sn, e_nx = en;                                   // (the first group's: loaded in front of the loop)
         if (have && !(RG_KO & 4)) { s_nx = park[8][lane]; e_nx = park[9][lane]; }
         else if (have) load_bounds(tile, s_nx, e_nx);
         nxt = make_tile(tile, s_nx, e_nx);
-        if (tile + gridDim.x < ntiles) request_bounds(tile + gridDim.x);  // (for the hand-over after this one)
+        if (tile2 < ntiles) request_bounds(tile2);                       // (for the hand-over after this one)
       }
     };
     bool done = false;
@@ -332,7 +358,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // f64 keys (low words of round numbers ARE equal): cleared by a comparison of the doubles.
       unsigned int dmin = 0xFFFFFFFFu, fdmin = 0xFFFFFFFFu;
       unsigned int plo = 0u;
-      double xp = 0.0;
+      double xp = __builtin_nan("");
       const unsigned int npts = cur.npts;
       uint2 rawA[8], rawB[8];                                            // the keys of the half block in work / of the next one
       // panel 1 has landed once at most the panels behind it are outstanding (requested at the hand-over: up to panel 3)
@@ -342,15 +368,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           else if (cur.lastp == 2u) rg_wait_vm<8>();
           else rg_wait_vm<0>();
         }
-        unsigned int in_b, in_b1;
-        block_base(0u, in_b, in_b1);
+        unsigned int in_b, dlt;
+        block_base(0u, in_b, dlt);
 #pragma unroll
-        for (int q = 0; q < 8; q++) rawA[q] = slot_key(in_b, in_b1, q);
+        for (int q = 0; q < 8; q++) rawA[q] = slot_key(in_b, dlt, q);
+        plo = ~rawA[0].x;                                                  // (the walk's first step has nothing in front of it)
       }
 #pragma nounroll
       for (unsigned int b = 0; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
-        unsigned int in_b, in_b1;
-        block_base(b, in_b, in_b1);
+        unsigned int in_b, dlt;
+        block_base(b, in_b, dlt);
         double T[8];
         // Masking: a lane is finished behind its container's last point, and stays finished.  Its sums are put aside at the end
         // of the half block (8 steps) in which it finishes; from then on it may compute what it likes.  So a half block in
@@ -364,11 +391,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         // ago; only then are the next half's keys requested, and those land under the arithmetic.
         double r8[8], rl8[8], hh8[8], kf8[8];
         auto constants = [&](int hb) {
-          const unsigned int k0 = (RG_DIAG & 1) ? 0u : b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
+          const double* const th = rtab4 + ((RG_DIAG & 1) ? 0u : (2u * b + (unsigned int)hb) * 32u);
 #pragma unroll
           for (int q = 0; q < 8; q++) {
-            r8[q] = rtab4[k0 + q]; hh8[q] = rtab4[2 * RG_TMAX + k0 + q];
-            if constexpr (DIVK) kf8[q] = rtab4[3 * RG_TMAX + k0 + q]; else rl8[q] = rtab4[RG_TMAX + k0 + q];
+            hh8[q] = th[16 + q];
+            if constexpr (DIVK) kf8[q] = th[24 + q]; else { r8[q] = th[q]; rl8[q] = th[8 + q]; }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
@@ -382,8 +409,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             T[q] = x;
             if (FULL || k < npts) {
               if (!(RG_DIAG & 2)) {
-                if constexpr (DIVK) { if (x == xp && k != 0u) dmin = 0u; }
-                else { const unsigned int d = raw[q].x ^ plo; if (k != 0u) dmin = dmin < d ? dmin : d; }
+                if constexpr (DIVK) { if (x == xp) dmin = 0u; }
+                else { const unsigned int d = raw[q].x ^ plo; dmin = dmin < d ? dmin : d; }
               }
               if (!(RG_KO & 1)) {
                 const double dx = x - mx;                                 // linear.rs:26
@@ -424,38 +451,57 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           stash_half(hb);
         };
         // first half: its keys were asked for a half block ago; the second half's are asked for now
-        unsigned long long q0 = 0, q1 = 0;
-        if (RG_PROF) q0 = rg_now();
         constants(0);
 #pragma unroll
-        for (int q = 0; q < 8; q++) rawB[q] = slot_key(in_b, in_b1, 8 + q);
-        if (RG_PROF) { q1 = rg_now(); pf[6] += q1 - q0; }
+        for (int q = 0; q < 8; q++) rawB[q] = slot_key(in_b, dlt, 8 + q);
         run_half(0, rawA);
-        if (RG_PROF) { q0 = rg_now(); pf[9] += q0 - q1; }
         // second half.  Every read of panel b is behind us: its ring slot takes panel b + 4 -- but nothing behind the walk's
         // last panel, so that at the end of the fit the ring still holds the tail of every row (the steps >= RG_STASH of the
         // error pass).  Then the first keys of the next block: panel b + 2 has landed once at most the panels behind it are
         // outstanding.
         constants(1);
-        if (RG_PROF) { q1 = rg_now(); pf[6] += q1 - q0; }
         if (!(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING);
-        if (RG_PROF) { q0 = rg_now(); pf[5] += q0 - q1; }
         if ((b + 1u) * (unsigned int)RG_ROW < cur.maxlen) {
           if (!(RG_KO & 4)) {
             if (cur.lastp >= b + 4u) rg_wait_vm<16>();
             else if (cur.lastp == b + 3u) rg_wait_vm<8>();
             else rg_wait_vm<0>();
           }
-          if (RG_PROF) { q1 = rg_now(); pf[8] += q1 - q0; q0 = q1; }
-          unsigned int nx_b, nx_b1;
-          block_base(b + 1u, nx_b, nx_b1);
+          unsigned int nx_b, nx_d;
+          block_base(b + 1u, nx_b, nx_d);
 #pragma unroll
-          for (int q = 0; q < 8; q++) rawA[q] = slot_key(nx_b, nx_b1, q);
+          for (int q = 0; q < 8; q++) rawA[q] = slot_key(nx_b, nx_d, q);
         }
-        if (RG_PROF) { q1 = rg_now(); pf[6] += q1 - q0; }
         run_half(1, rawB);
-        if (RG_PROF) { q0 = rg_now(); pf[9] += q0 - q1; }
-        if (RG_PROF) pf[7] += rg_now() - q0;
+      }
+      if (cur.maxfar > (unsigned int)RG_MAXPTS) {
+        // ---- the lanes with more than 240 points (3 in 10 000 leaves of the metric configuration) go on from the key array: the same
+        //      steps, 8 keys a trip, every step tested; the other lanes' sums were put aside where their walks ended
+        for (unsigned int k0 = (unsigned int)RG_MAXPTS; k0 < cur.maxfar; k0 += 8u) {
+          K kk[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const unsigned int k = k0 + (unsigned int)q;
+            kk[q] = keys[(uint64_t)cur.lo + (k < npts ? k : 0u)];
+          }
+          const double* const th = rtab4 + (k0 >> 3) * 32u;
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const unsigned int k = k0 + (unsigned int)q;
+            const unsigned long long bits = key_to_bits_rg<K>(kk[q]);
+            const double x = KeyTraits<K>::as_float(kk[q]);
+            if (k < npts) {
+              if constexpr (DIVK) { if (x == xp) dmin = 0u; }
+              else { const unsigned int d = (unsigned int)bits ^ plo; dmin = dmin < d ? dmin : d; }
+              const double dx = x - mx;
+              if constexpr (DIVK) mx += dx / th[24 + q]; else mx += div_by_count2(dx, th[q], th[8 + q]);
+              cc += dx * th[16 + q];
+              m2 += dx * (x - mx);
+              xp = x; plo = (unsigned int)bits;
+            }
+          }
+        }
+        if (npts > (unsigned int)RG_MAXPTS) { fmx = mx; fcc = cc; fm2 = m2; fdmin = dmin; }
       }
       mark(0);
       if (!(RG_KO & 4)) { k_hi = parked_key(0); k_lom1 = parked_key(2); k_next = parked_key(4); k_prev = parked_key(6); }
@@ -484,16 +530,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           else { pb = cov / var; pa = my - pb * mx; }                      // no fma: linear.rs:56
         } else if (cur.ck == 1) { pa = (double)cur.lo; pb = 0.0; }         // Q4: one borrowed point (two identical items)
         if (cur.valid) { params[2 * j] = pa; params[2 * j + 1] = pb; }
+      if (!(RG_KO & 2) && cur.maxfar > (unsigned int)RG_MAXPTS) {
+        // (the steps of the long containers behind the ring's reach: from the key array once more, 16 keys a lane and trip)
+        for (unsigned int k0 = (unsigned int)RG_MAXPTS; __any(k0 < eend); k0 += 16u) {
+          K kk[16];
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const unsigned int k = k0 + (unsigned int)q;
+            kk[q] = keys[(uint64_t)cur.lo + (k < eend ? k : 0u)];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const unsigned int k = k0 + (unsigned int)q;
+            if (k < eend) err_step(KeyTraits<K>::as_float(kk[q]), k);
+          }
+        }
+      }
       if (!(RG_KO & 2)) {
         // the steps behind the stash: still in the ring (masked the plain way: a few blocks)
 #pragma nounroll
         for (unsigned int b = (unsigned int)RG_SBLK; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
-          unsigned int in_b, in_b1;
-          block_base(b, in_b, in_b1);
+          unsigned int in_b, dlt;
+          block_base(b, in_b, dlt);
 #pragma unroll
           for (int qq = 0; qq < RG_ROW; qq++) {
             const unsigned int k = b * (unsigned int)RG_ROW + (unsigned int)qq;
-            const double x = rg_as_float<K>(slot_key(in_b, in_b1, qq));
+            const double x = rg_as_float<K>(slot_key(in_b, dlt, qq));
             if (k < eend) err_step(x, k);
           }
         }
@@ -503,28 +565,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       hand_over();
       mark(2);
       if (!(RG_KO & 2)) {
-        if (es == 0u && eend > 0u) err_step(xs[0], 0u);                  // (step 0 belongs to the leaf only where the container starts with it)
+        if ((int)es <= 0 && eend > 0u) err_step(xs[0], 0u);              // (step 0 belongs to the leaf only where the container starts with it or behind it)
+        if (es == 0xFFFFFFFFu && cur.act) err_step(KeyTraits<K>::as_float(k_lom1), 0xFFFFFFFFu);
         const unsigned int sl = cur.maxlen < (unsigned int)RG_STASH ? cur.maxlen : (unsigned int)RG_STASH;
+        // (tried: bank by bank statically, the banks with a leaf's end noted for a second loop: no search for the bank's code, but the
+        //  register allocator moves parts of the stash around between the banks' codes -- error pass 13 % slower)
 #pragma nounroll
         for (unsigned int b = 0; b * (unsigned int)RG_ROW < sl; b++) {
           const unsigned int kb0 = b * (unsigned int)RG_ROW;
-          // a block without an end in it and without step 0: straight from the bank's registers (one copy of the 16 steps per bank:
-          // 6 instructions a step); else through T[] with the tests
+          // a block in which no leaf ends, and not the one with step 0: straight from the bank's registers under ONE test (one
+          // copy of the 16 steps per bank: 5.5 instructions a step); else through T[] with a test per step
           if (b != 0u && __all(eend >= kb0 + 16u || eend <= kb0)) {
-            auto group = [&](auto g_tag) {
-              constexpr int g = decltype(g_tag)::value;
-              rg_static_for<(g == 0 ? 1 : 4 * g), 4 * g + 4>([&](auto i_tag) {
-                constexpr int i = decltype(i_tag)::value;
-                if (b == (unsigned int)i) {
+            if (eend > kb0) {
+              auto group = [&](auto g_tag) {
+                constexpr int g = decltype(g_tag)::value;
+                rg_static_for<(g == 0 ? 1 : 4 * g), 4 * g + 4>([&](auto i_tag) {
+                  constexpr int i = decltype(i_tag)::value;
+                  if (b == (unsigned int)i) {
 #pragma unroll
-                  for (int qq = 0; qq < RG_ROW; qq++) err_step(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq));
-                  asm volatile("; stash bank %0" ::"n"(i));
-                }
-              });
-            };
-            if (b < 4u) group(std::integral_constant<int, 0>{});
-            if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
-            if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
+                    for (int qq = 0; qq < RG_ROW; qq++) err_step(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq));
+                    asm volatile("; stash bank %0" ::"n"(i));
+                  }
+                });
+              };
+              if (b < 4u) group(std::integral_constant<int, 0>{});
+              if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
+              if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
+            }
             continue;
           }
           double T[RG_ROW];
@@ -544,55 +611,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
             if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
           }
-          // (as in the fit: a leaf's maximum is put aside behind its last key)
 #pragma unroll
-          for (int hb = 0; hb < 2; hb++) {
-            const unsigned int k0 = kb0 + (unsigned int)(hb * 8);
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-              const unsigned int k = k0 + (unsigned int)q;
-              if (k < eend && k != 0u) err_step(T[hb * 8 + q], k);          // (step 0: above)
-            }
-            if (eend > k0 && eend <= k0 + 8u) femax = emax;
+          for (int qq = 0; qq < RG_ROW; qq++) {
+            const unsigned int k = kb0 + (unsigned int)qq;
+            if (k < eend && k != 0u) err_step(T[qq], k);                    // (step 0: above)
           }
         }
-        if (eend <= (unsigned int)RG_STASH) emax = femax;                 // (a leaf that ends behind the stash was alive to the end here)
       }
       mark(3);
-      // ---- finish the leaf (two_layer.rs:185-197, 226-259, the row of codegen.rs:288-315, the terms of :267-287)
-      unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;
-      double st_l2 = 0.0, st_lg = 0.0;
+      // ---- what k_regs_finalize needs to finish the leaf: the raw maximum and the keys on either side of the leaf (they lie in this
+      //      wave's LDS; there they would be two scattered loads per leaf).  The rest of the leaf's end -- widening, row, counts, the
+      //      group's aggregate record: ~400 instructions a lane, a logarithm and a division among them -- costs a lone wave 6 us per
+      //      group here and a fully occupied launch ~15 us for ALL groups.
       if (cur.valid) {
-        double pp[2] = {pa, pb};
-        uint64_t final_err, cnt_j;
-        const uint64_t s = cur.s, e = cur.e;
-        finalize_one_pre<K_LINEAR, K>(j, s, e, sp, L, keys, pp, (uint64_t)emax, 0ull, st->last_target, k_next, k_prev, final_err, cnt_j);
-        if (!(s < e)) { params[2 * j] = pp[0]; params[2 * j + 1] = pp[1]; }
-        leaf_err[j] = final_err;
-        leaf_count[j] = cnt_j;
-        double* rp = reinterpret_cast<double*>(rows + j * 24);
-        rp[0] = pp[0]; rp[1] = pp[1];
-        *reinterpret_cast<unsigned long long*>(rows + j * 24 + 16) = final_err;
-        for (int p = 0; p < peers.n; p++) {                              // (wave-uniform trip count; 24-byte rows: three 8-byte stores)
-          double* pr = reinterpret_cast<double*>(peers.tab[p] + j * 24);
-          pr[0] = pp[0]; pr[1] = pp[1];
-          *reinterpret_cast<unsigned long long*>(peers.tab[p] + j * 24 + 16) = final_err;
-        }
-        st_mx = final_err; st_mi = j;
-        st_sum = cnt_j * final_err;                                      // wrapping u64, like the reference's sum
-        const double v = (double)st_sum;
-        st_l2 = (v * v) / (double)sp.n;
-        st_lg = (double)cnt_j * log2((double)(2 * final_err + 2));
+        const uint64_t jl = (uint64_t)done_tile * 64 + (uint64_t)lane_j;
+        leaf_maxerr[j] = (unsigned long long)emax;
+        bnext[jl] = k_next; bprev[jl] = k_prev;
       }
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) {                                 // (lexicographic maximum and sums: any order combines)
-        const unsigned long long omx = shfl_down_u64(st_mx, d), omi = shfl_down_u64(st_mi, d);
-        if (omx > st_mx || (omx == st_mx && omi > st_mi)) { st_mx = omx; st_mi = omi; }
-        st_sum += shfl_down_u64(st_sum, d);
-        st_l2 += __shfl_down(st_l2, d);
-        st_lg += __shfl_down(st_lg, d);
-      }
-      if (lane == 0) partials[done_tile] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
+      if (lane == 0) tile_slow[done_tile] = 0;
       if (flags) atomicOr(&st->err_flags, flags);
       mark(4);
       done = true;
@@ -601,18 +637,72 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if (!done) {
       // not taken here: the group goes on the list of k_leaf_lanes_listed, launched behind this kernel (the general walk inside
       // this kernel would share its registers with the stash: the compiler then keeps a third of the stash in scratch memory)
-      if (have && lane == 0) slow_list[atomicAdd(slow_count, 1u)] = done_tile;
+      if (have && lane == 0) { slow_list[atomicAdd(slow_count, 1u)] = done_tile; tile_slow[done_tile] = 1; }
       hand_over();
     }
     if (!more) break;
     cur = nxt;
     have = true;
-    tile += gridDim.x;
+    done_tile = tile;
+    tile = tile2;
+    tile2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)tile3);
   }
   if (RG_PROF && prof != nullptr && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 10; i++) atomicAdd(prof + i, pf[i]);
   }
+}
+
+// The end of the leaves k_leaf_regs has fitted and measured (two_layer.rs:185-197, 226-259, the row of codegen.rs:288-315, the terms
+// of :267-287): one thread per leaf, a wave = one group of 64 leaves = one aggregate record, as in k_leaf_lanes.  Groups that went
+// through k_leaf_lanes_listed were finished there.
+template <typename K>
+__global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ keys, Span sp, uint64_t L,
+                                                       const unsigned long long* __restrict__ leaf_start, const DevState* __restrict__ st,
+                                                       double* __restrict__ params, const unsigned long long* __restrict__ leaf_maxerr,
+                                                       const K* __restrict__ bnext, const K* __restrict__ bprev,
+                                                       const unsigned char* __restrict__ tile_slow, unsigned int ntiles,
+                                                       unsigned long long* __restrict__ leaf_err, unsigned long long* __restrict__ leaf_count,
+                                                       unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, PeerRows peers) {
+  const uint64_t jl = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned int tile = (unsigned int)(jl >> 6);
+  if (tile >= ntiles || tile_slow[tile] != 0) return;                  // (wave-uniform)
+  const uint64_t j = sp.leaf_lo + jl;
+  unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;
+  double st_l2 = 0.0, st_lg = 0.0;
+  if (j < sp.leaf_hi) {
+    const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+    double pp[2] = {params[2 * j], params[2 * j + 1]};
+    const K k_next = e < sp.n ? bnext[jl] : KeyTraits<K>::max_value();
+    const K k_prev = s > 0 ? bprev[jl] : KeyTraits<K>::zero_value();
+    uint64_t final_err, cnt_j;
+    finalize_one_pre<K_LINEAR, K>(j, s, e, sp, L, keys, pp, leaf_maxerr[j], 0ull, st->last_target, k_next, k_prev, final_err, cnt_j);
+    if (!(s < e)) { params[2 * j] = pp[0]; params[2 * j + 1] = pp[1]; }
+    leaf_err[j] = final_err;
+    leaf_count[j] = cnt_j;
+    double* rp = reinterpret_cast<double*>(rows + j * 24);
+    rp[0] = pp[0]; rp[1] = pp[1];
+    *reinterpret_cast<unsigned long long*>(rows + j * 24 + 16) = final_err;
+    for (int p = 0; p < peers.n; p++) {                                // (the direct exchange of a sharded training: rmi_lanes.hip.h)
+      double* pr = reinterpret_cast<double*>(peers.tab[p] + j * 24);
+      pr[0] = pp[0]; pr[1] = pp[1];
+      *reinterpret_cast<unsigned long long*>(peers.tab[p] + j * 24 + 16) = final_err;
+    }
+    st_mx = final_err; st_mi = j;
+    st_sum = cnt_j * final_err;                                        // wrapping u64, like the reference's sum
+    const double v = (double)st_sum;
+    st_l2 = (v * v) / (double)sp.n;
+    st_lg = (double)cnt_j * log2((double)(2 * final_err + 2));
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {                                   // (lexicographic maximum and sums: the order of k_leaf_lanes)
+    const unsigned long long omx = shfl_down_u64(st_mx, d), omi = shfl_down_u64(st_mi, d);
+    if (omx > st_mx || (omx == st_mx && omi > st_mi)) { st_mx = omx; st_mi = omi; }
+    st_sum += shfl_down_u64(st_sum, d);
+    st_l2 += __shfl_down(st_l2, d);
+    st_lg += __shfl_down(st_lg, d);
+  }
+  if ((threadIdx.x & 63) == 0) partials[tile] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
 }
 
 // The groups k_leaf_regs did not take: the body of k_leaf_lanes per listed group (a fixed grid; nothing listed: the blocks leave).

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import os
+os.chdir(os.environ.get("GRAFT_REPO_ROOT", "."))
 n = sys.argv[1] if len(sys.argv) > 1 else "200000000"
 L = sys.argv[2] if len(sys.argv) > 2 else "1048576"
 steps = sys.argv[3] if len(sys.argv) > 3 else "20"
