@@ -38,7 +38,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 KERNELS_EXACT = ["k_fit_stream", "k_fill", "k_fit_long", "k_err_range", "k_finalize+stats"]            # RMI_HIP_PIPELINE=2
-KERNELS_LANES = ["k_leaf_lanes", "k_lane_reduce", "-", "-", "-"]                                    # the default exact path
+KERNELS_REGS = ["k_leaf_regs", "k_leaf_lanes_listed+k_regs_finalize", "k_lane_reduce", "-", "-"]      # the default exact path (pipeline 4)
+KERNELS_LANES = ["k_leaf_lanes", "k_lane_reduce", "-", "-", "-"]                                    # pipeline 3 (RMI_HIP_REGS=0, and where 4 does not apply)
 KERNELS_LANES_INSTREAM = ["k_leaf_lanes", "k_list", "k_list_tail", "k_finalize_listed+stats", "-"]    # RMI_HIP_OPT_TAIL=0
 KERNELS_ONEPASS = ["k_sigma2", "k_fill", "k_list", "k_list_tail", "k_finalize+stats"]
 MODES = {"exact": 0, "onepass_guarded": 1, "onepass": 2}
@@ -113,6 +114,47 @@ def cpu_baseline(keys_np, spec, leaves_total, n_total):
     }
 
 
+def sources_sha256():
+    """sha256 over the kernel sources the library is built from: ties a counter file under profiles/ to the code it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rmi_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def env_info(torch):
+    """Versions and clocks of the box the line was measured on (best effort: never fails the bench)."""
+    import subprocess
+    info = {"torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+    try:
+        info["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        info["rccl"] = None
+    try:
+        p = torch.cuda.get_device_properties(0)
+        info["device"] = p.name
+        info["cus"] = p.multi_processor_count
+        info["gcn_arch"] = getattr(p, "gcnArchName", None)
+    except Exception:
+        pass
+    try:
+        info["rocm_version"] = open("/opt/rocm/.info/version").read().strip()
+    except Exception:
+        info["rocm_version"] = None
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout)
+        c0 = j.get("card0", {})
+        info["clocks"] = {k: v for k, v in c0.items() if "sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower()}
+    except Exception as ex:
+        info["clocks"] = "unavailable: " + str(ex)[:80]
+    return info
+
+
 def parity_against(o, g, what):
     """The three output clauses of north_star, measured: the GPU result `g` of the timed mode against the oracle's `o`
     on the same keys (bucket table and integers bit for bit, coefficients relative)."""
@@ -135,10 +177,14 @@ def parity_against(o, g, what):
         "slope_frac_within_1e-9": float((slope <= 1e-9).mean()) if slope.size else 1.0,
         "intercept_max_abs_diff": float(np.abs(gp[:, 0] - op[:, 0]).max()) if gp.size else 0.0,   # in positions (what a prediction moves by)
         "leaves": int(len(o.leaf_err)),
-        # the model-level aggregates (two_layer.rs:267-287): maximum and its leaf, average error exactly; the f64 sums to 1e-12
+        # the model-level aggregates (two_layer.rs:267-287): maximum and its leaf, average error exactly; the f64 sums to 1e-12 (log2) / 1e-9 (l2)
         "aggregates_equal": bool(int(g.model_max_error) == int(o.model_max_error) and int(g.model_max_error_idx) == int(o.model_max_error_idx)
                                  and float(g.model_avg_error) == float(o.model_avg_error)
-                                 and abs(float(g.model_avg_log2_error) - float(o.model_avg_log2_error)) <= 1e-12 * max(1.0, abs(float(o.model_avg_log2_error)))),
+                                 and abs(float(g.model_avg_log2_error) - float(o.model_avg_log2_error)) <= 1e-12 * max(1.0, abs(float(o.model_avg_log2_error)))
+                                 and abs(float(g.model_avg_l2_error) - float(o.model_avg_l2_error)) <= 1e-9 * max(1.0, abs(float(o.model_avg_l2_error)))),
+        # (the two f64 sums are the reference's in leaf order, here per group of 64 leaves and then over the groups: not the same roundings)
+        "avg_l2_rel_diff": abs(float(g.model_avg_l2_error) - float(o.model_avg_l2_error)) / max(1e-300, abs(float(o.model_avg_l2_error))),
+        "avg_log2_rel_diff": abs(float(g.model_avg_log2_error) - float(o.model_avg_log2_error)) / max(1e-300, abs(float(o.model_avg_log2_error))),
     }
 
 
@@ -352,7 +398,8 @@ def main():
     if rank == 0:
         used = int(getattr(res, "fit_mode_used", 0))
         lanes_path = used == 0 and leaf_kind in (0, 1) and os.environ.get("RMI_HIP_PIPELINE", "3") not in ("1", "2") and n_local >= 1024
-        names = KERNELS_ONEPASS if used else ((KERNELS_LANES_INSTREAM if os.environ.get("RMI_HIP_OPT_TAIL", "1") == "0" else KERNELS_LANES) if lanes_path else KERNELS_EXACT)
+        regs_path = lanes_path and int(tr._lib.rmi_hip_last_pipeline(tr._h)) == 4
+        names = KERNELS_ONEPASS if used else ((KERNELS_REGS if regs_path else (KERNELS_LANES_INSTREAM if os.environ.get("RMI_HIP_OPT_TAIL", "1") == "0" else KERNELS_LANES)) if lanes_path else KERNELS_EXACT)
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global / (elapsed / args.steps)
         kernel_us = (kernel_ns / args.steps / 1e3)[:5]
@@ -367,7 +414,11 @@ def main():
         # (the timed trainings' arrays, through the wrapper: one more training of the same configuration, before any other one)
         g_head = tr.train_leaves(root, leaf_kind, L_global).materialize() if world == 1 else None
         mode_text = {
-            0: ("exact, leaf-lane kernels: leaf boundaries by search (k_leaf_search), then 64 leaves per wave in lockstep -- the reference's "
+            0: ("exact, register-resident leaf kernel: leaf boundaries by search (k_leaf_search), then 64 leaves per wave in lockstep, ONE wave "
+                "per SIMD with 512 registers -- the reference's recurrence per leaf in reference order (coefficients bit-identical); the keys "
+                "arrive by LDS-DMA and stay in the lane's registers for the error pass behind the fit (k_leaf_regs): the keys are read ONCE; "
+                "the leaf's widening, row and aggregates in k_regs_finalize") if regs_path else
+               ("exact, leaf-lane kernels: leaf boundaries by search (k_leaf_search), then 64 leaves per wave in lockstep -- the reference's "
                 "recurrence per leaf in reference order (coefficients bit-identical), the error pass and the leaf's finalize behind it in the "
                 "same kernel (k_leaf_lanes); the keys are read twice, the second time through the Infinity Cache") if lanes_path else
                "exact: reference-order recurrence per leaf, two streaming passes over the keys; coefficients bit-identical",
@@ -405,7 +456,7 @@ def main():
                                   "kernel (kernel_us[0]), one only the whole call (device_us_per_step), two carry no event -- an event "
                                   "between two kernels idles the device ~5.5 us and costs the host ~4 us; the other kernels: events over "
                                   "the warm-up steps; unbracketed_us = device time of a step outside the first kernel (k_leaf_samples "
-                                  "with the init, k_leaf_search, k_lane_reduce)",
+                                  "with the init, k_leaf_search, k_lane_reduce; pipeline 4: the listed groups and k_regs_finalize too)",
                 "traffic": None,
             },
         }
@@ -413,16 +464,50 @@ def main():
             out["per_rank"] = per_rank
             if getattr(sh, "auto_report", None):
                 out["exchange_ab"] = sh.auto_report
-        tpath = os.path.join(ROOT, "profiles", "traffic_r03_%s.json" % ("exact" if not used else "onepass_guarded"))
+        tpath = os.path.join(ROOT, "profiles", "traffic_r04_%s.json" % ("exact" if not used else "onepass_guarded"))
         if os.path.exists(tpath) and world == 1 and args.config == "M":
             try:
                 tj = json.load(open(tpath))
                 ent = tj.get(names[dom], {})
-                out["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
-                out["roofline"]["traffic_note"] = "NOT measured in this run: rocprofv3 FETCH_SIZE/WRITE_SIZE of the same command, from " \
-                                                  + os.path.relpath(tpath, ROOT) + " (" + str(tj.get("note", "")) + ")"
+                # the counters were taken on a build of these very sources, or the figure is not quoted
+                if tj.get("sources_sha256") == sources_sha256():
+                    out["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
+                    out["roofline"]["traffic_note"] = "NOT measured in this run: rocprofv3 FETCH_SIZE/WRITE_SIZE of the same command on a build of the same " \
+                                                      "kernel sources (sha256 " + sources_sha256()[:12] + "), from " + os.path.relpath(tpath, ROOT) + \
+                                                      " (" + str(tj.get("note", "")) + ")"
+                else:
+                    out["roofline"]["traffic_note"] = "profiles/ holds counters of OTHER kernel sources (" + str(tj.get("sources_sha256"))[:12] + \
+                                                      " against " + sources_sha256()[:12] + "): not quoted; tools/profile_r04.sh takes them again"
             except Exception:
                 pass
+
+        # the box's own streaming read rate, measured in this run on the resident key array (a read-only kernel,
+        # non-temporal 16-byte loads): what "HBM-bound" can mean on this machine, beside the 8 TB/s of the data sheet
+        if world == 1:
+            try:
+                bw = max(tr.measure_read_bandwidth(5) for _ in range(3))
+                out["roofline"]["measured_peak"] = float(bw)
+                out["roofline"]["frac_of_measured"] = float(path_gbs / bw) if bw > 0 else None
+                out["roofline"]["kernel_frac_of_measured"] = float(dom_gbs / bw) if bw > 0 else None
+                out["roofline"]["measured_peak_note"] = "rmi_hip_measure_read_bandwidth: best of 3 x 5 passes of a read-only kernel over the same key array, this run"
+            except Exception as ex:                                     # (never the reason a bench line is lost)
+                out["roofline"]["measured_peak"] = None
+                out["roofline"]["measured_peak_note"] = "failed: " + str(ex)[:120]
+        out["env"] = env_info(torch)
+        # the driver's flags give a 12 ms timed region; the same steps once more over 200 (the protocol of profiles/)
+        if world == 1 and args.steps < 200 and not args.no_extras:
+            tr.set_profile_level(-1)
+            for _ in range(20):
+                run_step()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(200):
+                run_step()
+            sync()
+            ms200 = (time.perf_counter() - t1) / 200 * 1e3
+            out["long_protocol"] = {"steps": 200, "warmup": 20 + args.steps + args.warmup, "ms_per_step": ms200, "value": n_global / (ms200 * 1e-3),
+                                    "note": "the same call, no events at all: 200 back-to-back steps behind the timed region"}
+            tr.set_profile_level(1)
 
         def frac_of(nkeys, kbytes, L, rowb, dsec):
             return (nkeys * kbytes + rowb * L) / dsec / 1e9 / HBM_PEAK_GBS if dsec > 0 else 0.0

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RMI_HIP_ABI_VERSION 4
+#define RMI_HIP_ABI_VERSION 5
 
 /* src/load.rs:15-19 */
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
@@ -147,6 +147,10 @@ enum { RMI_K_BOUNDARIES = 0, RMI_K_FILL = 1, RMI_K_FIT = 2, RMI_K_ERR = 3, RMI_K
 
 /* ---- lifetime ---- */
 int rmi_hip_abi_version(void);
+/* Which leaf kernels the context's last training ran: 4 = k_leaf_regs + k_regs_finalize (one read of the keys: 8-byte keys, linear
+ * leaves, <= 208 keys per leaf on average; kernel_ns[0] = k_leaf_regs, [1] = the groups it listed for k_leaf_lanes + k_regs_finalize,
+ * [2] = k_lane_reduce), 3 = k_leaf_lanes, 2 / 1 = the round-1/2 pipelines.  (v5) */
+int rmi_hip_last_pipeline(rmi_hip_ctx* ctx);
 int rmi_hip_device_count(void);
 int rmi_hip_create(int device_id, rmi_hip_ctx** out);
 void rmi_hip_destroy(rmi_hip_ctx* ctx);

@@ -40,6 +40,7 @@ class Result(C.Structure):
 # every symbol include/rmi_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("rmi_hip_abi_version", C.c_int, []),
+    ("rmi_hip_last_pipeline", C.c_int, [C.c_void_p]),
     ("rmi_hip_device_count", C.c_int, []),
     ("rmi_hip_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("rmi_hip_destroy", None, [C.c_void_p]),

@@ -186,6 +186,7 @@ static void set_err(rmi_hip_ctx* c, const char* fmt, ...) {
 extern "C" {
 
 int rmi_hip_abi_version(void) { return RMI_HIP_ABI_VERSION; }
+int rmi_hip_last_pipeline(rmi_hip_ctx* c) { return !c ? RMI_ERR_BAD_ARG : (c->last_regs ? 4 : (c->last_lanes ? 3 : (c->pipeline == 1 ? 1 : 2))); }
 
 int rmi_hip_device_count(void) {
   int n = 0;
@@ -1253,6 +1254,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           else
             hipLaunchKernelGGL((k_leaf_regs<K, false>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
                                L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
+          mark();                                                       // (slot 0: k_leaf_regs alone; slot 1: the listed groups + k_regs_finalize)
           const unsigned int lgrid = wb < 512 ? (unsigned int)wb : 512u;    // (as a rule nothing is listed: few blocks to start and to leave)
           hipLaunchKernelGGL((k_leaf_lanes_listed<K>), dim3(lgrid), dim3(64), 0, s, c->d_slow_list, c->d_tickets + 1, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin,
                              maxerr, run, L, err, count, rows, part, rp, peers);

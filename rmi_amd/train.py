@@ -118,6 +118,7 @@ class TrainedRMI:
     merged_leaves: int = 0          # one-pass mode 2: long leaves fitted from merged partial sums
     guard_leaves: int = 0           # ... of which flagged by the guard (mode 2: counted only)
     generation: int = 0             # which train call of the trainer's context produced the per-leaf arrays
+    pipeline: int = 0               # leaf kernels that ran: 4 k_leaf_regs (one read of the keys), 3 k_leaf_lanes, 2 / 1 the older pipelines
     _trainer: object = field(default=None, repr=False)
     _cache: dict = field(default_factory=dict, repr=False)
 
@@ -355,7 +356,7 @@ class Trainer:
             partial={"max_error": int(res.model_max_error), "max_error_idx": int(res.model_max_error_idx),
                      "sum_n_err": int(res.sum_n_err), "sum_l2": float(res.sum_l2), "sum_log2": float(res.sum_log2)},
             fit_mode_used=int(res.fit_mode_used), exact_leaves=int(res.exact_leaves), merged_leaves=int(res.merged_leaves), guard_leaves=int(res.guard_leaves),
-            generation=int(res.generation), _trainer=self)
+            generation=int(res.generation), pipeline=int(self._lib.rmi_hip_last_pipeline(self._h)), _trainer=self)
 
     def fit_root_host(self, keys: np.ndarray, root: str | int, num_leaves: int) -> Model:
         """The exact root fit from keys in HOST memory, no device involved (linear, robust_linear; linear_spline and radix
