@@ -1,0 +1,83 @@
+"""The register-resident leaf kernel (rmi_amd/csrc/rmi_regs.hip.h: k_leaf_regs, k_regs_finalize, k_leaf_lanes_listed) against the
+oracle through the C ABI, and against the leaf-lane pipeline it replaces: every variant of the path (non-temporal / plain
+loads, a handful of persistent waves, every group on the list, groups dealt from the counter), on the seeded generators and on
+key sets that exercise its special cases -- containers of more than 240 points (the lanes that go on from the key array),
+of more than 1 008 (the group is listed), duplicate keys found while walking (listed), the leaf behind the split, empty
+leaves, f64 keys (IEEE division), shards.  Bar: bucket table, error integers, counts AND coefficients bit-identical."""
+import numpy as np
+import pytest
+
+from rmi_amd import datagen as dg
+
+from tests.test_gpu_lanes import _check
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    "default": {"RMI_HIP_REGS": "1"},
+    "plain_loads": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_NT": "0"},
+    "seven_waves": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_GRID": "7"},          # every wave takes many groups, the last ones uneven
+    "all_listed": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_SLOW": "1"},           # k_leaf_lanes_listed does all the work
+    "counter": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_QUEUE": "1", "RMI_HIP_REGS_GRID": "16"},
+    "any_average": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_MAX_AVG": "100000"},  # also where most groups hold long containers
+}
+CASES = [
+    ("uniform_u64", 300_000, 4096, "linear"), ("uniform_u64", 300_000, 16384, "linear"), ("uniform_u64", 1_000_000, 8192, "linear"),
+    # ~200 keys per leaf: containers on both sides of 240 points in most groups
+    ("uniform_u64", 2_000_000, 10_000, "linear"), ("uniform_u64", 1_000_000, 5300, "linear"),
+    # skewed: containers of more than 1 008 points beside short ones, empty leaves
+    ("books_u64", 300_000, 4096, "linear"), ("books_u64", 1_000_000, 20_000, "linear"), ("clustered_u64", 300_000, 2048, "linear"),
+    # duplicates: found while walking, the group goes on the list
+    ("dups_u64", 300_000, 4096, "linear"), ("dups_u64", 200_000, 40_000, "linear"),
+    ("uniform_f64", 300_000, 4096, "linear"), ("uniform_f64", 1_000_000, 6000, "linear"),
+    ("uniform_u64", 300_000, 4096, "radix"), ("uniform_u64", 70_000, 1000, "linear"), ("uniform_u64", 5_000, 64, "linear"),
+    ("uniform_u64", 300_000, 100_000, "linear"), ("uniform_u64", 300_001, 1000, "linear"),
+]
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("gen,n,L,root", CASES)
+def test_regs_variants(monkeypatch, oracle, variant, gen, n, L, root):
+    g = _check(monkeypatch, oracle, VARIANTS[variant], dg.GENERATORS[gen](n), root, L)
+    if g is not None and n >= 1024 and n <= (100000 if variant == "any_average" else 208) * L:
+        assert g.pipeline == 4
+
+
+@pytest.mark.parametrize("name", sorted(dg.ADVERSARIAL))
+def test_regs_adversarial(monkeypatch, oracle, name):
+    """Key sets with exact linear structure (progressions, keys around 2^53 and 2^63, an outlier): the closed form of the y
+    half and the 32-bit duplicate test on keys whose low words repeat."""
+    keys = dg.ADVERSARIAL[name](300_000)
+    for L in (2048, 4096):
+        _check(monkeypatch, oracle, {"RMI_HIP_REGS": "1"}, keys, "linear", L)
+
+
+def test_regs_equals_lanes_rows(monkeypatch):
+    """The two pipelines leave the same bytes in every output array (rows, parameters, error integers, counts)."""
+    from rmi_amd import train
+    keys = dg.uniform_u64(1_500_000)
+    out = {}
+    for name, v in (("lanes", "0"), ("regs", "1")):
+        monkeypatch.setenv("RMI_HIP_REGS", v)
+        tr = train.Trainer(keys)
+        g = tr.train("linear,linear", 8192)
+        assert g.pipeline == (4 if v == "1" else 3)
+        out[name] = (g.rows.copy(), g.leaf_params.copy(), g.last_layer_max_l1s.copy(), g.leaf_counts.copy(), g.leaf_starts.copy(),
+                     g.model_max_error, g.model_max_error_idx, g.model_avg_error, g.model_avg_l2_error, g.model_avg_log2_error)
+        tr.close()
+    for a, b in zip(out["lanes"], out["regs"]):
+        assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+
+
+def test_regs_repeated_trainings_one_context(monkeypatch, oracle):
+    """The persistent kernel's counters and lists are reset by every training: different L on one context, back and forth."""
+    from rmi_amd import train
+    monkeypatch.setenv("RMI_HIP_REGS", "1")
+    keys = dg.books_u64(400_000)
+    tr = train.Trainer(keys)
+    for L in (4096, 2048, 16384, 4096, 100_000, 2048):
+        g = tr.train("linear,linear", L)
+        o = oracle.train_two_layer("linear", "linear", keys, L)
+        assert np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64))
+        assert np.array_equal(g.last_layer_max_l1s, o.leaf_err) and np.array_equal(g.leaf_counts, o.leaf_count)
+    tr.close()
