@@ -1,6 +1,8 @@
 """Multi-GPU row on one GPU: the shards of a G-way split are run one after the
 other on the same device, each with only its own keys + halo resident, and the concatenation must
 be byte-identical to the unsharded result (and therefore to the oracle)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -293,3 +295,55 @@ def test_upload_overlaps_the_host_root_fit(oracle):
     o = oracle.train_two_layer("linear", "linear", keys, 4096)
     assert g.root.p == o.root.p and np.array_equal(g.leaf_params, o.leaf_params) and np.array_equal(g.last_layer_max_l1s, o.leaf_err)
     tr.close()
+
+
+def _run_ranks(world, args_of, timeout=600):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_trainer_worker, args=args_of(r, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    return sorted(res)
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "direct"])
+def test_sharded_trainer_eight_ranks_one_gpu(exchange):
+    """Eight ranks (eight processes on the one GPU of the box, gloo for the rendezvous): the shard planner at G = 8, and with the
+    direct exchange the rows of every rank stored to SEVEN peers' IPC-mapped tables from the kernels themselves (PeerRows),
+    the 8-flag mailbox wait, three steps through both halves of the double buffer.  Every rank ends with the byte-identical
+    table of the unsharded run.  (Across eight devices this has not run: no such box was available.)"""
+    res = _run_ranks(8, lambda r, port, q: (r, 8, port, 4_000_000, 32768, q, exchange))
+    assert res == [(r, True) for r in range(8)]
+
+
+def test_sharded_direct_exchange_eight_ranks_one_lists():
+    """The `pending` protocol at eight ranks: rank 5 hands nearly every leaf to the list kernels, the other seven none; every rank
+    reads it from the exchanged records, rank 5 finishes its leaves, all exchange once more.  Same table on all eight."""
+    res = _run_ranks(8, lambda r, port, q: (r, 8, port, 4_000_000, 32768, q, "direct", 5))
+    assert res == [(r, True) for r in range(8)]
+
+
+def test_bench_eight_ranks_gloo_direct(tmp_path):
+    """bench.py as the driver launches it for N = 8 (torch.distributed.run, one rank per process) -- on one GPU, gloo for
+    torch.distributed, the direct exchange for the rows: one JSON line with eight per_rank entries."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "2", "--backend", "gloo", "--exchange", "direct",
+           "--keys", "8000000", "--leaves", "65536", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 8 and len(d["per_rank"]) == 8 and d["value"] > 0
+    assert sum(p["leaves"] for p in d["per_rank"]) == 65536 and sum(p["keys"] for p in d["per_rank"]) >= 8000000
