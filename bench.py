@@ -249,6 +249,20 @@ def side_configs(T, tr_m, device, with_oracle):
         e, r_exact = run(t2, root, 0, L, 0, 3, 200_000_000, 8)
         ent["exact"] = e
         g_exact = r_exact.materialize()
+        # what bounds the exact mode here: the recurrence of a leaf is ONE sequential chain by the definition of bit-identical
+        # coefficients; the longest container sets the floor -- on a host core (~3.2 ns a point, containers of more than
+        # RMI_HIP_HOST_MIN = 262 144 points) or on one wave of the device (~28 ns a point)
+        try:
+            ls = np.asarray(g_exact.leaf_starts, dtype=np.int64)
+            longest = int(np.diff(np.append(ls, 200_000_000)).max()) + 2
+            host_min = int(os.environ.get("RMI_HIP_HOST_MIN", "262144"))
+            ns_pt = 3.2 if (host_min > 0 and longest > host_min) else 28.0
+            ent["exact"]["longest_container"] = longest
+            ent["exact"]["chain_floor_ms"] = longest * ns_pt * 1e-6
+            ent["exact"]["chain_floor_note"] = (f"{longest} points x {ns_pt} ns a point ({'host core' if ns_pt < 10 else 'one wave'}): the sequential chain of the longest "
+                                                "leaf; lowering RMI_HIP_HOST_MIN was measured (tools/c2_sweep.py): 131 072 -> 47 ms, 32 768 -> 76 ms against 11.7 ms")
+        except Exception:
+            pass
         for mname, m, steps in (("onepass_guarded", 1, 3), ("onepass", 2, 10)):
             e, r = run(t2, root, 0, L, m, steps, 200_000_000, 8)
             e["ints_equal_to_exact"] = bool(np.array_equal(r.last_layer_max_l1s, g_exact.last_layer_max_l1s))

@@ -4,6 +4,8 @@
 // returns RMI_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1217,7 +1219,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // with the whole slot in the second exchange of the `pending` protocol
       PeerRows peers; std::memset(&peers, 0, sizeof peers);
       c->rows_pushed = false;
-      if (lanes_fused_plan && c->peer_fuse_n > 0) {                 // (linear and linear_spline leaves: rows of 24 bytes)
+      // (only with the published-early result: with the list kernels in-stream, RMI_HIP_OPT_TAIL=0, `pending` is 0, no second exchange
+      //  follows, and the rows of the listed leaves would never reach the peers -- k_peer_push then carries the whole slot)
+      if (lanes_fused_plan && c->peer_fuse_n > 0 && optimistic) {   // (linear and linear_spline leaves: rows of 24 bytes)
         peers.n = c->peer_fuse_n;
         for (int p = 0; p < peers.n; p++) peers.tab[p] = c->peer_fuse_tab[p];
         c->rows_pushed = true;
@@ -1523,17 +1527,34 @@ static int giant_host_fit(rmi_hip_ctx* c, const GiantLeaf* list, uint64_t cnt, h
   const std::vector<GiantLeaf>& g = c->giant_list;
   std::vector<double>& ab = c->giant_ab;
   const K* keys = (const K*)c->lp.keys;
+  // every container's keys on their way first (one queue of copies, ONE synchronisation), the longest chain first in the fit
   std::vector<std::vector<K>> bufs(cnt);
-  std::vector<int> rcs(cnt, RMI_OK);
-  std::vector<std::thread> th;
-  for (uint64_t i = 0; i < cnt; i++) {
-    const uint64_t npts = g[i].hi - g[i].lo + 1;
-    bufs[i].resize(npts);
-    HIPCHK(c, hipMemcpyAsync(bufs[i].data(), keys + g[i].lo, npts * sizeof(K), hipMemcpyDeviceToHost, cs));
-    HIPCHK(c, hipStreamSynchronize(cs));
-    th.emplace_back([&, i, npts]() { rcs[i] = rmi_host::leaf_slr<K>(bufs[i].data(), npts, g[i].lo, g[i].y0, &ab[2 * i], &ab[2 * i + 1]); });
-    if (th.size() >= 16) { for (auto& t : th) t.join(); th.clear(); }
+  std::vector<uint64_t> order(cnt);
+  for (uint64_t i = 0; i < cnt; i++) { bufs[i].resize(g[i].hi - g[i].lo + 1); order[i] = i; }
+  std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return bufs[a].size() > bufs[b].size(); });
+  for (uint64_t q = 0; q < cnt; q++) {
+    const uint64_t i = order[q];
+    HIPCHK(c, hipMemcpyAsync(bufs[i].data(), keys + g[i].lo, bufs[i].size() * sizeof(K), hipMemcpyDeviceToHost, cs));
   }
+  HIPCHK(c, hipStreamSynchronize(cs));
+  // (no early return below: every thread is joined before the function is left)
+  std::vector<int> rcs(cnt, RMI_OK);
+  std::atomic<uint64_t> next{0};
+  const unsigned hw = std::thread::hardware_concurrency();
+  uint64_t nth = hw ? hw : 16;
+  if (nth > cnt) nth = cnt;
+  if (nth > 128) nth = 128;
+  auto work = [&]() {
+    for (;;) {
+      const uint64_t q = next.fetch_add(1);
+      if (q >= cnt) return;
+      const uint64_t i = order[q];
+      rcs[i] = rmi_host::leaf_slr<K>(bufs[i].data(), bufs[i].size(), g[i].lo, g[i].y0, &ab[2 * i], &ab[2 * i + 1]);
+    }
+  };
+  std::vector<std::thread> th;
+  for (uint64_t t = 1; t < nth; t++) th.emplace_back(work);
+  work();
   for (auto& t : th) t.join();
   for (uint64_t i = 0; i < cnt; i++)
     if (rcs[i] != RMI_OK) { set_err(c, "%s", rmi_hip_strerror(rcs[i])); return rcs[i]; }

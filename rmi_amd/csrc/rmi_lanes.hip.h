@@ -315,7 +315,8 @@ __device__ __forceinline__ void leaf_lanes_body(const unsigned int wid, typename
   const unsigned int npts = ck == 2 ? (unsigned int)((hi - lo + 1 < 0xFFFFFFFFull) ? hi - lo + 1 : 0xFFFFFFFFull) : 0u;
   // leaves for the list kernels (one wave per leaf: exact fit + its error pass): containers longer than the lockstep
   // walk takes, and whatever lies beyond 32-bit offsets from the wave base
-  constexpr uint64_t FAR = 1ull << 30;
+  // (the row descriptors are 32-bit BYTE offsets from the wave base: 2^32 / sizeof(K) keys, less a margin of panels)
+  constexpr uint64_t FAR = (1ull << 32) / sizeof(K) - (1ull << 16);
   // (linear_spline leaves: no walk for the fit, but a leaf far longer than its neighbours would hold the wave's error pass)
   const bool handed = valid && ((ck == 2 && (npts + 1u > long_min || hi - wb >= FAR)) || (e > s && e - wb >= FAR) ||
                                 (LEAFK != K_LINEAR && e - s > (uint64_t)long_min));

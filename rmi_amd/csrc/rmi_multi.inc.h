@@ -117,14 +117,15 @@ __global__ void __launch_bounds__(64) k_peer_signal(unsigned char* const* __rest
 }
 // wait for the `world` flags of this epoch in the own mailbox, then hand the aggregates to the host copy
 __global__ void __launch_bounds__(64) k_peer_wait(unsigned long long* __restrict__ mail, int world, unsigned long long epoch,
-                                                  unsigned long long* __restrict__ stats_all, rmi::DevState* __restrict__ st) {
+                                                  unsigned long long* __restrict__ stats_all, rmi::DevState* __restrict__ st,
+                                                  unsigned long long timeout_ticks) {
   const int r = threadIdx.x;
   if (r >= world) return;
   const unsigned long long t0 = wall_clock64();                      // 100 MHz
   bool ok = true;
   while (__hip_atomic_load(&mail[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
     __builtin_amdgcn_s_sleep(32);
-    if (wall_clock64() - t0 > 500000000ull) { ok = false; break; }  // 5 s
+    if (wall_clock64() - t0 > timeout_ticks) { ok = false; break; }  // (100 MHz ticks; RMI_HIP_PEER_TIMEOUT_S, default 60 s)
   }
   if (!ok) { atomicOr(&st->err_flags, rmi::EF_PEER_TIMEOUT); return; }
   for (int q = 0; q < RMI_STATS_WORDS; q++) stats_all[r * RMI_STATS_WORDS + q] = __hip_atomic_load(&mail[64 + r * RMI_STATS_WORDS + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -298,6 +299,15 @@ static bool sharded_totals(rmi_hip_ctx* c, rmi_hip_multi* m, rmi_hip_result* out
 
 // The exchange as peer stores (include/rmi_hip.h).  Epoch e uses half e & 1 of every rank's table: a rank that runs ahead
 // stores into the half its peers are not reading.
+// how long k_peer_wait waits for a peer's flag: a peer may still be walking a listed leaf of 10^8 points on one wave (28 ns a point)
+static unsigned long long peer_timeout_ticks() {
+  static const unsigned long long t = [] {
+    const char* e = std::getenv("RMI_HIP_PEER_TIMEOUT_S");
+    const double s = (e && *e) ? std::atof(e) : 60.0;
+    return (unsigned long long)((s > 0.0 ? s : 60.0) * 1e8);              // wall_clock64: 100 MHz
+  }();
+  return t;
+}
 static int direct_exchange(rmi_hip_ctx* c, rmi_hip_multi* m, unsigned long long epoch, uint64_t off, uint64_t bytes, bool rows_there) {
   unsigned char* table = m->d_rows2 + (epoch & 1ull) * m->rows2_slot;
   // (peer pointers of this epoch's half: the tables hold the bases, the half is part of the byte offset)
@@ -306,13 +316,14 @@ static int direct_exchange(rmi_hip_ctx* c, rmi_hip_multi* m, unsigned long long 
   // (rows_there: k_leaf_lanes has stored its rows into the peers' tables itself)
   if (!rows_there) hipLaunchKernelGGL(k_peer_push, dim3(512), dim3(256), 0, c->stream, (const uint4*)(table + off), n16, (unsigned char* const*)m->d_peer_rows, byte_off, m->rank, m->world);
   hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, c->stream, (unsigned char* const*)m->d_peer_mail, (const unsigned long long*)&c->d_state->max_err, m->rank, m->world, epoch);
-  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, (unsigned long long*)m->d_mail, m->world, epoch, (unsigned long long*)m->d_stats_all, c->d_state);
+  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, c->stream, (unsigned long long*)m->d_mail, m->world, epoch, (unsigned long long*)m->d_stats_all, c->d_state,
+                     peer_timeout_ticks());
   HIPCHK(c, hipMemcpyAsync(m->h_stats_all, m->d_stats_all, RMI_STATS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&c->h_state->err_flags, &c->d_state->err_flags, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));   // (k_peer_wait may have raised the timeout)
   if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->h_state->err_flags & EF_PEER_TIMEOUT) { set_err(c, "direct exchange: a peer's flag of epoch %llu did not arrive within 5 s", epoch); return RMI_ERR_HIP; }
+  if (c->h_state->err_flags & EF_PEER_TIMEOUT) { set_err(c, "direct exchange: a peer's flag of epoch %llu did not arrive within %.0f s (RMI_HIP_PEER_TIMEOUT_S); the peers' tables of this epoch are undefined", epoch, (double)peer_timeout_ticks() / 1e8); return RMI_ERR_HIP; }
   return RMI_OK;
 }
 
@@ -331,6 +342,7 @@ static int train_sharded_direct(rmi_hip_ctx* c, rmi_hip_multi* m, const rmi_hip_
     for (int r = 0; r < m->world; r++)
       if (r != m->rank) c->peer_fuse_tab[c->peer_fuse_n++] = m->peer_rows[r] + (epoch & 1ull) * m->rows2_slot;
   }
+  c->rows_pushed = false;                                              // (set by the launch only if its kernels really store to the peers)
   int rc = rmi_hip_train_two_layer(c, root, leaf_kind, num_leaves, out);
   c->defer_sync = false;
   c->peer_fuse_n = 0;

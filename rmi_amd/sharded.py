@@ -300,32 +300,55 @@ class ShardedTrainer:
             # A/B on the machine itself: the direct exchange is taken only if it completes, gives the SAME table as the
             # RCCL exchange on every rank, and is faster (max over ranks of the median step)
             rep = {"rccl_ms": None, "direct_ms": None, "same_table": None, "chosen": "rccl"}
+
+            def all_ok(ok: bool) -> bool:
+                """Every rank reports; every rank takes the same branch (a rank that failed locally must not leave the others
+                waiting in the next collective)."""
+                v = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                return bool(int(v.item()))
+
+            def med(k=12):
+                """Median step time (max over the ranks).  A step that raises on this rank is remembered, the collectives go on."""
+                ts, ok = [], True
+                for _ in range(k):
+                    dist.barrier(); torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    try:
+                        self.step(); torch.cuda.synchronize()
+                    except Exception as ex:
+                        ok = False
+                        rep["error"] = str(ex)
+                    ts.append(time.perf_counter() - t1)
+                v = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=dev)
+                dist.all_reduce(v, op=dist.ReduceOp.MAX)
+                return float(v.item()), all_ok(ok)
+
+            ok = True
             try:
                 setup_direct()
-
-                def med(k=12):
-                    ts = []
-                    for _ in range(k):
-                        dist.barrier(); torch.cuda.synchronize()
-                        t1 = time.perf_counter(); self.step(); torch.cuda.synchronize()
-                        ts.append(time.perf_counter() - t1)
-                    v = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=dev)
-                    dist.all_reduce(v, op=dist.ReduceOp.MAX)
-                    return float(v.item())
-                rep["rccl_ms"] = med() * 1e3
-                ref_rows = self.full_rows().copy()
-                T._check(lib.rmi_hip_set_exchange(tr._h, 1), tr._h)
-                rep["direct_ms"] = med() * 1e3
-                same = torch.tensor([1 if np.array_equal(ref_rows, self.full_rows()) else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                rep["same_table"] = bool(int(same.item()))
-                if rep["same_table"] and rep["direct_ms"] < rep["rccl_ms"]:
-                    rep["chosen"] = "direct"
-                    self.exchange = "library (direct peer stores: chosen by the A/B at start-up)"
-                else:
-                    T._check(lib.rmi_hip_set_exchange(tr._h, 0), tr._h)
-            except Exception as ex:                     # (a failure of the experimental path must not take the run down)
+            except Exception as ex:
+                ok = False
                 rep["error"] = str(ex)
+            if all_ok(ok):
+                t_rccl, ok_r = med()
+                rep["rccl_ms"] = t_rccl * 1e3
+                ref_rows = self.full_rows().copy() if ok_r else None
+                ok_s = lib.rmi_hip_set_exchange(tr._h, 1) == 0
+                if all_ok(ok_r and ok_s):
+                    t_dir, ok_d = med()
+                    rep["direct_ms"] = t_dir * 1e3
+                    same = ok_d and bool(np.array_equal(ref_rows, self.full_rows()))
+                    rep["same_table"] = all_ok(same)
+                    # the choice is rank 0's, sent to all (the medians are maxima over the ranks already: same on every rank)
+                    pick = torch.tensor([1 if (rep["same_table"] and rep["direct_ms"] < rep["rccl_ms"]) else 0], dtype=torch.int32, device=dev)
+                    dist.broadcast(pick, src=0)
+                    if int(pick.item()) == 1:
+                        rep["chosen"] = "direct"
+                        self.exchange = "library (direct peer stores: chosen by the A/B at start-up)"
+                if rep["chosen"] != "direct":
+                    lib.rmi_hip_set_exchange(tr._h, 0)
+            else:
                 lib.rmi_hip_set_exchange(tr._h, 0)
             self.auto_report = rep
         if not self.on_gpu:
