@@ -145,3 +145,31 @@ def test_host_root_target_of_float_roots(lib, oracle):
         m = _lib.ModelParams()
         m.kind = kind
         assert lib.rmi_hip_root_target(C.byref(m), 0, 5, L, C.byref(C.c_uint64())) < 0
+
+
+def test_struct_layout_matches_a_c_consumer(tmp_path):
+    """tests/abi_check.c includes include/rmi_hip.h and prints sizeof / offsetof of every structure that crosses the boundary;
+    the ctypes mirrors of rmi_amd/_lib.py must say the same (a header edit that moves a field fails here, not in a caller)."""
+    import ctypes as C
+    import subprocess
+    from rmi_amd import _lib
+    exe = str(tmp_path / "abi_check")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_check.c"), "-o", exe], check=True)
+    lines = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    mirrors = {"rmi_hip_model_params": _lib.ModelParams, "rmi_hip_shard": _lib.Shard, "rmi_hip_result": _lib.Result}
+    seen = {k: set() for k in mirrors}
+    for ln in lines:
+        w = ln.split()
+        if not w:
+            continue
+        if w[0] == "abi":
+            assert int(w[1]) == 5
+        elif w[1] == "size":
+            assert C.sizeof(mirrors[w[0]]) == int(w[2]), ln
+        else:
+            sname, fname = w[0].split(".")
+            f = getattr(mirrors[sname], fname)
+            assert (f.offset, f.size) == (int(w[1]), int(w[2])), ln
+            seen[sname].add(fname)
+    for sname, cls in mirrors.items():                                   # ... and the C program names every field of every mirror
+        assert seen[sname] == {n for n, _ in cls._fields_ if not n.startswith("_")}, sname
