@@ -22,10 +22,22 @@ def trainer_mod():
     return train
 
 
-@pytest.fixture(autouse=True, params=["3", "2", "1"], ids=["pipeline3", "pipeline2", "pipeline1"])
+# The whole matrix runs on the default pipelines (3 = leaf-lane kernels, with the register-resident kernel of pipeline 4 taking the
+# configurations it applies to); the round-1/2 pipelines (RMI_HIP_PIPELINE=2: streaming passes, =1: one kernel per reference
+# pass) serve as fall-backs for tiny key sets and special leaves and keep a smoke set of their own.
+LEGACY_SMOKE = {"test_parity_config1", "test_parity_tiny", "test_parity_degenerate_inputs", "test_parity_long_leaves",
+                "test_parity_many_empty_leaves", "test_parity_f64_keys", "test_parity_chunk_geometry", "test_error_codes"}
+
+
+def pytest_generate_tests(metafunc):
+    if "pipeline" in metafunc.fixturenames:
+        params = ["3", "2", "1"] if metafunc.function.__name__ in LEGACY_SMOKE else ["3"]
+        metafunc.parametrize("pipeline", params, ids=[f"pipeline{p}" for p in params], indirect=True)
+
+
+@pytest.fixture(autouse=True)
 def pipeline(request, monkeypatch):
-    """Both device pipelines (streaming/tiled kernels and the one-kernel-per-pass version) are
-    held to the same parity bar; small chunks force leaves to straddle lane/wave boundaries."""
+    """Every test of this module under RMI_HIP_PIPELINE = its parameter (see LEGACY_SMOKE)."""
     monkeypatch.setenv("RMI_HIP_PIPELINE", request.param)
     return request.param
 
