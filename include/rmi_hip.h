@@ -226,6 +226,22 @@ uint64_t rmi_hip_num_keys(const rmi_hip_ctx* ctx);
  * independent trainings on one key set can then be in flight together, one context per caller thread
  * (optimizer.rs:220-231 trains its configurations with par_iter).  The buffer stays owned by `ctx`. */
 int rmi_hip_key_buffer(const rmi_hip_ctx* ctx, const void** device_keys, uint64_t* n, int* dtype);
+/* Many trainings on the resident keys in ONE call: what optimizer.rs:220-231 and the --param-grid mode (src/main.rs:241-248) do
+ * with `par_iter` over their configurations.  `count` configurations (fitted root, leaf kind, branching factor), `in_flight`
+ * (1 .. 16) at a time, each on a context of the library's own that borrows the keys (most configurations fill the GPU alone, but
+ * those with few, long leaves are a handful of sequential chains: in flight together they cost the time of one).  results[i] holds
+ * the aggregates of configs[i] (the per-leaf arrays are not kept); rcs (may be NULL) the per-configuration return codes -- where
+ * the reference panics for ONE configuration the others still train.  Returns the first non-zero code, or RMI_OK.  (v5) */
+typedef struct {
+  rmi_hip_model_params root;      /* from rmi_hip_fit_root / rmi_hip_fit_root_fast */
+  int32_t leaf_kind;              /* RMI_MODEL_* */
+  int32_t _pad;
+  uint64_t num_leaves;
+  const uint32_t* root_table;     /* radix-table roots (radix8/18/22/26/28): the hint table on the HOST (rmi_hip_download_root_table), else NULL */
+  uint64_t root_table_entries;
+} rmi_hip_train_config;
+int rmi_hip_train_many(rmi_hip_ctx* ctx, const rmi_hip_train_config* configs, uint64_t count, int in_flight,
+                       rmi_hip_result* results, int* rcs);
 /* Synthetic sorted keys generated in HBM (bit-identical to rmi_amd/datagen.py):
  * generator 0 = uniform, 1 = uniform with duplicate runs.  Produces indices
  * [start, start+count) of the n_global-key array (so ranks can generate their own shard).

@@ -13,6 +13,11 @@ class ModelParams(C.Structure):
     _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("p", C.c_double * 4), ("ip", C.c_uint64 * 4)]
 
 
+class TrainConfig(C.Structure):
+    _fields_ = [("root", ModelParams), ("leaf_kind", C.c_int32), ("_pad", C.c_int32), ("num_leaves", C.c_uint64),
+                ("root_table", C.c_void_p), ("root_table_entries", C.c_uint64)]
+
+
 class Shard(C.Structure):
     _fields_ = [("n_global", C.c_uint64), ("read_lo", C.c_uint64), ("read_hi", C.c_uint64),
                 ("key_lo", C.c_uint64), ("key_hi", C.c_uint64), ("leaf_lo", C.c_uint64), ("leaf_hi", C.c_uint64),
@@ -47,6 +52,7 @@ SYMBOLS = [
     ("rmi_hip_last_error", C.c_char_p, [C.c_void_p]),
     ("rmi_hip_strerror", C.c_char_p, [C.c_int]),
     ("rmi_hip_key_buffer", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    ("rmi_hip_train_many", C.c_int, [C.c_void_p, C.POINTER(TrainConfig), C.c_uint64, C.c_int, C.POINTER(Result), C.POINTER(C.c_int)]),
     ("rmi_hip_set_profile_level", C.c_int, [C.c_void_p, C.c_int]),
     ("rmi_hip_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_set_fit_mode", C.c_int, [C.c_void_p, C.c_int, C.c_double]),

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cmath>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -97,6 +98,7 @@ struct rmi_hip_ctx {
   bool regs_queue = false;                      // RMI_HIP_REGS_QUEUE=1: groups dealt to the waves from a counter instead of by wave number (measured: 473 against 460 us)
   double* d_regtab = nullptr;                   // the interleaved step table of k_leaf_regs
   unsigned long long* d_regprof = nullptr;      // RG_PROF builds: cycles per phase, summed over the waves
+  std::vector<rmi_hip_ctx*> many_views;         // rmi_hip_train_many: contexts that borrow this one's keys (kept for the next call)
   void* d_bnext = nullptr;                      // the keys on either side of every leaf, for k_regs_finalize: [2][64 groups]
   unsigned char* d_tile_slow = nullptr;         // per group: finished by k_leaf_lanes_listed
   unsigned int* d_slow_list = nullptr;          // groups of 64 leaves left to k_leaf_lanes_listed (counter: d_tickets[1])
@@ -355,6 +357,8 @@ static void free_outputs(rmi_hip_ctx* c) {
 static void free_multi(rmi_hip_ctx* c);
 void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (!c) return;
+  for (rmi_hip_ctx* v : c->many_views) rmi_hip_destroy(v);
+  c->many_views.clear();
   if (c->upload_thread.joinable()) c->upload_thread.join();
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -455,6 +459,57 @@ int rmi_hip_key_buffer(const rmi_hip_ctx* c, const void** device_keys, uint64_t*
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
   *device_keys = c->d_keys; *n = c->n; *dtype = c->dtype;
   return RMI_OK;
+}
+
+// optimizer.rs:220-231 / src/main.rs:241-248 (`par_iter` over the configurations): `count` trainings on the context's resident keys,
+// `in_flight` at a time, each on a context of its own that borrows the keys -- the threads are the library's.
+int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_t count, int in_flight, rmi_hip_result* results, int* rcs) {
+  if (!c || (count && (!cfgs || !results))) return RMI_ERR_BAD_ARG;
+  if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
+  if (c->upload_thread.joinable()) { const int urc = rmi_hip_upload_wait(c); if (urc != RMI_OK) return urc; }
+  if (in_flight < 1) in_flight = 1;
+  if ((uint64_t)in_flight > count) in_flight = (int)(count ? count : 1);
+  if (in_flight > 16) in_flight = 16;
+  // the views: kept with the context; their keys are attached anew (the key set may have changed since the last call)
+  while ((int)c->many_views.size() < in_flight - 1) {
+    rmi_hip_ctx* v = nullptr;
+    const int crc = rmi_hip_create(c->device, &v);
+    if (crc != RMI_OK) { set_err(c, "rmi_hip_train_many: a view could not be created (%s)", rmi_hip_strerror(crc)); return crc; }
+    c->many_views.push_back(v);
+  }
+  for (int t = 0; t + 1 < in_flight; t++) {
+    const int arc = rmi_hip_attach_device_keys(c->many_views[t], c->d_keys, c->n, c->dtype);
+    if (arc != RMI_OK) return arc;
+    c->many_views[t]->fit_mode = c->fit_mode;
+  }
+  std::atomic<uint64_t> next{0};
+  std::vector<int> lrc(count, RMI_OK);
+  auto work = [&](rmi_hip_ctx* w) {
+    (void)hipSetDevice(w->device);
+    for (;;) {
+      const uint64_t i = next.fetch_add(1);
+      if (i >= count) return;
+      std::memset(&results[i], 0, sizeof results[i]);
+      lrc[i] = cfgs[i].root_table ? rmi_hip_set_root_table(w, cfgs[i].root_table, cfgs[i].root_table_entries) : RMI_OK;
+      if (lrc[i] == RMI_OK) lrc[i] = rmi_hip_train_two_layer(w, &cfgs[i].root, cfgs[i].leaf_kind, cfgs[i].num_leaves, &results[i]);
+      if (lrc[i] != RMI_OK && w != c) {                                // (the first message is the caller's to read)
+        static std::mutex mu;
+        std::lock_guard<std::mutex> g(mu);
+        if (c->err.empty()) c->err = w->err;
+      }
+    }
+  };
+  c->err.clear();
+  std::vector<std::thread> th;
+  for (int t = 0; t + 1 < in_flight; t++) th.emplace_back(work, c->many_views[t]);
+  work(c);
+  for (auto& t : th) t.join();
+  int first = RMI_OK;
+  for (uint64_t i = 0; i < count; i++) {
+    if (rcs) rcs[i] = lrc[i];
+    if (first == RMI_OK && lrc[i] != RMI_OK) first = lrc[i];
+  }
+  return first;
 }
 
 int rmi_hip_set_shard(rmi_hip_ctx* c, const rmi_hip_shard* sh) {

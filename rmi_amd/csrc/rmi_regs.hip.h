@@ -64,14 +64,14 @@ __device__ __forceinline__ void rg_static_for(F&& f) {
 
 // The step tables of this kernel, four arrays of RG_TMAX doubles for the running count k = i + 1: RN(1 / k), the tail of the
 // reciprocal (1 / k = r + rl to 2^-105: div_by_count2 of rmi_stream.hip.h, one FMA fewer than div_by_count -- an FMA costs 7.3
-// cycles on this chip, an addition or a multiplication 4), (k - 1) / 2, k.  A half block of 8 steps takes its constants with
-// one 64-byte scalar load per array.
+// cycles on this chip, an addition or a multiplication 4), (k - 1) / 2, k.  The walk takes them a quarter block (4 steps) at a time,
+// one ahead: 128 bytes per quarter, two scalar loads.
 __global__ void __launch_bounds__(256) k_regs_table(double* __restrict__ tab, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) {
     const double nf = (double)(i + 1), r = 1.0 / nf;
-    double* const t = tab + (i >> 3) * 32 + (i & 7);                     // (the 32 doubles of a half block lie together: one address per half)
-    t[0] = r; t[8] = recip_tail(nf, r); t[16] = (double)i * 0.5; t[24] = nf;
+    double* const t = tab + (i >> 2) * 16 + (i & 3);                     // (the 16 doubles of a quarter block -- 4 steps -- lie together)
+    t[0] = r; t[4] = recip_tail(nf, r); t[8] = (double)i * 0.5; t[12] = nf;
   }
 }
 constexpr int RG_TMAX = 1024;                       // steps the table covers
@@ -361,6 +361,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       double xp = __builtin_nan("");
       const unsigned int npts = cur.npts;
       uint2 rawA[8], rawB[8];                                            // the keys of the half block in work / of the next one
+      double cA[12], cB[12];                                             // the constants of the quarter block in work / of the next one
+      auto request = [&](double (&c)[12], unsigned int quarter_index) {
+        const double* const tq = rtab4 + ((RG_DIAG & 1) ? 0u : quarter_index * 16u);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { c[u] = tq[u]; c[4 + u] = DIVK ? tq[12 + u] : tq[4 + u]; c[8 + u] = tq[8 + u]; }
+      };
+      request(cA, 0u);
       // panel 1 has landed once at most the panels behind it are outstanding (requested at the hand-over: up to panel 3)
       if (cur.maxlen > 0u) {
         if (!(RG_KO & 4)) {
@@ -389,22 +396,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         // without returning in order: a wait for them is a wait for every LDS read in flight.  So they are asked for FIRST and
         // waited for at once (a hit in the scalar cache: tens of cycles), together with this half's keys, asked for a half block
         // ago; only then are the next half's keys requested, and those land under the arithmetic.
-        double r8[8], rl8[8], hh8[8], kf8[8];
-        auto constants = [&](int hb) {
-          const double* const th = rtab4 + ((RG_DIAG & 1) ? 0u : (2u * b + (unsigned int)hb) * 32u);
-#pragma unroll
-          for (int q = 0; q < 8; q++) {
-            hh8[q] = th[16 + q];
-            if constexpr (DIVK) kf8[q] = th[24 + q]; else { r8[q] = th[q]; rl8[q] = th[8 + q]; }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        auto half = [&](int hb, const uint2 (&raw)[8], auto full_tag) {
+        // The constants of the steps come through the scalar cache, a quarter block (4 steps) at a time and one quarter AHEAD, in two
+        // alternating sets (cA, cB: 24 SGPRs each).  Scalar loads share their counter with the LDS reads without returning in order,
+        // so a wait for them is a wait for every LDS read in flight: the waits stand where the keys asked for a half block ago are
+        // needed anyway (a half's start) and in the middle of a half, 4 steps behind the next half's key requests.
+        // (the builtin, not an asm statement: the compiler keeps its own score of the LDS reads and scalar loads in flight, and
+        //  what it cannot see waited for it waits for again -- with lgkmcnt(0) at every step while a scalar load is out)
+        auto landed = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };   // vmcnt 63, expcnt 7, lgkmcnt 0
+        auto quarter = [&](int hb, int qr, const uint2 (&raw)[8], const double (&c)[12], auto full_tag) {
           constexpr bool FULL = decltype(full_tag)::value;
-          const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
+          const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8 + qr * 4);
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const unsigned int k = k0 + (unsigned int)q;
+          for (int u = 0; u < 4; u++) {
+            const int q = qr * 4 + u;
+            const unsigned int k = k0 + (unsigned int)u;
             const double x = rg_as_float<K>(raw[q]);
             T[q] = x;
             if (FULL || k < npts) {
@@ -414,8 +419,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
               }
               if (!(RG_KO & 1)) {
                 const double dx = x - mx;                                 // linear.rs:26
-                if constexpr (DIVK) mx += dx / kf8[q]; else mx += div_by_count2(dx, r8[q], rl8[q]);   // :27
-                cc += dx * hh8[q];                                        // :28-29 in closed form (head of rmi_lanes.hip.h)
+                if constexpr (DIVK) mx += dx / c[4 + u]; else mx += div_by_count2(dx, c[u], c[4 + u]);   // :27
+                cc += dx * c[8 + u];                                      // :28-29 in closed form (head of rmi_lanes.hip.h)
                 m2 += dx * (x - mx);                                      // :30-31
               }
             }
@@ -442,37 +447,43 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
           if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
         };
-        auto run_half = [&](int hb, const uint2 (&raw)[8]) {
+        auto run_half = [&](int hb, const uint2 (&raw)[8], auto&& prefetch) {
           const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
-          if ((RG_DIAG & 8) || __all(npts >= k0 + 8u || npts <= k0)) half(hb, raw, std::true_type{});
-          else half(hb, raw, std::false_type{});
+          const bool full = (RG_DIAG & 8) || __all(npts >= k0 + 8u || npts <= k0);
+          landed();                                                      // (cA and this half's keys)
+          request(cB, 4u * b + 2u * (unsigned int)hb + 1u);
+          prefetch();                                                    // (the next half's keys: they land under the arithmetic)
+          if (full) quarter(hb, 0, raw, cA, std::true_type{}); else quarter(hb, 0, raw, cA, std::false_type{});
+          landed();                                                      // (cB)
+          request(cA, 4u * b + 2u * (unsigned int)hb + 2u);
+          if (full) quarter(hb, 1, raw, cB, std::true_type{}); else quarter(hb, 1, raw, cB, std::false_type{});
           const bool ends = npts > k0 && npts <= k0 + 8u;
           if (__any(ends)) { if (ends) { fmx = mx; fcc = cc; fm2 = m2; fdmin = dmin; } }
           stash_half(hb);
         };
         // first half: its keys were asked for a half block ago; the second half's are asked for now
-        constants(0);
+        run_half(0, rawA, [&]() {
 #pragma unroll
-        for (int q = 0; q < 8; q++) rawB[q] = slot_key(in_b, dlt, 8 + q);
-        run_half(0, rawA);
+          for (int q = 0; q < 8; q++) rawB[q] = slot_key(in_b, dlt, 8 + q);
+        });
         // second half.  Every read of panel b is behind us: its ring slot takes panel b + 4 -- but nothing behind the walk's
         // last panel, so that at the end of the fit the ring still holds the tail of every row (the steps >= RG_STASH of the
         // error pass).  Then the first keys of the next block: panel b + 2 has landed once at most the panels behind it are
         // outstanding.
-        constants(1);
-        if (!(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING);
-        if ((b + 1u) * (unsigned int)RG_ROW < cur.maxlen) {
-          if (!(RG_KO & 4)) {
-            if (cur.lastp >= b + 4u) rg_wait_vm<16>();
-            else if (cur.lastp == b + 3u) rg_wait_vm<8>();
-            else rg_wait_vm<0>();
-          }
-          unsigned int nx_b, nx_d;
-          block_base(b + 1u, nx_b, nx_d);
+        run_half(1, rawB, [&]() {
+          if (!(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING);
+          if ((b + 1u) * (unsigned int)RG_ROW < cur.maxlen) {
+            if (!(RG_KO & 4)) {
+              if (cur.lastp >= b + 4u) rg_wait_vm<16>();
+              else if (cur.lastp == b + 3u) rg_wait_vm<8>();
+              else rg_wait_vm<0>();
+            }
+            unsigned int nx_b, nx_d;
+            block_base(b + 1u, nx_b, nx_d);
 #pragma unroll
-          for (int q = 0; q < 8; q++) rawA[q] = slot_key(nx_b, nx_d, q);
-        }
-        run_half(1, rawB);
+            for (int q = 0; q < 8; q++) rawA[q] = slot_key(nx_b, nx_d, q);
+          }
+        });
       }
       if (cur.maxfar > (unsigned int)RG_MAXPTS) {
         // ---- the lanes with more than 240 points (3 in 10 000 leaves of the metric configuration) go on from the key array: the same
@@ -484,18 +495,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             const unsigned int k = k0 + (unsigned int)q;
             kk[q] = keys[(uint64_t)cur.lo + (k < npts ? k : 0u)];
           }
-          const double* const th = rtab4 + (k0 >> 3) * 32u;
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             const unsigned int k = k0 + (unsigned int)q;
+            const double* const th = rtab4 + ((k0 >> 2) + (unsigned int)(q >> 2)) * 16u + (unsigned int)(q & 3);
             const unsigned long long bits = key_to_bits_rg<K>(kk[q]);
             const double x = KeyTraits<K>::as_float(kk[q]);
             if (k < npts) {
               if constexpr (DIVK) { if (x == xp) dmin = 0u; }
               else { const unsigned int d = (unsigned int)bits ^ plo; dmin = dmin < d ? dmin : d; }
               const double dx = x - mx;
-              if constexpr (DIVK) mx += dx / th[24 + q]; else mx += div_by_count2(dx, th[q], th[8 + q]);
-              cc += dx * th[16 + q];
+              if constexpr (DIVK) mx += dx / th[12]; else mx += div_by_count2(dx, th[0], th[4]);
+              cc += dx * th[8];
               m2 += dx * (x - mx);
               xp = x; plo = (unsigned int)bits;
             }

@@ -148,13 +148,11 @@ def second_phase_configs(first_phase: list[RMIStatistics]) -> list[tuple[str, in
 def measure_rmis(tr: train.Trainer, configs: list[tuple[str, int]], threads: int = 4,
                  root_cache: dict | None = None, progress=None, root_mode: str = "exact",
                  in_flight: int = 4) -> list[RMIStatistics]:
-    """optimizer.rs:220-231.  Root fits (host, exact, sequential each) run `threads` at a time and are
-    shared between the configurations that have the same (root, branching factor).  The leaf passes
-    over the resident keys run `in_flight` at a time, each on a context of its own (`Trainer.view`):
-    most configurations fill the GPU by themselves, but the ones with few, long leaves are a handful
-    of sequential chains (one wave per leaf, 28 ns per key) that leave it idle -- in flight together
-    they cost the time of one."""
-    import queue
+    """optimizer.rs:220-231.  Root fits (host, exact, sequential each) run `threads` at a time and are shared between the
+    configurations that have the same (root, branching factor).  The leaf passes over the resident keys are ONE call of the
+    library (rmi_hip_train_many: `in_flight` at a time, each on a context of its own that borrows the keys -- most
+    configurations fill the GPU by themselves, but the ones with few, long leaves are a handful of sequential chains that
+    leave it idle: in flight together they cost the time of one)."""
     root_cache = {} if root_cache is None else root_cache
     tr.download_keys()                           # host copy for the root fits
     parsed = [(train.parse_spec(m), m, bf) for m, bf in configs]
@@ -162,35 +160,19 @@ def measure_rmis(tr: train.Trainer, configs: list[tuple[str, int]], threads: int
     for (rk, _lk), _m, bf in parsed:
         if (rk, bf) not in root_cache and (rk, bf) not in need:
             need.append((rk, bf))
-    views = [tr] + [tr.view() for _ in range(max(1, in_flight) - 1)]
-    free = queue.Queue()
-    for v in views:
-        free.put(v)
-    try:
-        with ThreadPoolExecutor(max_workers=max(1, threads)) as root_pool, ThreadPoolExecutor(max_workers=len(views)) as leaf_pool:
-            futs = {key: root_pool.submit(tr.fit_root, key[0], key[1], root_mode) for key in need}
-
-            def leaf_job(rk, lk, bf):
-                root = root_cache[(rk, bf)] if (rk, bf) in root_cache else futs[(rk, bf)].result()
-                v = free.get()
-                try:
-                    rmi = v.train_leaves(root, lk, bf)
-                finally:
-                    free.put(v)
-                return RMIStatistics.from_trained(rmi), rmi
-            jobs = [leaf_pool.submit(leaf_job, rk, lk, bf) for (rk, lk), _m, bf in parsed]
-            out = []
-            for (rk, _lk), _m, bf in parsed:
-                if (rk, bf) not in root_cache:
-                    root_cache[(rk, bf)] = futs[(rk, bf)].result()
-            for j in jobs:
-                stats, rmi = j.result()
-                out.append(stats)
-                if progress:
-                    progress(stats, rmi)
-    finally:
-        for v in views[1:]:
-            v.close()
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as root_pool:
+        futs = {key: root_pool.submit(tr.fit_root, key[0], key[1], root_mode) for key in need}
+        for key, f in futs.items():
+            root_cache[key] = f.result()
+    done = tr.train_many([(root_cache[(rk, bf)], lk, bf) for (rk, lk), _m, bf in parsed], in_flight=max(1, in_flight))
+    out = []
+    for (rc, rmi), (_k, m, bf) in zip(done, parsed):
+        if rc != 0:
+            raise train.RMIError(rc, f"{m} {bf}")
+        stats = RMIStatistics.from_trained(rmi)
+        out.append(stats)
+        if progress:
+            progress(stats, rmi)
     return out
 
 

@@ -358,6 +358,43 @@ class Trainer:
             fit_mode_used=int(res.fit_mode_used), exact_leaves=int(res.exact_leaves), merged_leaves=int(res.merged_leaves), guard_leaves=int(res.guard_leaves),
             generation=int(res.generation), pipeline=int(self._lib.rmi_hip_last_pipeline(self._h)), _trainer=self)
 
+    def train_many(self, configs, in_flight: int = 4):
+        """rmi_hip_train_many: `configs` = [(root Model, leaf kind or name, branching factor), ...] on the resident keys, in ONE call
+        of the library (its own threads and contexts: what optimizer.rs:220-231 does with par_iter).  Returns a list of
+        (return code, TrainedRMI with the aggregates only -- the per-leaf arrays of these trainings are not kept)."""
+        self.wait_keys()
+        n = len(configs)
+        cfg = (_lib.TrainConfig * max(n, 1))()
+        kinds, keep = [], []
+        for i, (root, leaf, L) in enumerate(configs):
+            lk = leaf if isinstance(leaf, int) else MODEL_NAMES.index(leaf)
+            kinds.append(lk)
+            cfg[i].root = root._c()
+            cfg[i].leaf_kind = lk
+            cfg[i].num_leaves = int(L)
+            if root.is_radix_table:
+                if root.table is None:
+                    raise ValueError("a radix-table root needs its hint table (Model.table)")
+                t = np.ascontiguousarray(root.table, dtype=np.uint32)
+                keep.append(t)
+                cfg[i].root_table = t.ctypes.data
+                cfg[i].root_table_entries = t.size
+        res = (_lib.Result * max(n, 1))()
+        rcs = (C.c_int * max(n, 1))()
+        rc = self._lib.rmi_hip_train_many(self._h, cfg, n, int(in_flight), res, rcs)
+        self._table_in_ctx = None                                 # (the context's table is whatever its last configuration set)
+        if rc not in (0,) and all(int(r) == 0 for r in rcs[:n]):
+            _check(rc, self._h)                                   # (the call itself failed, not a configuration)
+        out = []
+        for i, (root, _leaf, L) in enumerate(configs):
+            if int(rcs[i]) != 0:
+                out.append((int(rcs[i]), None))
+                continue
+            t = self._result(res[i], root, kinds[i], int(L))
+            t._trainer = None
+            out.append((0, t))
+        return out
+
     def fit_root_host(self, keys: np.ndarray, root: str | int, num_leaves: int) -> Model:
         """The exact root fit from keys in HOST memory, no device involved (linear, robust_linear; linear_spline and radix
         through the same entry point): what train_streamed needs before the keys are uploaded."""

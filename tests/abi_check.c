@@ -17,6 +17,9 @@ int main(void) {
   SZ(rmi_hip_shard);
   F(rmi_hip_shard, n_global); F(rmi_hip_shard, read_lo); F(rmi_hip_shard, read_hi); F(rmi_hip_shard, key_lo); F(rmi_hip_shard, key_hi);
   F(rmi_hip_shard, leaf_lo); F(rmi_hip_shard, leaf_hi); F(rmi_hip_shard, split_idx); F(rmi_hip_shard, split_target);
+  SZ(rmi_hip_train_config);
+  F(rmi_hip_train_config, root); F(rmi_hip_train_config, leaf_kind); F(rmi_hip_train_config, num_leaves);
+  F(rmi_hip_train_config, root_table); F(rmi_hip_train_config, root_table_entries);
   SZ(rmi_hip_result);
   F(rmi_hip_result, num_rows); F(rmi_hip_result, num_leaves); F(rmi_hip_result, leaf_kind); F(rmi_hip_result, params_per_leaf);
   F(rmi_hip_result, row_bytes); F(rmi_hip_result, model_avg_error); F(rmi_hip_result, model_avg_l2_error);

@@ -156,7 +156,8 @@ def test_struct_layout_matches_a_c_consumer(tmp_path):
     exe = str(tmp_path / "abi_check")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_check.c"), "-o", exe], check=True)
     lines = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
-    mirrors = {"rmi_hip_model_params": _lib.ModelParams, "rmi_hip_shard": _lib.Shard, "rmi_hip_result": _lib.Result}
+    mirrors = {"rmi_hip_model_params": _lib.ModelParams, "rmi_hip_shard": _lib.Shard, "rmi_hip_result": _lib.Result,
+               "rmi_hip_train_config": _lib.TrainConfig}
     seen = {k: set() for k in mirrors}
     for ln in lines:
         w = ln.split()

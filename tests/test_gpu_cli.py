@@ -155,3 +155,38 @@ def test_bounded_cli_end_to_end(tmp_path, oracle):
     r = subprocess.run([sys.executable, "-m", "rmi_amd.cli", k32, "rmi", "linear,linear", "64", "--bounded", "8"],
                        cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True)
     assert r.returncode != 0 and "u64" in (r.stdout + r.stderr)
+
+
+def test_train_many_equals_single_trainings(oracle):
+    """rmi_hip_train_many (optimizer.rs:220-231's par_iter as ONE call of the library): the aggregates of every configuration equal
+    those of a training of its own, bit for bit, whatever runs beside it; a configuration the reference panics on reports its
+    code and the others still train."""
+    from rmi_amd import train
+    keys = dg.books_u64(400_000)
+    tr = train.Trainer(keys)
+    cfgs = [("linear", "linear", 4096), ("cubic", "linear", 1024), ("radix", "linear_spline", 2048), ("linear", "cubic", 512),
+            ("radix18", "linear", 8192), ("linear", "linear", 64), ("linear", "linear", 100_000), ("robust_linear", "linear", 256)]
+    roots = [tr.fit_root(r, L) for r, _l, L in cfgs]
+    singles = [tr.train_leaves(root, leaf, L) for root, (_r, leaf, L) in zip(roots, cfgs)]
+    for in_flight in (1, 3, 8):
+        many = tr.train_many([(root, leaf, L) for root, (_r, leaf, L) in zip(roots, cfgs)], in_flight=in_flight)
+        assert len(many) == len(cfgs)
+        for (rc, m), s_ in zip(many, singles):
+            assert rc == 0
+            for f in ("model_avg_error", "model_avg_l2_error", "model_avg_log2_error", "model_max_error", "model_max_error_idx",
+                      "model_max_log2_error", "num_rmi_rows", "branching_factor", "models"):
+                assert getattr(m, f) == getattr(s_, f), f
+    # robust_linear leaves of three points or fewer are an assertion of the reference (linear.rs:248); the same root with linear
+    # leaves trains: one configuration of the call reports the code, the other its result
+    L = 200_000
+    root = tr.fit_root("linear", L)
+    res = tr.train_many([(root, "linear", L), (root, "robust_linear", L), (root, "linear_spline", L)], in_flight=3)
+    t2 = tr
+    for (rc, m), leaf in zip(res, ("linear", "robust_linear", "linear_spline")):
+        try:
+            o = oracle.train_two_layer("linear", leaf, keys, L)
+            assert rc == 0 and m.model_max_error == o.model_max_error and m.model_avg_error == o.model_avg_error
+        except oracle.OracleError as oe:
+            assert rc == oe.code and m is None
+    assert {rc for rc, _ in res} != {0}, "the test wants a configuration the reference panics on"
+    tr.close()
