@@ -1,24 +1,27 @@
-"""List the loops (backward branches) of one kernel in an ISA dump with instruction counts by class.
-usage: python tools/isa_loops.py file.s"""
-import re
-import sys
-
-lines = open(sys.argv[1]).read().split("\n")
-labels = {}
-for i, l in enumerate(lines):
-    m = re.match(r"^(\.LBB\d+_\d+):", l)
+#!/usr/bin/env python3
+"""usage: tools/isa_loops.py kernel.s -> the loops of one kernel's ISA listing (backward branches) with what each holds:
+waits, scratch traffic, SGPR spills to lanes, f64 ops, LDS / scalar / global memory instructions, AGPR moves."""
+import re, sys
+lines = open(sys.argv[1]).read().split('\n')
+lab, ins = {}, []
+for l in lines:
+    m = re.match(r'^(\.LBB\d+_\d+):', l)
     if m:
-        labels[m.group(1)] = i
-for i, l in enumerate(lines):
-    m = re.match(r"^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.match(r"^\s+s_branch\s+(\.LBB\d+_\d+)", l)
-    if m and m.group(1) in labels and labels[m.group(1)] < i:
-        body = [x.strip() for x in lines[labels[m.group(1)]:i + 1] if re.match(r"^\s+[a-z]", x)]
-        cnt = {}
-        for ins in body:
-            op = ins.split()[0]
-            cls = ("valu" if op.startswith("v_") else "salu" if op.startswith("s_") and not op.startswith("s_waitcnt") and not op.startswith("s_nop") else
-                   "lds" if op.startswith("ds_") else "vmem" if op.startswith(("global_", "buffer_", "flat_")) else
-                   "wait" if op.startswith("s_waitcnt") else "nop" if op.startswith("s_nop") else "other")
-            cnt[cls] = cnt.get(cls, 0) + 1
-        f64 = sum(1 for ins in body if re.match(r"v_\w+_f64", ins))
-        print(f"{m.group(1)} lines {labels[m.group(1)]}-{i}: {len(body)} instr {cnt} f64={f64}")
+        lab[m.group(1)] = len(ins)
+        continue
+    s = l.strip()
+    if not s or s.startswith(';') or s.startswith('.'):
+        continue
+    ins.append(s)
+print(len(ins), 'instructions')
+loops = []
+for i, s in enumerate(ins):
+    m = re.match(r's_c?branch\S*\s+(\.LBB\d+_\d+)', s)
+    if m and m.group(1) in lab and lab[m.group(1)] <= i:
+        loops.append((lab[m.group(1)], i, m.group(1)))
+for a, b, n in sorted(loops):
+    body = ins[a:b + 1]
+    c = lambda p: sum(1 for x in body if re.search(p, x))
+    print(f"{n:12s} {a:5d}-{b:5d} n={b-a+1:5d} wait={c('s_waitcnt'):3d} vm0={c(r'vmcnt.0.'):2d} scratch={c('scratch_'):2d} "
+          f"lane={c('v_writelane|v_readlane'):3d} f64={c('_f64'):4d} ds={c('^ds_'):3d} sload={c('^s_load'):3d} glob={c('^global_'):3d} "
+          f"acc={c('accvgpr'):3d} br={c('^s_c?branch'):3d}")

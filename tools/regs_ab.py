@@ -38,3 +38,6 @@ for name, lib in libs:
         env["RMI_HIP_LIB"] = lib
     out = subprocess.run([sys.executable, "-c", CODE, n, L, steps], env=env, capture_output=True, text=True, timeout=300)
     print(f"{name:16s}", out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ("ERR " + out.stderr[-300:]), flush=True)
+    for line in out.stderr.splitlines():
+        if "cycles" in line:                       # (RG_PROF builds: the phase clocks, printed when the context is destroyed)
+            print("   ", line.strip(), flush=True)
