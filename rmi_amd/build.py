@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "librmi_hip.so")
 SOURCES = ["rmi_hip.hip"]
-HEADERS = ["rmi_kernels.hip.h", "rmi_stream.hip.h", "rmi_sigma.hip.h", "rmi_lanes.hip.h", "rmi_regs.hip.h", "rmi_multi.inc.h", "rmi_device.hip.h", "rmi_root_host.h", "../../include/rmi_hip.h"]
+HEADERS = ["rmi_kernels.hip.h", "rmi_stream.hip.h", "rmi_sigma.hip.h", "rmi_lanes.hip.h", "rmi_regs.hip.h", "rmi_regs_block.inc.h", "rmi_multi.inc.h", "rmi_device.hip.h", "rmi_root_host.h", "../../include/rmi_hip.h"]
 
 # -ffp-contract=off: HIP's default (fast-honor-pragmas) would fuse `c += dx*(y-mean_y)` into an
 # FMA and break bit parity with the reference's unfused Rust arithmetic.

@@ -58,8 +58,11 @@ __device__ __forceinline__ void rg_static_for(F&& f) {
 #ifndef RG_PROF
 #define RG_PROF 0                // 1: cycles per phase of a group, summed over the waves into prof[] (printed by the host at destroy)
 #endif
+#ifndef RG_UBLK
+#define RG_UBLK 9                // blocks of the walk whose code is written out per block (STATIC in k_leaf_regs); 0: none
+#endif
 #ifndef RG_DIAG
-#define RG_DIAG 0                // & 1 the constants of the first half block for all, & 2 no duplicate test, & 8 no lane ever tests, & 16 only bank 0 stashed
+#define RG_DIAG 0                // & 1 the constants of the first half block for all, & 2 no duplicate test, & 8 no lane ever tests, & 16 only bank 0 stashed, & 64 all panels from one place (cache hits: results wrong)
 #endif
 
 // The step tables of this kernel, four arrays of RG_TMAX doubles for the running count k = i + 1: RN(1 / k), the tail of the
@@ -125,6 +128,8 @@ __device__ __forceinline__ unsigned int rg_wave_max(unsigned int v) {
 
 // `key as f64` from the two halves of the key as they lie in LDS (models/mod.rs:83; see KeyTraits<uint64_t>::as_float -- written
 // on the halves because the compiler turns (double)(uint32_t)(k >> 32) back into a 64-bit conversion with one addition more)
+__device__ __forceinline__ unsigned int rg_block_index(unsigned int b) { return b; }
+template <int B> __device__ __forceinline__ unsigned int rg_block_index(std::integral_constant<int, B>) { return (unsigned int)B; }
 template <typename K> __device__ __forceinline__ unsigned long long key_to_bits_rg(K k) {
   if constexpr (std::is_same<K, double>::value) return (unsigned long long)__double_as_longlong(k); else return (unsigned long long)k;
 }
@@ -173,9 +178,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
 
-  unsigned long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                   // (RG_PROF)
+  unsigned long long pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                   // (RG_PROF)
   unsigned long long pt = 0;
   auto mark = [&](int i) { if (RG_PROF) { const unsigned long long t = rg_now(); pf[i] += t - pt; pt = t; } };
+  unsigned long long pst = 0;                                                   // (RG_PROF 2: inside the fit's blocks)
+  auto sub0 = [&]() { if (RG_PROF > 1) pst = rg_now(); };
+  auto sub = [&](int i) { if (RG_PROF > 1) { const unsigned long long t = rg_now(); pf[i] += t - pst; pst = t; } };
   // ---- a group of 64 leaves ("tile"): per-lane view and what is wave-uniform
   struct Tile {
     bool fast;                          // uniform: the register path takes it
@@ -185,6 +193,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     unsigned int a0;                    // slot of the container's first point in its first line
     unsigned int maxlen, lastp;         // uniform: longest walk through the ring (<= RG_MAXPTS steps), last panel any row needs
     unsigned int maxfar;                // uniform: longest container (> RG_MAXPTS: those lanes go on from the key array)
+    bool ulong;                         // uniform: every container walked here has more than RG_UBLK * 16 points
     const K* kb;                        // uniform: keys + wave base (line aligned)
   };
   // (all lanes: a loader lane serves the rows 8 i + lane / 8, whatever its own leaf does)
@@ -196,7 +205,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const unsigned int o = s_off[row] + p * 128u, l = s_lim[row];
       off[i] = (o < l ? o : l) + piece;                               // (a finished row keeps re-reading its last line)
     }
-    rg_dma_panel<NT>(kb, ring_lds + (p & (unsigned int)(RG_RING - 1)) * (unsigned int)RG_PANEL_B, off);
+    rg_dma_panel<NT>((RG_DIAG & 64) ? (const K*)keys + 4096 : kb, ring_lds + (p & (unsigned int)(RG_RING - 1)) * (unsigned int)RG_PANEL_B, off);   // (& 64: every group's panels from the same 100 KB)
   };
   unsigned int nxt_off = 0u, nxt_lim = 0u;                             // row descriptors of the group requested last (this lane's row)
   // descriptor of tile `tl` from its leaves' boundaries; a fast tile's first panels are requested at once
@@ -229,6 +238,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     t.maxfar = rg_wave_max(t.npts);
     t.maxlen = t.maxfar < (unsigned int)RG_MAXPTS ? t.maxfar : (unsigned int)RG_MAXPTS;
     t.lastp = rg_wave_max(t.act ? (t.a0 + wl - 1u) >> 4 : 0u);
+    t.ulong = __all(!t.act || t.npts > (unsigned int)(RG_UBLK * RG_ROW));
     if (t.fast) {
       wave_sync();
       nxt_off = (rel & ~(unsigned int)(RG_ROW - 1)) * 8u;
@@ -381,109 +391,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         for (int q = 0; q < 8; q++) rawA[q] = slot_key(in_b, dlt, q);
         plo = ~rawA[0].x;                                                  // (the walk's first step has nothing in front of it)
       }
+      // One block of 16 steps.  STATIC: `b` is a constant of the call (the first RG_UBLK blocks of a group whose containers are
+      // all longer than that: no lane ends there, so no test, no sums put aside, and every double goes straight to its register
+      // of the stash); else rolled (any block of any group).
+      // (the block index comes as a type in the STATIC case: every written-out block is then its own instantiation with ONE call,
+      //  which the inliner takes in its normal order; as `always_inline` the rolled loop came out a third longer, with spills)
+      // the first RG_UBLK blocks of a group whose containers are all longer than that, written out: no lane ends there, so no
+      // test, no sums put aside, no search for the bank (every double goes straight to its register of the stash)
+      unsigned int b0 = 0u;
+      if (RG_UBLK > 0 && cur.ulong) {
+#pragma unroll
+        for (unsigned int b = 0; b < (unsigned int)RG_UBLK; b++) {
+          constexpr bool STATIC = true;
+#include "rmi_regs_block.inc.h"
+        }
+        b0 = (unsigned int)RG_UBLK;
+      }
 #pragma nounroll
-      for (unsigned int b = 0; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
-        unsigned int in_b, dlt;
-        block_base(b, in_b, dlt);
-        double T[8];
-        // Masking: a lane is finished behind its container's last point, and stays finished.  Its sums are put aside at the end
-        // of the half block (8 steps) in which it finishes; from then on it may compute what it likes.  So a half block in
-        // which every lane is either alive for all 8 steps or finished before the first -- the rule while the walk is younger
-        // than the shortest container -- runs WITHOUT any test; else every step tests.  (Tried: narrowing EXEC once per step
-        // by v_cmpx behind the compiler's back -- cheap, but every copy or spill the register allocator places inside such a
-        // region moves only the lanes still alive, and at 500 registers it places them.)
-        // The constants of a half block come through the scalar cache, and scalar loads share their counter with the LDS reads
-        // without returning in order: a wait for them is a wait for every LDS read in flight.  So they are asked for FIRST and
-        // waited for at once (a hit in the scalar cache: tens of cycles), together with this half's keys, asked for a half block
-        // ago; only then are the next half's keys requested, and those land under the arithmetic.
-        // The constants of the steps come through the scalar cache, a quarter block (4 steps) at a time and one quarter AHEAD, in two
-        // alternating sets (cA, cB: 24 SGPRs each).  Scalar loads share their counter with the LDS reads without returning in order,
-        // so a wait for them is a wait for every LDS read in flight: the waits stand where the keys asked for a half block ago are
-        // needed anyway (a half's start) and in the middle of a half, 4 steps behind the next half's key requests.
-        // (the builtin, not an asm statement: the compiler keeps its own score of the LDS reads and scalar loads in flight, and
-        //  what it cannot see waited for it waits for again -- with lgkmcnt(0) at every step while a scalar load is out)
-        auto landed = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };   // vmcnt 63, expcnt 7, lgkmcnt 0
-        auto quarter = [&](int hb, int qr, const uint2 (&raw)[8], const double (&c)[12], auto full_tag) {
-          constexpr bool FULL = decltype(full_tag)::value;
-          const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8 + qr * 4);
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int q = qr * 4 + u;
-            const unsigned int k = k0 + (unsigned int)u;
-            const double x = rg_as_float<K>(raw[q]);
-            T[q] = x;
-            if (FULL || k < npts) {
-              if (!(RG_DIAG & 2)) {
-                if constexpr (DIVK) { if (x == xp) dmin = 0u; }
-                else { const unsigned int d = raw[q].x ^ plo; dmin = dmin < d ? dmin : d; }
-              }
-              if (!(RG_KO & 1)) {
-                const double dx = x - mx;                                 // linear.rs:26
-                if constexpr (DIVK) mx += dx / c[4 + u]; else mx += div_by_count2(dx, c[u], c[4 + u]);   // :27
-                cc += dx * c[8 + u];                                      // :28-29 in closed form (head of rmi_lanes.hip.h)
-                m2 += dx * (x - mx);                                      // :30-31
-              }
-            }
-            xp = x; plo = raw[q].x;
-          }
-        };
-        // a half block's doubles to their registers of the stash
-        auto stash_half = [&](int hb) {
-          // (a chain of tests in three groups of four: as a `switch` the cases meet in one block of phis, and the register
-          //  allocator then shuffles the whole stash around in every case)
-          auto group = [&](auto g_tag) {
-            constexpr int g = decltype(g_tag)::value;
-            rg_static_for<4 * g, 4 * g + 4>([&](auto i_tag) {
-              constexpr int i = decltype(i_tag)::value;
-              if (b == (unsigned int)i && !((RG_DIAG & 16) && i > 0)) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) xs[i * RG_ROW + hb * 8 + q] = T[q];
-                asm volatile("; stash bank %0" ::"n"(i));                 // (keeps the cases apart: merged, xs[] would be indexed by b, i.e. memory)
-              }
-            });
-          };
-          static_assert(RG_SBLK == 12, "three groups of four banks");
-          if (b < 4u) group(std::integral_constant<int, 0>{});
-          if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
-          if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
-        };
-        auto run_half = [&](int hb, const uint2 (&raw)[8], auto&& prefetch) {
-          const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
-          const bool full = (RG_DIAG & 8) || __all(npts >= k0 + 8u || npts <= k0);
-          landed();                                                      // (cA and this half's keys)
-          request(cB, 4u * b + 2u * (unsigned int)hb + 1u);
-          prefetch();                                                    // (the next half's keys: they land under the arithmetic)
-          if (full) quarter(hb, 0, raw, cA, std::true_type{}); else quarter(hb, 0, raw, cA, std::false_type{});
-          landed();                                                      // (cB)
-          request(cA, 4u * b + 2u * (unsigned int)hb + 2u);
-          if (full) quarter(hb, 1, raw, cB, std::true_type{}); else quarter(hb, 1, raw, cB, std::false_type{});
-          const bool ends = npts > k0 && npts <= k0 + 8u;
-          if (__any(ends)) { if (ends) { fmx = mx; fcc = cc; fm2 = m2; fdmin = dmin; } }
-          stash_half(hb);
-        };
-        // first half: its keys were asked for a half block ago; the second half's are asked for now
-        run_half(0, rawA, [&]() {
-#pragma unroll
-          for (int q = 0; q < 8; q++) rawB[q] = slot_key(in_b, dlt, 8 + q);
-        });
-        // second half.  Every read of panel b is behind us: its ring slot takes panel b + 4 -- but nothing behind the walk's
-        // last panel, so that at the end of the fit the ring still holds the tail of every row (the steps >= RG_STASH of the
-        // error pass).  Then the first keys of the next block: panel b + 2 has landed once at most the panels behind it are
-        // outstanding.
-        run_half(1, rawB, [&]() {
-          if (!(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING);
-          if ((b + 1u) * (unsigned int)RG_ROW < cur.maxlen) {
-            if (!(RG_KO & 4)) {
-              if (cur.lastp >= b + 4u) rg_wait_vm<16>();
-              else if (cur.lastp == b + 3u) rg_wait_vm<8>();
-              else rg_wait_vm<0>();
-            }
-            unsigned int nx_b, nx_d;
-            block_base(b + 1u, nx_b, nx_d);
-#pragma unroll
-            for (int q = 0; q < 8; q++) rawA[q] = slot_key(nx_b, nx_d, q);
-          }
-        });
+      for (unsigned int b = b0; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
+        constexpr bool STATIC = false;
+#include "rmi_regs_block.inc.h"
       }
       if (cur.maxfar > (unsigned int)RG_MAXPTS) {
         // ---- the lanes with more than 240 points (3 in 10 000 leaves of the metric configuration) go on from the key array: the same
@@ -540,7 +467,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           if (var == 0.0) { pa = my; pb = 0.0; }                           // linear.rs:50-53
           else { pb = cov / var; pa = my - pb * mx; }                      // no fma: linear.rs:56
         } else if (cur.ck == 1) { pa = (double)cur.lo; pb = 0.0; }         // Q4: one borrowed point (two identical items)
-        if (cur.valid) { params[2 * j] = pa; params[2 * j + 1] = pb; }
       if (!(RG_KO & 2) && cur.maxfar > (unsigned int)RG_MAXPTS) {
         // (the steps of the long containers behind the ring's reach: from the key array once more, 16 keys a lane and trip)
         for (unsigned int k0 = (unsigned int)RG_MAXPTS; __any(k0 < eend); k0 += 16u) {
@@ -563,16 +489,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         for (unsigned int b = (unsigned int)RG_SBLK; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
           unsigned int in_b, dlt;
           block_base(b, in_b, dlt);
+          // (the 8 reads of a half block together, then its steps: read one by one as they are used, every step would wait
+          //  out an LDS round trip -- this wave has no other to fill it)
 #pragma unroll
-          for (int qq = 0; qq < RG_ROW; qq++) {
-            const unsigned int k = b * (unsigned int)RG_ROW + (unsigned int)qq;
-            const double x = rg_as_float<K>(slot_key(in_b, dlt, qq));
-            if (k < eend) err_step(x, k);
+          for (int hb = 0; hb < 2; hb++) {
+            uint2 rk[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) rk[q] = slot_key(in_b, dlt, hb * 8 + q);
+            __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const unsigned int k = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8 + q);
+              if (k < eend) err_step(rg_as_float<K>(rk[q]), k);
+            }
           }
         }
       }
       mark(1);
       asm volatile("" : "+v"(k_next), "+v"(k_prev));                   // (read from their parking rows before the next group's keys are sent there)
+      // Every load of the compiler's own is waited for HERE, by the builtin its score keeping understands: behind the hand-over the
+      // next group's panels are in flight, which it does not count -- a wait it places there for a load of the far lanes' (a
+      // register about to be overwritten) comes out as vmcnt(0) and stands until the panels have landed, at the head of the
+      // error pass that was to run under them.
+      // (stores count as well: the coefficients are stored behind this wait, not in front of it)
+      __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
+      if (cur.valid) { params[2 * j] = pa; params[2 * j + 1] = pb; }
       hand_over();
       mark(2);
       if (!(RG_KO & 2)) {
@@ -660,7 +602,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   }
   if (RG_PROF && prof != nullptr && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 10; i++) atomicAdd(prof + i, pf[i]);
+    for (int i = 0; i < 12; i++) atomicAdd(prof + i, pf[i]);
   }
 }
 

@@ -1,5 +1,5 @@
 """Timing of k_leaf_regs builds on the same box: the in-tree library and every build_ab/var/*.so (experiment macros).
-usage: python tools/regs_ab.py [n L steps]"""
+usage: python tools/regs_ab.py [n L steps]   (RMI_AB_ONLY=name: that library only)"""
 import glob
 import os
 import subprocess
@@ -32,6 +32,9 @@ for _ in range(steps):
 print("device %.4f ms  kernels(us) %s" % (dev / steps / 1e6, [round(k / 1e3, 1) for k in acc[:4]]))
 '''
 libs = [("in-tree", None)] + [(os.path.basename(p)[:-3], os.path.abspath(p)) for p in sorted(glob.glob("build_ab/var/*.so"))]
+only = os.environ.get("RMI_AB_ONLY")               # one library only (tools/regs_prof.sh: a profiler follows the LAST child it sees)
+if only:
+    libs = [(n, l) for n, l in libs if n == only]
 for name, lib in libs:
     env = dict(os.environ)
     if lib:

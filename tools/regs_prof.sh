@@ -9,6 +9,6 @@ run() {  # name, env...
   local F=$(find $OUT/kt_$name -name "*kernel_stats.csv" 2>/dev/null | head -1)
   if [ -n "$F" ]; then cp "$F" $OUT/kernel_stats_$name.csv; echo "== $name"; grep "k_leaf_regs\|k_leaf_lanes\|k_leaf_search\|k_regs_finalize\|k_lane_reduce" $OUT/kernel_stats_$name.csv | cut -d, -f1,2,4 ; else echo "== $name: no kernel stats"; tail -3 $OUT/kt_$name.log; fi
 }
-run lanes RMI_HIP_REGS=0
-run regs RMI_HIP_REGS=1
-for v in "$@"; do run "$v" RMI_HIP_REGS=1 RMI_HIP_LIB=$GRAFT_REPO_ROOT/build_ab/var/$v.so; done
+run lanes RMI_HIP_REGS=0 RMI_AB_ONLY=in-tree
+run regs RMI_HIP_REGS=1 RMI_AB_ONLY=in-tree
+for v in "$@"; do run "$v" RMI_HIP_REGS=1 RMI_AB_ONLY=$v; done
