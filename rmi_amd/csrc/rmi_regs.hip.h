@@ -342,6 +342,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const unsigned int pr = min(sg_cvt_u32(f), n32);                      // models/mod.rs:735-737, two_layer.rs:14-18
       emax = max(emax, sg_absdiff(pr, cur.lo + k));
     };
+    // two steps at once: the conversions and absolute differences are asm statements, behind which the compiler places a wait state
+    // when the next instruction reads their result -- of two interleaved steps each fills the other's, and one v_max3 closes both
+    auto err_pair = [&](double x1, unsigned int k1, double x2, unsigned int k2) {
+      const double f1 = __builtin_fma(pb, x1, pa), f2 = __builtin_fma(pb, x2, pa);
+      const unsigned int c1 = sg_cvt_u32(f1), c2 = sg_cvt_u32(f2);
+      const unsigned int d1 = sg_absdiff(min(c1, n32), cur.lo + k1), d2 = sg_absdiff(min(c2, n32), cur.lo + k2);
+      emax = max(emax, max(d1, d2));
+    };
     // ---- hand-over: the ring is free -- the next group's descriptor and its first panels, under the rest of this group's work
     Tile nxt = cur;
     auto hand_over = [&]() {
@@ -536,7 +544,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                   constexpr int i = decltype(i_tag)::value;
                   if (b == (unsigned int)i) {
 #pragma unroll
-                    for (int qq = 0; qq < RG_ROW; qq++) err_step(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq));
+                    for (int qq = 0; qq < RG_ROW; qq += 2)
+                      err_pair(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
                     asm volatile("; stash bank %0" ::"n"(i));
                   }
                 });
