@@ -177,6 +177,56 @@ __global__ void __launch_bounds__(64) WPE k_err(Out* o, int iters, double pa, do
   if (emax == 12345u) o->sink = emax;
 }
 
+// 8: the error step with its 16 doubles in AGPRs (v_accvgpr_read x 2 in front of every fma): what k_leaf_regs' error pass pays for
+//    the two thirds of the stash that live there
+__global__ void __launch_bounds__(64) WPE k_err_acc(Out* o, int iters, double pa, double pb, unsigned int n32) {
+  unsigned int al[16], ah[16];                      // (held in AGPRs by the constraints)
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const double x = (double)(threadIdx.x * 16 + u) * 1e15;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(al[u]) : "v"(__double2loint(x)));
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(ah[u]) : "v"(__double2hiint(x)));
+  }
+  unsigned int emax = 0, lo = threadIdx.x;
+  const unsigned long long t0 = stime();
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      int xl, xh;
+      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(xl) : "a"(al[u]));
+      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(xh) : "a"(ah[u]));
+      const double f = __builtin_fma(pb, __hiloint2double(xh, xl), pa);
+      unsigned int pr; asm("v_cvt_u32_f64 %0, %1" : "=v"(pr) : "v"(f));
+      pr = pr < n32 ? pr : n32;
+      unsigned int d; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(pr), "v"(lo + (unsigned)u + (unsigned)i));
+      emax = emax > d ? emax : d;
+    }
+  }
+  const unsigned long long t1 = stime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { o->cyc = t1 - t0; }
+  if (emax == 12345u) o->sink = emax;
+}
+// 9: 16 doubles to AGPRs per trip (the stash's writes)
+__global__ void __launch_bounds__(64) WPE k_acc_write(Out* o, int iters, double a) {
+  double x = (double)threadIdx.x;
+  unsigned int acc[32];
+  const unsigned long long t0 = stime();
+  for (int i = 0; i < iters; i++) {
+    x += a;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(acc[2 * u]) : "v"(__double2loint(x) + u));
+      asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(acc[2 * u + 1]) : "v"(__double2hiint(x)));
+    }
+  }
+  const unsigned long long t1 = stime();
+  unsigned int sum = 0;
+#pragma unroll
+  for (int u = 0; u < 32; u++) { unsigned int v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[u])); sum += v; }
+  if (threadIdx.x == 0 && blockIdx.x == 0) { o->cyc = t1 - t0; }
+  if (sum == 12345u) o->sink = (double)sum;
+}
+
 int main(int argc, char** argv) {
   const int wpc = argc > 1 ? atoi(argv[1]) : 4;
   int ncu = 256;
@@ -213,6 +263,8 @@ int main(int argc, char** argv) {
     RUN("dependent 32-bit mul+add", 16, k_i32, dim3(grid), dim3(64), 0, 0, o, iters, 7u);
     RUN("32-bit VOP2 (add, xor) x 8", 16, k_add32, dim3(grid), dim3(64), 0, 0, o, iters, 7u);
     RUN("error step (5 ops)", 16, k_err, dim3(grid), dim3(64), 0, 0, o, iters, 0.5, 1e-15, 200000000u);
+    RUN("error step, x from AGPRs (7 ops)", 16, k_err_acc, dim3(grid), dim3(64), 0, 0, o, iters, 0.5, 1e-15, 200000000u);
+    RUN("a double to AGPRs (2 writes)", 16, k_acc_write, dim3(grid), dim3(64), 0, 0, o, iters, 0.25);
   }
   return 0;
 }
