@@ -363,6 +363,16 @@ def main():
     # hipEvents on the library's stream.  An event between two kernels costs ~5.5 us of idle device time, so the
     # timed steps bracket only the first (dominant) kernel of the path, and the per-kernel breakdown is taken in the
     # warm-up steps.
+    # the box's own streaming read rate, measured in this run on the resident key array (a read-only kernel,
+    # non-temporal 16-byte loads): what "HBM-bound" can mean on this machine, beside the 8 TB/s of the data sheet.  It runs
+    # HERE, in front of the warm-up: the exact root fit before it keeps the host busy for ~1 s with the GPU idle, and a device
+    # that has dropped to its low-power state needs more than W = 5 steps of 0.5 ms to be back at its clocks.
+    measured_bw, measured_bw_err = None, None
+    if world == 1:
+        try:
+            measured_bw = float(max(tr.measure_read_bandwidth(10) for _ in range(3)))
+        except Exception as ex:                                         # (never the reason a bench line is lost)
+            measured_bw_err = str(ex)[:120]
     tr.set_profile_level(2)
     warm_ns = np.zeros(8, dtype=np.float64)
     res = None
@@ -495,18 +505,17 @@ def main():
             except Exception:
                 pass
 
-        # the box's own streaming read rate, measured in this run on the resident key array (a read-only kernel,
-        # non-temporal 16-byte loads): what "HBM-bound" can mean on this machine, beside the 8 TB/s of the data sheet
         if world == 1:
-            try:
-                bw = max(tr.measure_read_bandwidth(5) for _ in range(3))
+            bw = measured_bw
+            if bw:
                 out["roofline"]["measured_peak"] = float(bw)
-                out["roofline"]["frac_of_measured"] = float(path_gbs / bw) if bw > 0 else None
-                out["roofline"]["kernel_frac_of_measured"] = float(dom_gbs / bw) if bw > 0 else None
-                out["roofline"]["measured_peak_note"] = "rmi_hip_measure_read_bandwidth: best of 3 x 5 passes of a read-only kernel over the same key array, this run"
-            except Exception as ex:                                     # (never the reason a bench line is lost)
+                out["roofline"]["frac_of_measured"] = float(path_gbs / bw)
+                out["roofline"]["kernel_frac_of_measured"] = float(dom_gbs / bw)
+                out["roofline"]["measured_peak_note"] = ("rmi_hip_measure_read_bandwidth: best of 3 x 10 passes of a read-only kernel over the same key array, "
+                                                         "this run, right in front of the warm-up steps")
+            else:
                 out["roofline"]["measured_peak"] = None
-                out["roofline"]["measured_peak_note"] = "failed: " + str(ex)[:120]
+                out["roofline"]["measured_peak_note"] = "failed: " + str(measured_bw_err)
         out["env"] = env_info(torch)
         # the driver's flags give a 12 ms timed region; the same steps once more over 200 (the protocol of profiles/)
         if world == 1 and args.steps < 200 and not args.no_extras:
