@@ -495,21 +495,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         // the steps behind the stash: still in the ring (masked the plain way: a few blocks)
 #pragma nounroll
         for (unsigned int b = (unsigned int)RG_SBLK; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
+          if (!__any(eend > b * (unsigned int)RG_ROW)) break;              // (a container's last point is not a key of its leaf: often nothing is left here)
           unsigned int in_b, dlt;
           block_base(b, in_b, dlt);
           // (the 8 reads of a half block together, then its steps: read one by one as they are used, every step would wait
           //  out an LDS round trip -- this wave has no other to fill it)
 #pragma unroll
           for (int hb = 0; hb < 2; hb++) {
+            if (hb == 1 && !(b * (unsigned int)RG_ROW + 8u < cur.maxlen)) break;
             uint2 rk[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) rk[q] = slot_key(in_b, dlt, hb * 8 + q);
             __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0)
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < 4; q++) {
               const unsigned int k = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8 + q);
               if (k < eend) err_step(rg_as_float<K>(rk[q]), k);
+            }
+            if (b * (unsigned int)RG_ROW + (unsigned int)(hb * 8 + 4) < cur.maxlen) {
+#pragma unroll
+              for (int q = 4; q < 8; q++) {
+                const unsigned int k = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8 + q);
+                if (k < eend) err_step(rg_as_float<K>(rk[q]), k);
+              }
             }
           }
         }

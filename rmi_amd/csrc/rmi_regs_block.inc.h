@@ -80,11 +80,18 @@
           prefetch();                                                    // (the next half's keys: they land under the arithmetic)
           if (full) quarter(hb, 0, raw, cA, std::true_type{}); else quarter(hb, 0, raw, cA, std::false_type{});
           sub(8);
-          landed();                                                      // (cB)
-          request(cA, 4u * b + 2u * (unsigned int)hb + 2u);
-          sub(9);
-          if (full) quarter(hb, 1, raw, cB, std::true_type{}); else quarter(hb, 1, raw, cB, std::false_type{});
-          sub(8);
+          // (the walk's last steps: where the longest container ends in a half's first quarter the second is not run -- with
+          //  evenly filled leaves EVERY group's last block holds one or two steps)
+          if (STATIC || k0 + 4u < cur.maxlen) {
+            landed();                                                    // (cB)
+            request(cA, 4u * b + 2u * (unsigned int)hb + 2u);
+            sub(9);
+            if (full) quarter(hb, 1, raw, cB, std::true_type{}); else quarter(hb, 1, raw, cB, std::false_type{});
+            sub(8);
+          } else {
+#pragma unroll
+            for (int q = 4; q < 8; q++) T[q] = 0.0;                      // (stashed with the others; no leaf has these steps)
+          }
           if constexpr (!STATIC) {
             const bool ends = npts > k0 && npts <= k0 + 8u;
             if (__any(ends)) { if (ends) { fmx = mx; fcc = cc; fm2 = m2; fdmin = dmin; } }
@@ -101,6 +108,7 @@
         // last panel, so that at the end of the fit the ring still holds the tail of every row (the steps >= RG_STASH of the
         // error pass).  Then the first keys of the next block: panel b + 2 has landed once at most the panels behind it are
         // outstanding.
+        if (STATIC || b * (unsigned int)RG_ROW + 8u < cur.maxlen)
         run_half(1, rawB, [&]() {
           if (!(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING);
           sub(5);
