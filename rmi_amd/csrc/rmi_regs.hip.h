@@ -120,10 +120,23 @@ __device__ __forceinline__ unsigned long long rg_now() {
 }
 template <int N> __device__ __forceinline__ void rg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// the maximum over the wave, in an SGPR: four DPP steps inside the rows of 16 lanes (swap neighbours, swap pairs, mirror the half
+// rows, mirror the rows), then the four rows' values by readlane.  (As six __shfl_xor it is six LDS round trips, each waited
+// out by a wave that has nobody to fill them: ~1 000 cycles per group for the two maxima a group descriptor needs.)
 __device__ __forceinline__ unsigned int rg_wave_max(unsigned int v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { const unsigned int o = (unsigned int)__shfl_xor((int)v, d); v = o > v ? o : v; }
-  return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+  auto step = [](unsigned int x, auto ctrl_tag) {
+    constexpr int CTRL = decltype(ctrl_tag)::value;
+    const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
+    return o > x ? o : x;
+  };
+  v = step(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1, 0, 3, 2]
+  v = step(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2, 3, 0, 1]
+  v = step(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+  v = step(v, std::integral_constant<int, 0x140>{});     // row_mirror
+  const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned int r2 = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned int a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
 }
 
 // `key as f64` from the two halves of the key as they lie in LDS (models/mod.rs:83; see KeyTraits<uint64_t>::as_float -- written
