@@ -173,7 +173,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   using B = unsigned long long;
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
   __shared__ __attribute__((aligned(1024))) unsigned char ringc[RG_RING * RG_PANEL_B];   // 32 KB: 4 waves per CU
-  __shared__ unsigned int s_off[64], s_lim[64];
   __shared__ unsigned int park[10][64];                              // k_hi, k_lom1, k_next, k_prev (two words each), next group's s, e
   static_assert(RG_RING * RG_PANEL_B >= 64 * LnGeom<K>::STRIDE * 8, "the ring holds the LDS image of k_leaf_lanes");
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -181,7 +180,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const unsigned int park_lds = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(lds_byte*)&park[0][0]);
 
   const int lane = threadIdx.x;
-  const unsigned int rowpart = (unsigned int)(lane >> 3) * 1024u + (unsigned int)(lane & 7) * 128u;   // this lane's row inside a panel
+  // A panel in LDS: instruction i of a request carries row 8 g + i for each group g of 8 loader lanes (LDS: i * 1 KB + g * 128 B),
+  // so that a loader lane's 8 rows are the 8 lanes of its own group -- their offsets reach it by DPP, not through LDS.
+  const unsigned int rowpart = (unsigned int)(lane & 7) * 1024u + (unsigned int)(lane >> 3) * 128u;   // this lane's row inside a panel
   const unsigned int piece = (unsigned int)(lane & 7) * 16u;         // its 16-byte piece of a line as a loader
   const unsigned int n32 = (unsigned int)sp.n;
   const uint64_t split_idx = st->split_idx, split_target = st->split_target;
@@ -208,16 +209,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     unsigned int maxfar;                // uniform: longest container (> RG_MAXPTS: those lanes go on from the key array)
     bool ulong;                         // uniform: every container walked here has more than RG_UBLK * 16 points
     const K* kb;                        // uniform: keys + wave base (line aligned)
+    unsigned int off, lim;              // this lane's row: byte offset from kb of its first line, of its last
   };
-  // (all lanes: a loader lane serves the rows 8 i + lane / 8, whatever its own leaf does)
-  auto issue_panel = [&](const K* kb, unsigned int p) {
+  // (all lanes: a loader lane serves the rows 8 (lane / 8) + i, whatever its own leaf does).  Every lane clamps its OWN row's offset
+  // (a finished row keeps re-reading its last line); lane 8 g + i's value reaches the 8 lanes of group g in two DPP moves: lane
+  // i mod 4 of every quad to its quad, then the right quad of the pair to both.  (Through LDS it was four round trips per panel.)
+  auto issue_panel = [&](const K* kb, unsigned int p, unsigned int off_own, unsigned int lim_own) {
+    const unsigned int o = off_own + p * 128u;
+    const int mine = (int)(o < lim_own ? o : lim_own);
     unsigned int off[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int row = i * 8 + (lane >> 3);
-      const unsigned int o = s_off[row] + p * 128u, l = s_lim[row];
-      off[i] = (o < l ? o : l) + piece;                               // (a finished row keeps re-reading its last line)
-    }
+    rg_static_for<0, 8>([&](auto i_tag) {
+      constexpr int i = decltype(i_tag)::value;
+      constexpr int QP = (i & 3) * 0x55;                                  // quad_perm [a, a, a, a]
+      const int t = __builtin_amdgcn_update_dpp(mine, mine, QP, 0xF, 0xF, false);
+      const int g = (i < 4) ? __builtin_amdgcn_update_dpp(t, t, 0x114, 0xF, 0xA, false)      // row_shr:4 into the upper quads
+                            : __builtin_amdgcn_update_dpp(t, t, 0x104, 0xF, 0x5, false);     // row_shl:4 into the lower quads
+      off[i] = (unsigned int)g + piece;
+    });
     rg_dma_panel<NT>((RG_DIAG & 64) ? (const K*)keys + 4096 : kb, ring_lds + (p & (unsigned int)(RG_RING - 1)) * (unsigned int)RG_PANEL_B, off);   // (& 64: every group's panels from the same 100 KB)
   };
   unsigned int nxt_off = 0u, nxt_lim = 0u;                             // row descriptors of the group requested last (this lane's row)
@@ -253,11 +261,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     t.lastp = rg_wave_max(t.act ? (t.a0 + wl - 1u) >> 4 : 0u);
     t.ulong = __all(!t.act || t.npts > (unsigned int)(RG_UBLK * RG_ROW));
     if (t.fast) {
-      wave_sync();
       nxt_off = (rel & ~(unsigned int)(RG_ROW - 1)) * 8u;
       nxt_lim = t.act ? ((rel + wl - 1u) & ~(unsigned int)(RG_ROW - 1)) * 8u : 0u;
-      s_off[lane] = nxt_off; s_lim[lane] = nxt_lim;
-      wave_sync();
+      t.off = nxt_off; t.lim = nxt_lim;
       unsigned long long m0t = 0;
       if (RG_PROF) m0t = rg_now();
       if (!(RG_KO & 4)) {
@@ -274,7 +280,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         rg_dma_dword(kbm, park_lds + 6u * 256u, o_prev); rg_dma_dword(kbm, park_lds + 7u * 256u, o_prev + 4u);
 #pragma unroll
         for (unsigned int p = 0; p < (unsigned int)RG_RING; p++)
-          if (p <= t.lastp) issue_panel(t.kb, p);
+          if (p <= t.lastp) issue_panel(t.kb, p, nxt_off, nxt_lim);
       }
       if (RG_PROF) pf[6] += rg_now() - m0t;
     }

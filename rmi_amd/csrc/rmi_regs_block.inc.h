@@ -110,7 +110,7 @@
         // outstanding.
         if (STATIC || b * (unsigned int)RG_ROW + 8u < cur.maxlen)
         run_half(1, rawB, [&]() {
-          if (!(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING);
+          if (!(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING, cur.off, cur.lim);
           sub(5);
           if ((b + 1u) * (unsigned int)RG_ROW < cur.maxlen) {
             if (!(RG_KO & 4)) {
