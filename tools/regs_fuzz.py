@@ -1,0 +1,63 @@
+"""Development aid for the GPU box: random configurations through pipeline 4 against the oracle, bit for bit (leaf boundaries,
+coefficients, error integers, counts, the integer aggregates) -- key sets of every generator, 2 000 .. 3 000 000 keys, 6 .. 300 keys
+per leaf on average (the written-out blocks, the rolled loop, the far lanes, the listed groups), a few seconds each.
+usage: python tools/regs_fuzz.py [seconds [seed]]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from rmi_amd import datagen as dg, train  # noqa: E402
+
+sys.path.insert(0, "tools")
+from lanes_check import mk  # noqa: E402
+
+
+def main():
+    from oracle import binding as orc
+    orc.build()
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260927)
+    gens = [g for g in dg.GENERATORS if g.endswith("u64") or g.endswith("f64")]
+    t0, done, bad, p4 = time.time(), 0, 0, 0
+    while time.time() - t0 < budget:
+        gen = gens[int(rng.integers(len(gens)))]
+        n = int(10 ** rng.uniform(3.3, 6.48))
+        per = float(10 ** rng.uniform(0.8, 2.48))
+        L = max(2, int(n / per))
+        env = {"RMI_HIP_REGS": "1"}
+        if rng.random() < 0.3:
+            env["RMI_HIP_REGS_GRID"] = str(int(rng.integers(1, 40)))
+        if rng.random() < 0.3:
+            env["RMI_HIP_REGS_MAX_AVG"] = "100000"
+        keys = dg.GENERATORS[gen](n)
+        tr = mk(env)
+        tr.set_keys(keys)
+        try:
+            root = tr.fit_root("linear", L)
+            o = orc.train_two_layer("linear", "linear", keys, L)
+        except orc.OracleError:
+            tr.close()
+            continue
+        try:
+            g = tr.train_leaves(root, "linear", L)
+        except train.RMIError as e:
+            print(f"BAD {gen} n={n} L={L} {env}: GPU error {e}", flush=True)
+            bad += 1
+            tr.close()
+            continue
+        ok = (np.array_equal(g.leaf_starts, o.leaf_start) and np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64))
+              and np.array_equal(g.last_layer_max_l1s, o.leaf_err) and np.array_equal(g.leaf_counts, o.leaf_count)
+              and g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx and g.model_avg_error == o.model_avg_error)
+        done += 1
+        p4 += int(g.pipeline == 4)
+        if not ok:
+            bad += 1
+            print(f"BAD {gen} n={n} L={L} {env}: pipeline {g.pipeline}", flush=True)
+        tr.close()
+    print(f"FUZZ {done} configurations ({p4} through pipeline 4), {bad} bad, {time.time() - t0:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
