@@ -70,7 +70,7 @@ struct DevState {
   unsigned long long split_target;  // two_layer.rs:152-156
   unsigned long long last_target;   // leaf of key[n-1] (owner of the Q7 extra count)
   unsigned int err_flags;
-  unsigned int _pad;
+  unsigned int regs_listed;         // pipeline 4: groups k_leaf_regs put on the list (the host stops taking it for key sets where that is most of them)
   // aggregate statistics (two_layer.rs:267-287), filled by the stats kernel
   unsigned long long max_err;
   unsigned long long max_err_idx;

@@ -95,6 +95,8 @@ struct rmi_hip_ctx {
   unsigned int regs_grid = 0;                   // persistent waves of k_leaf_regs (0: 4 per CU)
   unsigned int regs_max_avg = 208;              // average keys per leaf above which most groups would not fit (RG_MAXPTS = 240 per container)
   unsigned int regs_slow = 0;                   // debugging: every group on the list
+  bool regs_backoff = true;                     // RMI_HIP_REGS_BACKOFF=0: k_leaf_regs also for key sets on which it listed most groups last time
+  uint64_t regs_off_epoch = 0; uint64_t regs_off_L[8] = {}; int regs_off_n = 0;   // ... the (key set, leaves) pairs remembered
   bool regs_queue = false;                      // RMI_HIP_REGS_QUEUE=1: groups dealt to the waves from a counter instead of by wave number (measured: 473 against 460 us)
   double* d_regtab = nullptr;                   // the interleaved step table of k_leaf_regs
   unsigned long long* d_regprof = nullptr;      // RG_PROF builds: cycles per phase, summed over the waves
@@ -310,6 +312,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* rg = std::getenv("RMI_HIP_REGS_GRID"); if (rg && *rg) c->regs_grid = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_MAX_AVG"); if (rg && *rg) c->regs_max_avg = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_QUEUE"); if (rg && *rg) c->regs_queue = std::atoi(rg) != 0; }
+  { const char* rg = std::getenv("RMI_HIP_REGS_BACKOFF"); if (rg && *rg) c->regs_backoff = std::atoi(rg) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS_SLOW"); if (rg && *rg) c->regs_slow = (unsigned int)std::atoi(rg); }
   { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) c->n_cu = cu; }
   if (hipMalloc(&c->d_lntab, sizeof(double) * (3 * LN_TMAX + 2 * (LS_SAMPLES + 1))) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
@@ -1292,7 +1295,12 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // pipeline 4: one read of the keys (8-byte keys, linear leaves, leaves short enough on average that most groups of 64 qualify)
       bool regs = false;
       if constexpr (LEAF == K_LINEAR && sizeof(K) == 8) {
-        regs = !verify && lanes_fused && c->regs && c->pipeline >= 3 && n_it <= (uint64_t)c->regs_max_avg * L_own;
+        // (a key set on which k_leaf_regs listed most groups -- duplicate-heavy keys: every group meets a duplicate -- is remembered, like
+        //  the one-pass modes' hint: the next trainings of it with that many leaves go straight to k_leaf_lanes, 0.80 against 2.25 ms)
+        bool regs_off = false;
+        if (c->regs_off_epoch == c->keys_epoch)
+          for (int h = 0; h < c->regs_off_n && h < 8; h++) regs_off = regs_off || c->regs_off_L[h] == L_own;
+        regs = !verify && lanes_fused && c->regs && !regs_off && c->pipeline >= 3 && n_it <= (uint64_t)c->regs_max_avg * L_own;
         if (regs) {
           if (c->slow_cap < wb) {
             if (c->d_slow_list) (void)hipFree(c->d_slow_list);
@@ -1317,7 +1325,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           const unsigned int lgrid = wb < 512 ? (unsigned int)wb : 512u;    // (as a rule nothing is listed: few blocks to start and to leave)
           hipLaunchKernelGGL((k_leaf_lanes_listed<K>), dim3(lgrid), dim3(64), 0, s, c->d_slow_list, c->d_tickets + 1, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin,
                              maxerr, run, L, err, count, rows, part, rp, peers);
-          hipLaunchKernelGGL((k_regs_finalize<K>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, (const DevState*)c->d_state, params,
+          hipLaunchKernelGGL((k_regs_finalize<K>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, (const unsigned int*)(c->d_tickets + 1), params,
                              (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
                              err, count, rows, part, peers);
           HIPCHK(c, hipGetLastError());
@@ -1816,6 +1824,10 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   if (c->last_sigma && (st.flag_count - st.merged_count) * 4 > L_own) {   // most leaves went through the list kernels: see hint_epoch
     if (c->hint_epoch != c->keys_epoch || c->hint_mode != c->fit_mode) { c->hint_epoch = c->keys_epoch; c->hint_mode = c->fit_mode; c->hint_n = 0; }
     c->hint_L[c->hint_n % 8] = L_own; c->hint_n++;
+  }
+  if (c->last_regs && c->regs_backoff && (uint64_t)st.regs_listed * 4 > (L_own + 63) / 64) {   // most groups went on the list: see regs_off
+    if (c->regs_off_epoch != c->keys_epoch) { c->regs_off_epoch = c->keys_epoch; c->regs_off_n = 0; }
+    c->regs_off_L[c->regs_off_n % 8] = L_own; c->regs_off_n++;
   }
   out->fit_mode_used = c->last_sigma ? (c->last_spline ? RMI_FIT_USED_ONEPASS_EXACT : c->fit_mode) : 0;
   out->exact_leaves = c->last_sigma ? st.flag_count - st.merged_count : 0;

@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // through k_leaf_lanes_listed were finished there.
 template <typename K>
 __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ keys, Span sp, uint64_t L,
-                                                       const unsigned long long* __restrict__ leaf_start, const DevState* __restrict__ st,
+                                                       const unsigned long long* __restrict__ leaf_start, DevState* st, const unsigned int* __restrict__ slow_count,
                                                        double* __restrict__ params, const unsigned long long* __restrict__ leaf_maxerr,
                                                        const K* __restrict__ bnext, const K* __restrict__ bprev,
                                                        const unsigned char* __restrict__ tile_slow, unsigned int ntiles,
@@ -656,6 +656,7 @@ __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ key
                                                        unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, PeerRows peers) {
   const uint64_t jl = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const unsigned int tile = (unsigned int)(jl >> 6);
+  if (jl == 0) st->regs_listed = *slow_count;                          // (into the record the host reads: rmi_hip.hip, regs_off)
   if (tile >= ntiles || tile_slow[tile] != 0) return;                  // (wave-uniform)
   const uint64_t j = sp.leaf_lo + jl;
   unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;
