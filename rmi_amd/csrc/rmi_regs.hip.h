@@ -14,17 +14,24 @@
 // refilled at the end of a group of leaves -- and replays them for the error pass.  Nothing is read twice.
 //
 // Data movement.  The keys arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, the register file belongs to the
-// stash): as in k_leaf_lanes a row (= a leaf's container) is fetched in aligned 128-byte lines, 8 rows per instruction, a
-// panel = 16 steps of all 64 rows = 8 instructions = 8 KB; the ring holds 4 panels (32 KB per wave, 4 waves per CU).  The
-// destination of an LDS-DMA instruction is linear in the lane, so a panel is stored row-major as fetched ([8 rows][128 B]
-// per instruction) and lane r reads slot (a0_r + k) of its row: the panel that slot lies in differs between lanes that have
-// and have not crossed a line boundary (one select per step).  The wave is PERSISTENT: it takes every gridDim.x-th group of
-// 64 leaves, and the first panels of the next group are requested before the register part of this group's error pass.
+// stash): as in k_leaf_lanes a row (= a leaf's container) is fetched in aligned 128-byte lines, a panel = 16 steps of all 64
+// rows = 8 instructions = 8 KB; the ring holds 4 panels (32 KB per wave, 4 waves per CU).  The destination of an LDS-DMA
+// instruction is linear in the lane (M0 + 16 lane): instruction i of a panel carries the rows 8 g + i of the 8 groups g of 8 loader
+// lanes, so that a loader lane's rows are the lanes of its own group and their offsets reach it by DPP; lane r reads slot
+// (a0_r + k) of its row: the panel that slot lies in differs between lanes that have and have not crossed a line boundary
+// (one select per step).  The wave is PERSISTENT: it takes every gridDim.x-th group of 64 leaves, and the first panels of the
+// next group are requested before the register part of this group's error pass.
 //
-// What takes this path: groups of 64 consecutive leaves whose containers hold at most RG_MAXPTS = 240 points, cover their
-// leaves (every leaf but the one behind the split, two_layer.rs:166-169) and hold no duplicate key (found while walking:
-// compared as doubles, a superset of key equality); 8-byte keys; linear leaves.  Every other group is put on a list and runs
-// the body of k_leaf_lanes in k_leaf_lanes_listed, launched behind this kernel: the same bits either way.
+// Code shape.  The walk is rolled over blocks of 16 steps (rmi_regs_block.inc.h); for a group whose containers all hold more than
+// RG_UBLK x 16 points the first RG_UBLK blocks are written out per block (static registers of the stash, no masks).  A lone
+// wave has nobody to fill an LDS or scalar-cache round trip: wave-wide maxima and the loaders' row offsets go by DPP, the
+// step constants are requested a quarter block ahead, the single keys a group needs late are parked in LDS by DMA.
+//
+// What takes this path: groups of 64 consecutive leaves whose containers hold at most RG_FARPTS = 1 008 points (the lanes with more
+// than RG_MAXPTS = 240 go on from the key array by themselves), cover their leaves (every leaf but the one behind the split,
+// two_layer.rs:166-169) and hold no duplicate key (found while walking: compared as doubles, a superset of key equality);
+// 8-byte keys; linear leaves.  Every other group is put on a list and runs the body of k_leaf_lanes in k_leaf_lanes_listed,
+// launched behind this kernel: the same bits either way.  The leaf ends (widening, rows, counts, aggregates): k_regs_finalize.
 #pragma once
 #include <type_traits>
 
