@@ -23,6 +23,7 @@
 #include "rmi_sigma.hip.h"
 #include "rmi_lanes.hip.h"
 #include "rmi_regs.hip.h"
+#include "rmi_scan_launch.h"
 #include "rmi_root_host.h"
 
 using namespace rmi;
@@ -107,6 +108,9 @@ struct rmi_hip_ctx {
   uint64_t slow_cap = 0;
   int n_cu = 256;
   bool last_regs = false;
+  bool scan = true;                             // pipeline 5 (rmi_scan.hip.h): linear_spline leaves by the key-parallel one-read kernel (RMI_HIP_SCAN=0: k_leaf_lanes)
+  bool last_scan = false;
+  unsigned int scan_waves = 0;                  // its persistent waves (0: 12 per CU, what the LDS holds)
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
   bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes (RMI_HIP_SPLINE_LANES=0: k_sigma2's spline variant)
   uint64_t edge_epoch = 0;                      // first / last resident key of the key set `keys_epoch` (radix roots: is the prefix common?)
@@ -192,7 +196,7 @@ static void set_err(rmi_hip_ctx* c, const char* fmt, ...) {
 extern "C" {
 
 int rmi_hip_abi_version(void) { return RMI_HIP_ABI_VERSION; }
-int rmi_hip_last_pipeline(rmi_hip_ctx* c) { return !c ? RMI_ERR_BAD_ARG : (c->last_regs ? 4 : (c->last_lanes ? 3 : (c->pipeline == 1 ? 1 : 2))); }
+int rmi_hip_last_pipeline(rmi_hip_ctx* c) { return !c ? RMI_ERR_BAD_ARG : (c->last_scan ? 5 : c->last_regs ? 4 : (c->last_lanes ? 3 : (c->pipeline == 1 ? 1 : 2))); }
 
 int rmi_hip_device_count(void) {
   int n = 0;
@@ -308,6 +312,8 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
   { const char* sl = std::getenv("RMI_HIP_SPLINE_LANES"); if (sl && *sl) c->spline_lanes = std::atoi(sl) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) c->regs = std::atoi(rg) != 0; }
+  { const char* sc = std::getenv("RMI_HIP_SCAN"); if (sc && *sc) c->scan = std::atoi(sc) != 0; }
+  { const char* sc = std::getenv("RMI_HIP_SCAN_WAVES"); if (sc && *sc) c->scan_waves = (unsigned int)std::atoi(sc); }
   { const char* rg = std::getenv("RMI_HIP_REGS_NT"); if (rg && *rg) c->regs_nt = std::atoi(rg) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS_GRID"); if (rg && *rg) c->regs_grid = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_MAX_AVG"); if (rg && *rg) c->regs_max_avg = (unsigned int)std::atoi(rg); }
@@ -1050,7 +1056,9 @@ int rmi_hip_root_stream_finish(rmi_hip_root_stream* r, rmi_hip_model_params* out
 
 }  // extern "C"
 
-static inline uint64_t lane_slices(uint64_t leaves) { return ((leaves + 63) / 64 + LF_SLICE - 1) / LF_SLICE; }
+// aggregate records of a training: one per wave of 64 leaves (k_leaf_lanes, k_leaf_regs) or one per persistent wave (k_spline_scan)
+static inline uint64_t agg_records(uint64_t leaves) { const uint64_t w = (leaves + 63) / 64; return w > SCAN_MAX_WAVES ? w : (uint64_t)SCAN_MAX_WAVES; }
+static inline uint64_t lane_slices(uint64_t leaves) { return (agg_records(leaves) + LF_SLICE - 1) / LF_SLICE; }
 static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   if (L <= c->cap_leaves && ppl <= c->cap_ppl) return RMI_OK;
   free_outputs(c);
@@ -1064,7 +1072,7 @@ static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   HIPCHK(c, hipMalloc(&c->d_tilemin, ((L + 1 + FILL_TILE - 1) / FILL_TILE + 1) * 8));
   // (per block of k_finalize, or: per wave of k_leaf_lanes, the slice records of k_list_tail, the blocks of
   //  k_finalize_listed, then the slice records of k_leaf_lanes' own reduction)
-  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * ((L + 63) / 64 + SG_REGIONS + 2 * FL_BLOCKS + 1 + lane_slices(L) + 1)));
+  HIPCHK(c, hipMalloc(&c->d_partials, sizeof(StatsPartial) * (agg_records(L) + SG_REGIONS + 2 * FL_BLOCKS + 1 + lane_slices(L) + 1)));
   HIPCHK(c, hipMalloc(&c->d_tickets, 64));
   c->cap_leaves = L; c->cap_ppl = ppl;
   return RMI_OK;
@@ -1153,8 +1161,12 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   // linear_spline leaves (the line through a container's two end points) need no sums and no guard: the one-pass kernel
   // reproduces them bit for bit, so it serves EVERY fit mode (RMI_HIP_SPLINE_ONEPASS=0: the per-pass kernels)
   // ... and, in front of it, the leaf-lane kernel (two end points per leaf, then its error pass with duplicates handled natively)
-  const bool spline_l = c->pipeline >= 3 && (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_lanes && n_it >= 1024 &&
-                        sp.n < (1ull << 32) - (1ull << 16);
+  // pipeline 5 (rmi_scan.hip.h): linear_spline leaves in ONE key-parallel pass, the bucketing scan included -- every root, every key type,
+  // any number of keys (an empty shard as well); 32-bit indices
+  const bool scan5 = c->pipeline >= 3 && (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->scan && c->lanes_fuse && sp.n < (1ull << 32) - (1ull << 16);
+  c->last_scan = scan5;
+  const bool spline_l = scan5 || (c->pipeline >= 3 && (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_lanes && n_it >= 1024 &&
+                        sp.n < (1ull << 32) - (1ull << 16));
   const bool spline1 = (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_onepass && !spline_l;
   const bool sigma = ((stream_fit && c->fit_mode != 0) || spline1) && !hinted && sp.n < (1ull << 32) - (1ull << 16) &&
                      n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
@@ -1184,10 +1196,11 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       lanes_search_plan = pfx == 0u || ((c->edge_first ^ c->edge_last) >> (64u - pfx)) == 0ull;
     }
   }
-  const bool init_arrays = !(lanes_fused_plan && lanes_search_plan);
+  if (scan5) lanes_search_plan = false;                    // (the scan finds the leaf starts itself)
+  const bool init_arrays = scan5 ? false : !(lanes_fused_plan && lanes_search_plan);
   if ((!c->stream_mode || c->stream_slot == 0) && pl >= 0) HIPCHK(c, hipEventRecord(c->ev[8], s));   // start of the device work of this call
   // (the leaf-lane pipeline with its search and its fused error pass: the launch of k_leaf_samples carries the init)
-  const bool init_folded = !init_arrays && (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE);
+  const bool init_folded = !scan5 && !init_arrays && (LEAF == K_LINEAR || LEAF == K_LINEAR_SPLINE);
   if (!init_folded) {
     const uint64_t ib = init_arrays ? (L_own + 1 + 255) / 256 : 1;
     hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
@@ -1236,7 +1249,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // --- leaf boundaries: lower bounds by search where the root is monotone by arithmetic, else the bucketing scan + fill ---
       bool searched = false;
       const uint64_t wb = (L_own + 63) / 64;
-      const unsigned int nsl = (unsigned int)lane_slices(L_own);
+      uint64_t nrec = wb;                                               // aggregate records the fitting kernel leaves (one per wave)
       // the result published by k_lane_reduce right behind k_leaf_lanes; the list kernels behind the synchronisation, if a leaf was handed over
       const bool optimistic = lanes_fused_plan && c->opt_tail && !c->stream_mode;
       if constexpr (ROOT == K_LINEAR || ROOT == K_RADIX || ROOT == K_CUBIC) {
@@ -1254,7 +1267,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         }
       }
       if (!(searched && init_folded)) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 12, s));   // (k_lane_reduce's arrival counter, k_leaf_regs' list counter and group counter)
-      if (!searched) {
+      if (!searched && !scan5) {
         constexpr uint64_t V = 16 / sizeof(K);
         const uint64_t blocks = ((n_it + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
         hipLaunchKernelGGL((k_bounds_vec<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
@@ -1332,7 +1345,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         }
       }
       c->last_regs = regs;
-      if (verify || regs) {
+      if (scan5) {
+        ScanLaunch sl; std::memset(&sl, 0, sizeof sl);
+        sl.keys = keys; sl.sp = sp; sl.rp = rp; sl.st = c->d_state; sl.fl = fl; sl.long_min = lmin;
+        sl.out.leaf_start = leaf_start; sl.out.params = params; sl.out.leaf_err = err; sl.out.leaf_count = count; sl.out.rows = rows; sl.out.partials = part;
+        sl.peers = peers;
+        sl.host_split = (c->have_shard && c->shard_split_idx != ~0ull) ? 1 : 0;
+        sl.max_waves = c->scan_waves ? c->scan_waves : 12u * (unsigned int)c->n_cu;
+        if (rmi_scan_launch(ROOT, c->dtype, sl, s) != 0) { set_err(c, "internal: k_spline_scan is not built for root %d / key type %d", ROOT, c->dtype); return RMI_ERR_HIP; }
+        nrec = sl.waves;
+      } else if (verify || regs) {
       } else if (lanes_fused)
         hipLaunchKernelGGL((k_leaf_lanes<K, true, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
                            L, err, count, rows, part, rp, peers);
@@ -1372,14 +1394,15 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         mk();
         // (waves' aggregate records: [0, wb); their 64 slice sums, by k_list_tail: [wb, wb + 64); the records of k_finalize_listed behind)
         hipLaunchKernelGGL((k_list_tail<K>), dim3(2048), dim3(64), 0, s, keys, sp, leaf_start, dst, params, fl, segs, maxerr, run,
-                           fused ? (const StatsPartial*)part : (const StatsPartial*)nullptr, (unsigned int)wb, part + wb);
+                           fused ? (const StatsPartial*)part : (const StatsPartial*)nullptr, (unsigned int)nrec, part + nrec);
         mk();
         if (fused)
           hipLaunchKernelGGL((k_finalize_listed<K>), dim3(FL_BLOCKS), dim3(FL_THREADS), 0, s, keys, sp, L, leaf_start, dst, params, maxerr, run, err, count, rows,
-                             fl, part + wb, (unsigned int)SG_REGIONS, part + wb + SG_REGIONS, fticket, dst, hcopy, (const GiantLeaf*)nullptr, hmin);
+                             fl, part + nrec, (unsigned int)SG_REGIONS, part + nrec + SG_REGIONS, fticket, dst, hcopy, (const GiantLeaf*)nullptr, hmin);
       };
       if (optimistic) {
-        hipLaunchKernelGGL(k_lane_reduce, dim3(nsl), dim3(LF_SLICE), 0, s, (const StatsPartial*)part, (unsigned int)wb, part + wb + SG_REGIONS + 2 * FL_BLOCKS + 1,
+        const unsigned int nsl = (unsigned int)((nrec + LF_SLICE - 1) / LF_SLICE);
+        hipLaunchKernelGGL(k_lane_reduce, dim3(nsl), dim3(LF_SLICE), 0, s, (const StatsPartial*)part, (unsigned int)nrec, part + nrec + SG_REGIONS + 2 * FL_BLOCKS + 1,
                            c->d_tickets, fl, dst, hcopy);
         mark(); mark();
         c->tail_armed = true;

@@ -133,11 +133,11 @@ __global__ void __launch_bounds__(256) k_cubic_root_sums(const K* __restrict__ k
 // (map_scale!, models/mod.rs:238-250); slots after the last present one hold table.len() (:112-114).
 // The first key of a slot differs from its predecessor, so its FixDups offset is its own index.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_table_init(unsigned long long* __restrict__ first_idx, uint64_t slots) {
+static __global__ void __launch_bounds__(256) k_table_init(unsigned long long* __restrict__ first_idx, uint64_t slots) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= slots; j += stride) first_idx[j] = NO_START;
 }
-__global__ void __launch_bounds__(256) k_table_from_starts(const unsigned long long* __restrict__ first_idx, uint64_t slots,
+static __global__ void __launch_bounds__(256) k_table_from_starts(const unsigned long long* __restrict__ first_idx, uint64_t slots,
                                                            double scale, int scaled, unsigned int* __restrict__ table) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < slots; j += stride) {
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_table_from_starts(const unsigned long l
 // ---------------------------------------------------------------------------------------------
 // `arrays` = false (the leaf-lane pipeline with its search and its fused error pass: every entry of the three arrays is
 // written by a plain store later on): only the sentinel, the list counters and the state -- a launch of one block.
-__global__ void __launch_bounds__(256) k_init(unsigned long long* __restrict__ leaf_start,
+static __global__ void __launch_bounds__(256) k_init(unsigned long long* __restrict__ leaf_start,
                                               unsigned long long* __restrict__ maxerr,
                                               unsigned long long* __restrict__ run, uint64_t L_own,
                                               unsigned long long sentinel, DevState* __restrict__ st, DevState init,
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) k_bounds_vec(const K* __restrict__ keys, 
 // ---------------------------------------------------------------------------------------------
 constexpr int FILL_TILE = 2048;
 
-__global__ void __launch_bounds__(256) k_fill_tilemin(const unsigned long long* __restrict__ ls, uint64_t count,
+static __global__ void __launch_bounds__(256) k_fill_tilemin(const unsigned long long* __restrict__ ls, uint64_t count,
                                                       unsigned long long* __restrict__ tile_min) {
   __shared__ unsigned long long sm[256];
   const uint64_t base = (uint64_t)blockIdx.x * FILL_TILE;
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) k_fill_tilemin(const unsigned long long* 
 }
 
 // single block: exclusive suffix-min over the tile minima (carry-in for each tile)
-__global__ void __launch_bounds__(1024) k_fill_scan_tiles(unsigned long long* __restrict__ tile_min, uint64_t ntiles) {
+static __global__ void __launch_bounds__(1024) k_fill_scan_tiles(unsigned long long* __restrict__ tile_min, uint64_t ntiles) {
   __shared__ unsigned long long sm[1024];
   // each thread owns a contiguous span of tiles, processed right-to-left
   const uint64_t per = (ntiles + 1023) / 1024;
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(1024) k_fill_scan_tiles(unsigned long long* __
   }
 }
 
-__global__ void __launch_bounds__(256) k_fill_apply(unsigned long long* __restrict__ ls, uint64_t count,
+static __global__ void __launch_bounds__(256) k_fill_apply(unsigned long long* __restrict__ ls, uint64_t count,
                                                     const unsigned long long* __restrict__ tile_carry) {
   // tile of 2048 entries; thread t owns 8 consecutive entries, block-level exclusive suffix-min
   // across threads via LDS.
@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(256) k_finalize(const K* __restrict__ keys, Sp
   if (threadIdx.x == 0) partials[blockIdx.x] = StatsPartial{st_mx, st_mi, st_sum, st_l2, st_lg};
 }
 
-__global__ void __launch_bounds__(1024) k_stats_reduce(const StatsPartial* __restrict__ partials, int count, DevState* __restrict__ st,
+static __global__ void __launch_bounds__(1024) k_stats_reduce(const StatsPartial* __restrict__ partials, int count, DevState* __restrict__ st,
                                                        DevState* __restrict__ host_copy) {
   unsigned long long mx = 0, mi = 0, sm = 0;
   double l2 = 0.0, lg = 0.0;

@@ -80,7 +80,7 @@ constexpr int LS_BLOCK = RMI_LS_BLOCK;   // leaves per block of k_leaf_search
 // RN(1 / k) for the running count k of the lockstep walk: rtab[i] = 1 / (i + 1).  Wave-uniform, read through the
 // scalar cache in two 64-byte loads per panel (SGPR operands of the quotient: no vector instruction, no VGPR).
 // ... and next to it the count itself and (k - 1) / 2 as doubles: tab[i], tab[LN_TMAX + i], tab[2 LN_TMAX + i] for k = i + 1.
-__global__ void __launch_bounds__(256) k_lane_table(double* __restrict__ tab, int count) {
+static __global__ void __launch_bounds__(256) k_lane_table(double* __restrict__ tab, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) { tab[i] = 1.0 / (double)(i + 1); tab[count + i] = (double)(i + 1); tab[2 * count + i] = (double)i * 0.5; }
 }
@@ -750,7 +750,7 @@ __device__ __forceinline__ void lf_block_reduce(StatsPartial& a, StatsPartial* s
   __syncthreads();
   if (threadIdx.x == 0) lf_combine(a, *s_w);
 }
-__global__ void __launch_bounds__(LF_SLICE) k_lane_reduce(const StatsPartial* __restrict__ partials, unsigned int nwaves,
+static __global__ void __launch_bounds__(LF_SLICE) k_lane_reduce(const StatsPartial* __restrict__ partials, unsigned int nwaves,
                                                           StatsPartial* __restrict__ slices, unsigned int* __restrict__ ticket,
                                                           SgList fl, DevState* __restrict__ st, DevState* __restrict__ host_copy) {
   static_assert(LF_SLICE == 128 && SG_REGIONS == 64, "two waves per block; one hand-over counter per lane");
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(256) k_verify_listed(const K* __restrict__ key
 }
 
 // the error pass of the giant leaves, once the host has written their coefficients: stretches for k_list_tail
-__global__ void __launch_bounds__(64) k_giant_segments(const GiantLeaf* __restrict__ giant, const unsigned long long* __restrict__ leaf_start,
+static __global__ void __launch_bounds__(64) k_giant_segments(const GiantLeaf* __restrict__ giant, const unsigned long long* __restrict__ leaf_start,
                                                        DevState* __restrict__ st, unsigned long long* __restrict__ segs,
                                                        unsigned long long* __restrict__ leaf_maxerr, unsigned long long* __restrict__ leaf_run) {
   const unsigned long long cnt = st->giant_count < st->giant_cap ? st->giant_count : st->giant_cap;

@@ -76,7 +76,7 @@ __device__ __forceinline__ void rg_static_for(F&& f) {
 // reciprocal (1 / k = r + rl to 2^-105: div_by_count2 of rmi_stream.hip.h, one FMA fewer than div_by_count -- an FMA costs 7.3
 // cycles on this chip, an addition or a multiplication 4), (k - 1) / 2, k.  The walk takes them a quarter block (4 steps) at a time,
 // one ahead: 128 bytes per quarter, two scalar loads.
-__global__ void __launch_bounds__(256) k_regs_table(double* __restrict__ tab, int count) {
+static __global__ void __launch_bounds__(256) k_regs_table(double* __restrict__ tab, int count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) {
     const double nf = (double)(i + 1), r = 1.0 / nf;

@@ -1,0 +1,53 @@
+// rmi_scan.hip -- translation unit of pipeline 5 (k_spline_scan, rmi_scan.hip.h) and its launcher.
+#include <hip/hip_runtime.h>
+
+#include "rmi_scan.hip.h"
+
+namespace rmi {
+
+template <int ROOT, typename K, int V>
+static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
+  using G = ScGeom<K, V>;
+  const K* keys = (const K*)a.keys;
+  // tiles start at 128-byte lines of the key array (the 16-byte chunks of a tile are aligned by ADDRESS)
+  const uint64_t align = 128 / sizeof(K);
+  const uint64_t mis = (uint64_t)((reinterpret_cast<uintptr_t>(keys + a.sp.it_lo) / sizeof(K)) % align);
+  const long long tile0 = (long long)a.sp.it_lo - (long long)mis;
+  const uint64_t rel_hi = a.sp.it_hi - (uint64_t)tile0;
+  const unsigned int ntiles = (unsigned int)(rel_hi / G::TILE + 1);             // (the position behind the last key lies in a tile)
+  const unsigned int tpx = (ntiles + 7u) / 8u;
+  unsigned int grid = (ntiles + 7u) & ~7u;
+  if (grid > a.max_waves) grid = a.max_waves & ~7u;
+  if (grid > SCAN_MAX_WAVES) grid = SCAN_MAX_WAVES;
+  if (grid < 8u) grid = 8u;
+  a.waves = grid;
+  ScanArgs ka;
+  ka.keys = a.keys; ka.tile0 = tile0; ka.ntiles = ntiles; ka.tiles_per_xcd = tpx; ka.long_min = a.long_min; ka.host_split = a.host_split;
+  ka.st = a.st; ka.sp = a.sp; ka.r = a.rp; ka.out = a.out; ka.fl = a.fl; ka.peers = a.peers;
+  hipLaunchKernelGGL((k_spline_scan<ROOT, K, V>), dim3(grid), dim3(64), 0, s, ka);
+  return 0;
+}
+
+template <int ROOT>
+static int scan_launch_k(int dtype, ScanLaunch& a, hipStream_t s) {
+  switch (dtype) {
+    case 0: return scan_launch_t<ROOT, uint64_t, 16>(a, s);
+    case 1: return scan_launch_t<ROOT, uint32_t, 32>(a, s);
+    case 2: return scan_launch_t<ROOT, double, 16>(a, s);
+  }
+  return -1;
+}
+
+int rmi_scan_launch(int root, int dtype, ScanLaunch& a, hipStream_t s) {
+  switch (root) {
+    case K_LINEAR: return scan_launch_k<K_LINEAR>(dtype, a, s);
+    case K_CUBIC: return scan_launch_k<K_CUBIC>(dtype, a, s);
+    case K_RADIX: return scan_launch_k<K_RADIX>(dtype, a, s);
+    case K_RADIX_TABLE: return scan_launch_k<K_RADIX_TABLE>(dtype, a, s);
+    case K_LOGLINEAR: return scan_launch_k<K_LOGLINEAR>(dtype, a, s);
+    case K_NORMAL: return scan_launch_k<K_NORMAL>(dtype, a, s);
+  }
+  return -1;
+}
+
+}  // namespace rmi

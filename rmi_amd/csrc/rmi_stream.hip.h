@@ -804,7 +804,7 @@ __global__ void __launch_bounds__(64, 4) k_err_range(const K* __restrict__ keys,
 
 // Read-only streaming kernel: the box's achievable HBM read bandwidth in this harness (the
 // denominator SURVEY.md section 8d asks to report next to the 8 TB/s spec peak).
-__global__ void __launch_bounds__(256) k_read_bw(const uint4* __restrict__ src, uint64_t n16, unsigned int* __restrict__ sink) {
+static __global__ void __launch_bounds__(256) k_read_bw(const uint4* __restrict__ src, uint64_t n16, unsigned int* __restrict__ sink) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   unsigned int acc = 0;
@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(256) k_read_bw(const uint4* __restrict__ src, 
 
 // Self-test of div_by_count against IEEE division: every count 1..FS_TMAX-1 with pseudo-random
 // numerators and with numerators constructed next to rounding midpoints of the quotient.
-__global__ void __launch_bounds__(256) k_selftest_div(unsigned long long trials_per_thread, unsigned long long seed,
+static __global__ void __launch_bounds__(256) k_selftest_div(unsigned long long trials_per_thread, unsigned long long seed,
                                                       unsigned long long* __restrict__ mismatches) {
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long bad = 0;
@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(64) k_fit_long(const K* __restrict__ keys, Spa
 }
 
 // recip_exact(n) == 1.0 / n for every integer n in [n_lo, n_hi)
-__global__ void __launch_bounds__(256) k_selftest_recip(unsigned long long n_lo, unsigned long long n_hi,
+static __global__ void __launch_bounds__(256) k_selftest_recip(unsigned long long n_lo, unsigned long long n_hi,
                                                         unsigned long long* __restrict__ mismatches) {
   unsigned long long bad = 0;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;

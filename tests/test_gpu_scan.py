@@ -1,0 +1,126 @@
+"""Pipeline 5 (rmi_amd/csrc/rmi_scan.hip.h: k_spline_scan -- bucketing scan, linear_spline end points, error pass and leaf
+ends in one key-parallel read) against the oracle through the C ABI.  Bar: bucket table, error integers, counts AND
+coefficients bit-identical (linear_spline.rs:13-35 has no order-dependent arithmetic), the reference's panics as the same
+error codes.  Every case asserts that pipeline 5 ran."""
+import numpy as np
+import pytest
+
+from rmi_amd import datagen as dg
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(monkeypatch, oracle, keys, root, L, env=None, expect_pipeline=5):
+    from rmi_amd import train
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    tr = train.Trainer(keys)
+    g_root = tr.fit_root(root, L)
+    try:
+        o = oracle.train_two_layer(root, "linear_spline", keys, L)
+    except oracle.OracleError as oe:
+        with pytest.raises(train.RMIError) as ge:
+            tr.train_leaves(g_root, "linear_spline", L)
+        assert ge.value.code == oe.code
+        tr.close()
+        return None
+    g = tr.train_leaves(g_root, "linear_spline", L)
+    assert g.pipeline == expect_pipeline
+    assert np.array_equal(g.leaf_starts, o.leaf_start), "bucket assignment differs"
+    bad = np.flatnonzero((g.leaf_params.view(np.uint64) != o.leaf_params.view(np.uint64)).any(axis=1))
+    assert bad.size == 0, f"{bad.size} coefficient rows differ, first at leaf {bad[:5]}"
+    bad = np.flatnonzero(g.last_layer_max_l1s != o.leaf_err)
+    assert bad.size == 0, f"{bad.size} error integers differ, first at leaf {bad[:5]}: {g.last_layer_max_l1s[bad[:5]]} vs {o.leaf_err[bad[:5]]}"
+    assert np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx
+    assert g.model_avg_error == o.model_avg_error
+    assert abs(g.model_avg_l2_error - o.model_avg_l2_error) <= 1e-9 * max(1.0, abs(o.model_avg_l2_error))
+    assert abs(g.model_avg_log2_error - o.model_avg_log2_error) <= 1e-9 * max(1.0, abs(o.model_avg_log2_error))
+    rows = g.rows.view(np.uint64).reshape(L, 3)
+    assert np.array_equal(rows[:, :2], g.leaf_params.view(np.uint64)) and np.array_equal(rows[:, 2], g.last_layer_max_l1s)
+    tr.close()
+    return g
+
+
+GENS = ["uniform_u64", "books_u64", "dups_u64", "clustered_u64", "uniform_u32", "dups_u32", "uniform_f64"]
+ROOTS = ["linear", "radix", "cubic", "linear_spline", "robust_linear", "radix18", "bradix", "normal", "loglinear"]
+
+
+@pytest.mark.parametrize("gen", GENS)
+@pytest.mark.parametrize("root", ROOTS)
+def test_scan_roots_and_key_types(monkeypatch, oracle, gen, root):
+    if gen == "uniform_f64" and root.startswith("radix"):
+        pytest.skip("radix roots take integer keys")
+    _check(monkeypatch, oracle, dg.GENERATORS[gen](300_000), root, 4096)
+
+
+@pytest.mark.parametrize("gen", ["uniform_u64", "dups_u64", "books_u64", "uniform_u32", "dups_u32"])
+@pytest.mark.parametrize("n,L", [
+    (300_000, 64),            # leaves far longer than a tile: every leaf runs over tiles, most go to the list kernels
+    (300_001, 1000), (299_999, 3333),
+    (300_000, 40_000),        # 7.5 keys per leaf: more leaf starts in a tile than a batch of slots holds
+    (100_000, 99_999),        # a key per leaf
+    (50_000, 200_000),        # more leaves than keys: long gaps of empty leaves
+    (2_000_000, 2048), (2_000_000, 1 << 17),
+    (1500, 7), (1, 1), (2, 2), (3, 4), (65, 1), (64, 2), (2048, 16), (2049, 16), (1024, 1024), (1025, 3),
+])
+def test_scan_geometry(monkeypatch, oracle, gen, n, L):
+    """Tile, slot-batch and look-ahead geometry: sizes around the tile (1 024 keys of 8 bytes, 2 048 of 4), leaves per tile
+    below / above the 64 slots of a batch, leaves longer than the look-ahead and than `long_min`, gaps of empty leaves."""
+    _check(monkeypatch, oracle, dg.GENERATORS[gen](n), "linear", L)
+
+
+@pytest.mark.parametrize("gen", ["uniform_u64", "dups_u64", "uniform_u32"])
+@pytest.mark.parametrize("env", [{"RMI_HIP_LONG_MIN": "64"}, {"RMI_HIP_LONG_MIN": "256", "RMI_HIP_OPT_TAIL": "0"}, {"RMI_HIP_SCAN_WAVES": "8"},
+                                 {"RMI_HIP_SCAN_WAVES": "40"}])
+def test_scan_lists_and_grids(monkeypatch, oracle, gen, env):
+    """Leaves that run on behind their tile for more than long_min keys go to the list kernels (behind the synchronisation, or in the
+    stream); few persistent waves: many tiles per wave."""
+    _check(monkeypatch, oracle, dg.GENERATORS[gen](400_000), "linear", 700, env=env)
+    _check(monkeypatch, oracle, dg.GENERATORS[gen](400_000), "radix" if gen != "uniform_f64" else "linear", 4096, env=env)
+
+
+@pytest.mark.parametrize("root,params", [("cubic", (0.0, 0.0, -1e-15, 3000.0)), ("cubic", (0.0, 0.0, 1e-13, 0.0)), ("cubic", (1e-50, -3e-32, 2e-14, 5.0)),
+                                         ("linear", (5000.0, -2e-16, 0.0, 0.0)), ("linear", (0.0, 1e-12, 0.0, 0.0))])
+def test_scan_reports_the_reference_panics(monkeypatch, oracle, root, params):
+    """Caller-provided roots that decrease, leave [0, L) or wiggle: the scan checks every adjacent pair of targets like
+    two_layer.rs:45-50; same error code (or the same result) as the scan-based pipeline 2."""
+    from rmi_amd import train
+    keys = dg.uniform_u64(300_000)
+    L = 4096
+    kind = {"linear": 0, "cubic": 2}[root]
+    model = train.Model(kind, params, (0, 0, 0, 0))
+    outs = []
+    for env in ({"RMI_HIP_PIPELINE": "3"}, {"RMI_HIP_PIPELINE": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = train.Trainer(keys)
+        try:
+            g = tr.train_leaves(model, "linear_spline", L).materialize()
+            outs.append(("ok", g.last_layer_max_l1s.copy(), g.leaf_params.copy(), g.pipeline))
+        except train.RMIError as e:
+            outs.append(("err", e.code, None, None))
+        tr.close()
+    assert outs[0][0] == outs[1][0], (outs[0][:2], outs[1][:2])
+    if outs[0][0] == "err":
+        assert outs[0][1] == outs[1][1]
+    else:
+        assert outs[0][3] == 5
+        assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2].view(np.uint64), outs[1][2].view(np.uint64))
+
+
+def test_scan_equals_the_leaf_lane_kernel(monkeypatch):
+    """k_spline_scan against k_leaf_lanes<.., K_LINEAR_SPLINE> (RMI_HIP_SCAN=0) on 20 M keys: every output array the same bytes."""
+    from rmi_amd import train
+    res = {}
+    for scan in ("1", "0"):
+        monkeypatch.setenv("RMI_HIP_SCAN", scan)
+        tr = train.Trainer()
+        tr.generate_keys("dups", np.uint32, 20_000_000)
+        root = tr.fit_root("radix", 1 << 18)
+        g = tr.train_leaves(root, "linear_spline", 1 << 18).materialize()
+        res[scan] = (g.pipeline, g.leaf_starts.copy(), g.rows.copy(), g.leaf_counts.copy(), g.model_max_error, g.model_max_error_idx, g.model_avg_error)
+        tr.close()
+    assert res["1"][0] == 5 and res["0"][0] == 3
+    for a, b in zip(res["1"][1:], res["0"][1:]):
+        assert np.array_equal(a, b)
