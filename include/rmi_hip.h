@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RMI_HIP_ABI_VERSION 5
+#define RMI_HIP_ABI_VERSION 6
 
 /* src/load.rs:15-19 */
 enum rmi_hip_key_dtype { RMI_KEY_U64 = 0, RMI_KEY_U32 = 1, RMI_KEY_F64 = 2 };
@@ -162,11 +162,14 @@ const char* rmi_hip_strerror(int code);
  * selects 2 at creation. */
 int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
 /* How linear leaves (linear.rs:12-59) are fitted:
- *   RMI_FIT_EXACT (default, and the fastest mode since the leaf-lane kernels of rmi_lanes.hip.h): the reference's
- *     recurrence in the reference's order; coefficients, error integers and counts bit-identical to the reference.  Leaf
- *     boundaries by search, 64 leaves per wave in lockstep, error pass and finalize fused behind the fit; containers of
- *     more than 4 096 points one wave each, of more than 262 144 points on a host core (RMI_HIP_HOST_MIN).  The keys are
- *     read twice (the second read largely from the Infinity Cache).  This is the mode every figure of merit is quoted in.
+ *   RMI_FIT_EXACT (default, and the fastest mode): the reference's recurrence in the reference's order; coefficients,
+ *     error integers and counts bit-identical to the reference.  Leaf boundaries by search, 64 leaves per wave in lockstep.
+ *     8-byte keys with at most 208 keys a leaf on average: k_leaf_regs (rmi_regs.hip.h) -- the keys are read ONCE and stay
+ *     in the lanes' registers between a leaf's fit and its error pass, the leaf ends in k_regs_finalize.  Otherwise
+ *     k_leaf_lanes (rmi_lanes.hip.h): error pass and finalize fused behind the fit, the keys are read twice (the second
+ *     read largely from the Infinity Cache).  Containers of more than 4 096 points one wave each, of more than 262 144
+ *     points on a host core (RMI_HIP_HOST_MIN).  This is the mode every figure of merit is quoted in; DESIGN.md holds the
+ *     table configuration -> kernels.
  *   RMI_FIT_ONEPASS_GUARDED (an opt-in FAST mode: its coefficients do NOT meet a 1e-9 relative tolerance on every
  *     leaf): ONE pass over the keys; a leaf's line from shifted sums (n, S dx, S dx^2,
  *     S dx dy) reduced in parallel, the error pass from LDS.  Bucket ids, per-leaf error integers and
@@ -195,9 +198,9 @@ int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
  * uniform / heavy-tailed / clustered key sets of 200 M keys, is 0.46 of the bound with factor 1).  Leaf kinds other
  * than `linear` ignore the mode. */
 enum rmi_hip_fit_mode { RMI_FIT_EXACT = 0, RMI_FIT_ONEPASS_GUARDED = 1, RMI_FIT_ONEPASS = 2 };
-/* linear_spline leaves (the line through the two end points of a container, linear_spline.rs:13-35) are exact in every
- * mode: through the leaf-lane kernels (fit_mode_used 0), or -- RMI_HIP_SPLINE_LANES=0 -- through the one-pass kernel,
- * which reproduces them bit for bit as well; rmi_hip_result.fit_mode_used then reads RMI_FIT_USED_ONEPASS_EXACT. */
+/* linear_spline leaves (the line through the two end points of a container, linear_spline.rs:13-35) have no recurrence and are
+ * exact in every mode (fit_mode_used 0): k_spline_scan (rmi_scan.hip.h) reads the keys ONCE, key-parallel -- bucketing scan,
+ * end points, error pass and leaf ends in the same pass, for every root and key type. */
 enum { RMI_FIT_USED_ONEPASS_EXACT = 3 };
 int rmi_hip_set_fit_mode(rmi_hip_ctx* ctx, int mode, double guard_k);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = context's own. */
@@ -231,7 +234,11 @@ int rmi_hip_key_buffer(const rmi_hip_ctx* ctx, const void** device_keys, uint64_
  * (1 .. 16) at a time, each on a context of the library's own that borrows the keys (most configurations fill the GPU alone, but
  * those with few, long leaves are a handful of sequential chains: in flight together they cost the time of one).  results[i] holds
  * the aggregates of configs[i] (the per-leaf arrays are not kept); rcs (may be NULL) the per-configuration return codes -- where
- * the reference panics for ONE configuration the others still train.  Returns the first non-zero code, or RMI_OK.  (v5) */
+ * the reference panics for ONE configuration the others still train.  Returns the first non-zero code, or RMI_OK; then
+ * rmi_hip_last_error holds every failing worker's first message.  What rmi_hip_set_fit_mode / rmi_hip_set_profile_level have set
+ * on `ctx` holds for every training of the batch.  RMI_ERR_BAD_ARG for a context that holds a shard (rmi_hip_set_shard) or a
+ * streamed training, and for a radix-table root without its table.  The worker contexts stay with `ctx` for the next call (each
+ * keeps per-leaf buffers of the largest leaf count it trained): rmi_hip_release_views frees them.  (v5; the rules v6) */
 typedef struct {
   rmi_hip_model_params root;      /* from rmi_hip_fit_root / rmi_hip_fit_root_fast */
   int32_t leaf_kind;              /* RMI_MODEL_* */
@@ -242,6 +249,7 @@ typedef struct {
 } rmi_hip_train_config;
 int rmi_hip_train_many(rmi_hip_ctx* ctx, const rmi_hip_train_config* configs, uint64_t count, int in_flight,
                        rmi_hip_result* results, int* rcs);
+int rmi_hip_release_views(rmi_hip_ctx* ctx);
 /* Synthetic sorted keys generated in HBM (bit-identical to rmi_amd/datagen.py):
  * generator 0 = uniform, 1 = uniform with duplicate runs.  Produces indices
  * [start, start+count) of the n_global-key array (so ranks can generate their own shard).
@@ -261,6 +269,9 @@ int rmi_hip_selftest_recip(rmi_hip_ctx* ctx, uint64_t n_lo, uint64_t n_hi, uint6
 /* Achieved HBM read bandwidth (GB/s) of a read-only streaming kernel over the resident keys:
  * the measured denominator reported next to the 8 TB/s spec peak. */
 int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* ctx, int iters, double* gb_per_s);
+/* ... by access pattern: 0 = grid-stride 16-byte loads (the function above), 1 = every wave reads contiguous pieces of 8 KB with
+ * non-temporal loads, the pattern of the one-read kernels and the best read-only pattern found on this machine.  (v6) */
+int rmi_hip_measure_read_bandwidth_ex(rmi_hip_ctx* ctx, int iters, int pattern, double* gb_per_s);
 
 /* ---- multi-GPU sharding ----
  * A rank owns the contiguous leaf range [leaf_lo, leaf_hi) and the keys [key_lo, key_hi) that the
@@ -321,7 +332,7 @@ int rmi_hip_download_rows_full(rmi_hip_ctx* ctx, void* host_out, uint64_t capaci
  * mailbox as IPC handles, imports its peers' (any channel carries the RMI_HIP_PEER_HANDLE_BYTES), and with
  * rmi_hip_set_exchange(ctx, RMI_EXCHANGE_DIRECT) rmi_hip_train_sharded ends with: one kernel that stores this rank's
  * slice into every peer's table, one that publishes the aggregates and an epoch flag in every peer's mailbox (system
- * scope), one that waits for the G flags of this epoch (bounded: 5 s, then RMI_ERR_HIP).  No RCCL needed.
+ * scope), one that waits for the G flags of this epoch (bounded: 60 s, then RMI_ERR_HIP).  No RCCL needed.
  * Works across processes on ONE device too (how it is tested here); across devices it has NOT run yet -- it is opt-in,
  * and bench.py --exchange auto validates its table against the RCCL exchange before preferring it. */
 #define RMI_HIP_PEER_HANDLE_BYTES 256

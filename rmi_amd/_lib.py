@@ -53,6 +53,8 @@ SYMBOLS = [
     ("rmi_hip_strerror", C.c_char_p, [C.c_int]),
     ("rmi_hip_key_buffer", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     ("rmi_hip_train_many", C.c_int, [C.c_void_p, C.POINTER(TrainConfig), C.c_uint64, C.c_int, C.POINTER(Result), C.POINTER(C.c_int)]),
+    ("rmi_hip_release_views", C.c_int, [C.c_void_p]),
+    ("rmi_hip_measure_read_bandwidth_ex", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("rmi_hip_set_profile_level", C.c_int, [C.c_void_p, C.c_int]),
     ("rmi_hip_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("rmi_hip_set_fit_mode", C.c_int, [C.c_void_p, C.c_int, C.c_double]),

@@ -108,9 +108,10 @@ struct rmi_hip_ctx {
   uint64_t slow_cap = 0;
   int n_cu = 256;
   bool last_regs = false;
+  void* d_gaps = nullptr;                       // pipeline 5: the listed stretches of empty leaves (GapRec)
   bool scan = true;                             // pipeline 5 (rmi_scan.hip.h): linear_spline leaves by the key-parallel one-read kernel (RMI_HIP_SCAN=0: k_leaf_lanes)
   bool last_scan = false;
-  unsigned int scan_waves = 0;                  // its persistent waves (0: 12 per CU, what the LDS holds)
+  unsigned int scan_waves = 0;                  // its persistent waves (0: as many as the device holds, rmi_scan_waves_per_cu)
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
   bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes (RMI_HIP_SPLINE_LANES=0: k_sigma2's spline variant)
   uint64_t edge_epoch = 0;                      // first / last resident key of the key set `keys_epoch` (radix roots: is the prefix common?)
@@ -355,6 +356,7 @@ static void free_outputs(rmi_hip_ctx* c) {
   if (c->d_cube) { (void)hipFree(c->d_cube); c->d_cube = nullptr; c->cube_cap = 0; }
   if (c->d_flist) { (void)hipFree(c->d_flist); c->d_flist = nullptr; c->flist_cap = 0; }
   if (c->d_flist_cnt) { (void)hipFree(c->d_flist_cnt); c->d_flist_cnt = nullptr; }
+  if (c->d_gaps) { (void)hipFree(c->d_gaps); c->d_gaps = nullptr; }
   if (c->d_bkeys) { (void)hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_cap = 0; }
   if (c->d_recs) { (void)hipFree(c->d_recs); c->d_recs = nullptr; c->recs_bytes = 0; }
   if (c->d_segs) { (void)hipFree(c->d_segs); c->d_segs = nullptr; c->segs_cap = 0; }
@@ -476,10 +478,22 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
   if (!c || (count && (!cfgs || !results))) return RMI_ERR_BAD_ARG;
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
   if (c->upload_thread.joinable()) { const int urc = rmi_hip_upload_wait(c); if (urc != RMI_OK) return urc; }
+  // a training of the batch is a plain training of the WHOLE resident key set on a context of its own: a shard, a running streamed
+  // training or a deferred synchronisation belong to one context and cannot be handed to the views
+  if (c->have_shard || c->stream_mode || c->defer_sync) {
+    set_err(c, "rmi_hip_train_many: the context holds a shard / a streamed or sharded training; train those one at a time");
+    return RMI_ERR_BAD_ARG;
+  }
+  for (uint64_t i = 0; i < count; i++)
+    if (cfgs[i].root.kind >= RMI_MODEL_RADIX8 && cfgs[i].root.kind <= RMI_MODEL_RADIX28 && !cfgs[i].root_table) {
+      set_err(c, "rmi_hip_train_many: configuration %llu has a radix-table root without its table", (unsigned long long)i);
+      return RMI_ERR_BAD_ARG;
+    }
   if (in_flight < 1) in_flight = 1;
   if ((uint64_t)in_flight > count) in_flight = (int)(count ? count : 1);
   if (in_flight > 16) in_flight = 16;
-  // the views: kept with the context; their keys are attached anew (the key set may have changed since the last call)
+  // the views: kept with the context (rmi_hip_release_views frees them); their keys are attached anew (the key set may have
+  // changed since the last call)
   while ((int)c->many_views.size() < in_flight - 1) {
     rmi_hip_ctx* v = nullptr;
     const int crc = rmi_hip_create(c->device, &v);
@@ -487,13 +501,17 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
     c->many_views.push_back(v);
   }
   for (int t = 0; t + 1 < in_flight; t++) {
-    const int arc = rmi_hip_attach_device_keys(c->many_views[t], c->d_keys, c->n, c->dtype);
+    rmi_hip_ctx* v = c->many_views[t];
+    const int arc = rmi_hip_attach_device_keys(v, c->d_keys, c->n, c->dtype);
     if (arc != RMI_OK) return arc;
-    c->many_views[t]->fit_mode = c->fit_mode;
+    // what the caller has set on the context holds for every training of the batch
+    v->fit_mode = c->fit_mode; v->guard_k = c->guard_k; v->profile_level = c->profile_level; v->host_min = c->host_min;
+    v->long_min = c->long_min; v->pipeline = c->pipeline; v->regs = c->regs; v->scan = c->scan; v->opt_tail = c->opt_tail;
   }
   std::atomic<uint64_t> next{0};
   std::vector<int> lrc(count, RMI_OK);
-  auto work = [&](rmi_hip_ctx* w) {
+  std::vector<std::string> werr((size_t)in_flight);                    // a worker's first message; merged behind the join
+  auto work = [&](rmi_hip_ctx* w, int slot) {
     (void)hipSetDevice(w->device);
     for (;;) {
       const uint64_t i = next.fetch_add(1);
@@ -501,24 +519,36 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
       std::memset(&results[i], 0, sizeof results[i]);
       lrc[i] = cfgs[i].root_table ? rmi_hip_set_root_table(w, cfgs[i].root_table, cfgs[i].root_table_entries) : RMI_OK;
       if (lrc[i] == RMI_OK) lrc[i] = rmi_hip_train_two_layer(w, &cfgs[i].root, cfgs[i].leaf_kind, cfgs[i].num_leaves, &results[i]);
-      if (lrc[i] != RMI_OK && w != c) {                                // (the first message is the caller's to read)
-        static std::mutex mu;
-        std::lock_guard<std::mutex> g(mu);
-        if (c->err.empty()) c->err = w->err;
+      if (lrc[i] != RMI_OK && werr[(size_t)slot].empty()) {
+        char head[64]; snprintf(head, sizeof head, "configuration %llu: ", (unsigned long long)i);
+        werr[(size_t)slot] = std::string(head) + w->err;
       }
     }
   };
   c->err.clear();
   std::vector<std::thread> th;
-  for (int t = 0; t + 1 < in_flight; t++) th.emplace_back(work, c->many_views[t]);
-  work(c);
+  for (int t = 0; t + 1 < in_flight; t++) th.emplace_back(work, c->many_views[t], t + 1);
+  work(c, 0);
   for (auto& t : th) t.join();
   int first = RMI_OK;
   for (uint64_t i = 0; i < count; i++) {
     if (rcs) rcs[i] = lrc[i];
     if (first == RMI_OK && lrc[i] != RMI_OK) first = lrc[i];
   }
+  if (first != RMI_OK) {                                               // (every failing worker's first message, in worker order)
+    std::string all;
+    for (const auto& e : werr) if (!e.empty()) { if (!all.empty()) all += "; "; all += e; }
+    c->err = all;
+  }
   return first;
+}
+
+// the contexts rmi_hip_train_many keeps between calls (each holds per-leaf buffers of the largest leaf count it trained)
+int rmi_hip_release_views(rmi_hip_ctx* c) {
+  if (!c) return RMI_ERR_BAD_ARG;
+  for (rmi_hip_ctx* v : c->many_views) rmi_hip_destroy(v);
+  c->many_views.clear();
+  return RMI_OK;
 }
 
 int rmi_hip_set_shard(rmi_hip_ctx* c, const rmi_hip_shard* sh) {
@@ -643,17 +673,21 @@ int rmi_hip_selftest_recip(rmi_hip_ctx* c, uint64_t n_lo, uint64_t n_hi, uint64_
   return RMI_OK;
 }
 
-int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* c, int iters, double* gb_per_s) {
-  if (!c || !gb_per_s || iters <= 0) return RMI_ERR_BAD_ARG;
+int rmi_hip_measure_read_bandwidth(rmi_hip_ctx* c, int iters, double* gb_per_s) { return rmi_hip_measure_read_bandwidth_ex(c, iters, 0, gb_per_s); }
+int rmi_hip_measure_read_bandwidth_ex(rmi_hip_ctx* c, int iters, int pattern, double* gb_per_s) {
+  if (!c || !gb_per_s || iters <= 0 || pattern < 0 || pattern > 1) return RMI_ERR_BAD_ARG;
   if (!c->d_keys || c->n == 0) return RMI_ERR_NO_KEYS;
   HIPCHK(c, hipSetDevice(c->device));
   const uint64_t bytes = c->n * key_size(c->dtype);
   const uint64_t n16 = bytes / 16;
   if (n16 == 0 || ((uintptr_t)c->d_keys & 15)) return RMI_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_read_bw, dim3(256 * 8), dim3(256), 0, c->stream, (const uint4*)c->d_keys, n16, (unsigned int*)c->d_state);
+  auto go = [&]() {
+    if (pattern == 1) hipLaunchKernelGGL(k_read_bw_chunk, dim3(256 * 2), dim3(256), 0, c->stream, (const uint4*)c->d_keys, n16, (unsigned int*)c->d_state);
+    else hipLaunchKernelGGL(k_read_bw, dim3(256 * 8), dim3(256), 0, c->stream, (const uint4*)c->d_keys, n16, (unsigned int*)c->d_state);
+  };
+  go();
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  for (int i = 0; i < iters; i++)
-    hipLaunchKernelGGL(k_read_bw, dim3(256 * 8), dim3(256), 0, c->stream, (const uint4*)c->d_keys, n16, (unsigned int*)c->d_state);
+  for (int i = 0; i < iters; i++) go();
   HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;
@@ -1057,7 +1091,7 @@ int rmi_hip_root_stream_finish(rmi_hip_root_stream* r, rmi_hip_model_params* out
 }  // extern "C"
 
 // aggregate records of a training: one per wave of 64 leaves (k_leaf_lanes, k_leaf_regs) or one per persistent wave (k_spline_scan)
-static inline uint64_t agg_records(uint64_t leaves) { const uint64_t w = (leaves + 63) / 64; return w > SCAN_MAX_WAVES ? w : (uint64_t)SCAN_MAX_WAVES; }
+static inline uint64_t agg_records(uint64_t leaves) { const uint64_t w = (leaves + 63) / 64, m = (uint64_t)SCAN_MAX_WAVES + SCAN_GAP_BLOCKS; return w > m ? w : m; }
 static inline uint64_t lane_slices(uint64_t leaves) { return (agg_records(leaves) + LF_SLICE - 1) / LF_SLICE; }
 static int ensure_outputs(rmi_hip_ctx* c, uint64_t L, int ppl) {
   if (L <= c->cap_leaves && ppl <= c->cap_ppl) return RMI_OK;
@@ -1182,10 +1216,12 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   // cubic roots: not monotone by arithmetic, but the search may assume it when k_leaf_lanes verifies every key's target
   // during its (fused) error pass -- no bucketing scan, no fill
   if constexpr (ROOT == K_CUBIC) lanes_search_plan = lanes && c->lanes_search && lanes_fused_plan && LEAF == K_LINEAR && std::isfinite(rp.p0) && std::isfinite(rp.p1) && std::isfinite(rp.p2) && std::isfinite(rp.p3);
+  bool scan_mono = false;                                  // pipeline 5: the root is monotone by arithmetic (its short form of a tile relies on it)
+  if constexpr (ROOT == K_LINEAR) scan_mono = scan5 && rp.p1 >= 0.0 && std::isfinite(rp.p0) && std::isfinite(rp.p1);
   if constexpr (ROOT == K_RADIX) {
     // (key << prefix) >> (64 - bits) is monotone in the key exactly when no key loses a distinguishing bit to the
     // shift: all resident keys share their top `prefix` bits.  First and last key of the sorted set decide; fetched once per key set.
-    if (lanes && c->lanes_search) {
+    if ((lanes && c->lanes_search) || scan5) {
       if (c->edge_epoch != c->keys_epoch) {
         K k0{}, k1{};
         HIPCHK(c, hipMemcpy(&k0, c->d_keys, sizeof(K), hipMemcpyDeviceToHost));
@@ -1194,6 +1230,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       }
       const unsigned pfx = rp.prefix & 63u;
       lanes_search_plan = pfx == 0u || ((c->edge_first ^ c->edge_last) >> (64u - pfx)) == 0ull;
+      scan_mono = scan5 && lanes_search_plan;
     }
   }
   if (scan5) lanes_search_plan = false;                    // (the scan finds the leaf starts itself)
@@ -1351,8 +1388,12 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         sl.out.leaf_start = leaf_start; sl.out.params = params; sl.out.leaf_err = err; sl.out.leaf_count = count; sl.out.rows = rows; sl.out.partials = part;
         sl.peers = peers;
         sl.host_split = (c->have_shard && c->shard_split_idx != ~0ull) ? 1 : 0;
-        sl.max_waves = c->scan_waves ? c->scan_waves : 12u * (unsigned int)c->n_cu;
+        sl.mono = scan_mono ? 1 : 0;
+        sl.max_waves = c->scan_waves ? c->scan_waves : rmi_scan_waves_per_cu() * (unsigned int)c->n_cu;
+        if (!c->d_gaps) HIPCHK(c, hipMalloc(&c->d_gaps, (size_t)SCAN_GAP_CAP * sizeof(GapRec)));
+        sl.gaps = (GapRec*)c->d_gaps; sl.gap_cnt = c->d_flist_cnt + 2 * SG_REGIONS + 1;   // (zeroed by k_init with the list counters)
         if (rmi_scan_launch(ROOT, c->dtype, sl, s) != 0) { set_err(c, "internal: k_spline_scan is not built for root %d / key type %d", ROOT, c->dtype); return RMI_ERR_HIP; }
+        (void)rmi_scan_gaps_launch(c->dtype, sl, s);
         nrec = sl.waves;
       } else if (verify || regs) {
       } else if (lanes_fused)

@@ -22,8 +22,8 @@ static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
   if (grid < 8u) grid = 8u;
   a.waves = grid;
   ScanArgs ka;
-  ka.keys = a.keys; ka.tile0 = tile0; ka.ntiles = ntiles; ka.tiles_per_xcd = tpx; ka.long_min = a.long_min; ka.host_split = a.host_split;
-  ka.st = a.st; ka.sp = a.sp; ka.r = a.rp; ka.out = a.out; ka.fl = a.fl; ka.peers = a.peers;
+  ka.keys = a.keys; ka.tile0 = tile0; ka.ntiles = ntiles; ka.tiles_per_xcd = tpx; ka.long_min = a.long_min; ka.host_split = a.host_split; ka.mono = a.mono;
+  ka.st = a.st; ka.sp = a.sp; ka.r = a.rp; ka.out = a.out; ka.fl = a.fl; ka.peers = a.peers; ka.gaps = a.gaps; ka.gap_cnt = a.gap_cnt;
   hipLaunchKernelGGL((k_spline_scan<ROOT, K, V>), dim3(grid), dim3(64), 0, s, ka);
   return 0;
 }
@@ -38,14 +38,30 @@ static int scan_launch_k(int dtype, ScanLaunch& a, hipStream_t s) {
   return -1;
 }
 
+unsigned int rmi_scan_waves_per_cu() { return 4u * RMI_SC_WPE; }
+
+int rmi_scan_gaps_launch(int dtype, ScanLaunch& a, hipStream_t s) {
+  StatsPartial* const part = a.out.partials + a.waves;
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL((k_scan_gaps<uint64_t>), dim3(SCAN_GAP_BLOCKS), dim3(256), 0, s, (const uint64_t*)a.keys, a.sp, a.rp.L, a.out, a.peers, (const GapRec*)a.gaps, (const unsigned long long*)a.gap_cnt, part); break;
+    case 1: hipLaunchKernelGGL((k_scan_gaps<uint32_t>), dim3(SCAN_GAP_BLOCKS), dim3(256), 0, s, (const uint32_t*)a.keys, a.sp, a.rp.L, a.out, a.peers, (const GapRec*)a.gaps, (const unsigned long long*)a.gap_cnt, part); break;
+    case 2: hipLaunchKernelGGL((k_scan_gaps<double>), dim3(SCAN_GAP_BLOCKS), dim3(256), 0, s, (const double*)a.keys, a.sp, a.rp.L, a.out, a.peers, (const GapRec*)a.gaps, (const unsigned long long*)a.gap_cnt, part); break;
+    default: return -1;
+  }
+  a.waves += SCAN_GAP_BLOCKS;
+  return 0;
+}
+
 int rmi_scan_launch(int root, int dtype, ScanLaunch& a, hipStream_t s) {
   switch (root) {
     case K_LINEAR: return scan_launch_k<K_LINEAR>(dtype, a, s);
-    case K_CUBIC: return scan_launch_k<K_CUBIC>(dtype, a, s);
     case K_RADIX: return scan_launch_k<K_RADIX>(dtype, a, s);
+#ifndef RMI_SC_DEV                    // (development builds: two roots compile in a third of the time)
+    case K_CUBIC: return scan_launch_k<K_CUBIC>(dtype, a, s);
     case K_RADIX_TABLE: return scan_launch_k<K_RADIX_TABLE>(dtype, a, s);
     case K_LOGLINEAR: return scan_launch_k<K_LOGLINEAR>(dtype, a, s);
     case K_NORMAL: return scan_launch_k<K_NORMAL>(dtype, a, s);
+#endif
   }
   return -1;
 }

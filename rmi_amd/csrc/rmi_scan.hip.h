@@ -29,6 +29,12 @@
 //   * P5  lane q = slot q: finalize_one_pre (two_layer.rs:185-197, 226-259), row (codegen.rs:288-315), counts, the terms of
 //         the aggregates (two_layer.rs:267-287) into per-lane accumulators that live as long as the wave; empty leaves in
 //         front of a leaf start are finished by the lane that holds the start (long gaps: by the whole wave).
+//   * The ORDINARY tile -- inside the launch, a root whose targets are monotone by arithmetic (linear with a slope >= 0, radix over a
+//     common prefix), at most one leaf start per lane, the open leaf's end within the look-ahead, the split of the 2-way join not
+//     nearby -- takes a short form of the same phases: the leaf start of a lane by bisection of its row (5 targets instead of 32),
+//     slot numbers from one ballot, containers [s - 1, e] without the closed form, an error pass without a test per key (the model
+//     switches where some lane's start lies: a scalar test), the widening in 32 bits.  Anything else falls back to the general form
+//     BEFORE a byte is stored: both forms write the same values.
 // No order-dependent reduction anywhere: integers and coefficients are the oracle's bit for bit by construction.
 // Algorithmic bytes: N sizeof(key) + 24 L; this kernel reads every key once (+ 1/16 of look-ahead that the
 // neighbouring wave of the same XCD has in L2) and writes rows, leaf_start and -- unless `lean` -- params, err, count.
@@ -42,6 +48,28 @@
 #ifndef RMI_SC_STOP
 #define RMI_SC_STOP 0                 // debugging: leave a tile after phase n (results wrong)
 #endif
+#ifndef RMI_SC_PROF
+#define RMI_SC_PROF 0                 // development: cycles per phase of the short form, printed by a few waves (perturbs the kernel)
+#endif
+#if RMI_SC_PROF
+#define SC_TICK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof[k] += t_ - tlast; tlast = t_; } while (0)
+#define SC_GT(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); gprof[k] += t_ - glast; glast = t_; } while (0)
+#else
+#define SC_TICK(k) do { } while (0)
+#define SC_GT(k) do { } while (0)
+#endif
+#ifndef RMI_SC_LEANTEST
+#define RMI_SC_LEANTEST 0
+#endif
+#ifndef RMI_SC_FAST
+#define RMI_SC_FAST 1                 // 0: every tile through the general form
+#endif
+#ifndef RMI_SC_FAST_DUPS
+#define RMI_SC_FAST_DUPS 1            // 0: tiles with duplicate keys through the general form
+#endif
+#ifndef RMI_SC_WPE
+#define RMI_SC_WPE 2                  // waves per SIMD the kernel is compiled for (register budget 512 / that)
+#endif
 #include "rmi_scan_launch.h"
 
 namespace rmi {
@@ -53,11 +81,18 @@ template <typename K, int V> struct ScGeom {
   static constexpr int ROWD = V * DW;                    // dwords of a lane's keys
   static constexpr int S = ROWD + 4;                     // padded row stride in dwords: 4 x odd
   static constexpr int NCH = ROWD / 4;                   // 16-byte chunks per lane and tile
-  static constexpr int EXTC = 32;                        // chunks of look-ahead behind the tile (lanes 1..32 of the aux load)
+  static constexpr int EXTC = 32;                        // chunks of look-ahead behind the tile
   static constexpr int EXTN = EXTC * KPC;                // ... in keys: 128 (4-byte keys), 64 (8-byte keys)
-  static constexpr int LDS_DW = 4 + 64 * S + EXTN * DW;  // [left halo chunk][tile rows][look-ahead]
-  static_assert(V <= 32 && (V & (V - 1)) == 0, "a bit per key in a 32-bit mask");
-  static_assert(ROWD % 8 == 0, "row stride 4 x odd");
+  static constexpr int FHC = 4;                          // chunks in front of the tile (FixDups offsets of the keys around a tile's first key)
+  static constexpr int FHN = FHC * KPC;                  // ... in keys: 16 / 8
+  // ONE address rule for the front chunks, the tile and the look-ahead: the key with tile-relative index rel (in [-FHN, TILE + EXTN))
+  // has its first dword at T0 + d + 4 floor(d / ROWD), d = rel DW -- rows of ROWD dwords, 4 dwords of padding behind each
+  static constexpr int T0 = FHC * 4 + 4;
+  static constexpr int LDS_DW = T0 + 64 * S + (EXTC * 4 / ROWD) * S;
+  static constexpr int LOGV = V == 32 ? 5 : (V == 16 ? 4 : (V == 8 ? 3 : -1));
+  static_assert(V <= 32 && LOGV > 0, "a bit per key in a 32-bit mask");
+  static_assert(ROWD == 32, "the address rule shifts by 5");
+  static_assert(FHC + EXTC <= 64, "one aux chunk per lane");
 };
 constexpr int SC_SLOTS = 64;                             // leaves per batch: one per lane in P3 / P5
 
@@ -105,25 +140,33 @@ struct ScAgg {
   }
 };
 
+// The kernarg segment, in the CONSTANT address space: a load through this pointer is a scalar load (through a generic pointer it
+// is a flat VECTOR load of host-visible memory -- microseconds, and a wait for every key load in flight).
 // (the builtin exists in the device pass only; the host pass merely parses the kernel)
-__device__ __forceinline__ const void* sc_kernarg_ptr() {
+#define SC_AS4 __attribute__((address_space(4)))
+typedef const SC_AS4 unsigned char* sc_kargp;
+__device__ __forceinline__ sc_kargp sc_kernarg_ptr() {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  return (sc_kargp)__builtin_amdgcn_kernarg_segment_ptr();
 #else
   return nullptr;
 #endif
 }
+// field `m` (type T) of the ScanArgs behind the kernarg pointer p
+template <typename T> struct ScAs4 { typedef const T SC_AS4* ptr; };
+#define SC_ARG(p, T, m) (*reinterpret_cast<typename ScAs4<T>::ptr>((p) + offsetof(ScanArgs, m)))
 
 // The kernel's arguments: ONE plain struct.  The kernel never names its parameter: it reads the fields through the kernarg segment
-// pointer, the hot ones once into registers, the cold ones (output pointers, peers' tables, the list) where they are used, behind a
-// compiler barrier on the pointer -- named parameters are all loaded at the kernel's entry and then live (= spilled: 100+ SGPRs)
-// for the whole kernel.
+// pointer, the hot ones once into registers, the cold ones (output pointers, peers' tables, the list) where they are used (SC_ARG),
+// behind a compiler barrier on the pointer -- named parameters are all loaded at the kernel's entry and then live (= spilled: 100+
+// SGPRs) for the whole kernel.
 struct ScanArgs {
   const void* keys;               // pre-offset: keys[global index]
   long long tile0;                // global index of the first tile's first position (<= it_lo, a 128-byte line of the key array)
   unsigned int ntiles, tiles_per_xcd;
   unsigned int long_min;
   int host_split;
+  int mono;                       // the root's targets are monotone in the key by arithmetic (the host has checked slope / prefix)
   DevState* st;
   Span sp;
   RootP r;
@@ -131,30 +174,41 @@ struct ScanArgs {
   ScanOut out;
   SgList fl;
   PeerRows peers;
+  GapRec* gaps;
+  unsigned long long* gap_cnt;
 };
 
 template <int ROOT, typename K, int V>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_spline_scan(ScanArgs) {
-  const ScanArgs* const ka = reinterpret_cast<const ScanArgs*>(sc_kernarg_ptr());
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_WPE, RMI_SC_WPE))) k_spline_scan(ScanArgs) {
+  const sc_kargp kp = sc_kernarg_ptr();
+  const ScanArgs* const ka = reinterpret_cast<const ScanArgs*>((const unsigned char*)kp);
   const K* const keys = (const K*)ka->keys;
   const long long tile0 = ka->tile0;
   const unsigned int ntiles = ka->ntiles, tiles_per_xcd = ka->tiles_per_xcd, long_min = ka->long_min;
   const int host_split = ka->host_split;
+  const bool mono = ka->mono != 0;
+  const unsigned int h_split = host_split ? (unsigned int)ka->st->split_idx : 0u;   // (a shard: the host has put the split there before the launch)
   DevState* const st = ka->st;
   const Span sp = ka->sp;
   const RootP r = ka->r;
   // the cold arguments, re-read where they are used
-  auto cold = [&]() -> const ScanArgs* { const ScanArgs* p = ka; asm volatile("" : "+s"(p)); return p; };
+  auto cold = [&]() -> sc_kargp { sc_kargp p = kp; asm volatile("" : "+s"(p)); return p; };
+  auto cold_out = [&](sc_kargp p) -> ScanOut {
+    ScanOut o;
+    o.leaf_start = SC_ARG(p, unsigned long long*, out.leaf_start); o.params = SC_ARG(p, double*, out.params);
+    o.leaf_err = SC_ARG(p, unsigned long long*, out.leaf_err); o.leaf_count = SC_ARG(p, unsigned long long*, out.leaf_count);
+    o.rows = SC_ARG(p, unsigned char*, out.rows); o.partials = SC_ARG(p, StatsPartial*, out.partials);
+    return o;
+  };
+  auto cold_peer = [&](sc_kargp p, int i) -> unsigned char* { return reinterpret_cast<typename ScAs4<unsigned char*>::ptr>(p + offsetof(ScanArgs, peers.tab))[i]; };
   using G = ScGeom<K, V>;
   using B = typename LnBits<K>::type;
-  constexpr int DW = G::DW, KPC = G::KPC, TILE = G::TILE, S = G::S, NCH = G::NCH, EXTN = G::EXTN;
+  constexpr int DW = G::DW, KPC = G::KPC, TILE = G::TILE, S = G::S, NCH = G::NCH, EXTN = G::EXTN, FHC = G::FHC, FHN = G::FHN, T0 = G::T0;
   __shared__ __attribute__((aligned(16))) unsigned int lds[G::LDS_DW];
   __shared__ unsigned int r_s[SC_SLOTS + 1], r_t[SC_SLOTS + 1], r_g0[SC_SLOTS + 1], r_yp[SC_SLOTS + 1];   // boundary records of a batch
   __shared__ __attribute__((aligned(16))) double m_ab[2 * (SC_SLOTS + 2)];                                   // (alpha, beta) per slot, one entry of padding either side
   __shared__ unsigned int m_err[SC_SLOTS + 2], m_run[SC_SLOTS + 2];
-  unsigned int* const hl = lds;                       // the 16 bytes in front of the tile
-  unsigned int* const trow = lds + 4;                 // lane l's keys at trow[l S ...]
-  unsigned int* const ext = lds + 4 + 64 * S;         // the keys behind the tile
+  unsigned int* const trow = lds + T0;                // lane l's keys at trow[l S ...]; the front chunks and the look-ahead by the same rule (ScGeom)
 
   const int lane = threadIdx.x;
   const unsigned int base32 = (unsigned int)(unsigned long long)tile0;          // global index of relative index 0 (mod 2^32)
@@ -178,10 +232,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     if constexpr (DW == 1) return (B)p[0];
     else return (B)(*reinterpret_cast<const unsigned long long*>(p));
   };
-  auto target_of = [&](K k, bool& oob) -> unsigned int { return s2_target<ROOT, K>(r, Lm1f, Lm1, k, KeyTraits<K>::as_float(k), oob); };
+  // min(L - 1, predict_to_int(key)) (models/mod.rs:735-737, two_layer.rs:49).  radix.rs:43-50 over 4-byte keys (widened to 64 bits,
+  // models/mod.rs:474-478): with 32 <= prefix and 1 <= bits <= 32 the two 64-bit shifts are two 32-bit shifts of the key
+  unsigned int rsh1 = 0u, rsh2 = 0u, oobcap32 = 0xFFFFFFFFu;
+  bool r32 = false;
+  if constexpr (ROOT == K_RADIX) {
+    const unsigned int pfx = r.prefix & 63u, sh = (64u - r.bits) & 63u;
+    if constexpr (std::is_same<K, uint32_t>::value) { r32 = pfx >= 32u && sh >= 32u; rsh1 = pfx - 32u; rsh2 = sh - 32u; }
+    oobcap32 = r.oob_cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)r.oob_cap;
+  }
+  auto target_of = [&](K k, bool& oob) -> unsigned int {
+    if constexpr (ROOT == K_RADIX) {
+      if constexpr (std::is_same<K, uint32_t>::value) {
+        if (r32) {                                                              // (wave-uniform)
+          const unsigned int p32 = ((unsigned int)k << rsh1) >> rsh2;
+          oob = p32 > oobcap32;
+          return min(p32, Lm1);
+        }
+      }
+      const uint64_t v = KeyTraits<K>::as_uint(k);
+      const uint64_t pr = (v << (r.prefix & 63u)) >> ((64u - r.bits) & 63u);
+      oob = pr > r.oob_cap;
+      return (unsigned int)(pr < r.cap ? pr : r.cap);
+    } else {
+      return s2_target<ROOT, K>(r, Lm1f, Lm1, k, KeyTraits<K>::as_float(k), oob);
+    }
+  };
 
   // ---- tile loads: NCH chunks per lane (chunk c 64 + lane of the tile) + one aux chunk (lane 0: the chunk in front of the
-  //      tile; lanes 1..EXTC: the look-ahead behind it).  A chunk is loaded iff it overlaps the readable keys [rd_lo, rd_hi).
+  //      tile; lanes FHC .. FHC + EXTC - 1: the look-ahead behind it).  A chunk is loaded iff it overlaps the readable keys [rd_lo, rd_hi);
+  //      a tile that lies inside them with its halo is loaded without the tests.
   uint4 pf[NCH], pfx;
   auto chunk_load = [&](long long rel_first) -> uint4 {                         // rel_first: relative index of the chunk's first key
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -192,13 +272,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     }
     return v;
   };
+  // relative index of the first key of this lane's aux chunk of the tile at relative index a
+  auto aux_first = [&](long long a) -> long long { return lane < FHC ? a - (long long)(FHC - lane) * KPC : a + TILE + (long long)(lane - FHC) * KPC; };
   auto load_tile = [&](unsigned int tile) {
     const long long a = (long long)tile * TILE;
+    if (a - FHN >= rd_lo_rel && a + TILE + EXTN <= rd_hi_rel) {                 // (wave-uniform)
+      typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
+      const raw_t* const p0 = reinterpret_cast<const raw_t*>(kb + a) + lane;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) { const raw_t rw = __builtin_nontemporal_load(p0 + c * 64); pf[c] = make_uint4(rw.x, rw.y, rw.z, rw.w); }
+      pfx = make_uint4(0u, 0u, 0u, 0u);
+      if (lane < FHC + G::EXTC) { const raw_t rw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(kb + aux_first(a))); pfx = make_uint4(rw.x, rw.y, rw.z, rw.w); }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < NCH; c++) pf[c] = chunk_load(a + (long long)(c * 64 + lane) * KPC);
-    const long long ax = lane == 0 ? a - KPC : a + TILE + (long long)(lane - 1) * KPC;
     pfx = make_uint4(0u, 0u, 0u, 0u);
-    if (lane <= G::EXTC) pfx = chunk_load(ax);
+    if (lane < FHC + G::EXTC) pfx = chunk_load(aux_first(a));
   };
   // persistent waves; block b runs on XCD b % 8 (observed, for speed only): each XCD streams a contiguous range of tiles, so
   // that the look-ahead of a tile is the neighbouring wave's tile in the same L2
@@ -208,7 +298,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   unsigned int tile = t_lo + wix;
   if (tile < t_hi) load_tile(tile);
 
+#if RMI_SC_PROF
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  const unsigned long long tstart = tlast;
+  unsigned int ntile = 0, nfast = 0;
+#endif
   for (; tile < t_hi; tile += wpx) {
+#if RMI_SC_PROF
+    ntile++;
+#endif
+    SC_TICK(7);
     const unsigned int relA = tile * (unsigned int)TILE;                        // relative index of the tile's first key
     const unsigned int A = base32 + relA;                                       // ... and its global index
     // ---- validity.  The tiles at the two ends of the launch hold positions outside [it_lo, it_hi): those take the value of the
@@ -234,7 +333,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       const long long a = (long long)relA;
 #pragma unroll
       for (int c = 0; c < NCH; c++) patch(pf[c], a + (long long)(c * 64 + lane) * KPC);
-      patch(pfx, lane == 0 ? a - KPC : a + TILE + (long long)(lane - 1) * KPC);
+      patch(pfx, aux_first(a));
     }
     // ---- stage the tile (padded rows) and the aux chunks
     wave_sync();
@@ -243,15 +342,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       const unsigned int kk0 = (unsigned int)(c * 64 + lane) * (unsigned int)KPC;   // key offset of the chunk in the tile
       *reinterpret_cast<uint4*>(trow + (kk0 / (unsigned int)V) * (unsigned int)S + (kk0 % (unsigned int)V) * (unsigned int)DW) = pf[c];
     }
-    if (lane == 0) *reinterpret_cast<uint4*>(hl) = pfx;
-    else if (lane <= G::EXTC) *reinterpret_cast<uint4*>(ext + (lane - 1) * 4) = pfx;
+    if (lane < FHC + G::EXTC) {
+      const int d0 = lane < FHC ? (lane - FHC) * 4 : 64 * G::ROWD + (lane - FHC) * 4;   // dword offset of the chunk from the tile's first key
+      *reinterpret_cast<uint4*>(trow + d0 + 4 * (d0 >> 5)) = pfx;
+    }
     wave_sync();
     // key (raw bits) at a global index near the tile: LDS where the tile, its front chunk or its look-ahead hold it
+    auto lds_bits = [&](int rel) -> B { const int d = rel * DW; return bits_at(trow + d + 4 * (d >> 5)); };   // rel in [-FHN, TILE + EXTN)
     auto key_bits = [&](unsigned int i) -> B {
-      const unsigned int rel = i - A;
-      if (rel < (unsigned int)TILE) return bits_at(trow + (rel / (unsigned int)V) * (unsigned int)S + (rel % (unsigned int)V) * (unsigned int)DW);
-      if (rel + (unsigned int)KPC < (unsigned int)KPC) return bits_at(hl + (rel + (unsigned int)KPC) * (unsigned int)DW);
-      if (rel - (unsigned int)TILE < (unsigned int)EXTN) return bits_at(ext + (rel - (unsigned int)TILE) * (unsigned int)DW);
+      const int rel = (int)(i - A);
+      if (rel >= -FHN && rel < TILE + EXTN) return lds_bits(rel);
       return key_to_bits<K>(kb[(unsigned int)(i - base32)]);
     };
     auto key_at = [&](unsigned int i) -> K { return bits_to_key<K>(key_bits(i)); };
@@ -269,8 +369,281 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       }
     }
     const B kprev_b = key_bits(f - 1u), knext_b = key_bits(f + (unsigned int)V);
+    SC_TICK(0);
     // ---- the next tile's loads: in flight during everything below
     { const unsigned int nt = tile + wpx; if (nt < t_hi) load_tile(nt); }
+    SC_TICK(1);
+
+    // y (FixDups offset, models/mod.rs:154-185) of the key in front of the tile: its run of equal keys is walked in the front chunks; a run that
+    // reaches beyond them is looked up in the key array
+    auto front_y = [&]() -> unsigned int {
+      unsigned int y = A - 1u;
+      if (lane == 0 && relA > rel_lo) {
+        const unsigned int lim = min((unsigned int)FHN, relA - rel_lo);          // the keys A - lim .. A - 1 belong to this launch
+        const K k1 = bits_to_key<K>(lds_bits(-1));
+        unsigned int back = 1u;
+        while (back < lim && bits_to_key<K>(lds_bits(-1 - (int)back)) == k1) back++;
+        if (back < lim || relA - rel_lo == back) y = A - back;
+        else y = (unsigned int)first_occurrence(keys, (uint64_t)(tile0 + (long long)relA - 1), sp.rd_lo);
+      }
+      return (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
+    };
+    // ================= the ordinary tile (see the head of the file): same values as the general form below, fewer instructions =================
+    if constexpr (s2_root_monotone<ROOT>() && RMI_SC_FAST) {
+      if (mono && !edge && relA >= rel_lo + (unsigned int)FHN + 1u) {
+        bool done = false;
+        do {
+          const unsigned int* const rowp = trow + lane * S;
+          bool oob_x = false, oob_l = false;
+          const unsigned int tp = target_of(bits_to_key<K>(kprev_b), oob_x);    // the key in front of the lane
+          const unsigned int tl = target_of(bits_to_key<K>(kk[V - 1]), oob_l);  // the lane's last key: the largest prediction of the lane
+          if constexpr (!root_needs_bounds_check<ROOT>()) { if (oob_l) flags |= EF_ROOT_OOB; }   // two_layer.rs:45-48
+          const bool has = tl != tp;                                            // a leaf starts in this lane (targets are monotone)
+          const unsigned long long hm = __ballot(has);
+          if (hm == 0ull) { done = true; break; }                               // the tile lies inside one leaf that started earlier
+          // ---- F1: the lane's first leaf start by bisection of its row
+          unsigned int p = (unsigned int)V, t_hi = tl;
+          {
+            unsigned int lo = 0u, hi = (unsigned int)V - 1u;                    // t(hi) != tp; t(v) == tp for v < lo
+#pragma unroll
+            for (int it = 0; it < G::LOGV; it++) {
+              const unsigned int mid = (lo + hi) >> 1;
+              bool o2;
+              const unsigned int tm = target_of(bits_to_key<K>(bits_at(rowp + mid * (unsigned int)DW)), o2);
+              const bool ne = tm != tp;
+              hi = ne ? mid : hi; t_hi = ne ? tm : t_hi; lo = ne ? lo : mid + 1u;
+            }
+            if (has) p = hi;
+          }
+          if (__any(has && (t_hi != tl || t_hi - tp > 5u))) break;              // a lane with more than one start, or more than 4 empty leaves in front of it
+          // ---- duplicates among the keys [A - 2, A + TILE + EXTN)
+          unsigned int hd = 0u;
+          bool dq = false;
+          {
+            K kp = bits_to_key<K>(kprev_b);
+#pragma unroll
+            for (int v = 0; v < V; v++) { const K kv = bits_to_key<K>(kk[v]); dq = dq || (kv == kp); kp = kv; }
+#pragma unroll
+            for (int o = 0; o < EXTN; o += 64) dq = dq || (bits_to_key<K>(lds_bits(TILE + o + lane)) == bits_to_key<K>(lds_bits(TILE + o + lane - 1)));
+            if (lane == 0) dq = dq || (bits_to_key<K>(lds_bits(-1)) == bits_to_key<K>(lds_bits(-2)));
+          }
+          const bool dups = __any(dq) != 0;
+          if (dups && !RMI_SC_FAST_DUPS) break;
+          // ---- the end of the leaf that is open at the tile's end: in the look-ahead, or the general form takes the tile
+          const unsigned int t_tile_last = sc_lane63(tl);
+          unsigned int term_rel = 0u, tt = 0u;
+          {
+            bool found = false;
+#pragma unroll
+            for (int o = 0; o < EXTN; o += 64) {
+              if (!found) {
+                bool o2;
+                const unsigned int t = target_of(bits_to_key<K>(lds_bits(TILE + o + lane)), o2);
+                const unsigned long long dm = __ballot(t != t_tile_last);
+                if (dm) {
+                  const int src = __builtin_ctzll(dm);
+                  term_rel = (unsigned int)(TILE + o + src);
+                  tt = (unsigned int)__builtin_amdgcn_readlane((int)t, src);
+                  found = true;
+                }
+              }
+            }
+            if (!found) break;
+          }
+          // ---- the split of the 2-way join (two_layer.rs:130-175) anywhere near: the general form knows Q2-Q4
+          if (host_split) {
+            if ((unsigned int)(h_split - (A - 2u)) <= (unsigned int)(TILE + EXTN + 2)) break;
+          } else {
+            bool o2;
+            const unsigned int t2 = target_of(bits_to_key<K>(lds_bits(-2)), o2);
+            if (t2 < mid && tt >= mid) break;                                   // the targets of [A - 2, end of the open leaf] cross L / 2
+          }
+          if (RMI_SC_STOP == 1) { done = true; break; }
+          SC_TICK(2);
+          // ---- slots (one per lane with a start, in lane order), the y carried into each lane
+          const unsigned int q = __builtin_amdgcn_mbcnt_hi((unsigned int)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)hm, 0u));
+          const unsigned int nb = (unsigned int)__builtin_popcountll(hm);
+          unsigned int y_in = f - 1u, yp = f + p - 1u;                           // (no duplicates: every key is its own first occurrence)
+          if (dups) {
+            K kp = bits_to_key<K>(kprev_b);
+#pragma unroll
+            for (int v = 0; v < V; v++) { const K kv = bits_to_key<K>(kk[v]); hd |= !(kv == kp) ? (1u << v) : 0u; kp = kv; }
+            const unsigned int lh = hd ? f + (31u - (unsigned int)__builtin_clz(hd)) + 1u : 0u;   // (index + 1 of this lane's last head)
+            const unsigned int lh_prev = sc_dpp<0x138, 0xF>(0u, lh);              // wave_shr:1
+            const unsigned int lh_ex = sc_scan_max(lh_prev);
+            const unsigned int y_tile = front_y();
+            y_in = lh_ex ? lh_ex - 1u : y_tile;
+            const unsigned int hb = hd & sc_mask_below(p);
+            yp = hb ? f + (31u - (unsigned int)__builtin_clz(hb)) : y_in;
+          }
+          // ---- F2: the records of the starts; the open leaf's end closes them
+          wave_sync();
+          if (has) { r_s[q] = f + p; r_t[q] = t_hi; r_g0[q] = tp + 1u; r_yp[q] = yp; }
+          if (lane == 0) r_s[nb] = A + term_rel;
+          wave_sync();
+          // ---- F3: the models.  Lane l: slot l.  Container [s - 1, e]: both end points exist (no split, no end of the data nearby) and their keys differ
+          unsigned int q_s = 0u, q_e = 0u, q_t = 0u;
+          K k_lo = KeyTraits<K>::zero_value(), k_hi = KeyTraits<K>::zero_value();
+          double ma = 0.0, mb = 0.0;
+          if ((unsigned int)lane < nb) {
+            q_s = r_s[lane]; q_e = r_s[lane + 1]; q_t = r_t[lane];
+            k_lo = bits_to_key<K>(lds_bits((int)(q_s - 1u - A))); k_hi = bits_to_key<K>(lds_bits((int)(q_e - A)));
+            const double x0 = KeyTraits<K>::as_float(k_lo), x1 = KeyTraits<K>::as_float(k_hi);
+            const double y0f = (double)r_yp[lane], y1f = (double)q_e;
+            mb = (y0f - y1f) / (x0 - x1);                                        // linear_spline.rs:27
+            ma = y0f - mb * x0;                                                  // :28, plain multiply-subtract
+            m_ab[2 * (lane + 1)] = ma; m_ab[2 * (lane + 1) + 1] = mb;
+            m_err[lane + 1] = 0u; m_run[lane + 1] = 0u;
+          }
+          // which positions hold some lane's start (a scalar mask: the error pass tests it, not the lanes)
+          unsigned int am = has ? (1u << p) : 0u;
+          am |= sc_dpp<0x111, 0xF>(0u, am); am |= sc_dpp<0x112, 0xF>(0u, am); am |= sc_dpp<0x114, 0xF>(0u, am); am |= sc_dpp<0x118, 0xF>(0u, am);
+          am |= sc_dpp<0x142, 0xA>(0u, am); am |= sc_dpp<0x143, 0xC>(0u, am);
+          am = sc_lane63(am);
+          wave_sync();
+          if (RMI_SC_STOP == 3) { done = true; break; }
+          SC_TICK(3);
+          // ---- F4: the error pass.  The lane's keys in front of its start belong to the leaf of slot q - 1 (table entry q; entry 0: a leaf
+          //      of an earlier tile, nothing is kept), those from the start on to slot q (entry q + 1)
+          {
+            double pa = m_ab[2 * q], pb = m_ab[2 * q + 1];
+            double pa1 = 0.0, pb1 = 0.0;
+            if (has) { pa1 = m_ab[2 * (q + 1)]; pb1 = m_ab[2 * (q + 1) + 1]; }
+            unsigned int m = 0u, m0 = 0u, rn = 0u, rn0 = 0u, y_last = 0u;
+#pragma unroll
+            for (int v = 0; v < V; v++) asm volatile("" : "+v"(kk[v]));
+            unsigned int amr = am;
+            if (!dups) {
+#pragma unroll
+              for (int v = 0; v < V; v++) {
+                asm volatile("" : "+s"(amr));
+                if (amr & 1u) {                                                  // (scalar) some lane's start lies at position v
+                  const bool sw = p == (unsigned int)v;
+                  m0 = sw ? m : m0; m = sw ? 0u : m;
+                  pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
+                }
+                amr >>= 1;
+                const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[v]));
+                const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);   // linear_spline.rs:52, models/mod.rs:735-737, two_layer.rs:14-18
+                m = max(m, sg_absdiff(pr, f + (unsigned int)v));
+              }
+            } else {
+              unsigned int y = y_in;
+              bool ne = !(bits_to_key<K>(kk[0]) == bits_to_key<K>(kprev_b));
+#pragma unroll
+              for (int v = 0; v < V; v++) {
+                asm volatile("" : "+s"(amr));
+                if (amr & 1u) {
+                  const bool sw = p == (unsigned int)v;
+                  m0 = sw ? m : m0; m = sw ? 0u : m;
+                  rn0 = sw ? rn : rn0; rn = sw ? 0u : rn;
+                  pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
+                }
+                amr >>= 1;
+                const K kv = bits_to_key<K>(kk[v]);
+                const K kn = bits_to_key<K>(v + 1 < V ? kk[v + 1 < V ? v + 1 : v] : knext_b);
+                const unsigned int i = f + (unsigned int)v;
+                y = ne ? i : y;
+                const double x = KeyTraits<K>::as_float(kv);
+                const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);
+                m = max(m, sg_absdiff(pr, y));
+                // a run of equal keys is recorded when the next different key arrives (lower_bound_correction.rs:108-119)
+                ne = !(kn == kv);
+                rn = max(rn, ne ? i + 1u - y : 0u);
+              }
+              y_last = y;
+            }
+            const unsigned int mA = has ? m0 : m, rA = has ? rn0 : rn;
+            if (q >= 1u) { if (mA) atomicMax(&m_err[q], mA); if (rA > 1u) atomicMax(&m_run[q], rA); }
+            if (has) { if (m) atomicMax(&m_err[q + 1u], m); if (rn > 1u) atomicMax(&m_run[q + 1u], rn); }
+            // ---- the keys of the open leaf behind the tile: [A + TILE, A + term_rel)
+            {
+              const double ta = m_ab[2 * nb], tb = m_ab[2 * nb + 1];
+              unsigned int em = 0u, rm = 0u;
+              unsigned int y_carry = (unsigned int)__builtin_amdgcn_readlane((int)y_last, 63);
+              for (unsigned int o = (unsigned int)TILE; o < term_rel; o += 64u) {
+                const unsigned int rel = o + (unsigned int)lane;
+                const bool in = rel < term_rel;
+                const K kv = bits_to_key<K>(lds_bits((int)(in ? rel : o)));
+                const unsigned int i = A + rel;
+                unsigned int y = i;
+                if (dups) {
+                  const K kpv = bits_to_key<K>(lds_bits((int)(in ? rel : o) - 1)), knx = bits_to_key<K>(lds_bits((int)(in ? rel : o) + 1));
+                  const unsigned int hidx = (in && !(kv == kpv)) ? i : 0u;
+                  const unsigned int pm = sc_scan_max(hidx);
+                  y = max(pm, y_carry);
+                  if (in && !(knx == kv)) rm = max(rm, i + 1u - y);
+                  y_carry = sc_lane63(y);
+                }
+                if (in) {
+                  const double x = KeyTraits<K>::as_float(kv);
+                  const unsigned int pr = min(sg_cvt_u32(__builtin_fma(tb, x, ta)), n32);
+                  em = max(em, sg_absdiff(pr, y));
+                }
+              }
+              if (term_rel > (unsigned int)TILE) {
+                if (em) atomicMax(&m_err[nb], em);
+                if (rm > 1u) atomicMax(&m_run[nb], rm);
+              }
+            }
+          }
+          wave_sync();
+          if (RMI_SC_STOP == 4) { done = true; break; }
+          SC_TICK(4);
+          // ---- F5: the leaf ends (two_layer.rs:185-197, 226-259) in 32 bits -- every index and every clamped prediction is below 2^32 --,
+          //      rows, aggregates; then the empty leaves in front of the starts
+          const sc_kargp cp = cold();
+          const ScanOut out = cold_out(cp);
+          const int npeers = SC_ARG(cp, int, peers.n);
+          auto store_leaf = [&](unsigned int j, unsigned int s_, double a, double b2, unsigned int final_err, unsigned int cnt_j) {
+            out.leaf_start[j] = (unsigned long long)s_;
+            if (out.params) { out.params[2 * (size_t)j] = a; out.params[2 * (size_t)j + 1] = b2; }
+            if (out.leaf_err) out.leaf_err[j] = (unsigned long long)final_err;
+            if (out.leaf_count) out.leaf_count[j] = (unsigned long long)cnt_j;
+            double* rp = reinterpret_cast<double*>(out.rows + (size_t)j * 24);
+            rp[0] = a; rp[1] = b2;
+            *reinterpret_cast<unsigned long long*>(out.rows + (size_t)j * 24 + 16) = (unsigned long long)final_err;
+            for (int pi = 0; pi < npeers; pi++) {                                // (wave-uniform trip count)
+              unsigned char* const pt = cold_peer(cp, pi);
+              double* pr = reinterpret_cast<double*>(pt + (size_t)j * 24);
+              pr[0] = a; pr[1] = b2;
+              *reinterpret_cast<unsigned long long*>(pt + (size_t)j * 24 + 16) = (unsigned long long)final_err;
+            }
+          };
+          if ((unsigned int)lane < nb) {
+            const unsigned int curr = m_err[lane + 1], ru = m_run[lane + 1];
+            const unsigned int up = min(sg_cvt_u32(__builtin_fma(mb, KeyTraits<K>::as_float(KeyTraits<K>::minus_eps(k_hi)), ma)), n32);   // lower_bound_correction.rs:47-49
+            const unsigned int upper = sg_absdiff(up, min(q_e + 1u, n32));                                                              // two_layer.rs:229-235
+            const unsigned int lw = min(sg_cvt_u32(__builtin_fma(mb, KeyTraits<K>::as_float(KeyTraits<K>::plus_eps(k_lo)), ma)), n32);    // lower_bound_correction.rs:62-63
+            const unsigned int lower = sg_absdiff(lw, q_t == 0u ? q_e : q_s);                                                          // two_layer.rs:237-247
+            const unsigned int final_err = max(max(curr, upper), lower) + (ru > 1u ? ru : 1u);                                       // :250-251 (a leaf with keys owns a recorded run)
+            const unsigned int cnt_j = q_e - q_s;
+            if (RMI_SC_STOP != 6) store_leaf(q_t, q_s, ma, mb, final_err, cnt_j);
+            if (RMI_SC_STOP != 5) agg.add((uint64_t)q_t, (uint64_t)final_err, (uint64_t)cnt_j, nf);
+            if (RMI_SC_STOP == 5) agg.sum += final_err + cnt_j;
+            // the empty leaves [g0, t) in front of this start (s == e): the constant model next_index = s (two_layer.rs:185-197), widened by 1
+            const unsigned int g0 = r_g0[lane];
+            for (unsigned int j = g0; j < q_t; j++) {
+              store_leaf(j, q_s, (double)q_s, 0.0, 1u, 0u);
+              agg.add((uint64_t)j, 1ull, 0ull, nf);
+            }
+          }
+          done = true;
+          SC_TICK(5);
+#if RMI_SC_PROF
+          nfast++;
+#endif
+        } while (false);
+        if (done) continue;
+      }
+    }
+#if RMI_SC_LEANTEST
+    continue;                                                                    // timing experiment (results wrong): no general form at all
+#endif
+#if RMI_SC_PROF
+    unsigned long long gprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast = __builtin_readcyclecounter();
+    const unsigned long long gstart = glast;
+#endif
     unsigned int force_lo = 0u, force_hi = 0u;                                   // bit of the position it_lo / it_hi in this lane
     if (edge) {
       if (n_it > 0u && rel_lo >= relf && rel_lo - relf < (unsigned int)V) force_lo = 1u << (rel_lo - relf);
@@ -318,14 +691,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       const unsigned int lh = hd ? f + (31u - (unsigned int)__builtin_clz(hd)) + 1u : 0u;   // (index + 1 of this lane's last head)
       const unsigned int lh_prev = sc_dpp<0x138, 0xF>(0u, lh);                    // wave_shr:1
       const unsigned int lh_ex = sc_scan_max(lh_prev);
-      // the key in front of the tile: its own first occurrence unless it equals the key before it (then: look it up)
-      unsigned int y_tile = A - 1u;
-      if (lane == 0 && relA > rel_lo) {
-        const long long ia = (long long)relA - 1;                                // relative index of that key: a valid key of the launch
-        if (ia - 1 >= rd_lo_rel && key_at(A - 2u) == key_at(A - 1u))
-          y_tile = (unsigned int)first_occurrence(keys, (uint64_t)(tile0 + ia), sp.rd_lo);
-      }
-      y_tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)y_tile);
+      const unsigned int y_tile = front_y();
       y_in = lh_ex ? lh_ex - 1u : y_tile;
     }
     const unsigned int anyb = sc_wave_or(bnd);
@@ -334,6 +700,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     unsigned int w_split = n32, w_stgt = 0u;                                     // the values leaf_container gets for this tile's leaves
     if (host_split) { w_split = (unsigned int)st->split_idx; w_stgt = (unsigned int)st->split_target; }
 
+    SC_GT(0);
     // ---- batches of SC_SLOTS leaf starts
     for (unsigned int qb = 0; qb < nb; qb += (unsigned int)SC_SLOTS) {
       const unsigned int cnt_b = min((unsigned int)SC_SLOTS, nb - qb);          // records of this batch
@@ -390,6 +757,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
           r_s[q - qb] = i; r_t[q - qb] = t; r_g0[q - qb] = g0; r_yp[q - qb] = yp;
         }
       }
+      SC_GT(1);
       // the split, if a lane of this wave saw it (at most one key in the whole data set crosses L / 2)
       if (!host_split) {
         const unsigned long long sm = __ballot(w_split != n32);
@@ -438,6 +806,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       }
       wave_sync();
       if (RMI_SC_STOP == 2) continue;
+      SC_GT(2);
       // ---- P3: the models.  Lane q: slot qb + q.
       const unsigned int own_b = last_batch ? (cnt_b - (virt_here ? 1u : 0u)) : cnt_b;     // real leaves among this batch's records
       const bool hand_q = handed && last_batch && (unsigned int)lane == own_b - 1u;
@@ -477,6 +846,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       }
       wave_sync();
       if (RMI_SC_STOP == 3) continue;
+      SC_GT(3);
       // ---- P4: the error pass over the lane's keys
       {
         // slot of the key in front of the lane, relative to the batch, + 1 (entry 0 and SLOTS + 1 of the tables are padding)
@@ -573,10 +943,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       }
       wave_sync();
       if (RMI_SC_STOP == 4) continue;
+      SC_GT(4);
       // ---- P5: the leaf ends.  Lane q: slot qb + q; then the empty leaves in front of the batch's starts.
-      const ScanArgs* const cp = cold();
-      const ScanOut out = cp->out;
-      const int npeers = cp->peers.n;
+      const sc_kargp cp = cold();
+      const ScanOut out = cold_out(cp);
+      const int npeers = SC_ARG(cp, int, peers.n);
       auto store_leaf = [&](uint64_t j, uint64_t s, double a, double b2, uint64_t final_err, uint64_t cnt_j) {
         out.leaf_start[j] = s;
         if (out.params) { out.params[2 * j] = a; out.params[2 * j + 1] = b2; }
@@ -586,7 +957,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         rp[0] = a; rp[1] = b2;
         *reinterpret_cast<unsigned long long*>(out.rows + j * 24 + 16) = final_err;
         for (int p = 0; p < npeers; p++) {                                       // (wave-uniform trip count)
-          unsigned char* const pt = cp->peers.tab[p];
+          unsigned char* const pt = cold_peer(cp, p);
           double* pr = reinterpret_cast<double*>(pt + j * 24);
           pr[0] = a; pr[1] = b2;
           *reinterpret_cast<unsigned long long*>(pt + j * 24 + 16) = final_err;
@@ -596,7 +967,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         const uint64_t j = q_t, s = q_s, e = q_e;
         if (hand_q) {
           out.leaf_start[j] = s;
-          cp->fl.push((unsigned int)j);
+          { SgList fl; fl.ids = SC_ARG(cp, unsigned int*, fl.ids); fl.cnt = SC_ARG(cp, unsigned long long*, fl.cnt); fl.cap = SC_ARG(cp, unsigned long long, fl.cap); fl.push((unsigned int)j); }
         } else {
           double pp[2] = {m_ab[2 * (lane + 1)], m_ab[2 * (lane + 1) + 1]};
           const unsigned int ru = m_run[lane + 1];
@@ -609,6 +980,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
           agg.add(j, final_err, cnt_j, nf);
         }
       }
+      SC_GT(6);
       // empty leaves [g0, t) in front of a start at index s: s == e, the constant model (two_layer.rs:185-197; the last leaf of
       // all keeps the empty model, Q6), no key is read
       auto empty_leaf = [&](uint64_t j, uint64_t s) {
@@ -621,7 +993,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       {
         unsigned int g0 = 0u, gt = 0u, gs = 0u;
         if ((unsigned int)lane < cnt_b) { g0 = r_g0[lane]; gt = r_t[lane]; gs = r_s[lane]; }
-        const unsigned int glen = gt > g0 ? gt - g0 : 0u;
+        unsigned int glen = gt > g0 ? gt - g0 : 0u;
+        if (glen >= SCAN_GAP_MIN) {                                              // a long stretch: k_scan_gaps writes it (if the list has room)
+          const unsigned long long pos = atomicAdd(SC_ARG(cp, unsigned long long*, gap_cnt), 1ull);
+          if (pos < (unsigned long long)SCAN_GAP_CAP) { SC_ARG(cp, GapRec*, gaps)[pos] = GapRec{g0, gt, gs, 0u}; glen = 0u; }
+        }
+#if RMI_SC_PROF
+        if (edge && (unsigned int)lane < cnt_b) printf("  tile %u lane %d: g0 %u gt %u gs %u own_b %u cnt_b %u\n", tile, lane, g0, gt, gs, own_b, cnt_b);
+#endif
         if (glen > 0u && glen <= 4u) for (unsigned int j = g0; j < gt; j++) empty_leaf((uint64_t)j, (uint64_t)gs);
         unsigned long long big = __ballot(glen > 4u);
         while (big) {
@@ -632,8 +1011,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
           for (unsigned int j = b0 + (unsigned int)lane; j < b1; j += 64u) empty_leaf((uint64_t)j, (uint64_t)bs);
         }
       }
+      SC_GT(5);
     }
+#if RMI_SC_PROF
+    if (lane == 0 && (unsigned long long)__builtin_readcyclecounter() - gstart > 100000ull)
+      printf("general tile %u (relA %u) edge %d nb %u: total %llu | P1 %llu P2 %llu ext %llu P3 %llu P4 %llu P5a %llu P5b %llu\n", tile, relA, (int)edge, nb,
+             (unsigned long long)__builtin_readcyclecounter() - gstart, gprof[0], gprof[1], gprof[2], gprof[3], gprof[4], gprof[6], gprof[5]);
+#endif
   }
+#if RMI_SC_PROF
+  if (lane == 0 && (blockIdx.x == 777 || (unsigned long long)__builtin_readcyclecounter() - tstart > 1800000ull))
+    printf("wave %u: tiles %u fast %u total %llu | stage %llu prefetch %llu F1 %llu F2-3 %llu F4 %llu F5 %llu looptop %llu\n", blockIdx.x, ntile, nfast,
+           (unsigned long long)__builtin_readcyclecounter() - tstart, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[7]);
+#endif
   if (flags) atomicOr(&st->err_flags, flags);
   // ---- this wave's aggregate record
   {
@@ -647,7 +1037,53 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       l2 += __shfl_down(l2, d);
       lg += __shfl_down(lg, d);
     }
-    if (lane == 0) cold()->out.partials[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
+    if (lane == 0) SC_ARG(cold(), StatsPartial*, out.partials)[blockIdx.x] = StatsPartial{mx, mi, sm, l2, lg};
+  }
+}
+
+// k_scan_gaps: the stretches of empty leaves k_spline_scan has listed (GapRec).  Thread t of the grid takes the leaves g0 + t, g0 + t + T, ...
+// of every record: empty model, constant next_index (two_layer.rs:185-197; the last leaf of all keeps the empty model, Q6), widening
+// (:226-259) -- the same finalize_one_pre call as k_spline_scan's own empty leaves.  An empty leaf counts no key: its only share of the
+// aggregates (:267-287) is the maximum and its leaf; block b leaves that in partials[b].
+template <typename K>
+__global__ void __launch_bounds__(256) k_scan_gaps(const K* __restrict__ keys, Span sp, uint64_t L, ScanOut out, PeerRows peers,
+                                                   const GapRec* __restrict__ gaps, const unsigned long long* __restrict__ gap_cnt, StatsPartial* __restrict__ partials) {
+  __shared__ unsigned long long s_mx[4], s_mi[4];
+  const unsigned long long cnt_raw = *gap_cnt;
+  const unsigned int cnt = cnt_raw < (unsigned long long)SCAN_GAP_CAP ? (unsigned int)cnt_raw : SCAN_GAP_CAP;
+  const unsigned int T = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long mx = 0ull, mi = 0ull;
+  for (unsigned int rix = 0; rix < cnt; rix++) {
+    const GapRec g = gaps[rix];
+    for (unsigned int j = g.g0 + t0; j < g.gt; j += T) {
+      double pp[2] = {0.0, 0.0};
+      uint64_t final_err, cnt_j;
+      finalize_one_pre<K_LINEAR, K>((uint64_t)j, (uint64_t)g.gs, (uint64_t)g.gs, sp, L, keys, pp, 0ull, 0ull, ~0ull, KeyTraits<K>::zero_value(), KeyTraits<K>::zero_value(), final_err, cnt_j);
+      out.leaf_start[j] = (unsigned long long)g.gs;
+      if (out.params) { out.params[2 * (size_t)j] = pp[0]; out.params[2 * (size_t)j + 1] = pp[1]; }
+      if (out.leaf_err) out.leaf_err[j] = final_err;
+      if (out.leaf_count) out.leaf_count[j] = cnt_j;
+      double* rp = reinterpret_cast<double*>(out.rows + (size_t)j * 24);
+      rp[0] = pp[0]; rp[1] = pp[1];
+      *reinterpret_cast<unsigned long long*>(out.rows + (size_t)j * 24 + 16) = final_err;
+      for (int p = 0; p < peers.n; p++) {
+        double* pr = reinterpret_cast<double*>(peers.tab[p] + (size_t)j * 24);
+        pr[0] = pp[0]; pr[1] = pp[1];
+        *reinterpret_cast<unsigned long long*>(peers.tab[p] + (size_t)j * 24 + 16) = final_err;
+      }
+      if (final_err > mx || (final_err == mx && (unsigned long long)j > mi)) { mx = final_err; mi = (unsigned long long)j; }   // max_by_key: the LAST maximum
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const unsigned long long omx = shfl_down_u64(mx, d), omi = shfl_down_u64(mi, d);
+    if (omx > mx || (omx == mx && omi > mi)) { mx = omx; mi = omi; }
+  }
+  if ((threadIdx.x & 63) == 0) { s_mx[threadIdx.x >> 6] = mx; s_mi[threadIdx.x >> 6] = mi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) if (s_mx[w] > mx || (s_mx[w] == mx && s_mi[w] > mi)) { mx = s_mx[w]; mi = s_mi[w]; }
+    partials[blockIdx.x] = StatsPartial{mx, mi, 0ull, 0.0, 0.0};
   }
 }
 

@@ -14,6 +14,12 @@ struct ScanOut {
   StatsPartial* partials;         // one record per wave
 };
 
+// A long stretch of empty leaves [g0, gt) in front of the leaf start at key index gs (or behind the last key): one wave would write them
+// 64 at a time -- 288 000 leaves behind the last key of the C5 key set took one wave 1.5 ms --, so stretches of SCAN_GAP_MIN leaves
+// or more are listed here and written by k_scan_gaps, all of the device at once.
+struct GapRec { unsigned int g0, gt, gs, pad; };
+constexpr unsigned int SCAN_GAP_MIN = 512, SCAN_GAP_CAP = 4096, SCAN_GAP_BLOCKS = 128;
+
 struct ScanLaunch {
   const void* keys;               // pre-offset: keys[global index]
   Span sp;
@@ -23,7 +29,11 @@ struct ScanLaunch {
   unsigned int long_min;
   ScanOut out;
   PeerRows peers;
+  GapRec* gaps;                   // SCAN_GAP_CAP records
+  unsigned long long* gap_cnt;    // their counter (zero before the launch)
   int host_split;                 // the split of the 2-way join is in *st already (a shard)
+  int mono;                       // the root's targets are monotone in the key by arithmetic: a linear root with finite coefficients and a slope >= 0, a radix
+                                  // root whose prefix is common to all resident keys (then equal targets at two keys prove that no leaf starts between them)
   unsigned int max_waves;         // persistent waves the device holds
   unsigned int waves;             // out: waves launched = aggregate records written
 };
@@ -32,5 +42,10 @@ constexpr unsigned int SCAN_MAX_WAVES = 4096;
 // root: K_LINEAR, K_CUBIC, K_RADIX, K_RADIX_TABLE, K_LOGLINEAR, K_NORMAL; dtype: RMI_KEY_*.  Returns 0, or -1 for a combination
 // that is not compiled.
 int rmi_scan_launch(int root, int dtype, ScanLaunch& a, hipStream_t s);
+// k_scan_gaps behind it on the same stream: the listed stretches of empty leaves; its SCAN_GAP_BLOCKS aggregate records go behind the
+// waves' (a.out.partials[a.waves ...]), a.waves counts them in afterwards
+int rmi_scan_gaps_launch(int dtype, ScanLaunch& a, hipStream_t s);
+// persistent waves a CU holds of this build of the kernel (4 SIMDs x the waves per SIMD it is compiled for)
+unsigned int rmi_scan_waves_per_cu();
 
 }  // namespace rmi

@@ -815,6 +815,28 @@ static __global__ void __launch_bounds__(256) k_read_bw(const uint4* __restrict_
   for (; i < n16; i += stride) { const uint4 a = src[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
   if (acc == 0x12345678u) sink[0] = acc;   // practically never; keeps the loads alive
 }
+// the same bytes with the access pattern of the one-read kernels: a wave owns contiguous pieces of 8 KB (8 non-temporal 16-byte
+// loads per lane back to back), pieces dealt round-robin to the waves -- the best read-only pattern of tools/probe/bw_probe.hip
+static __global__ void __launch_bounds__(256) k_read_bw_chunk(const uint4* __restrict__ src, uint64_t n16, unsigned int* __restrict__ sink) {
+  typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
+  constexpr int U = 8;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / 64, lane = threadIdx.x % 64;
+  const uint64_t nwaves = (uint64_t)gridDim.x * blockDim.x / 64;
+  const raw_t* const s4 = reinterpret_cast<const raw_t*>(src);
+  unsigned int acc = 0;
+  uint64_t c = wave;
+  for (; (c + 1) * U * 64 <= n16; c += nwaves) {
+    const raw_t* p = s4 + c * U * 64 + lane;
+    raw_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(p + u * 64);
+#pragma unroll
+    for (int u = 0; u < U; u++) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+  }
+  if (c * U * 64 < n16 && c * U * 64 + U * 64 > n16)                     // the last, partial piece
+    for (uint64_t i = c * U * 64 + lane; i < n16; i += 64) { const raw_t v = s4[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
 
 
 // Self-test of div_by_count against IEEE division: every count 1..FS_TMAX-1 with pseudo-random

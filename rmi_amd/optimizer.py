@@ -17,7 +17,7 @@ from __future__ import annotations
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ThreadPoolExecutor, as_completed
 from dataclasses import dataclass
 
 from . import codegen, train
@@ -160,15 +160,33 @@ def measure_rmis(tr: train.Trainer, configs: list[tuple[str, int]], threads: int
     for (rk, _lk), _m, bf in parsed:
         if (rk, bf) not in root_cache and (rk, bf) not in need:
             need.append((rk, bf))
+    # the leaf passes of the configurations whose roots are fitted go out in batches while the other root fits (a host core each,
+    # about a second for 200 M keys) are still running
+    done: list = [None] * len(parsed)
+    pending = list(range(len(parsed)))
+    errors: dict = {}
+
+    def flush(final: bool) -> None:
+        batch = [i for i in pending if (parsed[i][0][0], parsed[i][2]) in root_cache]
+        if not batch or (not final and len(batch) < max(1, in_flight)):
+            return
+        res = tr.train_many([(root_cache[(parsed[i][0][0], parsed[i][2])], parsed[i][0][1], parsed[i][2]) for i in batch], in_flight=max(1, in_flight))
+        for i, d in zip(batch, res):
+            done[i] = d
+            if d[0] != 0:
+                errors[i] = getattr(tr, "last_many_error", "")
+        pending[:] = [i for i in pending if i not in batch]
+
     with ThreadPoolExecutor(max_workers=max(1, threads)) as root_pool:
-        futs = {key: root_pool.submit(tr.fit_root, key[0], key[1], root_mode) for key in need}
-        for key, f in futs.items():
-            root_cache[key] = f.result()
-    done = tr.train_many([(root_cache[(rk, bf)], lk, bf) for (rk, lk), _m, bf in parsed], in_flight=max(1, in_flight))
+        futs = {root_pool.submit(tr.fit_root, key[0], key[1], root_mode): key for key in need}
+        for f in as_completed(futs):
+            root_cache[futs[f]] = f.result()
+            flush(False)
+    flush(True)
     out = []
     for (rc, rmi), (_k, m, bf) in zip(done, parsed):
         if rc != 0:
-            raise train.RMIError(rc, f"{m} {bf}")
+            raise train.RMIError(rc, f"{m} {bf}: {errors.get(len(out), '')}")
         stats = RMIStatistics.from_trained(rmi)
         out.append(stats)
         if progress:

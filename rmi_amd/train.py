@@ -264,11 +264,12 @@ class Trainer:
         self._host_keys = a
         return a
 
-    def measure_read_bandwidth(self, iters: int = 10) -> float:
-        """GB/s of a read-only streaming kernel over the resident keys (the box's achievable HBM rate)."""
+    def measure_read_bandwidth(self, iters: int = 10, pattern: int = 0) -> float:
+        """GB/s of a read-only streaming kernel over the resident keys (the box's achievable HBM rate).  pattern 0: grid-stride
+        16-byte loads; 1: contiguous 8 KB pieces per wave, non-temporal loads (the pattern of the one-read kernels)."""
         v = C.c_double()
         self.wait_keys()
-        _check(self._lib.rmi_hip_measure_read_bandwidth(self._h, iters, C.byref(v)), self._h)
+        _check(self._lib.rmi_hip_measure_read_bandwidth_ex(self._h, iters, int(pattern), C.byref(v)), self._h)
         return float(v.value)
 
     def set_profile_level(self, level: int):
@@ -385,6 +386,7 @@ class Trainer:
         self._table_in_ctx = None                                 # (the context's table is whatever its last configuration set)
         if rc not in (0,) and all(int(r) == 0 for r in rcs[:n]):
             _check(rc, self._h)                                   # (the call itself failed, not a configuration)
+        self.last_many_error = (self._lib.rmi_hip_last_error(self._h) or b"").decode() if rc else ""   # every failing worker's first message
         out = []
         for i, (root, _leaf, L) in enumerate(configs):
             if int(rcs[i]) != 0:
@@ -392,8 +394,13 @@ class Trainer:
                 continue
             t = self._result(res[i], root, kinds[i], int(L))
             t._trainer = None
+            t.pipeline = 0                                        # (rmi_hip_last_pipeline speaks of the caller's context only: not known per configuration)
             out.append((0, t))
         return out
+
+    def release_views(self):
+        """Frees the worker contexts train_many keeps between calls (each holds per-leaf buffers of the largest leaf count it trained)."""
+        _check(self._lib.rmi_hip_release_views(self._h), self._h)
 
     def fit_root_host(self, keys: np.ndarray, root: str | int, num_leaves: int) -> Model:
         """The exact root fit from keys in HOST memory, no device involved (linear, robust_linear; linear_spline and radix

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.rmi_hip_abi_version() == 5
+    assert lib.rmi_hip_abi_version() == 6
 
 
 def test_registry_names(lib):
