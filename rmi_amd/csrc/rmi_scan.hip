@@ -14,7 +14,7 @@ static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
   const uint64_t mis = (uint64_t)((reinterpret_cast<uintptr_t>(keys + a.sp.it_lo) / sizeof(K)) % align);
   const long long tile0 = (long long)a.sp.it_lo - (long long)mis;
   const uint64_t rel_hi = a.sp.it_hi - (uint64_t)tile0;
-  const unsigned int ntiles = (unsigned int)(rel_hi / G::TILE + 1);             // (the position behind the last key lies in a tile)
+  const unsigned int ntiles = (unsigned int)(rel_hi / G::BTILE + 1);            // big tiles (the position behind the last key lies in one)
   const unsigned int tpx = (ntiles + 7u) / 8u;
   unsigned int grid = (ntiles + 7u) & ~7u;
   if (grid > a.max_waves) grid = a.max_waves & ~7u;
@@ -38,7 +38,12 @@ static int scan_launch_k(int dtype, ScanLaunch& a, hipStream_t s) {
   return -1;
 }
 
-unsigned int rmi_scan_waves_per_cu() { return 4u * RMI_SC_WPE; }
+// (what the registers and the LDS of a CU hold: 4 SIMDs x RMI_SC_WPE waves, 160 KB over the kernel's static LDS -- the tile image and 2.7 KB of tables;
+//  the same for every instance.  A launch of more waves than are resident would run its surplus as a second round behind the first.)
+unsigned int rmi_scan_waves_per_cu() {
+  const unsigned int by_lds = 163840u / ((unsigned int)ScGeom<uint32_t, 32>::LDS_DW * 4u + 2720u);
+  return by_lds < 4u * RMI_SC_WPE ? by_lds : 4u * RMI_SC_WPE;
+}
 
 int rmi_scan_gaps_launch(int dtype, ScanLaunch& a, hipStream_t s) {
   StatsPartial* const part = a.out.partials + a.waves;

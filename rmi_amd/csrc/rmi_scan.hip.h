@@ -88,8 +88,15 @@ template <typename K, int V> struct ScGeom {
   // ONE address rule for the front chunks, the tile and the look-ahead: the key with tile-relative index rel (in [-FHN, TILE + EXTN))
   // has its first dword at T0 + d + 4 floor(d / ROWD), d = rel DW -- rows of ROWD dwords, 4 dwords of padding behind each
   static constexpr int T0 = FHC * 4 + 4;
-  static constexpr int LDS_DW = T0 + 64 * S + (EXTC * 4 / ROWD) * S;
+  // A wave takes NSUB consecutive tiles at a time (a "big tile": 128 rows): the short form of an ordinary big tile gives a lane NSUB
+  // consecutive rows (VF keys) -- the phases around the error pass cost the same for twice the keys --, the general form takes the
+  // big tile as NSUB tiles one after the other, out of the same LDS image.
+  static constexpr int NSUB = 2;
+  static constexpr int BTILE = NSUB * TILE, NCHB = NSUB * NCH, VF = NSUB * V;
+  static constexpr int LDS_DW = T0 + NSUB * 64 * S + (EXTC * 4 / ROWD) * S;
   static constexpr int LOGV = V == 32 ? 5 : (V == 16 ? 4 : (V == 8 ? 3 : -1));
+  static constexpr int LOGVF = LOGV + 1;
+  static_assert(VF <= 64, "a bit per key of a lane in a 64-bit mask");
   static_assert(V <= 32 && LOGV > 0, "a bit per key in a 32-bit mask");
   static_assert(ROWD == 32, "the address rule shifts by 5");
   static_assert(FHC + EXTC <= 64, "one aux chunk per lane");
@@ -204,11 +211,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
   using G = ScGeom<K, V>;
   using B = typename LnBits<K>::type;
   constexpr int DW = G::DW, KPC = G::KPC, TILE = G::TILE, S = G::S, NCH = G::NCH, EXTN = G::EXTN, FHC = G::FHC, FHN = G::FHN, T0 = G::T0;
+  constexpr int NSUB = G::NSUB, BTILE = G::BTILE, NCHB = G::NCHB, VF = G::VF;
   __shared__ __attribute__((aligned(16))) unsigned int lds[G::LDS_DW];
   __shared__ unsigned int r_s[SC_SLOTS + 1], r_t[SC_SLOTS + 1], r_g0[SC_SLOTS + 1], r_yp[SC_SLOTS + 1];   // boundary records of a batch
   __shared__ __attribute__((aligned(16))) double m_ab[2 * (SC_SLOTS + 2)];                                   // (alpha, beta) per slot, one entry of padding either side
   __shared__ unsigned int m_err[SC_SLOTS + 2], m_run[SC_SLOTS + 2];
-  unsigned int* const trow = lds + T0;                // lane l's keys at trow[l S ...]; the front chunks and the look-ahead by the same rule (ScGeom)
+  unsigned int* const trow0 = lds + T0;               // row r of the big tile at trow0[r S ...]; the front chunks and the look-ahead by the same rule (ScGeom)
 
   const int lane = threadIdx.x;
   const unsigned int base32 = (unsigned int)(unsigned long long)tile0;          // global index of relative index 0 (mod 2^32)
@@ -259,36 +267,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
     }
   };
 
-  // ---- tile loads: NCH chunks per lane (chunk c 64 + lane of the tile) + one aux chunk (lane 0: the chunk in front of the
-  //      tile; lanes FHC .. FHC + EXTC - 1: the look-ahead behind it).  A chunk is loaded iff it overlaps the readable keys [rd_lo, rd_hi);
-  //      a tile that lies inside them with its halo is loaded without the tests.
-  uint4 pf[NCH], pfx;
-  auto chunk_load = [&](long long rel_first) -> uint4 {                         // rel_first: relative index of the chunk's first key
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (rel_first + KPC > rd_lo_rel && rel_first < rd_hi_rel) {
-      typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
-      const raw_t rw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(kb + rel_first));
-      v = make_uint4(rw.x, rw.y, rw.z, rw.w);
-    }
-    return v;
+  // ---- big-tile loads.  A PLAIN big tile -- every chunk of it, of its front chunks and of its look-ahead readable, every position of tile
+  //      and look-ahead a key of this launch -- comes in by NCHB coalesced 16-byte non-temporal loads per lane (chunk c 64 + lane) + one aux
+  //      chunk (lanes 0 .. FHC - 1: the chunks in front; lanes FHC .. FHC + EXTC - 1: the look-ahead), issued a big tile ahead.  The others (the
+  //      two ends of a launch) are staged chunk by chunk when their turn comes (stage_slow below): their tests and 64-bit index arithmetic stay out of
+  //      the registers of the loop.
+  uint4 pf[NCHB], pfx;
+  auto plain = [&](unsigned int tile) -> bool {                                // (wave-uniform)
+    const long long a = (long long)tile * BTILE;
+    return a - FHN >= rd_lo_rel && a + BTILE + EXTN <= rd_hi_rel && a >= (long long)rel_lo + 1 && a + BTILE + EXTN + 1 <= (long long)rel_hi;
   };
-  // relative index of the first key of this lane's aux chunk of the tile at relative index a
-  auto aux_first = [&](long long a) -> long long { return lane < FHC ? a - (long long)(FHC - lane) * KPC : a + TILE + (long long)(lane - FHC) * KPC; };
-  auto load_tile = [&](unsigned int tile) {
-    const long long a = (long long)tile * TILE;
-    if (a - FHN >= rd_lo_rel && a + TILE + EXTN <= rd_hi_rel) {                 // (wave-uniform)
-      typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
-      const raw_t* const p0 = reinterpret_cast<const raw_t*>(kb + a) + lane;
+  // (`ln`: the lane number behind a compiler barrier inside the loop -- the per-chunk addresses are then recomputed per big tile, two
+  //  instructions each, instead of being kept as 40 loop invariants in registers the loop does not have)
+  auto load_tile = [&](unsigned int tile, int ln) {
+    typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
+    const long long a = (long long)tile * BTILE;
+    const raw_t* const p0 = reinterpret_cast<const raw_t*>(kb + a) + ln;
 #pragma unroll
-      for (int c = 0; c < NCH; c++) { const raw_t rw = __builtin_nontemporal_load(p0 + c * 64); pf[c] = make_uint4(rw.x, rw.y, rw.z, rw.w); }
-      pfx = make_uint4(0u, 0u, 0u, 0u);
-      if (lane < FHC + G::EXTC) { const raw_t rw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(kb + aux_first(a))); pfx = make_uint4(rw.x, rw.y, rw.z, rw.w); }
-      return;
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; c++) pf[c] = chunk_load(a + (long long)(c * 64 + lane) * KPC);
+    for (int c = 0; c < NCHB; c++) { const raw_t rw = __builtin_nontemporal_load(p0 + c * 64); pf[c] = make_uint4(rw.x, rw.y, rw.z, rw.w); }
     pfx = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < FHC + G::EXTC) pfx = chunk_load(aux_first(a));
+    if (ln < FHC + G::EXTC) {
+      const long long ax = ln < FHC ? a - (long long)(FHC - ln) * KPC : a + BTILE + (long long)(ln - FHC) * KPC;
+      const raw_t rw = __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(kb + ax));
+      pfx = make_uint4(rw.x, rw.y, rw.z, rw.w);
+    }
   };
   // persistent waves; block b runs on XCD b % 8 (observed, for speed only): each XCD streams a contiguous range of tiles, so
   // that the look-ahead of a tile is the neighbouring wave's tile in the same L2
@@ -296,7 +298,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
   const unsigned int t_lo = xcd * tiles_per_xcd, t_hi = min(ntiles, t_lo + tiles_per_xcd);
   ScAgg agg{0ull, 0ull, 0ull, 0.0, 0.0};
   unsigned int tile = t_lo + wix;
-  if (tile < t_hi) load_tile(tile);
+  if (tile < t_hi && plain(tile)) load_tile(tile, lane);
 
 #if RMI_SC_PROF
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -308,128 +310,146 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
     ntile++;
 #endif
     SC_TICK(7);
-    const unsigned int relA = tile * (unsigned int)TILE;                        // relative index of the tile's first key
-    const unsigned int A = base32 + relA;                                       // ... and its global index
-    // ---- validity.  The tiles at the two ends of the launch hold positions outside [it_lo, it_hi): those take the value of the
-    //      nearest valid key BEFORE the tile goes to LDS (no leaf start, no new key value arises among them, and the key behind the
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const unsigned int relA2 = tile * (unsigned int)BTILE;                      // relative index of the big tile's first key
+    const unsigned int A2 = base32 + relA2;                                     // ... and its global index
+    // ---- validity.  The big tiles at the two ends of the launch hold positions outside [it_lo, it_hi): those take the value of the
+    //      nearest valid key on their way to LDS (no leaf start, no new key value arises among them, and the key behind the
     //      last key equals it: no run is recorded there, Q5); the launch's first key and the position behind its last key are leaf
     //      starts by decree (below).
-    const bool edge = relA < rel_lo + 1u || relA + (unsigned int)TILE + (unsigned int)EXTN + 1u > rel_hi;   // (wave-uniform)
-    if (edge && n_it > 0u) {
-      const B k_first = (B)key_to_bits<K>(kb[rel_lo]), k_last = (B)key_to_bits<K>(kb[rel_hi - 1u]);
-      auto patch = [&](uint4& q, long long rel_first) {
-        unsigned int w[4] = {q.x, q.y, q.z, q.w};
+    const bool edge2 = relA2 < rel_lo + 1u || relA2 + (unsigned int)BTILE + (unsigned int)EXTN + 1u > rel_hi;   // (wave-uniform)
+    const bool plain_t = plain(tile);                                           // (implies !edge2)
+    // ---- stage the big tile (padded rows) and the aux chunks
+    wave_sync();
+    if (plain_t) {
 #pragma unroll
-        for (int k = 0; k < KPC; k++) {
-          const long long rel = rel_first + k;
-          if (rel < (long long)rel_lo || rel >= (long long)rel_hi) {
-            const B kv = rel < (long long)rel_lo ? k_first : k_last;
-            if constexpr (DW == 1) w[k] = (unsigned int)kv;
-            else { w[2 * k] = (unsigned int)kv; w[2 * k + 1] = (unsigned int)((unsigned long long)kv >> 32); }
+      for (int c = 0; c < NCHB; c++) {
+        const int d0 = (c * 64 + ln) * 4;                                        // dword offset of the chunk from the big tile's first key
+        *reinterpret_cast<uint4*>(trow0 + d0 + 4 * (d0 >> 5)) = pf[c];
+      }
+      if (ln < FHC + G::EXTC) {
+        const int d0 = ln < FHC ? (ln - FHC) * 4 : NSUB * 64 * G::ROWD + (ln - FHC) * 4;
+        *reinterpret_cast<uint4*>(trow0 + d0 + 4 * (d0 >> 5)) = pfx;
+      }
+    } else {
+      // stage_slow: chunk by chunk from the key array; a chunk is loaded iff it overlaps the readable keys [rd_lo, rd_hi)
+      const long long a = (long long)relA2;
+      B k_first = 0, k_last = 0;
+      if (n_it > 0u) { k_first = (B)key_to_bits<K>(kb[rel_lo]); k_last = (B)key_to_bits<K>(kb[rel_hi - 1u]); }
+      constexpr int NCHT = FHC + NCHB * 64 + G::EXTC;                            // chunks of the LDS image
+#pragma unroll 1
+      for (int ch = lane; ch < NCHT; ch += 64) {
+        const int d0 = (ch - FHC) * 4;
+        const long long rel_first = a + (long long)(ch - FHC) * KPC;
+        unsigned int w[4] = {0u, 0u, 0u, 0u};
+        if (rel_first + KPC > rd_lo_rel && rel_first < rd_hi_rel) {
+          const uint4 q = *reinterpret_cast<const uint4*>(kb + rel_first);
+          w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        }
+        if (edge2 && n_it > 0u) {
+#pragma unroll
+          for (int k = 0; k < KPC; k++) {
+            const long long rel = rel_first + k;
+            if (rel < (long long)rel_lo || rel >= (long long)rel_hi) {
+              const B kv = rel < (long long)rel_lo ? k_first : k_last;
+              if constexpr (DW == 1) w[k] = (unsigned int)kv;
+              else { w[2 * k] = (unsigned int)kv; w[2 * k + 1] = (unsigned int)((unsigned long long)kv >> 32); }
+            }
           }
         }
-        q = make_uint4(w[0], w[1], w[2], w[3]);
-      };
-      const long long a = (long long)relA;
-#pragma unroll
-      for (int c = 0; c < NCH; c++) patch(pf[c], a + (long long)(c * 64 + lane) * KPC);
-      patch(pfx, aux_first(a));
-    }
-    // ---- stage the tile (padded rows) and the aux chunks
-    wave_sync();
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      const unsigned int kk0 = (unsigned int)(c * 64 + lane) * (unsigned int)KPC;   // key offset of the chunk in the tile
-      *reinterpret_cast<uint4*>(trow + (kk0 / (unsigned int)V) * (unsigned int)S + (kk0 % (unsigned int)V) * (unsigned int)DW) = pf[c];
-    }
-    if (lane < FHC + G::EXTC) {
-      const int d0 = lane < FHC ? (lane - FHC) * 4 : 64 * G::ROWD + (lane - FHC) * 4;   // dword offset of the chunk from the tile's first key
-      *reinterpret_cast<uint4*>(trow + d0 + 4 * (d0 >> 5)) = pfx;
-    }
-    wave_sync();
-    // key (raw bits) at a global index near the tile: LDS where the tile, its front chunk or its look-ahead hold it
-    auto lds_bits = [&](int rel) -> B { const int d = rel * DW; return bits_at(trow + d + 4 * (d >> 5)); };   // rel in [-FHN, TILE + EXTN)
-    auto key_bits = [&](unsigned int i) -> B {
-      const int rel = (int)(i - A);
-      if (rel >= -FHN && rel < TILE + EXTN) return lds_bits(rel);
-      return key_to_bits<K>(kb[(unsigned int)(i - base32)]);
-    };
-    auto key_at = [&](unsigned int i) -> K { return bits_to_key<K>(key_bits(i)); };
-    // ---- the lane's keys
-    const unsigned int relf = relA + (unsigned int)(lane * V);                  // relative index of the lane's first key
-    const unsigned int f = base32 + relf;
-    B kk[V];
-    {
-      const unsigned int* rowp = trow + lane * S;
-#pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        const uint4 q = *reinterpret_cast<const uint4*>(rowp + 4 * c);
-        if constexpr (DW == 1) { kk[4 * c] = q.x; kk[4 * c + 1] = q.y; kk[4 * c + 2] = q.z; kk[4 * c + 3] = q.w; }
-        else { kk[2 * c] = ((B)q.y << 32) | q.x; kk[2 * c + 1] = ((B)q.w << 32) | q.z; }
+        *reinterpret_cast<uint4*>(trow0 + d0 + 4 * (d0 >> 5)) = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
-    const B kprev_b = key_bits(f - 1u), knext_b = key_bits(f + (unsigned int)V);
+    wave_sync();
+    // key (raw bits) with the relative index rel0 from the big tile's first key, in [-FHN, BTILE + EXTN)
+    auto lds_bits0 = [&](int rel0) -> B { const int d = rel0 * DW; return bits_at(trow0 + d + 4 * (d >> 5)); };
     SC_TICK(0);
-    // ---- the next tile's loads: in flight during everything below
-    { const unsigned int nt = tile + wpx; if (nt < t_hi) load_tile(nt); }
+    // ---- the next big tile's loads: in flight during everything below
+    { const unsigned int nt = tile + wpx; if (nt < t_hi && plain(nt)) load_tile(nt, ln); }
     SC_TICK(1);
 
-    // y (FixDups offset, models/mod.rs:154-185) of the key in front of the tile: its run of equal keys is walked in the front chunks; a run that
-    // reaches beyond them is looked up in the key array
-    auto front_y = [&]() -> unsigned int {
-      unsigned int y = A - 1u;
-      if (lane == 0 && relA > rel_lo) {
-        const unsigned int lim = min((unsigned int)FHN, relA - rel_lo);          // the keys A - lim .. A - 1 belong to this launch
-        const K k1 = bits_to_key<K>(lds_bits(-1));
+    // y (FixDups offset, models/mod.rs:154-185) of the key in front of the (sub-)tile that starts hoff keys into the big tile, at the global
+    // index A_ (relative index relA_): its run of equal keys is walked in the keys in front of it; a run that reaches beyond the front
+    // chunks is looked up in the key array
+    auto front_y = [&](int hoff, unsigned int A_, unsigned int relA_) -> unsigned int {
+      unsigned int y = A_ - 1u;
+      if (lane == 0 && relA_ > rel_lo) {
+        const unsigned int lim = min((unsigned int)FHN, relA_ - rel_lo);         // the keys A_ - lim .. A_ - 1 belong to this launch
+        const K k1 = bits_to_key<K>(lds_bits0(hoff - 1));
         unsigned int back = 1u;
-        while (back < lim && bits_to_key<K>(lds_bits(-1 - (int)back)) == k1) back++;
-        if (back < lim || relA - rel_lo == back) y = A - back;
-        else y = (unsigned int)first_occurrence(keys, (uint64_t)(tile0 + (long long)relA - 1), sp.rd_lo);
+        while (back < lim && bits_to_key<K>(lds_bits0(hoff - 1 - (int)back)) == k1) back++;
+        if (back < lim || relA_ - rel_lo == back) y = A_ - back;
+        else y = (unsigned int)first_occurrence(keys, (uint64_t)(tile0 + (long long)relA_ - 1), sp.rd_lo);
       }
       return (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
     };
-    // ================= the ordinary tile (see the head of the file): same values as the general form below, fewer instructions =================
+    // ================= the ordinary big tile (see the head of the file): same values as the general form below, fewer instructions =================
     if constexpr (s2_root_monotone<ROOT>() && RMI_SC_FAST) {
-      if (mono && !edge && relA >= rel_lo + (unsigned int)FHN + 1u) {
+      if (mono && plain_t && relA2 >= rel_lo + (unsigned int)FHN + 1u) {
         bool done = false;
         do {
-          const unsigned int* const rowp = trow + lane * S;
+          constexpr int LOGV = G::LOGV;
+          const unsigned int* const rowp = trow0 + (NSUB * ln) * S;             // the lane's NSUB consecutive rows: VF keys
+          const unsigned int f = A2 + (unsigned int)(lane * VF);                // global index of the lane's first key
+          // (a row at a time in registers: the next big tile's loads hold 68 of them for the whole pass)
+          B kk[V];
+          auto read_row = [&](int rr) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+              const uint4 q = *reinterpret_cast<const uint4*>(rowp + rr * S + 4 * c);
+              if constexpr (DW == 1) { kk[4 * c] = q.x; kk[4 * c + 1] = q.y; kk[4 * c + 2] = q.z; kk[4 * c + 3] = q.w; }
+              else { kk[2 * c] = ((B)q.y << 32) | q.x; kk[2 * c + 1] = ((B)q.w << 32) | q.z; }
+            }
+          };
+          const B kprev_b = lds_bits0(lane * VF - 1), knext_b = lds_bits0((lane + 1) * VF), klast_b = lds_bits0((lane + 1) * VF - 1);
           bool oob_x = false, oob_l = false;
           const unsigned int tp = target_of(bits_to_key<K>(kprev_b), oob_x);    // the key in front of the lane
-          const unsigned int tl = target_of(bits_to_key<K>(kk[V - 1]), oob_l);  // the lane's last key: the largest prediction of the lane
+          const unsigned int tl = target_of(bits_to_key<K>(klast_b), oob_l);    // the lane's last key: the largest prediction of the lane
           if constexpr (!root_needs_bounds_check<ROOT>()) { if (oob_l) flags |= EF_ROOT_OOB; }   // two_layer.rs:45-48
           const bool has = tl != tp;                                            // a leaf starts in this lane (targets are monotone)
           const unsigned long long hm = __ballot(has);
-          if (hm == 0ull) { done = true; break; }                               // the tile lies inside one leaf that started earlier
-          // ---- F1: the lane's first leaf start by bisection of its row
-          unsigned int p = (unsigned int)V, t_hi = tl;
+          if (hm == 0ull) { done = true; break; }                               // the big tile lies inside one leaf that started earlier
+          // ---- the look-ahead's targets and the duplicate tests first: independent of the bisection below, their LDS round trips overlap
+          unsigned int t_ext[EXTN / 64];
+          bool dq = false;
           {
-            unsigned int lo = 0u, hi = (unsigned int)V - 1u;                    // t(hi) != tp; t(v) == tp for v < lo
 #pragma unroll
-            for (int it = 0; it < G::LOGV; it++) {
+            for (int o = 0; o < EXTN; o += 64) {
+              bool o2;
+              const K kx = bits_to_key<K>(lds_bits0(BTILE + o + lane));
+              t_ext[o / 64] = target_of(kx, o2);
+              dq = dq || (kx == bits_to_key<K>(lds_bits0(BTILE + o + lane - 1)));
+            }
+            if (lane == 0) dq = dq || (bits_to_key<K>(lds_bits0(-1)) == bits_to_key<K>(lds_bits0(-2)));
+            K kp = bits_to_key<K>(kprev_b);
+#pragma unroll
+            for (int rr = 0; rr < NSUB; rr++) {
+              read_row(rr);
+#pragma unroll
+              for (int v = 0; v < V; v++) { const K kv = bits_to_key<K>(kk[v]); dq = dq || (kv == kp); kp = kv; }
+            }
+          }
+          bool o2x;
+          const unsigned int t2 = target_of(bits_to_key<K>(lds_bits0(-2)), o2x);
+          // ---- F1: the lane's first leaf start by bisection of its rows
+          unsigned int p = (unsigned int)VF, t_hi = tl;
+          {
+            unsigned int lo = 0u, hi = (unsigned int)VF - 1u;                   // t(hi) != tp; t(v) == tp for v < lo
+#pragma unroll
+            for (int it = 0; it < G::LOGVF; it++) {
               const unsigned int mid = (lo + hi) >> 1;
               bool o2;
-              const unsigned int tm = target_of(bits_to_key<K>(bits_at(rowp + mid * (unsigned int)DW)), o2);
+              const unsigned int tm = target_of(bits_to_key<K>(bits_at(rowp + (mid >> LOGV) * (unsigned int)S + (mid & (unsigned int)(V - 1)) * (unsigned int)DW)), o2);
               const bool ne = tm != tp;
               hi = ne ? mid : hi; t_hi = ne ? tm : t_hi; lo = ne ? lo : mid + 1u;
             }
             if (has) p = hi;
           }
           if (__any(has && (t_hi != tl || t_hi - tp > 5u))) break;              // a lane with more than one start, or more than 4 empty leaves in front of it
-          // ---- duplicates among the keys [A - 2, A + TILE + EXTN)
-          unsigned int hd = 0u;
-          bool dq = false;
-          {
-            K kp = bits_to_key<K>(kprev_b);
-#pragma unroll
-            for (int v = 0; v < V; v++) { const K kv = bits_to_key<K>(kk[v]); dq = dq || (kv == kp); kp = kv; }
-#pragma unroll
-            for (int o = 0; o < EXTN; o += 64) dq = dq || (bits_to_key<K>(lds_bits(TILE + o + lane)) == bits_to_key<K>(lds_bits(TILE + o + lane - 1)));
-            if (lane == 0) dq = dq || (bits_to_key<K>(lds_bits(-1)) == bits_to_key<K>(lds_bits(-2)));
-          }
-          const bool dups = __any(dq) != 0;
+          const bool dups = __any(dq) != 0;                                     // duplicates among the keys [A2 - 2, A2 + BTILE + EXTN)
           if (dups && !RMI_SC_FAST_DUPS) break;
-          // ---- the end of the leaf that is open at the tile's end: in the look-ahead, or the general form takes the tile
+          // ---- the end of the leaf that is open at the big tile's end: in the look-ahead, or the general form takes the tiles
           const unsigned int t_tile_last = sc_lane63(tl);
           unsigned int term_rel = 0u, tt = 0u;
           {
@@ -437,13 +457,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
 #pragma unroll
             for (int o = 0; o < EXTN; o += 64) {
               if (!found) {
-                bool o2;
-                const unsigned int t = target_of(bits_to_key<K>(lds_bits(TILE + o + lane)), o2);
-                const unsigned long long dm = __ballot(t != t_tile_last);
+                const unsigned long long dm = __ballot(t_ext[o / 64] != t_tile_last);
                 if (dm) {
                   const int src = __builtin_ctzll(dm);
-                  term_rel = (unsigned int)(TILE + o + src);
-                  tt = (unsigned int)__builtin_amdgcn_readlane((int)t, src);
+                  term_rel = (unsigned int)(BTILE + o + src);
+                  tt = (unsigned int)__builtin_amdgcn_readlane((int)t_ext[o / 64], src);
                   found = true;
                 }
               }
@@ -452,11 +470,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
           }
           // ---- the split of the 2-way join (two_layer.rs:130-175) anywhere near: the general form knows Q2-Q4
           if (host_split) {
-            if ((unsigned int)(h_split - (A - 2u)) <= (unsigned int)(TILE + EXTN + 2)) break;
+            if ((unsigned int)(h_split - (A2 - 2u)) <= (unsigned int)(BTILE + EXTN + 2)) break;
           } else {
-            bool o2;
-            const unsigned int t2 = target_of(bits_to_key<K>(lds_bits(-2)), o2);
-            if (t2 < mid && tt >= mid) break;                                   // the targets of [A - 2, end of the open leaf] cross L / 2
+            if (t2 < mid && tt >= mid) break;                                   // the targets of [A2 - 2, end of the open leaf] cross L / 2
           }
           if (RMI_SC_STOP == 1) { done = true; break; }
           SC_TICK(2);
@@ -465,21 +481,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
           const unsigned int nb = (unsigned int)__builtin_popcountll(hm);
           unsigned int y_in = f - 1u, yp = f + p - 1u;                           // (no duplicates: every key is its own first occurrence)
           if (dups) {
+            unsigned long long hd = 0ull;
             K kp = bits_to_key<K>(kprev_b);
 #pragma unroll
-            for (int v = 0; v < V; v++) { const K kv = bits_to_key<K>(kk[v]); hd |= !(kv == kp) ? (1u << v) : 0u; kp = kv; }
-            const unsigned int lh = hd ? f + (31u - (unsigned int)__builtin_clz(hd)) + 1u : 0u;   // (index + 1 of this lane's last head)
+            for (int rr = 0; rr < NSUB; rr++) {
+              read_row(rr);
+#pragma unroll
+              for (int v = 0; v < V; v++) { const K kv = bits_to_key<K>(kk[v]); hd |= !(kv == kp) ? (1ull << (rr * V + v)) : 0ull; kp = kv; }
+            }
+            const unsigned int lh = hd ? f + (63u - (unsigned int)__builtin_clzll(hd)) + 1u : 0u;   // (index + 1 of this lane's last head)
             const unsigned int lh_prev = sc_dpp<0x138, 0xF>(0u, lh);              // wave_shr:1
             const unsigned int lh_ex = sc_scan_max(lh_prev);
-            const unsigned int y_tile = front_y();
+            const unsigned int y_tile = front_y(0, A2, relA2);
             y_in = lh_ex ? lh_ex - 1u : y_tile;
-            const unsigned int hb = hd & sc_mask_below(p);
-            yp = hb ? f + (31u - (unsigned int)__builtin_clz(hb)) : y_in;
+            const unsigned long long hb = hd & ((1ull << (p & 63u)) - 1ull);      // (p < VF <= 64 in the lanes that use it)
+            yp = hb ? f + (63u - (unsigned int)__builtin_clzll(hb)) : y_in;
           }
           // ---- F2: the records of the starts; the open leaf's end closes them
           wave_sync();
           if (has) { r_s[q] = f + p; r_t[q] = t_hi; r_g0[q] = tp + 1u; r_yp[q] = yp; }
-          if (lane == 0) r_s[nb] = A + term_rel;
+          if (lane == 0) r_s[nb] = A2 + term_rel;
           wave_sync();
           // ---- F3: the models.  Lane l: slot l.  Container [s - 1, e]: both end points exist (no split, no end of the data nearby) and their keys differ
           unsigned int q_s = 0u, q_e = 0u, q_t = 0u;
@@ -487,7 +508,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
           double ma = 0.0, mb = 0.0;
           if ((unsigned int)lane < nb) {
             q_s = r_s[lane]; q_e = r_s[lane + 1]; q_t = r_t[lane];
-            k_lo = bits_to_key<K>(lds_bits((int)(q_s - 1u - A))); k_hi = bits_to_key<K>(lds_bits((int)(q_e - A)));
+            k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))); k_hi = bits_to_key<K>(lds_bits0((int)(q_e - A2)));
             const double x0 = KeyTraits<K>::as_float(k_lo), x1 = KeyTraits<K>::as_float(k_hi);
             const double y0f = (double)r_yp[lane], y1f = (double)q_e;
             mb = (y0f - y1f) / (x0 - x1);                                        // linear_spline.rs:27
@@ -496,10 +517,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
             m_err[lane + 1] = 0u; m_run[lane + 1] = 0u;
           }
           // which positions hold some lane's start (a scalar mask: the error pass tests it, not the lanes)
-          unsigned int am = has ? (1u << p) : 0u;
-          am |= sc_dpp<0x111, 0xF>(0u, am); am |= sc_dpp<0x112, 0xF>(0u, am); am |= sc_dpp<0x114, 0xF>(0u, am); am |= sc_dpp<0x118, 0xF>(0u, am);
-          am |= sc_dpp<0x142, 0xA>(0u, am); am |= sc_dpp<0x143, 0xC>(0u, am);
-          am = sc_lane63(am);
+          unsigned long long am;
+          {
+            unsigned int a0 = (has && p < 32u) ? (1u << p) : 0u, a1 = (has && p >= 32u) ? (1u << (p - 32u)) : 0u;
+            a0 |= sc_dpp<0x111, 0xF>(0u, a0); a0 |= sc_dpp<0x112, 0xF>(0u, a0); a0 |= sc_dpp<0x114, 0xF>(0u, a0); a0 |= sc_dpp<0x118, 0xF>(0u, a0);
+            a0 |= sc_dpp<0x142, 0xA>(0u, a0); a0 |= sc_dpp<0x143, 0xC>(0u, a0);
+            if constexpr (VF > 32) {
+              a1 |= sc_dpp<0x111, 0xF>(0u, a1); a1 |= sc_dpp<0x112, 0xF>(0u, a1); a1 |= sc_dpp<0x114, 0xF>(0u, a1); a1 |= sc_dpp<0x118, 0xF>(0u, a1);
+              a1 |= sc_dpp<0x142, 0xA>(0u, a1); a1 |= sc_dpp<0x143, 0xC>(0u, a1);
+            }
+            am = ((unsigned long long)sc_lane63(a1) << 32) | (unsigned long long)sc_lane63(a0);
+          }
           wave_sync();
           if (RMI_SC_STOP == 3) { done = true; break; }
           SC_TICK(3);
@@ -510,65 +538,82 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
             double pa1 = 0.0, pb1 = 0.0;
             if (has) { pa1 = m_ab[2 * (q + 1)]; pb1 = m_ab[2 * (q + 1) + 1]; }
             unsigned int m = 0u, m0 = 0u, rn = 0u, rn0 = 0u, y_last = 0u;
-#pragma unroll
-            for (int v = 0; v < V; v++) asm volatile("" : "+v"(kk[v]));
-            unsigned int amr = am;
+            unsigned int amlo = (unsigned int)am, amhi = (unsigned int)(am >> 32);
             if (!dups) {
 #pragma unroll
-              for (int v = 0; v < V; v++) {
-                asm volatile("" : "+s"(amr));
-                if (amr & 1u) {                                                  // (scalar) some lane's start lies at position v
-                  const bool sw = p == (unsigned int)v;
-                  m0 = sw ? m : m0; m = sw ? 0u : m;
-                  pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
+              for (int rr = 0; rr < NSUB; rr++) {
+                read_row(rr);
+#pragma unroll
+                for (int v = 0; v < V; v++) asm volatile("" : "+v"(kk[v]));
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                  const int gv = rr * V + v;                                     // position among the lane's VF keys
+                  unsigned int& amr = gv < 32 ? amlo : amhi;
+                  asm volatile("" : "+s"(amr));
+                  if (amr & 1u) {                                                // (scalar) some lane's start lies at this position
+                    const bool sw = p == (unsigned int)gv;
+                    m0 = sw ? m : m0; m = sw ? 0u : m;
+                    pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
+                  }
+                  amr >>= 1;
+                  const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[v]));
+                  const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);   // linear_spline.rs:52, models/mod.rs:735-737, two_layer.rs:14-18
+                  m = max(m, sg_absdiff(pr, f + (unsigned int)gv));
                 }
-                amr >>= 1;
-                const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[v]));
-                const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);   // linear_spline.rs:52, models/mod.rs:735-737, two_layer.rs:14-18
-                m = max(m, sg_absdiff(pr, f + (unsigned int)v));
               }
             } else {
               unsigned int y = y_in;
-              bool ne = !(bits_to_key<K>(kk[0]) == bits_to_key<K>(kprev_b));
+              bool ne = false;
 #pragma unroll
-              for (int v = 0; v < V; v++) {
-                asm volatile("" : "+s"(amr));
-                if (amr & 1u) {
-                  const bool sw = p == (unsigned int)v;
-                  m0 = sw ? m : m0; m = sw ? 0u : m;
-                  rn0 = sw ? rn : rn0; rn = sw ? 0u : rn;
-                  pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
+              for (int rr = 0; rr < NSUB; rr++) {
+                read_row(rr);
+                const B krow_next = rr + 1 < NSUB ? bits_at(rowp + (rr + 1 < NSUB ? rr + 1 : rr) * S) : knext_b;   // the key behind this row
+                if (rr == 0) ne = !(bits_to_key<K>(kk[0]) == bits_to_key<K>(kprev_b));
+#pragma unroll
+                for (int v = 0; v < V; v++) asm volatile("" : "+v"(kk[v]));
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                  const int gv = rr * V + v;
+                  unsigned int& amr = gv < 32 ? amlo : amhi;
+                  asm volatile("" : "+s"(amr));
+                  if (amr & 1u) {
+                    const bool sw = p == (unsigned int)gv;
+                    m0 = sw ? m : m0; m = sw ? 0u : m;
+                    rn0 = sw ? rn : rn0; rn = sw ? 0u : rn;
+                    pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
+                  }
+                  amr >>= 1;
+                  const K kv = bits_to_key<K>(kk[v]);
+                  const K kn = bits_to_key<K>(v + 1 < V ? kk[v + 1 < V ? v + 1 : v] : krow_next);
+                  const unsigned int i = f + (unsigned int)gv;
+                  y = ne ? i : y;
+                  const double x = KeyTraits<K>::as_float(kv);
+                  const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);
+                  m = max(m, sg_absdiff(pr, y));
+                  // a run of equal keys is recorded when the next different key arrives (lower_bound_correction.rs:108-119)
+                  ne = !(kn == kv);
+                  rn = max(rn, ne ? i + 1u - y : 0u);
                 }
-                amr >>= 1;
-                const K kv = bits_to_key<K>(kk[v]);
-                const K kn = bits_to_key<K>(v + 1 < V ? kk[v + 1 < V ? v + 1 : v] : knext_b);
-                const unsigned int i = f + (unsigned int)v;
-                y = ne ? i : y;
-                const double x = KeyTraits<K>::as_float(kv);
-                const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);
-                m = max(m, sg_absdiff(pr, y));
-                // a run of equal keys is recorded when the next different key arrives (lower_bound_correction.rs:108-119)
-                ne = !(kn == kv);
-                rn = max(rn, ne ? i + 1u - y : 0u);
               }
               y_last = y;
             }
             const unsigned int mA = has ? m0 : m, rA = has ? rn0 : rn;
             if (q >= 1u) { if (mA) atomicMax(&m_err[q], mA); if (rA > 1u) atomicMax(&m_run[q], rA); }
             if (has) { if (m) atomicMax(&m_err[q + 1u], m); if (rn > 1u) atomicMax(&m_run[q + 1u], rn); }
-            // ---- the keys of the open leaf behind the tile: [A + TILE, A + term_rel)
+            // ---- the keys of the open leaf behind the big tile: [A2 + BTILE, A2 + term_rel)
             {
               const double ta = m_ab[2 * nb], tb = m_ab[2 * nb + 1];
               unsigned int em = 0u, rm = 0u;
               unsigned int y_carry = (unsigned int)__builtin_amdgcn_readlane((int)y_last, 63);
-              for (unsigned int o = (unsigned int)TILE; o < term_rel; o += 64u) {
+              for (unsigned int o = (unsigned int)BTILE; o < term_rel; o += 64u) {
                 const unsigned int rel = o + (unsigned int)lane;
                 const bool in = rel < term_rel;
-                const K kv = bits_to_key<K>(lds_bits((int)(in ? rel : o)));
-                const unsigned int i = A + rel;
+                const int rr = (int)(in ? rel : o);
+                const K kv = bits_to_key<K>(lds_bits0(rr));
+                const unsigned int i = A2 + rel;
                 unsigned int y = i;
                 if (dups) {
-                  const K kpv = bits_to_key<K>(lds_bits((int)(in ? rel : o) - 1)), knx = bits_to_key<K>(lds_bits((int)(in ? rel : o) + 1));
+                  const K kpv = bits_to_key<K>(lds_bits0(rr - 1)), knx = bits_to_key<K>(lds_bits0(rr + 1));
                   const unsigned int hidx = (in && !(kv == kpv)) ? i : 0u;
                   const unsigned int pm = sc_scan_max(hidx);
                   y = max(pm, y_carry);
@@ -581,7 +626,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
                   em = max(em, sg_absdiff(pr, y));
                 }
               }
-              if (term_rel > (unsigned int)TILE) {
+              if (term_rel > (unsigned int)BTILE) {
                 if (em) atomicMax(&m_err[nb], em);
                 if (rm > 1u) atomicMax(&m_run[nb], rm);
               }
@@ -640,6 +685,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
 #if RMI_SC_LEANTEST
     continue;                                                                    // timing experiment (results wrong): no general form at all
 #endif
+    // ================= the general form: the big tile's NSUB tiles one after the other, lane l <-> row 64 h + l =================
+    for (int h = 0; h < NSUB; h++) {
+    const unsigned int relA = relA2 + (unsigned int)(h * TILE);                  // relative index of the tile's first key
+    const unsigned int A = base32 + relA;                                       // ... and its global index
+    unsigned int* const trow = trow0 + h * 64 * S;
+    const bool edge = relA < rel_lo + 1u || relA + (unsigned int)TILE + (unsigned int)EXTN + 1u > rel_hi;   // (wave-uniform; implies edge2: the positions outside the launch are filled)
+    // key (raw bits) at a global index near the tile: LDS where the big tile, its front chunks or its look-ahead hold it
+    auto lds_bits = [&](int rel) -> B { return lds_bits0(rel + h * TILE); };     // rel in [-FHN - h TILE, (NSUB - h) TILE + EXTN)
+    auto key_bits = [&](unsigned int i) -> B {
+      const int rel = (int)(i - A);
+      if (rel >= -FHN - h * TILE && rel < (NSUB - h) * TILE + EXTN) return lds_bits(rel);
+      return key_to_bits<K>(kb[(unsigned int)(i - base32)]);
+    };
+    auto key_at = [&](unsigned int i) -> K { return bits_to_key<K>(key_bits(i)); };
+    // ---- the lane's keys
+    const unsigned int relf = relA + (unsigned int)(lane * V);                  // relative index of the lane's first key
+    const unsigned int f = base32 + relf;
+    B kk[V];
+    {
+      const unsigned int* rowp = trow + lane * S;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const uint4 q = *reinterpret_cast<const uint4*>(rowp + 4 * c);
+        if constexpr (DW == 1) { kk[4 * c] = q.x; kk[4 * c + 1] = q.y; kk[4 * c + 2] = q.z; kk[4 * c + 3] = q.w; }
+        else { kk[2 * c] = ((B)q.y << 32) | q.x; kk[2 * c + 1] = ((B)q.w << 32) | q.z; }
+      }
+    }
+    const B kprev_b = key_bits(f - 1u), knext_b = key_bits(f + (unsigned int)V);
 #if RMI_SC_PROF
     unsigned long long gprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast = __builtin_readcyclecounter();
     const unsigned long long gstart = glast;
@@ -691,7 +764,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
       const unsigned int lh = hd ? f + (31u - (unsigned int)__builtin_clz(hd)) + 1u : 0u;   // (index + 1 of this lane's last head)
       const unsigned int lh_prev = sc_dpp<0x138, 0xF>(0u, lh);                    // wave_shr:1
       const unsigned int lh_ex = sc_scan_max(lh_prev);
-      const unsigned int y_tile = front_y();
+      const unsigned int y_tile = front_y(h * TILE, A, relA);
       y_in = lh_ex ? lh_ex - 1u : y_tile;
     }
     const unsigned int anyb = sc_wave_or(bnd);
@@ -1018,6 +1091,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
       printf("general tile %u (relA %u) edge %d nb %u: total %llu | P1 %llu P2 %llu ext %llu P3 %llu P4 %llu P5a %llu P5b %llu\n", tile, relA, (int)edge, nb,
              (unsigned long long)__builtin_readcyclecounter() - gstart, gprof[0], gprof[1], gprof[2], gprof[3], gprof[4], gprof[6], gprof[5]);
 #endif
+    }  // h
   }
 #if RMI_SC_PROF
   if (lane == 0 && (blockIdx.x == 777 || (unsigned long long)__builtin_readcyclecounter() - tstart > 1800000ull))
