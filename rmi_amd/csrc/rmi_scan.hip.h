@@ -58,6 +58,9 @@
 #define SC_TICK(k) do { } while (0)
 #define SC_GT(k) do { } while (0)
 #endif
+#ifndef RMI_SC_BRANCHFREE
+#define RMI_SC_BRANCHFREE 0           // the error pass switches a lane's model without the scalar test: one basic block for all keys of a row
+#endif
 #ifndef RMI_SC_LEANTEST
 #define RMI_SC_LEANTEST 0
 #endif
@@ -315,9 +318,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
     const unsigned int relA2 = tile * (unsigned int)BTILE;                      // relative index of the big tile's first key
     const unsigned int A2 = base32 + relA2;                                     // ... and its global index
     // ---- validity.  The big tiles at the two ends of the launch hold positions outside [it_lo, it_hi): those take the value of the
-    //      nearest valid key on their way to LDS (no leaf start, no new key value arises among them, and the key behind the
-    //      last key equals it: no run is recorded there, Q5); the launch's first key and the position behind its last key are leaf
-    //      starts by decree (below).
+    //      nearest valid key on their way to LDS -- in front the launch's first key, behind its last key the key that follows it in the key
+    //      set (the next shard's first) or, at the end of the data, the last key itself (no run is recorded there, Q5): no leaf start and no
+    //      new key value arises among them; the launch's first key and the position behind its last key are leaf starts by decree (below).
     const bool edge2 = relA2 < rel_lo + 1u || relA2 + (unsigned int)BTILE + (unsigned int)EXTN + 1u > rel_hi;   // (wave-uniform)
     const bool plain_t = plain(tile);                                           // (implies !edge2)
     // ---- stage the big tile (padded rows) and the aux chunks
@@ -336,7 +339,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
       // stage_slow: chunk by chunk from the key array; a chunk is loaded iff it overlaps the readable keys [rd_lo, rd_hi)
       const long long a = (long long)relA2;
       B k_first = 0, k_last = 0;
-      if (n_it > 0u) { k_first = (B)key_to_bits<K>(kb[rel_lo]); k_last = (B)key_to_bits<K>(kb[rel_hi - 1u]); }
+      // (behind the last key of a SHARD the next shard's first key follows: a different key -- leaf-aligned cuts --, so the run of equal keys
+      //  that ends with the shard's last key IS recorded, lower_bound_correction.rs:108-119; behind the last key of all nothing follows, Q5)
+      if (n_it > 0u) { k_first = (B)key_to_bits<K>(kb[rel_lo]); k_last = (B)key_to_bits<K>(sp.it_hi < sp.n ? keys[sp.it_hi] : kb[rel_hi - 1u]); }
       constexpr int NCHT = FHC + NCHB * 64 + G::EXTC;                            // chunks of the LDS image
 #pragma unroll 1
       for (int ch = lane; ch < NCHT; ch += 64) {
@@ -548,6 +553,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
 #pragma unroll
                 for (int v = 0; v < V; v++) {
                   const int gv = rr * V + v;                                     // position among the lane's VF keys
+#if RMI_SC_BRANCHFREE
+                  {
+                    const bool sw = p == (unsigned int)gv;
+                    m0 = sw ? m : m0; m = sw ? 0u : m;
+                    pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
+                  }
+#else
                   unsigned int& amr = gv < 32 ? amlo : amhi;
                   asm volatile("" : "+s"(amr));
                   if (amr & 1u) {                                                // (scalar) some lane's start lies at this position
@@ -556,6 +568,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
                     pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
                   }
                   amr >>= 1;
+#endif
                   const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[v]));
                   const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);   // linear_spline.rs:52, models/mod.rs:735-737, two_layer.rs:14-18
                   m = max(m, sg_absdiff(pr, f + (unsigned int)gv));
@@ -574,6 +587,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
 #pragma unroll
                 for (int v = 0; v < V; v++) {
                   const int gv = rr * V + v;
+#if RMI_SC_BRANCHFREE
+                  {
+                    const bool sw = p == (unsigned int)gv;
+                    m0 = sw ? m : m0; m = sw ? 0u : m;
+                    rn0 = sw ? rn : rn0; rn = sw ? 0u : rn;
+                    pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
+                  }
+#else
                   unsigned int& amr = gv < 32 ? amlo : amhi;
                   asm volatile("" : "+s"(amr));
                   if (amr & 1u) {
@@ -583,6 +604,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
                     pa = sw ? pa1 : pa; pb = sw ? pb1 : pb;
                   }
                   amr >>= 1;
+#endif
                   const K kv = bits_to_key<K>(kk[v]);
                   const K kn = bits_to_key<K>(v + 1 < V ? kk[v + 1 < V ? v + 1 : v] : krow_next);
                   const unsigned int i = f + (unsigned int)gv;
@@ -696,9 +718,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
     auto key_bits = [&](unsigned int i) -> B {
       const int rel = (int)(i - A);
       if (rel >= -FHN - h * TILE && rel < (NSUB - h) * TILE + EXTN) return lds_bits(rel);
-      return key_to_bits<K>(kb[(unsigned int)(i - base32)]);
+      return key_to_bits<K>(keys[i]);                                            // (n < 2^32: i IS the global index)
     };
     auto key_at = [&](unsigned int i) -> K { return bits_to_key<K>(key_bits(i)); };
+    // the key at a global index that may lie outside the launch -- a shard's halo: the point in front of its first leaf, the point behind its
+    // last -- : the key array's value, never the nearest valid key the LDS image holds at such a position
+    auto key_true = [&](unsigned int i) -> K { return ((unsigned int)(i - base32) - rel_lo < n_it) ? key_at(i) : keys[i]; };
     // ---- the lane's keys
     const unsigned int relf = relA + (unsigned int)(lane * V);                  // relative index of the lane's first key
     const unsigned int f = base32 + relf;
@@ -815,7 +840,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
               if (i == 0u) { if (t >= mid) flags |= EF_DEGENERATE_SPLIT; }       // split_idx == 0 -> two_layer.rs:27
               else if ((long long)reli - 1 >= rd_lo_rel) {
                 // a shard's first key: the key in front of it is the previous shard's last -- the prev-last point of the first leaf
-                const unsigned int tp = target_of(kb[reli - 1u], oob);           // (from the key array: LDS holds the launch's first key there)
+                const unsigned int tp = target_of(keys[i - 1u], oob);            // (from the key array: LDS holds the launch's first key there)
                 if (t < tp) flags |= EF_NON_MONOTONE;
                 yp = (unsigned int)first_occurrence(keys, (uint64_t)(tile0 + (long long)reli - 1), sp.rd_lo);
                 note_split(tp);
@@ -897,7 +922,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
             // FixDups offsets of the two end points: the key in front of a leaf start carries the record's y; a leaf's first key and
             // the next leaf's first key are their own first occurrences
             const unsigned int lo32 = (unsigned int)lo, hi32 = (unsigned int)hi;
-            const K k0 = key_at(lo32), k1 = key_at(hi32);
+            const K k0 = key_true(lo32), k1 = key_true(hi32);
             unsigned int y0;
             if (lo32 + 1u == q_s) y0 = r_yp[lane];
             else if (lo32 == q_s) y0 = q_s;
@@ -1004,7 +1029,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
             {
               const K kpv = key_at(i - 1u);
               if (kpv == kv) y = (unsigned int)first_occurrence(keys, (uint64_t)(tile0 + (long long)(unsigned int)(i - base32)), sp.rd_lo);
-              if (i + 1u - base32 < rel_hi) { const K kn = key_at(i + 1u); if (!(kn == kv)) rm = max(rm, i + 1u - y); }
+              if (i + 1u < n32) { const K kn = key_true(i + 1u); if (!(kn == kv)) rm = max(rm, i + 1u - y); }
             }
             const double x = KeyTraits<K>::as_float(kv);
             const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);
@@ -1044,8 +1069,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
         } else {
           double pp[2] = {m_ab[2 * (lane + 1)], m_ab[2 * (lane + 1) + 1]};
           const unsigned int ru = m_run[lane + 1];
-          const K k_next = e < sp.n ? key_at((unsigned int)e) : KeyTraits<K>::max_value();
-          const K k_prev = s > 0 ? key_at((unsigned int)s - 1u) : KeyTraits<K>::zero_value();
+          const K k_next = e < sp.n ? key_true((unsigned int)e) : KeyTraits<K>::max_value();
+          const K k_prev = s > 0 ? key_true((unsigned int)s - 1u) : KeyTraits<K>::zero_value();
           uint64_t final_err, cnt_j;
           finalize_one_pre<K_LINEAR, K>(j, s, e, sp, r.L, keys, pp, (uint64_t)m_err[lane + 1], ru > 1u ? (uint64_t)ru : 0ull,
                                         e == sp.n ? j : ~0ull, k_next, k_prev, final_err, cnt_j);

@@ -382,8 +382,9 @@ class Trainer:
                 cfg[i].root_table_entries = t.size
         res = (_lib.Result * max(n, 1))()
         rcs = (C.c_int * max(n, 1))()
-        rc = self._lib.rmi_hip_train_many(self._h, cfg, n, int(in_flight), res, rcs)
-        self._table_in_ctx = None                                 # (the context's table is whatever its last configuration set)
+        with self._ctx_lock:                                      # (root fits that use the device run on this context too)
+            rc = self._lib.rmi_hip_train_many(self._h, cfg, n, int(in_flight), res, rcs)
+            self._table_in_ctx = None                             # (the context's table is whatever its last configuration set)
         if rc not in (0,) and all(int(r) == 0 for r in rcs[:n]):
             _check(rc, self._h)                                   # (the call itself failed, not a configuration)
         self.last_many_error = (self._lib.rmi_hip_last_error(self._h) or b"").decode() if rc else ""   # every failing worker's first message

@@ -129,6 +129,24 @@ def test_scan_ordinary_tiles(monkeypatch, oracle, gen, root, n, L):
     _check(monkeypatch, oracle, dg.GENERATORS[gen](n // 3), root, L)
 
 
+@pytest.mark.parametrize("gen,root,n,L,chunks", [("uniform_u32", "radix", 150_000, 1024, 4), ("dups_u32", "radix", 150_000, 1024, 16), ("uniform_u64", "linear", 150_000, 1024, 8),
+                                                 ("dups_u64", "linear", 1_500_000, 4096, 16), ("books_u64", "linear", 400_000, 512, 8), ("uniform_u32", "radix", 5_000_000, 1 << 15, 2)])
+def test_scan_shards_of_a_streamed_training(oracle, gen, root, n, L, chunks):
+    """rmi_hip_train_streamed cuts the key set into leaf-aligned shards, one launch each: the point in front of a shard's first leaf and the
+    point behind its last are keys OUTSIDE the launch (its halo) -- the key array's values, not the filled-in positions of the LDS image."""
+    from rmi_amd import train
+    keys = dg.GENERATORS[gen](n)
+    tr = train.Trainer()
+    g = tr.train_streamed(keys, tr.fit_root_host(keys, root, L), "linear_spline", L, chunks=chunks).materialize()
+    o = oracle.train_two_layer(root, "linear_spline", keys, L)
+    assert g.pipeline == 5
+    assert np.array_equal(g.leaf_starts, o.leaf_start)
+    assert np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64))
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err) and np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx and g.model_avg_error == o.model_avg_error
+    tr.close()
+
+
 def test_scan_equals_the_leaf_lane_kernel(monkeypatch):
     """k_spline_scan against k_leaf_lanes<.., K_LINEAR_SPLINE> (RMI_HIP_SCAN=0) on 20 M keys: every output array the same bytes."""
     from rmi_amd import train
