@@ -164,7 +164,7 @@ def test_struct_layout_matches_a_c_consumer(tmp_path):
         if not w:
             continue
         if w[0] == "abi":
-            assert int(w[1]) == 5
+            assert int(w[1]) == 6
         elif w[1] == "size":
             assert C.sizeof(mirrors[w[0]]) == int(w[2]), ln
         else:
