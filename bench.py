@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 KERNELS_EXACT = ["k_fit_stream", "k_fill", "k_fit_long", "k_err_range", "k_finalize+stats"]            # RMI_HIP_PIPELINE=2
 KERNELS_REGS = ["k_leaf_regs", "k_leaf_lanes_listed+k_regs_finalize", "k_lane_reduce", "-", "-"]      # the default exact path (pipeline 4)
+KERNELS_SCAN = ["k_spline_scan", "k_scan_gaps+k_lane_reduce", "-", "-", "-"]                         # pipeline 5: linear_spline leaves
 KERNELS_LANES = ["k_leaf_lanes", "k_lane_reduce", "-", "-", "-"]                                    # pipeline 3 (RMI_HIP_REGS=0, and where 4 does not apply)
 KERNELS_LANES_INSTREAM = ["k_leaf_lanes", "k_list", "k_list_tail", "k_finalize_listed+stats", "-"]    # RMI_HIP_OPT_TAIL=0
 KERNELS_ONEPASS = ["k_sigma2", "k_fill", "k_list", "k_list_tail", "k_finalize+stats"]
@@ -74,9 +75,10 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures (fast mode, other configurations, PCIe-inclusive, fast root)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side figures of the other BASELINE configurations")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo for functional tests)")
-    ap.add_argument("--exchange", default="rccl", choices=["rccl", "direct", "auto"],
-                    help="N>1: how the rows reach every rank -- ncclAllGather (default), direct peer stores over xGMI (rmi_hip_peer_*), "
-                         "or an A/B at start-up that takes the direct form only if its table equals RCCL's and it is faster")
+    ap.add_argument("--exchange", default=None, choices=["rccl", "direct", "auto"],
+                    help="N>1: how the rows reach every rank -- ncclAllGather, direct peer stores over xGMI (rmi_hip_peer_*), or (default "
+                         "with the nccl backend) an A/B at start-up that takes the direct form only if its table equals RCCL's and it is "
+                         "faster, and prints both timings (exchange_ab)")
     a = ap.parse_args()
     keys, leaves, spec, dataset, dtype, scaling = CONFIGS[a.config or "M"]
     a.keys = a.keys or keys
@@ -86,6 +88,8 @@ def parse_args():
     a.dtype = a.dtype or dtype
     a.scaling = a.scaling or scaling or "strong"
     a.config = a.config or "M"
+    if a.exchange is None:                # an unflagged N > 1 run measures both exchanges (xGMI is point-to-point: a ring all-gather alone would miss the target)
+        a.exchange = "auto" if a.backend == "nccl" else "rccl"
     return a
 
 
@@ -211,11 +215,41 @@ def side_configs(T, tr_m, device, with_oracle):
     res = {}
 
     def run(tr, root, leaf_kind, L, mode, steps, nkeys, kbytes, rowb=24):
+        """One configuration: wall and device time per step, the dominant kernel (first kernel group of the call) with its own bracket,
+        the algorithmic bytes and the fractions of the 8 TB/s roofline they give."""
         tr.set_fit_mode(mode)
+        tr.set_profile_level(1)
+        k0 = 0.0
+        for _ in range(4):
+            k0 += tr.train_leaves(root, leaf_kind, L).kernel_ns[0]
+        tr.set_profile_level(0)
         w, d, r = time_steps(lambda: tr.train_leaves(root, leaf_kind, L), steps, warm=2)
-        return {"ms_per_step": w * 1e3, "value": nkeys / w, "unit": "keys/s",
-                "frac": (nkeys * kbytes + rowb * L) / d / 1e9 / HBM_PEAK_GBS, "mode_used": int(r.fit_mode_used),
-                "listed_long_leaves": int(r.long_leaves), "exact_refit_leaves": int(r.exact_leaves)}, r
+        pl = int(getattr(r, "pipeline", 0))
+        b = nkeys * kbytes + rowb * L
+        return {"ms_per_step": w * 1e3, "device_ms": d * 1e3, "value": nkeys / w, "unit": "keys/s", "algorithmic_bytes": int(b),
+                "frac": b / d / 1e9 / HBM_PEAK_GBS, "frac_wall": b / w / 1e9 / HBM_PEAK_GBS,
+                "kernel": {5: "k_spline_scan", 4: "k_leaf_regs", 3: "k_leaf_lanes"}.get(pl, "k_fit_stream" if not int(r.fit_mode_used) else "k_sigma2"),
+                "kernel_us": k0 / 4 / 1e3, "kernel_frac": b / (k0 / 4 * 1e-9) / 1e9 / HBM_PEAK_GBS if k0 else None, "pipeline": pl,
+                "mode_used": int(r.fit_mode_used), "listed_long_leaves": int(r.long_leaves), "exact_refit_leaves": int(r.exact_leaves)}, r
+
+    # the shard shapes of the 8-GPU configurations on this one GPU: what a rank's kernels cost at N = 8 (DESIGN section 6 quotes these)
+    for name, nk, L in (("M shard 1/8: linear,linear 131072 leaves on 25M u64", 25_000_000, 1 << 17),
+                        ("C4 shard 1/8: linear,linear 262144 leaves on 100M u64 (381 keys a leaf)", 100_000_000, 1 << 18)):
+        try:
+            ts = T.Trainer(device=device)
+            ts.generate_keys("uniform", np.uint64, nk)
+            root = ts.fit_root("linear", L, mode="fast")
+            e, r = run(ts, root, 0, L, 0, 20, nk, 8)
+            ts.set_profile_level(2)
+            acc = np.zeros(8)
+            for _ in range(4):
+                acc += np.array(ts.train_leaves(root, 0, L).kernel_ns, dtype=float)
+            e["kernel_groups_us"] = [float(x) / 4e3 for x in acc[:5]]
+            e["note"] = "root from the parallel sums (its coefficients do not matter to the leaf path's time); single GPU, exact mode, no exchange"
+            res[name] = {"exact": e}
+            ts.close()
+        except Exception as ex:
+            res[name] = {"error": str(ex)}
 
     # C3: cubic root over the metric configuration's keys (already resident)
     try:
@@ -367,10 +401,13 @@ def main():
     # non-temporal 16-byte loads): what "HBM-bound" can mean on this machine, beside the 8 TB/s of the data sheet.  It runs
     # HERE, in front of the warm-up: the exact root fit before it keeps the host busy for ~1 s with the GPU idle, and a device
     # that has dropped to its low-power state needs more than W = 5 steps of 0.5 ms to be back at its clocks.
-    measured_bw, measured_bw_err = None, None
+    measured_bw, measured_bw_stride, measured_bw_err = None, None, None
     if world == 1:
         try:
-            measured_bw = float(max(tr.measure_read_bandwidth(10) for _ in range(3)))
+            # the best read-only pattern found on this machine (contiguous 8 KB pieces per wave, non-temporal loads: what the one-read
+            # kernels issue), and the grid-stride pattern of rounds 1-4 beside it
+            measured_bw = float(max(tr.measure_read_bandwidth(10, 1) for _ in range(3)))
+            measured_bw_stride = float(max(tr.measure_read_bandwidth(10, 0) for _ in range(3)))
         except Exception as ex:                                         # (never the reason a bench line is lost)
             measured_bw_err = str(ex)[:120]
     tr.set_profile_level(2)
@@ -422,8 +459,10 @@ def main():
     if rank == 0:
         used = int(getattr(res, "fit_mode_used", 0))
         lanes_path = used == 0 and leaf_kind in (0, 1) and os.environ.get("RMI_HIP_PIPELINE", "3") not in ("1", "2") and n_local >= 1024
-        regs_path = lanes_path and int(tr._lib.rmi_hip_last_pipeline(tr._h)) == 4
-        names = KERNELS_ONEPASS if used else ((KERNELS_REGS if regs_path else (KERNELS_LANES_INSTREAM if os.environ.get("RMI_HIP_OPT_TAIL", "1") == "0" else KERNELS_LANES)) if lanes_path else KERNELS_EXACT)
+        last_pl = int(tr._lib.rmi_hip_last_pipeline(tr._h))
+        regs_path = lanes_path and last_pl == 4
+        scan_path = lanes_path and last_pl == 5
+        names = KERNELS_ONEPASS if used else ((KERNELS_SCAN if scan_path else KERNELS_REGS if regs_path else (KERNELS_LANES_INSTREAM if os.environ.get("RMI_HIP_OPT_TAIL", "1") == "0" else KERNELS_LANES)) if lanes_path else KERNELS_EXACT)
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global / (elapsed / args.steps)
         kernel_us = (kernel_ns / args.steps / 1e3)[:5]
@@ -438,7 +477,9 @@ def main():
         # (the timed trainings' arrays, through the wrapper: one more training of the same configuration, before any other one)
         g_head = tr.train_leaves(root, leaf_kind, L_global).materialize() if world == 1 else None
         mode_text = {
-            0: ("exact, register-resident leaf kernel: leaf boundaries by search (k_leaf_search), then 64 leaves per wave in lockstep, ONE wave "
+            0: ("exact, key-parallel one-read kernel for linear_spline leaves (k_spline_scan): bucketing scan, the containers' end points, the error "
+                "pass and the leaf ends in one pass over coalesced 16-byte loads; no recurrence, coefficients bit-identical") if scan_path else
+               ("exact, register-resident leaf kernel: leaf boundaries by search (k_leaf_search), then 64 leaves per wave in lockstep, ONE wave "
                 "per SIMD with 512 registers -- the reference's recurrence per leaf in reference order (coefficients bit-identical); the keys "
                 "arrive by LDS-DMA and stay in the lane's registers for the error pass behind the fit (k_leaf_regs): the keys are read ONCE; "
                 "the leaf's widening, row and aggregates in k_regs_finalize") if regs_path else
@@ -488,20 +529,22 @@ def main():
             out["per_rank"] = per_rank
             if getattr(sh, "auto_report", None):
                 out["exchange_ab"] = sh.auto_report
-        tpath = os.path.join(ROOT, "profiles", "traffic_r04_%s.json" % ("exact" if not used else "onepass_guarded"))
-        if os.path.exists(tpath) and world == 1 and args.config == "M":
+        tag = args.config.lower() + ("_dups" if args.dataset == "dups" and args.config == "C5" else "")
+        tpath = os.path.join(ROOT, "profiles", "traffic_r05_%s.json" % tag)
+        if os.path.exists(tpath) and world == 1 and not used:
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get(names[dom], {})
                 # the counters were taken on a build of these very sources, or the figure is not quoted
                 if tj.get("sources_sha256") == sources_sha256():
-                    out["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
-                    out["roofline"]["traffic_note"] = "NOT measured in this run: rocprofv3 FETCH_SIZE/WRITE_SIZE of the same command on a build of the same " \
-                                                      "kernel sources (sha256 " + sources_sha256()[:12] + "), from " + os.path.relpath(tpath, ROOT) + \
-                                                      " (" + str(tj.get("note", "")) + ")"
+                    out["roofline"]["traffic"] = tj.get("step_hbm_bytes")
+                    out["roofline"]["traffic_ratio"] = tj.get("traffic_ratio")
+                    out["roofline"]["traffic_kernels"] = {k: v.get("hbm_bytes_per_launch") for k, v in tj.get("kernels", {}).items()}
+                    out["roofline"]["traffic_note"] = "the STEP's sum over its kernels; NOT measured in this run: rocprofv3 FETCH_SIZE / WRITE_SIZE of the same " \
+                                                      "workload (tools/profile_r05.sh) on a build of the same kernel sources (sha256 " + sources_sha256()[:12] + \
+                                                      "), from " + os.path.relpath(tpath, ROOT) + " (" + str(tj.get("note", ""))[:160] + " ...)"
                 else:
                     out["roofline"]["traffic_note"] = "profiles/ holds counters of OTHER kernel sources (" + str(tj.get("sources_sha256"))[:12] + \
-                                                      " against " + sources_sha256()[:12] + "): not quoted; tools/profile_r04.sh takes them again"
+                                                      " against " + sources_sha256()[:12] + "): not quoted; tools/profile_r05.sh takes them again"
             except Exception:
                 pass
 
@@ -511,8 +554,11 @@ def main():
                 out["roofline"]["measured_peak"] = float(bw)
                 out["roofline"]["frac_of_measured"] = float(path_gbs / bw)
                 out["roofline"]["kernel_frac_of_measured"] = float(dom_gbs / bw)
-                out["roofline"]["measured_peak_note"] = ("rmi_hip_measure_read_bandwidth: best of 3 x 10 passes of a read-only kernel over the same key array, "
-                                                         "this run, right in front of the warm-up steps")
+                out["roofline"]["measured_peak_grid_stride"] = measured_bw_stride
+                out["roofline"]["measured_peak_note"] = ("rmi_hip_measure_read_bandwidth_ex, pattern 1: best of 3 x 10 passes of a read-only kernel over the same key "
+                                                         "array (every wave reads contiguous 8 KB pieces with non-temporal 16-byte loads -- the best read-only pattern "
+                                                         "found on this machine), this run, right in front of the warm-up steps; measured_peak_grid_stride: the "
+                                                         "grid-stride pattern rounds 1-4 quoted")
             else:
                 out["roofline"]["measured_peak"] = None
                 out["roofline"]["measured_peak_note"] = "failed: " + str(measured_bw_err)

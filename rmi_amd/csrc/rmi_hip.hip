@@ -77,6 +77,7 @@ struct rmi_hip_ctx {
   bool opt_tail = true;                         // k_lane_reduce publishes the result behind k_leaf_lanes; the list kernels run behind the synchronisation, and only if a leaf was handed over
   bool tail_armed = false;
   std::function<int()> tail_fn;                 // the list kernels + k_finalize_listed of the last launch (listed_epilogue)
+  std::function<int()> regs_listed_fn;          // pipeline 4: k_leaf_lanes_listed + k_lane_reduce once more, run behind the synchronisation and only if k_leaf_regs listed a group
   std::function<void()> refinalize_fn;          // one-pass modes: k_finalize + k_stats_reduce once more, behind the host fit of giant leaves
   unsigned int* d_tickets = nullptr;            // arrival counter of k_lane_reduce's blocks
   int peer_fuse_n = 0;                          // direct exchange, <= 8 ranks: the peers' tables of the running epoch (k_leaf_lanes stores its rows there too)
@@ -1243,7 +1244,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
                        L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS + 8, init_arrays);
   }
-  c->tail_armed = false; c->tail_fn = nullptr; c->giant_early = false; c->giant_fitted = false;
+  c->tail_armed = false; c->tail_fn = nullptr; c->regs_listed_fn = nullptr; c->giant_early = false; c->giant_fitted = false;
 
   auto ensure_lists = [&]() -> int {
     const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
@@ -1367,14 +1368,35 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           if ((uint64_t)grid > wb) grid = (unsigned int)wb;
           if (c->regs_nt)
             hipLaunchKernelGGL((k_leaf_regs<K, true>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
-                               L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
+                               L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
           else
             hipLaunchKernelGGL((k_leaf_regs<K, false>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
-                               L, err, count, rows, part, rp, peers, (unsigned int)wb, c->regs_slow, c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
+                               L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
           mark();                                                       // (slot 0: k_leaf_regs alone; slot 1: the listed groups + k_regs_finalize)
-          const unsigned int lgrid = wb < 512 ? (unsigned int)wb : 512u;    // (as a rule nothing is listed: few blocks to start and to leave)
-          hipLaunchKernelGGL((k_leaf_lanes_listed<K>), dim3(lgrid), dim3(64), 0, s, c->d_slow_list, c->d_tickets + 1, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin,
-                             maxerr, run, L, err, count, rows, part, rp, peers);
+          // The groups k_leaf_regs listed.  As a rule there are none: with the result published early (k_lane_reduce) and the host
+          // synchronising itself, the kernel is launched only when the record says a group was listed (DevState::regs_listed) --
+          // an empty launch cost 4.6 us and a gap in every step; in-stream otherwise (a sharded or streamed training).
+          const unsigned int lgrid = wb < 512 ? (unsigned int)wb : 512u;
+          unsigned int* const slow_list = c->d_slow_list;
+          unsigned int* const slow_cnt = c->d_tickets + 1;
+          double* const lntab = c->d_lntab;
+          DevState* const dstate = c->d_state;
+          auto listed = [=]() {
+            hipLaunchKernelGGL((k_leaf_lanes_listed<K>), dim3(lgrid), dim3(64), 0, s, slow_list, slow_cnt, keys, sp, leaf_start, dstate, params, lntab, fl, lmin,
+                               maxerr, run, L, err, count, rows, part, rp, peers);
+          };
+          const bool listed_late = optimistic && !c->defer_sync && peers.n == 0;
+          if (listed_late) {
+            StatsPartial* const slices = part + nrec + SG_REGIONS + 2 * FL_BLOCKS + 1;
+            unsigned int* const tickets = c->d_tickets;
+            DevState* const hcopy_l = c->h_state_dev;
+            const unsigned int nrec_l = (unsigned int)nrec;
+            c->regs_listed_fn = [=]() -> int {
+              listed();
+              hipLaunchKernelGGL(k_lane_reduce, dim3((nrec_l + LF_SLICE - 1) / LF_SLICE), dim3(LF_SLICE), 0, s, (const StatsPartial*)part, nrec_l, slices, tickets, fl, dstate, hcopy_l);
+              return RMI_OK;
+            };
+          } else listed();
           hipLaunchKernelGGL((k_regs_finalize<K>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, (const unsigned int*)(c->d_tickets + 1), params,
                              (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
                              err, count, rows, part, peers);
@@ -1827,6 +1849,19 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
   if (c->defer_sync) return RMI_OK;                            // (rmi_hip_train_sharded goes on from here)
   if (c->giant_early && !c->tail_armed) { rc = giant_early_fit(c); if (rc) return rc; }   // (one-pass modes: k_list is already running)
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->regs_listed_fn) {
+    // pipeline 4 published its record without the groups k_leaf_regs listed: they run now, and the aggregates are combined once more
+    if (c->h_state->regs_listed > 0) {
+      const unsigned int listed_groups = c->h_state->regs_listed;
+      rc = c->regs_listed_fn();
+      c->regs_listed_fn = nullptr;
+      if (rc) return rc;
+      if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->h_state->regs_listed = listed_groups;                       // (the second record's copy of the state holds it as well; kept explicit)
+    }
+    c->regs_listed_fn = nullptr;
+  }
   if (c->tail_armed) {
     // k_lane_reduce has published the result: final unless k_leaf_lanes handed leaves to the list kernels
     c->tail_armed = false;
@@ -1889,7 +1924,8 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
     if (c->hint_epoch != c->keys_epoch || c->hint_mode != c->fit_mode) { c->hint_epoch = c->keys_epoch; c->hint_mode = c->fit_mode; c->hint_n = 0; }
     c->hint_L[c->hint_n % 8] = L_own; c->hint_n++;
   }
-  if (c->last_regs && c->regs_backoff && (uint64_t)st.regs_listed * 4 > (L_own + 63) / 64) {   // most groups went on the list: see regs_off
+  if (c->last_regs && c->regs_backoff && st.regs_listed >= (L_own + 63) / 64) c->last_regs = false;   // every group listed (regs_dups): k_leaf_lanes_listed did the work -- pipeline 3
+  if (c->regs_backoff && c->regs && (uint64_t)st.regs_listed * 4 > (L_own + 63) / 64) {   // most groups went on the list: see regs_off
     if (c->regs_off_epoch != c->keys_epoch) { c->regs_off_epoch = c->keys_epoch; c->regs_off_n = 0; }
     c->regs_off_L[c->regs_off_n % 8] = L_own; c->regs_off_n++;
   }

@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
     const double jf = (double)j;
     uint64_t lo = A, hi = Bn;                                        // the answer lies in [lo, hi]
     double pv = 0.0;                                                 // unfloored root value of the first key of the last probe
+    bool dup_seen = false;                                           // a probe held two equal keys
     // pair probe at i (lo <= i < hi): narrows [lo, hi] by the keys i and i + 1
     auto probe = [&](uint64_t i) {
       typedef typename LnBits<K>::type BT;
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
         typedef BT vec_t __attribute__((ext_vector_type(2), aligned(sizeof(K))));
         const vec_t v = *reinterpret_cast<const vec_t*>(keys + i);
         k0 = bits_to_key<K>(v.x); k1 = bits_to_key<K>(v.y);
+        dup_seen = dup_seen || (k0 == k1);
       } else { k0 = keys[i]; k1 = k0; }
       bool oob;
       const bool b0 = root_target_f<ROOT, K>(r, Lm1f, k0, oob) < jf;
@@ -244,6 +246,10 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
       }
     } else hi = lo;
     leaf_start[j] = (unsigned long long)lo;
+    {
+      const unsigned long long dm = __ballot(dup_seen);
+      if (dm != 0ull && (threadIdx.x & 63) == __builtin_ctzll(dm)) atomicAdd(&st->regs_dups, (unsigned long long)__builtin_popcountll(dm));
+    }
     if (j == r.L / 2 && lo < sp.it_hi) {                              // two_layer.rs:131-136, 152-156
       if (lo == 0) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);     // split_idx == 0 -> :27
       else if (lo > sp.rd_lo) {

@@ -193,6 +193,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const unsigned int piece = (unsigned int)(lane & 7) * 16u;         // its 16-byte piece of a line as a loader
   const unsigned int n32 = (unsigned int)sp.n;
   const uint64_t split_idx = st->split_idx, split_target = st->split_target;
+  // duplicate-heavy keys (DevState::regs_dups): every group would meet a duplicate and go on the list after its panels were requested
+  // and its walk begun; listed at once instead, k_leaf_lanes_listed takes them all
+  slow = (slow & 1u) | (((slow & 2u) && st->regs_dups * 64ull > (unsigned long long)(sp.leaf_hi - sp.leaf_lo)) ? 1u : 0u);   // (bit 1 of the argument: the routing is on)
   auto wave_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -40,7 +40,9 @@ CASES = [
 def test_regs_variants(monkeypatch, oracle, variant, gen, n, L, root):
     g = _check(monkeypatch, oracle, VARIANTS[variant], dg.GENERATORS[gen](n), root, L)
     if g is not None and n >= 1024 and n <= (100000 if variant == "any_average" else 208) * L:
-        assert g.pipeline == 4
+        # (every group listed -- by the switch, because the boundary search met duplicates, or because every group met keys whose f64 images
+        #  collapse: k_leaf_lanes_listed did the work, reported as 3)
+        assert g.pipeline in ((3, 4) if (variant == "all_listed" or gen.startswith("dups") or gen == "clustered_u64") else (4,))
 
 
 @pytest.mark.parametrize("name", sorted(dg.ADVERSARIAL))
@@ -84,9 +86,10 @@ def test_regs_repeated_trainings_one_context(monkeypatch, oracle):
 
 
 def test_regs_backs_off_on_duplicate_heavy_keys(monkeypatch, oracle):
-    """Every group of a duplicate-heavy key set meets a duplicate and goes on the list: the context remembers (key set, leaves) and
-    takes the leaf-lane kernel from the second training on (0.80 against 2.25 ms at the metric size); same bits either way; new keys
-    or another leaf count start afresh; RMI_HIP_REGS_BACKOFF=0 keeps pipeline 4."""
+    """Every group of a duplicate-heavy key set meets a duplicate and goes on the list.  The boundary search sees the duplicates in its probes
+    (DevState::regs_dups) and k_leaf_regs then lists every group at once, without walking any: pipeline 3 already on the FIRST training; the
+    context remembers (key set, leaves) and does not launch k_leaf_regs from the second training on; same bits either way; new keys start
+    afresh; RMI_HIP_REGS_BACKOFF=0 keeps pipeline 4."""
     from rmi_amd import train
     monkeypatch.setenv("RMI_HIP_REGS", "1")
     keys = dg.dups_u64(400_000)
@@ -98,8 +101,8 @@ def test_regs_backs_off_on_duplicate_heavy_keys(monkeypatch, oracle):
         seen.append(g.pipeline)
         assert np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64))
         assert np.array_equal(g.last_layer_max_l1s, o.leaf_err) and np.array_equal(g.leaf_counts, o.leaf_count)
-    assert seen == [4, 3, 3]
-    assert tr.train("linear,linear", 2048).pipeline == 4              # (another leaf count: not remembered)
+    assert seen == [3, 3, 3]
+    assert tr.train("linear,linear", 2048).pipeline == 3              # (another leaf count: routed by its own probes)
     tr.set_keys(dg.uniform_u64(400_000))
     assert [tr.train("linear,linear", 4096).pipeline for _ in range(2)] == [4, 4]
     tr.close()
