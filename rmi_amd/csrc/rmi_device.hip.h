@@ -92,7 +92,7 @@ struct DevState {
   unsigned long long seg_cap;
   unsigned long long giant_count;   // listed leaves whose exact fit is left to the host (GiantLeaf entries), see rmi_hip.hip
   unsigned long long giant_cap;
-  // k_leaf_search: leaves whose boundary probes (pairs of neighbouring keys) met two equal keys.  Pipeline 4 takes a group of 64 leaves
+  // k_leaf_search: leaves (of every 16th block) whose boundary probes (pairs of neighbouring keys) met two equal keys.  Pipeline 4 takes a group of 64 leaves
   // only if none of its ~12 000 keys repeats: when the probes -- some twenty keys a leaf -- see a repeat at more than one leaf per group,
   // k_leaf_regs lists every group at once, without walking any (duplicate-heavy keys on the FIRST training of a key set)
   unsigned long long regs_dups;

@@ -77,7 +77,7 @@ struct rmi_hip_ctx {
   bool opt_tail = true;                         // k_lane_reduce publishes the result behind k_leaf_lanes; the list kernels run behind the synchronisation, and only if a leaf was handed over
   bool tail_armed = false;
   std::function<int()> tail_fn;                 // the list kernels + k_finalize_listed of the last launch (listed_epilogue)
-  std::function<int()> regs_listed_fn;          // pipeline 4: k_leaf_lanes_listed + k_lane_reduce once more, run behind the synchronisation and only if k_leaf_regs listed a group
+  std::function<int(unsigned int)> regs_listed_fn;          // pipeline 4: k_leaf_lanes_listed + k_lane_reduce once more, run behind the synchronisation and only if k_leaf_regs listed a group
   std::function<void()> refinalize_fn;          // one-pass modes: k_finalize + k_stats_reduce once more, behind the host fit of giant leaves
   unsigned int* d_tickets = nullptr;            // arrival counter of k_lane_reduce's blocks
   int peer_fuse_n = 0;                          // direct exchange, <= 8 ranks: the peers' tables of the running epoch (k_leaf_lanes stores its rows there too)
@@ -1381,8 +1381,8 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           unsigned int* const slow_cnt = c->d_tickets + 1;
           double* const lntab = c->d_lntab;
           DevState* const dstate = c->d_state;
-          auto listed = [=]() {
-            hipLaunchKernelGGL((k_leaf_lanes_listed<K>), dim3(lgrid), dim3(64), 0, s, slow_list, slow_cnt, keys, sp, leaf_start, dstate, params, lntab, fl, lmin,
+          auto listed = [=](unsigned int grid_l) {
+            hipLaunchKernelGGL((k_leaf_lanes_listed<K>), dim3(grid_l), dim3(64), 0, s, slow_list, slow_cnt, keys, sp, leaf_start, dstate, params, lntab, fl, lmin,
                                maxerr, run, L, err, count, rows, part, rp, peers);
           };
           const bool listed_late = optimistic && !c->defer_sync && peers.n == 0;
@@ -1391,12 +1391,13 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
             unsigned int* const tickets = c->d_tickets;
             DevState* const hcopy_l = c->h_state_dev;
             const unsigned int nrec_l = (unsigned int)nrec;
-            c->regs_listed_fn = [=]() -> int {
-              listed();
+            const unsigned int wb_l = (unsigned int)wb;
+            c->regs_listed_fn = [=](unsigned int groups) -> int {                 // (as many waves as groups: a duplicate-heavy key set lists them all)
+              listed(groups < wb_l ? (groups > 0u ? groups : 1u) : wb_l);
               hipLaunchKernelGGL(k_lane_reduce, dim3((nrec_l + LF_SLICE - 1) / LF_SLICE), dim3(LF_SLICE), 0, s, (const StatsPartial*)part, nrec_l, slices, tickets, fl, dstate, hcopy_l);
               return RMI_OK;
             };
-          } else listed();
+          } else listed(lgrid);
           hipLaunchKernelGGL((k_regs_finalize<K>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, (const unsigned int*)(c->d_tickets + 1), params,
                              (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
                              err, count, rows, part, peers);
@@ -1853,7 +1854,7 @@ int rmi_hip_train_two_layer(rmi_hip_ctx* c, const rmi_hip_model_params* root, in
     // pipeline 4 published its record without the groups k_leaf_regs listed: they run now, and the aggregates are combined once more
     if (c->h_state->regs_listed > 0) {
       const unsigned int listed_groups = c->h_state->regs_listed;
-      rc = c->regs_listed_fn();
+      rc = c->regs_listed_fn(listed_groups);
       c->regs_listed_fn = nullptr;
       if (rc) return rc;
       if (c->profile_level >= 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));

@@ -154,11 +154,11 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
   __shared__ double t_tgt[LS_SAMPLES + 1], t_val[LS_SAMPLES + 1];
   for (int t = threadIdx.x; t <= LS_SAMPLES; t += LS_BLOCK) { t_tgt[t] = smp[t]; t_val[t] = smp[LS_SAMPLES + 1 + t]; }
   __syncthreads();
+  bool dup_seen = false;                                             // a probe of this leaf held two equal keys
   if (j < sp.leaf_hi) {
     const double jf = (double)j;
     uint64_t lo = A, hi = Bn;                                        // the answer lies in [lo, hi]
     double pv = 0.0;                                                 // unfloored root value of the first key of the last probe
-    bool dup_seen = false;                                           // a probe held two equal keys
     // pair probe at i (lo <= i < hi): narrows [lo, hi] by the keys i and i + 1
     auto probe = [&](uint64_t i) {
       typedef typename LnBits<K>::type BT;
@@ -246,10 +246,6 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
       }
     } else hi = lo;
     leaf_start[j] = (unsigned long long)lo;
-    {
-      const unsigned long long dm = __ballot(dup_seen);
-      if (dm != 0ull && (threadIdx.x & 63) == __builtin_ctzll(dm)) atomicAdd(&st->regs_dups, (unsigned long long)__builtin_popcountll(dm));
-    }
     if (j == r.L / 2 && lo < sp.it_hi) {                              // two_layer.rs:131-136, 152-156
       if (lo == 0) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);     // split_idx == 0 -> :27
       else if (lo > sp.rd_lo) {
@@ -260,6 +256,11 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && sp.n - 1 >= sp.it_lo && sp.n - 1 < sp.it_hi) st->last_target = (unsigned long long)tgt(sp.n - 1);
+  // DevState::regs_dups from every 16th block (a sample: thousands of additions to one counter serialise at ~26 ns each)
+  if ((blockIdx.x & 15u) == 0u) {
+    const int nd = __syncthreads_count(dup_seen ? 1 : 0);
+    if (threadIdx.x == 0 && nd > 0) atomicAdd(&st->regs_dups, (unsigned long long)nd);
+  }
 }
 
 // The direct exchange of a sharded training (rmi_multi.inc.h) inside k_leaf_lanes: a finished leaf's row goes not only to this

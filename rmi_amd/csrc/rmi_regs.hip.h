@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const uint64_t split_idx = st->split_idx, split_target = st->split_target;
   // duplicate-heavy keys (DevState::regs_dups): every group would meet a duplicate and go on the list after its panels were requested
   // and its walk begun; listed at once instead, k_leaf_lanes_listed takes them all
-  slow = (slow & 1u) | (((slow & 2u) && st->regs_dups * 64ull > (unsigned long long)(sp.leaf_hi - sp.leaf_lo)) ? 1u : 0u);   // (bit 1 of the argument: the routing is on)
+  slow = (slow & 1u) | (((slow & 2u) && st->regs_dups * (64ull * 16ull) > (unsigned long long)(sp.leaf_hi - sp.leaf_lo)) ? 1u : 0u);   // (bit 1 of the argument: the routing is on)
   auto wave_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
