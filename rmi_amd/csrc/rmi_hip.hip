@@ -117,6 +117,10 @@ struct rmi_hip_ctx {
   bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes (RMI_HIP_SPLINE_LANES=0: k_sigma2's spline variant)
   uint64_t edge_epoch = 0;                      // first / last resident key of the key set `keys_epoch` (radix roots: is the prefix common?)
   uint64_t edge_first = 0, edge_last = 0;
+  uint64_t edgef_epoch = 0;                     // ... as doubles (cubic roots: is the polynomial increasing between them?)
+  double edge_first_f = 0.0, edge_last_f = 0.0;
+  bool cubic_margin = true;                     // RMI_HIP_CUBIC_MARGIN=0: cubic roots always with the per-key verification (k_leaf_lanes, pipeline 3)
+  double cubic_margin_scale = 1.0;              // testing: RMI_HIP_CUBIC_MARGIN_SCALE widens the margin (1e13: every leaf is verified key by key)
   bool last_lanes = false;
   // giant leaves (containers of more than host_min points): recorded by k_list, fitted on host cores after the device
   // pipeline, their error pass and finalize in a short epilogue (giant_epilogue).  Plain single-context trainings only.
@@ -179,6 +183,24 @@ struct rmi_hip_ctx {
 };
 
 static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_hip_result* out);
+
+// Is the cubic ((a x + b) x + c) x + d increasing on [xlo, xhi] as an exact polynomial?  Its derivative 3 a x^2 + 2 b x + c takes its minimum
+// at an end of the interval or at the vertex -b / (3 a); evaluated in long double (64-bit mantissa: the coefficients are exact there) and
+// required to exceed 1e-15 of the sum of its terms' magnitudes -- a thousand times long double's own rounding.  "No" (flat, decreasing
+// somewhere, not finite) only costs the per-key verification.
+static bool cubic_increasing_on(const RootP& rp, double xlo, double xhi) {
+  if (!(std::isfinite(rp.p0) && std::isfinite(rp.p1) && std::isfinite(rp.p2) && std::isfinite(rp.p3) && std::isfinite(xlo) && std::isfinite(xhi)) || !(xlo <= xhi)) return false;
+  const long double a = rp.p0, b = rp.p1, cc = rp.p2;
+  auto fp = [&](long double x) -> long double { return (3.0L * a * x + 2.0L * b) * x + cc; };
+  long double m = fp((long double)xlo) < fp((long double)xhi) ? fp((long double)xlo) : fp((long double)xhi);
+  if (a != 0.0L) {
+    const long double xv = -b / (3.0L * a);
+    if (xv > (long double)xlo && xv < (long double)xhi && fp(xv) < m) m = fp(xv);
+  }
+  const long double xm = fabsl((long double)xlo) > fabsl((long double)xhi) ? fabsl((long double)xlo) : fabsl((long double)xhi);
+  const long double scale = fabsl(3.0L * a) * xm * xm + fabsl(2.0L * b) * xm + fabsl(cc);
+  return std::isfinite((double)m) && m > 1e-15L * scale;
+}
 
 static void set_err(rmi_hip_ctx* c, const char* fmt, ...) {
   char buf[512];
@@ -315,6 +337,8 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* sl = std::getenv("RMI_HIP_SPLINE_LANES"); if (sl && *sl) c->spline_lanes = std::atoi(sl) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) c->regs = std::atoi(rg) != 0; }
   { const char* sc = std::getenv("RMI_HIP_SCAN"); if (sc && *sc) c->scan = std::atoi(sc) != 0; }
+  { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN"); if (cm && *cm) c->cubic_margin = std::atoi(cm) != 0; }
+  { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN_SCALE"); if (cm && *cm) c->cubic_margin_scale = std::atof(cm); }
   { const char* sc = std::getenv("RMI_HIP_SCAN_WAVES"); if (sc && *sc) c->scan_waves = (unsigned int)std::atoi(sc); }
   { const char* rg = std::getenv("RMI_HIP_REGS_NT"); if (rg && *rg) c->regs_nt = std::atoi(rg) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS_GRID"); if (rg && *rg) c->regs_grid = (unsigned int)std::atoi(rg); }
@@ -1335,9 +1359,32 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         for (int p = 0; p < peers.n; p++) peers.tab[p] = c->peer_fuse_tab[p];
         c->rows_pushed = true;
       }
+      // pipeline 4's conditions besides the root's: 8-byte keys, linear leaves, leaves short enough on average that most groups of 64 qualify,
+      // not a key set on which k_leaf_regs listed most groups last time
+      bool regs_plan = false;
+      if constexpr (LEAF == K_LINEAR && sizeof(K) == 8) {
+        bool regs_off = false;
+        if (c->regs_off_epoch == c->keys_epoch)
+          for (int h = 0; h < c->regs_off_n && h < 8; h++) regs_off = regs_off || c->regs_off_L[h] == L_own;
+        regs_plan = lanes_fused_plan && c->regs && !regs_off && c->pipeline >= 3 && n_it <= (uint64_t)c->regs_max_avg * L_own;
+      }
+      // a cubic root on pipeline 4: increasing over the resident keys' range as an exact polynomial (here), every leaf's end keys clear
+      // their leaf's interval by the rounding bound (k_regs_finalize<K, K_CUBIC>) -- else the per-key verification of k_leaf_lanes
+      bool cubic_margin = false;
+      if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR && sizeof(K) == 8) {
+        if (searched && regs_plan && c->cubic_margin) {
+          if (c->edgef_epoch != c->keys_epoch) {
+            K k0{}, k1{};
+            HIPCHK(c, hipMemcpy(&k0, c->d_keys, sizeof(K), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&k1, (const K*)c->d_keys + (c->n - 1), sizeof(K), hipMemcpyDeviceToHost));
+            c->edge_first_f = rmi_host::as_float(k0); c->edge_last_f = rmi_host::as_float(k1); c->edgef_epoch = c->keys_epoch;
+          }
+          cubic_margin = cubic_increasing_on(rp, c->edge_first_f, c->edge_last_f);
+        }
+      }
       bool verify = false;
       if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR) {
-        if (searched) {                                                 // (searched implies fused: the verification rides on the error pass)
+        if (searched && !cubic_margin) {                                // (searched implies fused: the verification rides on the error pass)
           hipLaunchKernelGGL((k_leaf_lanes<K, true, K_LINEAR, K_CUBIC>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
                              L, err, count, rows, part, rp, peers);
           verify = true;
@@ -1348,10 +1395,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       if constexpr (LEAF == K_LINEAR && sizeof(K) == 8) {
         // (a key set on which k_leaf_regs listed most groups -- duplicate-heavy keys: every group meets a duplicate -- is remembered, like
         //  the one-pass modes' hint: the next trainings of it with that many leaves go straight to k_leaf_lanes, 0.80 against 2.25 ms)
-        bool regs_off = false;
-        if (c->regs_off_epoch == c->keys_epoch)
-          for (int h = 0; h < c->regs_off_n && h < 8; h++) regs_off = regs_off || c->regs_off_L[h] == L_own;
-        regs = !verify && lanes_fused && c->regs && !regs_off && c->pipeline >= 3 && n_it <= (uint64_t)c->regs_max_avg * L_own;
+        regs = !verify && lanes_fused && regs_plan;
         if (regs) {
           if (c->slow_cap < wb) {
             if (c->d_slow_list) (void)hipFree(c->d_slow_list);
@@ -1398,9 +1442,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
               return RMI_OK;
             };
           } else listed(lgrid);
-          hipLaunchKernelGGL((k_regs_finalize<K>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, (const unsigned int*)(c->d_tickets + 1), params,
-                             (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
-                             err, count, rows, part, peers);
+          if (cubic_margin)
+            hipLaunchKernelGGL((k_regs_finalize<K, K_CUBIC>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, (const unsigned int*)(c->d_tickets + 1), params,
+                               (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
+                               err, count, rows, part, peers, rp, c->cubic_margin_scale);
+          else
+            hipLaunchKernelGGL((k_regs_finalize<K>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, (const unsigned int*)(c->d_tickets + 1), params,
+                               (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
+                               err, count, rows, part, peers, rp, 1.0);
           HIPCHK(c, hipGetLastError());
         }
       }

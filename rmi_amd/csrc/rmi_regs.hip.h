@@ -656,19 +656,70 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // The end of the leaves k_leaf_regs has fitted and measured (two_layer.rs:185-197, 226-259, the row of codegen.rs:288-315, the terms
 // of :267-287): one thread per leaf, a wave = one group of 64 leaves = one aggregate record, as in k_leaf_lanes.  Groups that went
 // through k_leaf_lanes_listed were finished there.
-template <typename K>
+// VROOT == K_CUBIC: the root's targets are not monotone by arithmetic (three nested fmas round independently) and k_leaf_regs has no
+// root evaluation in its error pass.  The search rests on the assumption that they are non-decreasing (two_layer.rs:50); it is PROVEN
+// here in O(L) instead of per key: the host has checked that the exact cubic is increasing over the resident keys' range (its
+// derivative's minimum there, rmi_hip.hip), the computed value c(x) differs from the exact one by at most E(x) = 2^-53 (|v3| + |x| |v2| +
+// x^2 |v1|) (one rounding per fma of the Horner form, cubic_spline.rs:146-148), so if the first key of leaf j computes to >= j + 2 E and
+// its last key to < j + 1 - 2 E, every key between them has an exact value in [j + E, j + 1 - E] and therefore the target j.  The margin
+// used is 4 E.  A leaf that does not clear it (an end key within ~1e-9 of a leaf border: about one leaf in a training of 2^20) is verified
+// key by key on the spot, by the 64 lanes of its wave together: the check k_leaf_lanes<.., K_CUBIC> makes for every key.
+__device__ __forceinline__ uint64_t rg_readlane_u64(uint64_t v, int src) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src), hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+template <typename K, int VROOT = -1>
 __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ keys, Span sp, uint64_t L,
                                                        const unsigned long long* __restrict__ leaf_start, DevState* st, const unsigned int* __restrict__ slow_count,
                                                        double* __restrict__ params, const unsigned long long* __restrict__ leaf_maxerr,
                                                        const K* __restrict__ bnext, const K* __restrict__ bprev,
                                                        const unsigned char* __restrict__ tile_slow, unsigned int ntiles,
                                                        unsigned long long* __restrict__ leaf_err, unsigned long long* __restrict__ leaf_count,
-                                                       unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, PeerRows peers) {
+                                                       unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, PeerRows peers, RootP vr,
+                                                       double margin_scale) {   // (1; a test widens the margin until every leaf falls back)
   const uint64_t jl = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const unsigned int tile = (unsigned int)(jl >> 6);
   if (jl == 0) st->regs_listed = *slow_count;                          // (into the record the host reads: rmi_hip.hip, regs_off)
-  if (tile >= ntiles || tile_slow[tile] != 0) return;                  // (wave-uniform)
+  if (tile >= ntiles) return;                                          // (wave-uniform)
   const uint64_t j = sp.leaf_lo + jl;
+  if constexpr (VROOT == K_CUBIC) {                                    // every leaf, whoever fitted it
+    bool ok = true;
+    uint64_t vs = 0, ve = 0;
+    if (j < sp.leaf_hi) {
+      const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
+      vs = s; ve = e;
+      if (s < e) {
+        auto val = [&](K k, double& E4) -> double {
+          const double x = KeyTraits<K>::as_float(k);
+          const double v1 = __builtin_fma(vr.p0, x, vr.p1), v2 = __builtin_fma(v1, x, vr.p2), v3 = __builtin_fma(v2, x, vr.p3);
+          E4 = margin_scale * 0x1p-51 * (fabs(v3) + fabs(x) * fabs(v2) + (x * x) * fabs(v1));
+          return v3;
+        };
+        double Ea, Eb;
+        const double ca = val(keys[s], Ea), cb = val(keys[e - 1], Eb);
+        const double Lf = (double)vr.L;
+        if (j > 0) ok = ok && (ca >= (double)j + Ea);
+        if (j + 1 < L) ok = ok && (cb < (double)(j + 1) - Eb);
+        else ok = ok && (cb < Lf - Eb);                                 // (the largest prediction of all: below L, two_layer.rs:45-48)
+      }                                                                 // (NaN and infinities: undecided as well)
+    }
+    unsigned long long um = __ballot(!ok);
+    unsigned int vflags = 0;
+    const unsigned int Lm1 = (unsigned int)(vr.L - 1);
+    while (um) {                                                        // an undecided leaf: its keys, 64 at a time
+      const int src = __builtin_ctzll(um);
+      um &= um - 1ull;
+      const uint64_t us = rg_readlane_u64(vs, src), ue = rg_readlane_u64(ve, src);
+      const unsigned int uj = (unsigned int)(sp.leaf_lo + (jl & ~63ull) + (uint64_t)src);
+      for (uint64_t i = us + (threadIdx.x & 63); i < ue; i += 64) {
+        const unsigned int rt = sg_cvt_u32(root_eval_f<K_CUBIC>(vr, KeyTraits<K>::as_float(keys[i])));
+        if (rt > Lm1) vflags |= EF_ROOT_OOB;
+        if ((rt < Lm1 ? rt : Lm1) != uj) vflags |= EF_NON_MONOTONE;
+      }
+    }
+    if (vflags) atomicOr(&st->err_flags, vflags);
+  }
+  if (tile_slow[tile] != 0) return;                                    // (wave-uniform)
   unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;
   double st_l2 = 0.0, st_lg = 0.0;
   if (j < sp.leaf_hi) {

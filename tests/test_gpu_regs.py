@@ -110,3 +110,16 @@ def test_regs_backs_off_on_duplicate_heavy_keys(monkeypatch, oracle):
     tr = train.Trainer(keys)
     assert [tr.train("linear,linear", 4096).pipeline for _ in range(2)] == [4, 4]
     tr.close()
+
+
+@pytest.mark.parametrize("gen,n,L", [("uniform_u64", 1_000_000, 8192), ("books_u64", 1_000_000, 20_000), ("uniform_f64", 300_000, 4096), ("dups_u64", 300_000, 4096),
+                                     ("clustered_u64", 300_000, 2048), ("uniform_u64", 2_000_000, 10_000)])
+@pytest.mark.parametrize("env,expect", [({}, (3, 4)), ({"RMI_HIP_CUBIC_MARGIN": "0"}, (3,)), ({"RMI_HIP_CUBIC_MARGIN_SCALE": "1e13"}, (3, 4))])
+def test_regs_cubic_root_by_margin(monkeypatch, oracle, gen, n, L, env, expect):
+    """A cubic root on pipeline 4: the host proves the exact polynomial increasing over the keys' range, k_regs_finalize<K, K_CUBIC> that every
+    leaf's end keys clear their leaf's interval by the rounding bound of the three fmas -- O(L) instead of a root evaluation per key.
+    RMI_HIP_CUBIC_MARGIN=0: the per-key verification in k_leaf_lanes (pipeline 3); a margin widened by 1e13 leaves every leaf undecided:
+    each is then verified key by key by its wave in k_regs_finalize.  Same bits every way, and the oracle's."""
+    g = _check(monkeypatch, oracle, dict({"RMI_HIP_REGS": "1"}, **env), dg.GENERATORS[gen](n), "cubic", L)
+    if g is not None:
+        assert g.pipeline in expect
