@@ -110,6 +110,11 @@ struct rmi_hip_ctx {
   int n_cu = 256;
   bool last_regs = false;
   void* d_gaps = nullptr;                       // pipeline 5: the listed stretches of empty leaves (GapRec)
+  // pipeline 5 writes the rows (codegen.rs:288-315: alpha, beta, error -- the 24 L bytes of SURVEY 8d) and the bucket table only; the separate
+  // coefficient / error / count arrays hold the same values and are filled from them when somebody downloads one (k_lean_arrays)
+  bool lean = true;                             // RMI_HIP_LEAN=0: the kernel writes all five arrays
+  bool last_lean = false, lean_derived = false;
+  unsigned long long lean_last_target = ~0ull;
   bool scan = true;                             // pipeline 5 (rmi_scan.hip.h): linear_spline leaves by the key-parallel one-read kernel (RMI_HIP_SCAN=0: k_leaf_lanes)
   bool last_scan = false;
   unsigned int scan_waves = 0;                  // its persistent waves (0: as many as the device holds, rmi_scan_waves_per_cu)
@@ -338,6 +343,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) c->regs = std::atoi(rg) != 0; }
   { const char* sc = std::getenv("RMI_HIP_SCAN"); if (sc && *sc) c->scan = std::atoi(sc) != 0; }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN"); if (cm && *cm) c->cubic_margin = std::atoi(cm) != 0; }
+  { const char* ln = std::getenv("RMI_HIP_LEAN"); if (ln && *ln) c->lean = std::atoi(ln) != 0; }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN_SCALE"); if (cm && *cm) c->cubic_margin_scale = std::atof(cm); }
   { const char* sc = std::getenv("RMI_HIP_SCAN_WAVES"); if (sc && *sc) c->scan_waves = (unsigned int)std::atoi(sc); }
   { const char* rg = std::getenv("RMI_HIP_REGS_NT"); if (rg && *rg) c->regs_nt = std::atoi(rg) != 0; }
@@ -1269,6 +1275,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
                        L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS + 8, init_arrays);
   }
   c->tail_armed = false; c->tail_fn = nullptr; c->regs_listed_fn = nullptr; c->giant_early = false; c->giant_fitted = false;
+  c->last_lean = false; c->lean_derived = false;
 
   auto ensure_lists = [&]() -> int {
     const uint64_t rcap = (L_own + SG_REGIONS - 1) / SG_REGIONS + 8;      // a region holds every leaf with its residue, and the odd re-listed one
@@ -1457,7 +1464,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       if (scan5) {
         ScanLaunch sl; std::memset(&sl, 0, sizeof sl);
         sl.keys = keys; sl.sp = sp; sl.rp = rp; sl.st = c->d_state; sl.fl = fl; sl.long_min = lmin;
-        sl.out.leaf_start = leaf_start; sl.out.params = params; sl.out.leaf_err = err; sl.out.leaf_count = count; sl.out.rows = rows; sl.out.partials = part;
+        const bool lean5 = c->lean && !c->stream_mode && !c->defer_sync;  // (a streamed / sharded training fills the arrays shard by shard: kept whole there)
+        sl.out.leaf_start = leaf_start; sl.out.rows = rows; sl.out.partials = part;
+        sl.out.params = lean5 ? nullptr : params; sl.out.leaf_err = lean5 ? nullptr : err; sl.out.leaf_count = lean5 ? nullptr : count;
+        c->last_lean = lean5;
         sl.peers = peers;
         sl.host_split = (c->have_shard && c->shard_split_idx != ~0ull) ? 1 : 0;
         sl.mono = scan_mono ? 1 : 0;
@@ -1956,6 +1966,7 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
     return rc;
   }
   c->last_L = L_own; c->last_ppl = ppl;
+  c->lean_last_target = st.last_target;
   std::memset(out, 0, sizeof *out);
   out->generation = c->generation;
   const uint64_t n_glob = c->have_shard ? c->shard.n : c->n;
@@ -1995,10 +2006,37 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
 
 extern "C" {
 
+}  // extern "C"
+
+// alpha, beta, error of every leaf from its row, its count from the bucket table (+ the last key's second visit, Q7)
+static __global__ void __launch_bounds__(256) k_lean_arrays(const unsigned char* __restrict__ rows, const unsigned long long* __restrict__ leaf_start, uint64_t L_own,
+                                                            uint64_t leaf_lo, unsigned long long last_target, double* __restrict__ params,
+                                                            unsigned long long* __restrict__ err, unsigned long long* __restrict__ count) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= L_own) return;
+  const double* rp = reinterpret_cast<const double*>(rows + j * 24);
+  params[2 * j] = rp[0]; params[2 * j + 1] = rp[1];
+  err[j] = *reinterpret_cast<const unsigned long long*>(rows + j * 24 + 16);
+  count[j] = leaf_start[j + 1] - leaf_start[j] + ((leaf_lo + j == last_target) ? 1ull : 0ull);
+}
+static int lean_fill(rmi_hip_ctx* c) {
+  if (!c->last_lean || c->lean_derived || !c->last_L) return RMI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t leaf_lo = c->have_shard ? c->shard.leaf_lo : 0;
+  hipLaunchKernelGGL(k_lean_arrays, dim3((unsigned)((c->last_L + 255) / 256)), dim3(256), 0, c->stream, (const unsigned char*)c->last_rows, (const unsigned long long*)c->d_leaf_start,
+                     c->last_L, leaf_lo, c->lean_last_target, c->d_params, c->d_err, c->d_count);
+  HIPCHK(c, hipGetLastError());
+  c->lean_derived = true;
+  return RMI_OK;
+}
+
+extern "C" {
+
 static int dl(rmi_hip_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c || !dst) return RMI_ERR_BAD_ARG;
   if (!c->last_L) return RMI_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
+  if (src == (const void*)c->d_params || src == (const void*)c->d_err || src == (const void*)c->d_count) { const int lrc = lean_fill(c); if (lrc) return lrc; }
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return RMI_OK;
