@@ -201,7 +201,7 @@ enum rmi_hip_fit_mode { RMI_FIT_EXACT = 0, RMI_FIT_ONEPASS_GUARDED = 1, RMI_FIT_
 /* linear_spline leaves (the line through the two end points of a container, linear_spline.rs:13-35) have no recurrence and are
  * exact in every mode (fit_mode_used 0): k_spline_scan (rmi_scan.hip.h) reads the keys ONCE, key-parallel -- bucketing scan,
  * end points, error pass and leaf ends in the same pass, for every root and key type. */
-enum { RMI_FIT_USED_ONEPASS_EXACT = 3 };
+enum { RMI_FIT_USED_ONEPASS_EXACT = 3 };   /* (rounds 2-4: linear_spline leaves through the one-pass kernel; not reported any more) */
 int rmi_hip_set_fit_mode(rmi_hip_ctx* ctx, int mode, double guard_k);
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = context's own. */
 int rmi_hip_set_stream(rmi_hip_ctx* ctx, void* hip_stream);

@@ -114,12 +114,12 @@ struct rmi_hip_ctx {
   // coefficient / error / count arrays hold the same values and are filled from them when somebody downloads one (k_lean_arrays)
   bool lean = true;                             // RMI_HIP_LEAN=0: the kernel writes all five arrays
   bool last_lean = false, lean_derived = false;
-  unsigned long long lean_last_target = ~0ull;
+  unsigned long long lean_last_target = ~0ull, lean_leaf_lo = 0;   // (of the training the arrays belong to: the shard may be gone when they are asked for)
   bool scan = true;                             // pipeline 5 (rmi_scan.hip.h): linear_spline leaves by the key-parallel one-read kernel (RMI_HIP_SCAN=0: k_leaf_lanes)
   bool last_scan = false;
   unsigned int scan_waves = 0;                  // its persistent waves (0: as many as the device holds, rmi_scan_waves_per_cu)
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
-  bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes (RMI_HIP_SPLINE_LANES=0: k_sigma2's spline variant)
+  bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes where k_spline_scan is switched off (RMI_HIP_SPLINE_LANES=0: the per-pass kernels)
   uint64_t edge_epoch = 0;                      // first / last resident key of the key set `keys_epoch` (radix roots: is the prefix common?)
   uint64_t edge_first = 0, edge_last = 0;
   uint64_t edgef_epoch = 0;                     // ... as doubles (cubic roots: is the polynomial increasing between them?)
@@ -155,7 +155,6 @@ struct rmi_hip_ctx {
   int fit_mode = 0;
   double guard_k = 2.0;
   uint64_t sigma_waves = 4096;                  // k_sigma2: chunks the keys are cut into (one wave each)
-  bool spline_onepass = true;                   // linear_spline leaves through the one-pass kernel, in every fit mode
   unsigned int sigma_min_leaf = 32;             // average keys per leaf below which the exact kernels are used
   unsigned int* d_flist = nullptr;              // leaves handed to the exact kernels: SG_REGIONS regions of flist_cap ids ...
   unsigned long long* d_flist_cnt = nullptr;    // ... and their counters
@@ -373,7 +372,6 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (gk && *gk) { const double v = std::atof(gk); if (v > 0.0) c->guard_k = v; }
   const char* sw = std::getenv("RMI_HIP_SIGMA_WAVES");
   if (sw && *sw) { const long v = std::atol(sw); if (v > 0) c->sigma_waves = (uint64_t)v; }
-  { const char* so = std::getenv("RMI_HIP_SPLINE_ONEPASS"); if (so && *so) c->spline_onepass = std::atoi(so) != 0; }
   *out = c;
   return RMI_OK;
 }
@@ -1232,7 +1230,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   c->last_scan = scan5;
   const bool spline_l = scan5 || (c->pipeline >= 3 && (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_lanes && n_it >= 1024 &&
                         sp.n < (1ull << 32) - (1ull << 16));
-  const bool spline1 = (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_onepass && !spline_l;
+  // (round 5: the one-pass kernel's linear_spline variant is gone -- k_spline_scan serves them, and where it does not (RMI_HIP_SCAN=0 with
+  //  RMI_HIP_SPLINE_LANES=0, 2^32 keys and more, RMI_HIP_PIPELINE <= 2) the per-pass kernels do; the variant missed the borrowed point of
+  //  a leaf behind an emptied split leaf, Q4)
+  const bool spline1 = false;
   const bool sigma = ((stream_fit && c->fit_mode != 0) || spline1) && !hinted && sp.n < (1ull << 32) - (1ull << 16) &&
                      n_it >= (uint64_t)c->sigma_min_leaf * L_own && n_it >= 4096;
   c->last_sigma = sigma;
@@ -1569,10 +1570,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
             sgp.recs = (SgRec*)c->d_recs; sgp.rec_cnt = (unsigned int*)((char*)c->d_recs + sblocks * rpw * sizeof(SgRec)); sgp.rpw = (unsigned int)rpw;
           }
           c->last_sg = sgp;
-          if constexpr (LEAF == K_LINEAR_SPLINE)
-            hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH, false, K_LINEAR_SPLINE>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state,
-                               (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
-          else if (c->fit_mode == 2)
+          if (c->fit_mode == 2)
             hipLaunchKernelGGL((k_sigma2<ROOT, K, RING, BATCH, true>), dim3((unsigned)sblocks), dim3(64), 0, s, keys, sp, rp, sgp, leaf_start, params, maxerr, c->d_state,
                                (K*)c->d_bkeys - sp.leaf_lo, (K*)c->d_bkeys + c->bkeys_cap - sp.leaf_lo);
           else
@@ -1967,6 +1965,7 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   }
   c->last_L = L_own; c->last_ppl = ppl;
   c->lean_last_target = st.last_target;
+  c->lean_leaf_lo = c->have_shard ? c->shard.leaf_lo : 0;
   std::memset(out, 0, sizeof *out);
   out->generation = c->generation;
   const uint64_t n_glob = c->have_shard ? c->shard.n : c->n;
@@ -2022,7 +2021,7 @@ static __global__ void __launch_bounds__(256) k_lean_arrays(const unsigned char*
 static int lean_fill(rmi_hip_ctx* c) {
   if (!c->last_lean || c->lean_derived || !c->last_L) return RMI_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  const uint64_t leaf_lo = c->have_shard ? c->shard.leaf_lo : 0;
+  const uint64_t leaf_lo = c->lean_leaf_lo;
   hipLaunchKernelGGL(k_lean_arrays, dim3((unsigned)((c->last_L + 255) / 256)), dim3(256), 0, c->stream, (const unsigned char*)c->last_rows, (const unsigned long long*)c->d_leaf_start,
                      c->last_L, leaf_lo, c->lean_last_target, c->d_params, c->d_err, c->d_count);
   HIPCHK(c, hipGetLastError());
