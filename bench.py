@@ -218,6 +218,7 @@ def side_configs(T, tr_m, device, with_oracle):
         """One configuration: wall and device time per step, the dominant kernel (first kernel group of the call) with its own bracket,
         the algorithmic bytes and the fractions of the 8 TB/s roofline they give."""
         tr.set_fit_mode(mode)
+        tr.train_leaves(root, leaf_kind, L)                         # (the first training of a configuration allocates)
         tr.set_profile_level(1)
         k0 = 0.0
         for _ in range(4):

@@ -10,7 +10,7 @@ R=$PWD; OUT=$R/gpurun_out/prof_r05/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 cd /tmp
 W="python $R/tools/cfg_run.py $CFG $DS"
 RMI_CFG_TRACE=1 RMI_CFG_BW=0 timeout -k 5 200 rocprofv3 --kernel-trace --stats -T -d $OUT/kt -o kt -f csv -- $W 50 < /dev/null > $OUT/kt.log 2>&1
-INC='k_spline_scan|k_leaf_regs|k_regs_finalize|k_leaf_lanes|k_leaf_search|k_leaf_samples|k_lane_reduce|k_list|k_finalize|k_init|k_verify|k_giant|k_long_regs'
+INC='k_spline_scan|k_scan_gaps|k_leaf_regs|k_regs_finalize|k_leaf_lanes|k_leaf_search|k_leaf_samples|k_lane_reduce|k_list|k_finalize|k_init|k_verify|k_giant|k_long_regs'
 if [ "$NOPMC" != "--no-pmc" ]; then
 RMI_CFG_TRACE=1 RMI_CFG_BW=0 timeout -k 5 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
    --kernel-include-regex "$INC" -d $OUT/pmc1 -o p -f csv -- $W 2 < /dev/null > $OUT/pmc1.log 2>&1

@@ -16,7 +16,7 @@ import numpy as np  # noqa: E402
 out_dir, cfg = sys.argv[1], sys.argv[2]
 ds = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
 n, L, root, leaf, ds0, dt = CFG[cfg]
-names = ["k_read_bw", "k_spline_scan", "k_leaf_regs", "k_long_regs", "k_regs_finalize", "k_leaf_lanes_listed", "k_leaf_lanes", "k_leaf_search", "k_leaf_samples", "k_lane_reduce",
+names = ["k_read_bw", "k_spline_scan", "k_scan_gaps", "k_leaf_regs", "k_long_regs", "k_regs_finalize", "k_leaf_lanes_listed", "k_leaf_lanes", "k_leaf_search", "k_leaf_samples", "k_lane_reduce",
          "k_verify_listed", "k_giant_scan", "k_finalize_listed", "k_finalize", "k_list_tail", "k_list", "k_init"]
 acc = defaultdict(lambda: defaultdict(list))
 for d in (f"{out_dir}/tf", f"{out_dir}/tw"):
