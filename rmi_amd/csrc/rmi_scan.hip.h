@@ -61,6 +61,9 @@
 #ifndef RMI_SC_BRANCHFREE
 #define RMI_SC_BRANCHFREE 0           // the error pass switches a lane's model without the scalar test: one basic block for all keys of a row
 #endif
+#ifndef RMI_SC_NSUB
+#define RMI_SC_NSUB 1                 // tiles per big tile: 1 (2: the short form's lanes hold two rows -- fewer instructions a key, but 21.7 KB of LDS and spills: 0.59 against 0.52 ms)
+#endif
 #ifndef RMI_SC_LEANTEST
 #define RMI_SC_LEANTEST 0
 #endif
@@ -94,7 +97,7 @@ template <typename K, int V> struct ScGeom {
   // A wave takes NSUB consecutive tiles at a time (a "big tile": 128 rows): the short form of an ordinary big tile gives a lane NSUB
   // consecutive rows (VF keys) -- the phases around the error pass cost the same for twice the keys --, the general form takes the
   // big tile as NSUB tiles one after the other, out of the same LDS image.
-  static constexpr int NSUB = 2;
+  static constexpr int NSUB = RMI_SC_NSUB;
   static constexpr int BTILE = NSUB * TILE, NCHB = NSUB * NCH, VF = NSUB * V;
   static constexpr int LDS_DW = T0 + NSUB * 64 * S + (EXTC * 4 / ROWD) * S;
   static constexpr int LOGV = V == 32 ? 5 : (V == 16 ? 4 : (V == 8 ? 3 : -1));
