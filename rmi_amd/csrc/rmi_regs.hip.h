@@ -638,6 +638,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // not taken here: the group goes on the list of k_leaf_lanes_listed, launched behind this kernel (the general walk inside
       // this kernel would share its registers with the stash: the compiler then keeps a third of the stash in scratch memory)
       if (have && lane == 0) { slow_list[atomicAdd(slow_count, 1u)] = done_tile; tile_slow[done_tile] = 1; }
+      rg_wait_vm<0>();                                               // (hand_over reads the parked bounds of the next group: DMA loads the compiler does not see)
       hand_over();
     }
     if (!more) break;

@@ -26,7 +26,9 @@ def trainer_mod():
 # configurations it applies to); the round-1/2 pipelines (RMI_HIP_PIPELINE=2: streaming passes, =1: one kernel per reference
 # pass) serve as fall-backs for tiny key sets and special leaves and keep a smoke set of their own.
 LEGACY_SMOKE = {"test_parity_config1", "test_parity_tiny", "test_parity_degenerate_inputs", "test_parity_long_leaves",
-                "test_parity_many_empty_leaves", "test_parity_f64_keys", "test_parity_chunk_geometry", "test_error_codes"}
+                "test_parity_many_empty_leaves", "test_parity_f64_keys", "test_parity_chunk_geometry", "test_error_codes",
+                # (the leaf kinds and roots only these pipelines serve on their own kernels: cubic and robust_linear leaves, a radix table)
+                "test_parity_cubic_leaves_f64", "test_parity_robust_linear_leaves", "test_radix_table_wider_than_the_key_range"}
 
 
 def pytest_generate_tests(metafunc):
