@@ -110,6 +110,8 @@ struct rmi_hip_ctx {
   int n_cu = 256;
   bool last_regs = false;
   void* d_gaps = nullptr;                       // pipeline 5: the listed stretches of empty leaves (GapRec)
+  unsigned int* d_tile_list = nullptr;          // ... the tiles the short form's kernel leaves to the general form's
+  uint64_t tile_list_cap = 0;
   // pipeline 5 writes the rows (codegen.rs:288-315: alpha, beta, error -- the 24 L bytes of SURVEY 8d) and the bucket table only; the separate
   // coefficient / error / count arrays hold the same values and are filled from them when somebody downloads one (k_lean_arrays)
   bool lean = true;                             // RMI_HIP_LEAN=0: the kernel writes all five arrays
@@ -117,7 +119,7 @@ struct rmi_hip_ctx {
   unsigned long long lean_last_target = ~0ull, lean_leaf_lo = 0;   // (of the training the arrays belong to: the shard may be gone when they are asked for)
   bool scan = true;                             // pipeline 5 (rmi_scan.hip.h): linear_spline leaves by the key-parallel one-read kernel (RMI_HIP_SCAN=0: k_leaf_lanes)
   bool last_scan = false;
-  unsigned int scan_waves = 0;                  // its persistent waves (0: as many as the device holds, rmi_scan_waves_per_cu)
+  unsigned int scan_waves = 0;                  // its persistent waves per kernel at most (0: as many as the device holds, rmi_scan_waves_per_cu)
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
   bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes where k_spline_scan is switched off (RMI_HIP_SPLINE_LANES=0: the per-pass kernels)
   uint64_t edge_epoch = 0;                      // first / last resident key of the key set `keys_epoch` (radix roots: is the prefix common?)
@@ -386,6 +388,7 @@ static void free_outputs(rmi_hip_ctx* c) {
   if (c->d_flist) { (void)hipFree(c->d_flist); c->d_flist = nullptr; c->flist_cap = 0; }
   if (c->d_flist_cnt) { (void)hipFree(c->d_flist_cnt); c->d_flist_cnt = nullptr; }
   if (c->d_gaps) { (void)hipFree(c->d_gaps); c->d_gaps = nullptr; }
+  if (c->d_tile_list) { (void)hipFree(c->d_tile_list); c->d_tile_list = nullptr; c->tile_list_cap = 0; }
   if (c->d_bkeys) { (void)hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_cap = 0; }
   if (c->d_recs) { (void)hipFree(c->d_recs); c->d_recs = nullptr; c->recs_bytes = 0; }
   if (c->d_segs) { (void)hipFree(c->d_segs); c->d_segs = nullptr; c->segs_cap = 0; }
@@ -1472,7 +1475,18 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         sl.peers = peers;
         sl.host_split = (c->have_shard && c->shard_split_idx != ~0ull) ? 1 : 0;
         sl.mono = scan_mono ? 1 : 0;
-        sl.max_waves = c->scan_waves ? c->scan_waves : rmi_scan_waves_per_cu() * (unsigned int)c->n_cu;
+        sl.max_waves = c->scan_waves;
+        sl.n_cu = (unsigned int)c->n_cu;
+        {
+          const uint64_t need = rmi_scan_tiles(c->dtype, n_it);
+          if (c->tile_list_cap < need) {
+            if (c->d_tile_list) (void)hipFree(c->d_tile_list);
+            c->d_tile_list = nullptr; c->tile_list_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_tile_list, need * 4));
+            c->tile_list_cap = need;
+          }
+        }
+        sl.tile_list = c->d_tile_list; sl.tile_cnt = c->d_flist_cnt + 2 * SG_REGIONS + 2;   // (zeroed by k_init with the list counters)
         if (!c->d_gaps) HIPCHK(c, hipMalloc(&c->d_gaps, (size_t)SCAN_GAP_CAP * sizeof(GapRec)));
         sl.gaps = (GapRec*)c->d_gaps; sl.gap_cnt = c->d_flist_cnt + 2 * SG_REGIONS + 1;   // (zeroed by k_init with the list counters)
         if (rmi_scan_launch(ROOT, c->dtype, sl, s) != 0) { set_err(c, "internal: k_spline_scan is not built for root %d / key type %d", ROOT, c->dtype); return RMI_ERR_HIP; }

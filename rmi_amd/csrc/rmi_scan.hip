@@ -16,15 +16,35 @@ static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
   const uint64_t rel_hi = a.sp.it_hi - (uint64_t)tile0;
   const unsigned int ntiles = (unsigned int)(rel_hi / G::BTILE + 1);            // big tiles (the position behind the last key lies in one)
   const unsigned int tpx = (ntiles + 7u) / 8u;
-  unsigned int grid = (ntiles + 7u) & ~7u;
-  if (grid > a.max_waves) grid = a.max_waves & ~7u;
-  if (grid > SCAN_MAX_WAVES) grid = SCAN_MAX_WAVES;
-  if (grid < 8u) grid = 8u;
-  a.waves = grid;
+  auto grid_for = [&](int phase) -> unsigned int {
+    unsigned int cap = rmi_scan_waves_per_cu(phase) * (a.n_cu ? a.n_cu : 256u);
+    if (a.max_waves && a.max_waves < cap) cap = a.max_waves;
+    unsigned int grid = (ntiles + 7u) & ~7u;
+    if (grid > cap) grid = cap & ~7u;
+    if (grid > SCAN_MAX_WAVES / 2) grid = SCAN_MAX_WAVES / 2;
+    if (grid < 8u) grid = 8u;
+    return grid;
+  };
   ScanArgs ka;
   ka.keys = a.keys; ka.tile0 = tile0; ka.ntiles = ntiles; ka.tiles_per_xcd = tpx; ka.long_min = a.long_min; ka.host_split = a.host_split; ka.mono = a.mono;
   ka.st = a.st; ka.sp = a.sp; ka.r = a.rp; ka.out = a.out; ka.fl = a.fl; ka.peers = a.peers; ka.gaps = a.gaps; ka.gap_cnt = a.gap_cnt;
-  hipLaunchKernelGGL((k_spline_scan<ROOT, K, V>), dim3(grid), dim3(64), 0, s, ka);
+  ka.tile_list = a.tile_list; ka.tile_cnt = a.tile_cnt;
+  a.waves = 0;
+  bool listed = false;
+  if constexpr (ScMono<ROOT>::value && RMI_SC_FAST) {
+    if (a.mono && a.tile_list != nullptr) {
+      // the short form's kernel over all tiles; what it leaves goes on the list
+      const unsigned int g0 = grid_for(0);
+      hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 0>), dim3(g0), dim3(64), 0, s, ka);
+      a.waves += g0;
+      ka.out.partials = a.out.partials + g0;
+      listed = true;
+    }
+  }
+  if (!listed) ka.tile_list = nullptr;                                            // the general form's kernel takes every tile
+  const unsigned int g1 = grid_for(1);
+  hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 1>), dim3(g1), dim3(64), 0, s, ka);
+  a.waves += g1;
   return 0;
 }
 
@@ -40,9 +60,14 @@ static int scan_launch_k(int dtype, ScanLaunch& a, hipStream_t s) {
 
 // (what the registers and the LDS of a CU hold: 4 SIMDs x RMI_SC_WPE waves, 160 KB over the kernel's static LDS -- the tile image and 2.7 KB of tables;
 //  the same for every instance.  A launch of more waves than are resident would run its surplus as a second round behind the first.)
-unsigned int rmi_scan_waves_per_cu() {
+unsigned int rmi_scan_waves_per_cu(int phase) {
   const unsigned int by_lds = 163840u / ((unsigned int)ScGeom<uint32_t, 32>::LDS_DW * 4u + 2720u);
-  return by_lds < 4u * RMI_SC_WPE ? by_lds : 4u * RMI_SC_WPE;
+  const unsigned int by_regs = 4u * (phase == 0 ? RMI_SC_WPE0 : RMI_SC_WPE);
+  return by_lds < by_regs ? by_lds : by_regs;
+}
+unsigned long long rmi_scan_tiles(int dtype, unsigned long long n_it) {
+  const unsigned long long tile = dtype == 1 ? ScGeom<uint32_t, 32>::BTILE : ScGeom<uint64_t, 16>::BTILE;
+  return n_it / tile + 8;
 }
 
 int rmi_scan_gaps_launch(int dtype, ScanLaunch& a, hipStream_t s) {

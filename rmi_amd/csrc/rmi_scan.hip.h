@@ -64,8 +64,8 @@
 #ifndef RMI_SC_NSUB
 #define RMI_SC_NSUB 1                 // tiles per big tile: 1 (2: the short form's lanes hold two rows -- fewer instructions a key, but 21.7 KB of LDS and spills: 0.59 against 0.52 ms)
 #endif
-#ifndef RMI_SC_LEANTEST
-#define RMI_SC_LEANTEST 0
+#ifndef RMI_SC_WPE0
+#define RMI_SC_WPE0 3                 // waves per SIMD of the short form's kernel (PHASE 0: 168 registers)
 #endif
 #ifndef RMI_SC_FAST
 #define RMI_SC_FAST 1                 // 0: every tile through the general form
@@ -107,6 +107,8 @@ template <typename K, int V> struct ScGeom {
   static_assert(ROWD == 32, "the address rule shifts by 5");
   static_assert(FHC + EXTC <= 64, "one aux chunk per lane");
 };
+// roots whose targets are monotone in the key by arithmetic (given a slope >= 0 / a common prefix: ScanArgs::mono)
+template <int ROOT> struct ScMono { static constexpr bool value = ROOT == K_LINEAR || ROOT == K_RADIX; };
 constexpr int SC_SLOTS = 64;                             // leaves per batch: one per lane in P3 / P5
 
 // DPP steps of the wave scans (gfx9 row_shr / row_bcast; lanes without a source keep `old`)
@@ -189,10 +191,15 @@ struct ScanArgs {
   PeerRows peers;
   GapRec* gaps;
   unsigned long long* gap_cnt;
+  unsigned int* tile_list;        // PHASE 0: the tiles it leaves to the general form; PHASE 1: the tiles to take (null: all tiles of the launch)
+  unsigned long long* tile_cnt;
 };
 
-template <int ROOT, typename K, int V>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_WPE, RMI_SC_WPE))) k_spline_scan(ScanArgs) {
+// PHASE 0: the short form alone, at RMI_SC_WPE0 waves per SIMD -- the general form's registers are what kept the whole kernel at 2 --; a tile
+//          it cannot take (an end of the launch, a lane with two leaf starts, a long gap or leaf, the split nearby) goes on a list.
+// PHASE 1: the general form over the tiles of that list, or -- a root that is not monotone by arithmetic: no PHASE 0 -- over all tiles.
+template <int ROOT, typename K, int V, int PHASE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE == 0 ? RMI_SC_WPE0 : RMI_SC_WPE, PHASE == 0 ? RMI_SC_WPE0 : RMI_SC_WPE))) k_spline_scan(ScanArgs) {
   const sc_kargp kp = sc_kernarg_ptr();
   const ScanArgs* const ka = reinterpret_cast<const ScanArgs*>((const unsigned char*)kp);
   const K* const keys = (const K*)ka->keys;
@@ -303,15 +310,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
   const unsigned int xcd = blockIdx.x & 7u, wix = blockIdx.x >> 3, wpx = (gridDim.x + 7u - xcd) >> 3;   // this wave's index among the wpx waves of its XCD
   const unsigned int t_lo = xcd * tiles_per_xcd, t_hi = min(ntiles, t_lo + tiles_per_xcd);
   ScAgg agg{0ull, 0ull, 0ull, 0.0, 0.0};
-  unsigned int tile = t_lo + wix;
-  if (tile < t_hi && plain(tile)) load_tile(tile, lane);
+  // the sequence of this wave's tiles: position k0, k0 + kstep, ... below kend; the tile at a position is the position itself, or the list's entry
+  const unsigned int* const tlist = PHASE == 1 ? SC_ARG(kp, unsigned int*, tile_list) : (const unsigned int*)nullptr;
+  unsigned int kpos = t_lo + wix, kstep = wpx, kend = t_hi;
+  if (PHASE == 1 && tlist != nullptr) {
+    const unsigned long long nl = *SC_ARG(kp, unsigned long long*, tile_cnt);
+    kpos = blockIdx.x; kstep = gridDim.x; kend = (unsigned int)(nl < (unsigned long long)ntiles ? nl : (unsigned long long)ntiles);
+  }
+  auto tile_at = [&](unsigned int k) -> unsigned int { return (PHASE == 1 && tlist != nullptr) ? tlist[k] : k; };
+  unsigned int tile = kpos < kend ? tile_at(kpos) : 0u;
+  if (kpos < kend && plain(tile)) load_tile(tile, lane);
 
 #if RMI_SC_PROF
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
   const unsigned long long tstart = tlast;
   unsigned int ntile = 0, nfast = 0;
 #endif
-  for (; tile < t_hi; tile += wpx) {
+  for (; kpos < kend; kpos += kstep) {
+    tile = tile_at(kpos);
+    const bool more_t = kpos + kstep < kend;
+    const unsigned int tile_nx = more_t ? tile_at(kpos + kstep) : 0u;
 #if RMI_SC_PROF
     ntile++;
 #endif
@@ -326,9 +344,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
     //      new key value arises among them; the launch's first key and the position behind its last key are leaf starts by decree (below).
     const bool edge2 = relA2 < rel_lo + 1u || relA2 + (unsigned int)BTILE + (unsigned int)EXTN + 1u > rel_hi;   // (wave-uniform)
     const bool plain_t = plain(tile);                                           // (implies !edge2)
+    // PHASE 0 leaves a tile to the general form: on the list
+    auto leave_tile = [&]() {
+      if (lane == 0) {
+        const unsigned long long pos = atomicAdd(SC_ARG(kp, unsigned long long*, tile_cnt), 1ull);
+        SC_ARG(kp, unsigned int*, tile_list)[pos] = tile;
+      }
+    };
+    // (ONE place that issues the next tile's loads, below: a second one makes the compiler carry the tile in two register sets)
+    const bool take = PHASE == 1 || (mono && plain_t && relA2 >= rel_lo + (unsigned int)FHN + 1u);
     // ---- stage the big tile (padded rows) and the aux chunks
     wave_sync();
-    if (plain_t) {
+    if (!take) {
+    } else if (PHASE == 0 || plain_t) {
 #pragma unroll
       for (int c = 0; c < NCHB; c++) {
         const int d0 = (c * 64 + ln) * 4;                                        // dword offset of the chunk from the big tile's first key
@@ -374,8 +402,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
     auto lds_bits0 = [&](int rel0) -> B { const int d = rel0 * DW; return bits_at(trow0 + d + 4 * (d >> 5)); };
     SC_TICK(0);
     // ---- the next big tile's loads: in flight during everything below
-    { const unsigned int nt = tile + wpx; if (nt < t_hi && plain(nt)) load_tile(nt, ln); }
+    if (more_t && plain(tile_nx)) load_tile(tile_nx, ln);
     SC_TICK(1);
+    if constexpr (PHASE == 0) { if (!take) { leave_tile(); continue; } }
 
     // y (FixDups offset, models/mod.rs:154-185) of the key in front of the (sub-)tile that starts hoff keys into the big tile, at the global
     // index A_ (relative index relA_): its run of equal keys is walked in the keys in front of it; a run that reaches beyond the front
@@ -393,8 +422,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
       return (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
     };
     // ================= the ordinary big tile (see the head of the file): same values as the general form below, fewer instructions =================
-    if constexpr (s2_root_monotone<ROOT>() && RMI_SC_FAST) {
-      if (mono && plain_t && relA2 >= rel_lo + (unsigned int)FHN + 1u) {
+    if constexpr (ScMono<ROOT>::value && PHASE == 0) {
+      {
         bool done = false;
         do {
           constexpr int LOGV = G::LOGV;
@@ -704,13 +733,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RMI_SC_
           nfast++;
 #endif
         } while (false);
-        if (done) continue;
+        if (!done) leave_tile();
+        continue;
       }
     }
-#if RMI_SC_LEANTEST
-    continue;                                                                    // timing experiment (results wrong): no general form at all
-#endif
     // ================= the general form: the big tile's NSUB tiles one after the other, lane l <-> row 64 h + l =================
+    if constexpr (PHASE == 1)
     for (int h = 0; h < NSUB; h++) {
     const unsigned int relA = relA2 + (unsigned int)(h * TILE);                  // relative index of the tile's first key
     const unsigned int A = base32 + relA;                                       // ... and its global index
