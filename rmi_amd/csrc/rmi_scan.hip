@@ -58,10 +58,11 @@ static int scan_launch_k(int dtype, ScanLaunch& a, hipStream_t s) {
   return -1;
 }
 
-// (what the registers and the LDS of a CU hold: 4 SIMDs x RMI_SC_WPE waves, 160 KB over the kernel's static LDS -- the tile image and 2.7 KB of tables;
+// (what the registers and the LDS of a CU hold: 4 SIMDs x the waves per SIMD the phase is compiled for, 160 KB over the kernel's static LDS;
 //  the same for every instance.  A launch of more waves than are resident would run its surplus as a second round behind the first.)
 unsigned int rmi_scan_waves_per_cu(int phase) {
-  const unsigned int by_lds = 163840u / ((unsigned int)ScGeom<uint32_t, 32>::LDS_DW * 4u + 2720u);
+  const unsigned int lds_bytes = (((unsigned int)ScGeom<uint32_t, 32>::LDS_DW * 4u + 2720u) + 511u) & ~511u;   // (the tile image + the slot tables, in the allocation's granules)
+  const unsigned int by_lds = 163840u / lds_bytes;
   const unsigned int by_regs = 4u * (phase == 0 ? RMI_SC_WPE0 : RMI_SC_WPE);
   return by_lds < by_regs ? by_lds : by_regs;
 }

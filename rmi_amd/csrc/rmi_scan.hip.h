@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
   __shared__ unsigned int r_s[SC_SLOTS + 1], r_t[SC_SLOTS + 1], r_g0[SC_SLOTS + 1], r_yp[SC_SLOTS + 1];   // boundary records of a batch
   __shared__ __attribute__((aligned(16))) double m_ab[2 * (SC_SLOTS + 2)];                                   // (alpha, beta) per slot, one entry of padding either side
   __shared__ unsigned int m_err[SC_SLOTS + 2], m_run[SC_SLOTS + 2];
+
   unsigned int* const trow0 = lds + T0;               // row r of the big tile at trow0[r S ...]; the front chunks and the look-ahead by the same rule (ScGeom)
 
   const int lane = threadIdx.x;
@@ -310,6 +311,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
   const unsigned int xcd = blockIdx.x & 7u, wix = blockIdx.x >> 3, wpx = (gridDim.x + 7u - xcd) >> 3;   // this wave's index among the wpx waves of its XCD
   const unsigned int t_lo = xcd * tiles_per_xcd, t_hi = min(ntiles, t_lo + tiles_per_xcd);
   ScAgg agg{0ull, 0ull, 0ull, 0.0, 0.0};
+  unsigned int amx = 0u, ami = 0u;                    // PHASE 0's aggregates: maximum and its leaf (32 bits there), the integer sum; the float sums in LDS
+  unsigned long long asum = 0ull;
+  // ... in the 16 bytes of padding behind row `lane` of the tile image, which no staging store touches (in registers they were spilled: 12 waves
+  // per CU leave 168; an array of their own took the LDS over what 12 waves can have)
+  double* const aggp = reinterpret_cast<double*>(trow0 + lane * G::S + G::ROWD);
+  if constexpr (PHASE == 0) { aggp[0] = 0.0; aggp[1] = 0.0; }
   // the sequence of this wave's tiles: position k0, k0 + kstep, ... below kend; the tile at a position is the position itself, or the list's entry
   const unsigned int* const tlist = PHASE == 1 ? SC_ARG(kp, unsigned int*, tile_list) : (const unsigned int*)nullptr;
   unsigned int kpos = t_lo + wix, kstep = wpx, kend = t_hi;
@@ -540,16 +547,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
           if (lane == 0) r_s[nb] = A2 + term_rel;
           wave_sync();
           // ---- F3: the models.  Lane l: slot l.  Container [s - 1, e]: both end points exist (no split, no end of the data nearby) and their keys differ
-          unsigned int q_s = 0u, q_e = 0u, q_t = 0u;
-          K k_lo = KeyTraits<K>::zero_value(), k_hi = KeyTraits<K>::zero_value();
-          double ma = 0.0, mb = 0.0;
+          // (nothing of a slot stays in registers across the error pass: F5 reads records, model and end keys from LDS again -- registers held
+          //  there were spilled, and a spilled register's reload waits for the key loads in flight)
           if ((unsigned int)lane < nb) {
-            q_s = r_s[lane]; q_e = r_s[lane + 1]; q_t = r_t[lane];
-            k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))); k_hi = bits_to_key<K>(lds_bits0((int)(q_e - A2)));
+            const unsigned int q_s = r_s[lane], q_e = r_s[lane + 1];
+            const K k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))), k_hi = bits_to_key<K>(lds_bits0((int)(q_e - A2)));
             const double x0 = KeyTraits<K>::as_float(k_lo), x1 = KeyTraits<K>::as_float(k_hi);
             const double y0f = (double)r_yp[lane], y1f = (double)q_e;
-            mb = (y0f - y1f) / (x0 - x1);                                        // linear_spline.rs:27
-            ma = y0f - mb * x0;                                                  // :28, plain multiply-subtract
+            const double mb = (y0f - y1f) / (x0 - x1);                           // linear_spline.rs:27
+            const double ma = y0f - mb * x0;                                     // :28, plain multiply-subtract
             m_ab[2 * (lane + 1)] = ma; m_ab[2 * (lane + 1) + 1] = mb;
             m_err[lane + 1] = 0u; m_run[lane + 1] = 0u;
           }
@@ -710,6 +716,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
             }
           };
           if ((unsigned int)lane < nb) {
+            const unsigned int q_s = r_s[lane], q_e = r_s[lane + 1], q_t = r_t[lane];
+            const K k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))), k_hi = bits_to_key<K>(lds_bits0((int)(q_e - A2)));
+            const double ma = m_ab[2 * (lane + 1)], mb = m_ab[2 * (lane + 1) + 1];
             const unsigned int curr = m_err[lane + 1], ru = m_run[lane + 1];
             const unsigned int up = min(sg_cvt_u32(__builtin_fma(mb, KeyTraits<K>::as_float(KeyTraits<K>::minus_eps(k_hi)), ma)), n32);   // lower_bound_correction.rs:47-49
             const unsigned int upper = sg_absdiff(up, min(q_e + 1u, n32));                                                              // two_layer.rs:229-235
@@ -717,14 +726,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
             const unsigned int lower = sg_absdiff(lw, q_t == 0u ? q_e : q_s);                                                          // two_layer.rs:237-247
             const unsigned int final_err = max(max(curr, upper), lower) + (ru > 1u ? ru : 1u);                                       // :250-251 (a leaf with keys owns a recorded run)
             const unsigned int cnt_j = q_e - q_s;
-            if (RMI_SC_STOP != 6) store_leaf(q_t, q_s, ma, mb, final_err, cnt_j);
-            if (RMI_SC_STOP != 5) agg.add((uint64_t)q_t, (uint64_t)final_err, (uint64_t)cnt_j, nf);
-            if (RMI_SC_STOP == 5) agg.sum += final_err + cnt_j;
+            store_leaf(q_t, q_s, ma, mb, final_err, cnt_j);
+            // the terms of the aggregates (two_layer.rs:267-287), as ScAgg::add forms them
+            auto agg_max = [&](unsigned int j, unsigned int e) { if (e > amx || (e == amx && j > ami)) { amx = e; ami = j; } };   // max_by_key: the LAST maximum
+            agg_max(q_t, final_err);
+            {
+              const unsigned long long ts = (unsigned long long)cnt_j * (unsigned long long)final_err;
+              asum += ts;
+              if (cnt_j) {
+                const double v = (double)ts;
+                aggp[0] += (v * v) / nf;
+                aggp[1] += (double)cnt_j * log2((double)(2ull * (unsigned long long)final_err + 2ull));
+              }
+            }
             // the empty leaves [g0, t) in front of this start (s == e): the constant model next_index = s (two_layer.rs:185-197), widened by 1
             const unsigned int g0 = r_g0[lane];
             for (unsigned int j = g0; j < q_t; j++) {
               store_leaf(j, q_s, (double)q_s, 0.0, 1u, 0u);
-              agg.add((uint64_t)j, 1ull, 0ull, nf);
+              agg_max(j, 1u);
             }
           }
           done = true;
@@ -1150,7 +1169,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
     }  // h
   }
 #if RMI_SC_PROF
-  if (lane == 0 && (blockIdx.x == 777 || (unsigned long long)__builtin_readcyclecounter() - tstart > 1800000ull))
+  if (lane == 0 && (blockIdx.x == 777 || blockIdx.x == 1500 || blockIdx.x == 2222))
     printf("wave %u: tiles %u fast %u total %llu | stage %llu prefetch %llu F1 %llu F2-3 %llu F4 %llu F5 %llu looptop %llu\n", blockIdx.x, ntile, nfast,
            (unsigned long long)__builtin_readcyclecounter() - tstart, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[7]);
 #endif
@@ -1159,6 +1178,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
   {
     unsigned long long mx = agg.mx, mi = agg.mi, sm = agg.sum;
     double l2 = agg.l2, lg = agg.lg;
+    if constexpr (PHASE == 0) { mx = amx; mi = ami; sm = asum; l2 = aggp[0]; lg = aggp[1]; }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
       const unsigned long long omx = shfl_down_u64(mx, d), omi = shfl_down_u64(mi, d);
