@@ -96,6 +96,8 @@ struct DevState {
   // only if none of its ~12 000 keys repeats: when the probes -- some twenty keys a leaf -- see a repeat at more than one leaf per group,
   // k_leaf_regs lists every group at once, without walking any (duplicate-heavy keys on the FIRST training of a key set)
   unsigned long long regs_dups;
+  // k_spline_scan: tiles the short form's kernel left to the general form's (the host sizes that kernel's launch by the last count)
+  unsigned long long scan_listed;
 };
 
 // A leaf whose container is so long that its sequential recurrence is faster on a host core (~4 ns per point against

@@ -110,6 +110,7 @@ struct rmi_hip_ctx {
   int n_cu = 256;
   bool last_regs = false;
   void* d_gaps = nullptr;                       // pipeline 5: the listed stretches of empty leaves (GapRec)
+  uint64_t scan_hint_epoch = 0, scan_hint_L = 0; unsigned int scan_hint_n = ~0u;   // ... and how many it left the last time (key set, leaves per launch)
   unsigned int* d_tile_list = nullptr;          // ... the tiles the short form's kernel leaves to the general form's
   uint64_t tile_list_cap = 0;
   // pipeline 5 writes the rows (codegen.rs:288-315: alpha, beta, error -- the 24 L bytes of SURVEY 8d) and the bucket table only; the separate
@@ -1276,7 +1277,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   if (!init_folded) {
     const uint64_t ib = init_arrays ? (L_own + 1 + 255) / 256 : 1;
     hipLaunchKernelGGL(k_init, dim3((unsigned)(ib < 2048 ? ib : 2048)), dim3(256), 0, s, a_leaf_start, a_maxerr, a_run,
-                       L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS + 8, init_arrays);
+                       L_own, (unsigned long long)sp.it_hi, c->d_state, init, c->d_flist_cnt, 2 * SG_REGIONS + 8, init_arrays, scan5 ? c->d_tickets : (unsigned int*)nullptr);
   }
   c->tail_armed = false; c->tail_fn = nullptr; c->regs_listed_fn = nullptr; c->giant_early = false; c->giant_fitted = false;
   c->last_lean = false; c->lean_derived = false;
@@ -1339,7 +1340,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           searched = true;
         }
       }
-      if (!(searched && init_folded)) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 12, s));   // (k_lane_reduce's arrival counter, k_leaf_regs' list counter and group counter)
+      if (!(searched && init_folded) && !scan5) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, 12, s));   // (k_lane_reduce's arrival counter, k_leaf_regs' list counter and group counter)
       if (!searched && !scan5) {
         constexpr uint64_t V = 16 / sizeof(K);
         const uint64_t blocks = ((n_it + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
@@ -1477,6 +1478,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         sl.mono = scan_mono ? 1 : 0;
         sl.max_waves = c->scan_waves;
         sl.n_cu = (unsigned int)c->n_cu;
+        // the general form's kernel gets as many waves as tiles were left to it by the last training of this (key set, leaf count) -- twice
+        // that and 64 more; a first training, or one in which the list outgrows them, launches what the device holds
+        sl.listed_hint = (c->scan_hint_epoch == c->keys_epoch && c->scan_hint_L == L_own) ? c->scan_hint_n : ~0u;
         {
           const uint64_t need = rmi_scan_tiles(c->dtype, n_it);
           if (c->tile_list_cap < need) {
@@ -1979,6 +1983,7 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   }
   c->last_L = L_own; c->last_ppl = ppl;
   c->lean_last_target = st.last_target;
+  if (c->last_scan && !c->stream_mode) { c->scan_hint_epoch = c->keys_epoch; c->scan_hint_L = L_own; c->scan_hint_n = (unsigned int)(st.scan_listed < 0xFFFFFFFFull ? st.scan_listed : 0xFFFFFFFFull); }
   c->lean_leaf_lo = c->have_shard ? c->shard.leaf_lo : 0;
   std::memset(out, 0, sizeof *out);
   out->generation = c->generation;

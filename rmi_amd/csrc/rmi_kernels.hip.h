@@ -158,7 +158,8 @@ static __global__ void __launch_bounds__(256) k_init(unsigned long long* __restr
                                               unsigned long long* __restrict__ maxerr,
                                               unsigned long long* __restrict__ run, uint64_t L_own,
                                               unsigned long long sentinel, DevState* __restrict__ st, DevState init,
-                                              unsigned long long* __restrict__ list_cnt, int n_list_cnt, bool arrays) {
+                                              unsigned long long* __restrict__ list_cnt, int n_list_cnt, bool arrays,
+                                              unsigned int* __restrict__ tickets = nullptr) {   // (3 arrival / list counters, where the caller has no memset for them)
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t lim = (arrays && L_own + 1 > (uint64_t)n_list_cnt) ? L_own + 1 : (uint64_t)n_list_cnt;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < lim; j += stride) {
@@ -166,7 +167,7 @@ static __global__ void __launch_bounds__(256) k_init(unsigned long long* __restr
     if (arrays && j < L_own) { maxerr[j] = 0; run[j] = 0; }
     if (j < (uint64_t)n_list_cnt) list_cnt[j] = 0ull;      // the one-pass mode's list counters (a memset of their own costs ~4 us)
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { *st = init; if (!arrays) leaf_start[L_own] = sentinel; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *st = init; if (!arrays) leaf_start[L_own] = sentinel; if (tickets) { tickets[0] = 0u; tickets[1] = 0u; tickets[2] = 0u; } }
 }
 
 // ---------------------------------------------------------------------------------------------

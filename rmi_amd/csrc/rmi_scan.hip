@@ -42,7 +42,11 @@ static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
     }
   }
   if (!listed) ka.tile_list = nullptr;                                            // the general form's kernel takes every tile
-  const unsigned int g1 = grid_for(1);
+  unsigned int g1 = grid_for(1);
+  if (listed && a.listed_hint != ~0u) {                                           // (a hint for the launch's size only: the kernel strides over whatever the list holds)
+    const unsigned long long want = 2ull * a.listed_hint + 64ull;
+    if (want < (unsigned long long)g1) g1 = (unsigned int)((want + 7ull) & ~7ull);
+  }
   hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 1>), dim3(g1), dim3(64), 0, s, ka);
   a.waves += g1;
   return 0;

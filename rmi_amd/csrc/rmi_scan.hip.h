@@ -1174,6 +1174,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
            (unsigned long long)__builtin_readcyclecounter() - tstart, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[7]);
 #endif
   if (flags) atomicOr(&st->err_flags, flags);
+  if constexpr (PHASE == 1) { if (blockIdx.x == 0 && lane == 0) st->scan_listed = tlist != nullptr ? *SC_ARG(kp, unsigned long long*, tile_cnt) : 0ull; }
   // ---- this wave's aggregate record
   {
     unsigned long long mx = agg.mx, mi = agg.mi, sm = agg.sum;

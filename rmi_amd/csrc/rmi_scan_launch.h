@@ -34,6 +34,7 @@ struct ScanLaunch {
   unsigned int* tile_list;        // the tiles the short form's kernel leaves to the general form's (room for every tile of the launch: rmi_scan_tiles)
   unsigned long long* tile_cnt;   // their counter (zero before the launch)
   unsigned int n_cu;              // compute units of the device
+  unsigned int listed_hint;       // tiles the short form left to the general form in the last training of this configuration (~0: unknown)
   int host_split;                 // the split of the 2-way join is in *st already (a shard)
   int mono;                       // the root's targets are monotone in the key by arithmetic: a linear root with finite coefficients and a slope >= 0, a radix
                                   // root whose prefix is common to all resident keys (then equal targets at two keys prove that no leaf starts between them)
