@@ -696,8 +696,13 @@ __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ key
           E4 = margin_scale * 0x1p-51 * (fabs(v3) + fabs(x) * fabs(v2) + (x * x) * fabs(v1));
           return v3;
         };
+        // the leaf's first key is the key behind leaf j - 1 (bnext[j - 1]), its last key the key in front of leaf j + 1 (bprev[j + 1]): k_leaf_regs
+        // has handed both over for the groups it took -- coalesced reads instead of two scattered lines per leaf
+        const uint64_t nl = sp.leaf_hi - sp.leaf_lo;
+        const K ka = (jl > 0 && tile_slow[(jl - 1) >> 6] == 0) ? bnext[jl - 1] : keys[s];
+        const K kb = (jl + 1 < nl && tile_slow[(jl + 1) >> 6] == 0) ? bprev[jl + 1] : keys[e - 1];
         double Ea, Eb;
-        const double ca = val(keys[s], Ea), cb = val(keys[e - 1], Eb);
+        const double ca = val(ka, Ea), cb = val(kb, Eb);
         const double Lf = (double)vr.L;
         if (j > 0) ok = ok && (ca >= (double)j + Ea);
         if (j + 1 < L) ok = ok && (cb < (double)(j + 1) - Eb);
