@@ -14,9 +14,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 sys.path.insert(0, ROOT)
-import torch  # noqa: E402
-torch.cuda.init()                     # (torch first: its HIP runtime must see the device before the library's does)
-from rmi_amd import train  # noqa: E402
+train = None
+
+
+def _gpu():
+    """torch first: its HIP runtime must see the device before the library's does (the other way round: "No HIP GPUs are available")"""
+    global train
+    import torch
+    torch.cuda.init()
+    from rmi_amd import train as t
+    train = t
+
 
 CFG = {
     "M": (200_000_000, 1 << 20, "linear", "linear", "uniform", np.uint64),
@@ -30,6 +38,7 @@ CFG = {
 
 
 def setup(cfg, dataset=None):
+    _gpu()
     n, L, root_kind, leaf, ds, dt = CFG[cfg]
     ds = dataset or ds
     tr = train.Trainer()

@@ -9,6 +9,8 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     n = name.split("(")[0]
+    if "k_spline_scan" in n:                              # two kernels of one template
+        return "k_spline_scan<short>" if n.rstrip().endswith(", 0>") else ("k_spline_scan<general>" if n.rstrip().endswith(", 1>") else "k_spline_scan")
     for key in ("k_spline_scan", "k_scan_gaps", "k_long_regs", "k_verify_listed", "k_giant_scan", "k_finalize_listed", "k_leaf_regs", "k_regs_finalize", "k_regs_table", "k_leaf_lanes_listed", "k_leaf_lanes", "k_leaf_search", "k_leaf_samples", "k_lane_reduce", "k_lane_table", "k_sigma2", "k_list_tail", "k_list", "k_err_long", "k_fit_list", "k_err_list", "k_read_bw", "k_init", "k_fit_stream", "k_err_range", "k_fit_long", "k_fill_tilemin", "k_fill_scan_tiles", "k_fill_apply", "k_finalize",
                 "k_stats_reduce", "k_generate", "k_boundaries", "k_fit_leaf", "k_err"):
         if key in n:

@@ -22,7 +22,10 @@ acc = defaultdict(lambda: defaultdict(list))
 for d in (f"{out_dir}/tf", f"{out_dir}/tw"):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = next((x for x in names if x in r["Kernel_Name"]), None)
+            kn = r["Kernel_Name"]
+            k = next((x for x in names if x in kn), None)
+            if k == "k_spline_scan":                      # two kernels of one template: the short form's (PHASE 0) and the general form's (PHASE 1)
+                k = "k_spline_scan<short form>" if kn.split("(")[0].rstrip().endswith(", 0>") else "k_spline_scan<general form>"
             if k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
