@@ -162,3 +162,44 @@ def test_scan_equals_the_leaf_lane_kernel(monkeypatch):
     assert res["1"][0] == 5 and res["0"][0] == 3
     for a, b in zip(res["1"][1:], res["0"][1:]):
         assert np.array_equal(a, b)
+
+
+def test_scan_repeated_trainings_lean_and_full(monkeypatch, oracle):
+    """The same configuration three times on one context (the second and third launch size the general form's kernel by the first one's list),
+    then with RMI_HIP_LEAN=0 (the kernel writes the coefficient / error / count arrays itself instead of leaving them to be filled from the
+    rows on download): every array the same bytes, and the oracle's."""
+    from rmi_amd import train
+    keys = dg.dups_u32(3_000_000)
+    L = 1 << 15
+    o = oracle.train_two_layer("radix", "linear_spline", keys, L)
+    outs = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("RMI_HIP_LEAN", lean)
+        tr = train.Trainer(keys)
+        root = tr.fit_root("radix", L)
+        for _ in range(3):
+            g = tr.train_leaves(root, "linear_spline", L).materialize()
+            assert g.pipeline == 5
+            outs.append((g.leaf_starts.copy(), g.leaf_params.copy(), g.last_layer_max_l1s.copy(), g.leaf_counts.copy(), g.rows.copy(),
+                         g.model_max_error, g.model_max_error_idx, g.model_avg_error))
+        tr.close()
+    for t in outs:
+        assert np.array_equal(t[0], o.leaf_start) and np.array_equal(t[1].view(np.uint64), o.leaf_params.view(np.uint64))
+        assert np.array_equal(t[2], o.leaf_err) and np.array_equal(t[3], o.leaf_count)
+        assert np.array_equal(t[4], outs[0][4]) and t[5:] == outs[0][5:]
+        assert (t[5], t[6], t[7]) == (o.model_max_error, o.model_max_error_idx, o.model_avg_error)
+
+
+def test_read_bandwidth_patterns_and_release_views():
+    """ABI v6: the two read-only patterns both report a positive rate; the worker contexts of train_many can be released and come back."""
+    from rmi_amd import train
+    tr = train.Trainer(dg.uniform_u64(2_000_000))
+    assert tr.measure_read_bandwidth(2, 0) > 0 and tr.measure_read_bandwidth(2, 1) > 0
+    root = tr.fit_root("linear", 1024)
+    cfgs = [(root, "linear", 1024), (root, "linear_spline", 1024), (root, "linear", 1024)]
+    a = tr.train_many(cfgs, in_flight=3)
+    tr.release_views()
+    b = tr.train_many(cfgs, in_flight=3)
+    assert [x[0] for x in a] == [0, 0, 0] and [x[0] for x in b] == [0, 0, 0]
+    assert [x[1].model_max_error for x in a] == [x[1].model_max_error for x in b]
+    tr.close()
