@@ -102,6 +102,7 @@ def _sharded_trainer_worker(rank, world, port, n_global, L, q, exchange="rccl", 
     from rmi_amd import sharded, train
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("RMI_HIP_PEER_TIMEOUT_S", "400")        # (processes that share ONE GPU on a slow box: the library's default is 60 s)
     if rank == listed_rank:
         os.environ["RMI_HIP_LONG_MIN"] = "64"                     # this rank hands (nearly) every leaf to the list kernels
     torch.cuda.set_device(0)                                      # both ranks share the one GPU of the box
@@ -341,7 +342,7 @@ def test_bench_eight_ranks_gloo_direct(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "2", "--backend", "gloo", "--exchange", "direct",
            "--keys", "8000000", "--leaves", "65536", "--no-cpu-baseline", "--no-extras"]
-    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, RMI_HIP_PEER_TIMEOUT_S="400"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
