@@ -320,6 +320,9 @@ class ShardedTrainer:
                         ok = False
                         rep["error"] = str(ex)
                     ts.append(time.perf_counter() - t1)
+                    if not all_ok(ok):                           # (outside the timed window; a failing exchange costs ONE peer time-out, not k)
+                        ok = False
+                        break
                 v = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64, device=dev)
                 dist.all_reduce(v, op=dist.ReduceOp.MAX)
                 return float(v.item()), all_ok(ok)
