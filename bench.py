@@ -233,6 +233,19 @@ def side_configs(T, tr_m, device, with_oracle):
                 "kernel_us": k0 / 4 / 1e3, "kernel_frac": b / (k0 / 4 * 1e-9) / 1e9 / HBM_PEAK_GBS if k0 else None, "pipeline": pl,
                 "mode_used": int(r.fit_mode_used), "listed_long_leaves": int(r.long_leaves), "exact_refit_leaves": int(r.exact_leaves)}, r
 
+    def with_traffic(e, tag):
+        """HBM bytes of the step from profiles/traffic_r05_<tag>.json (rocprofv3 counters of the same workload), quoted only if that
+        file was taken on a build of these kernel sources."""
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r05_%s.json" % tag)))
+            if tj.get("sources_sha256") == sources_sha256():
+                e["traffic"] = tj.get("step_hbm_bytes")
+                e["traffic_ratio"] = tj.get("traffic_ratio")
+                e["traffic_note"] = "not measured in this run: profiles/traffic_r05_%s.json (tools/profile_r05.sh), same kernel sources" % tag
+        except Exception:
+            pass
+        return e
+
     # the shard shapes of the 8-GPU configurations on this one GPU: what a rank's kernels cost at N = 8 (DESIGN section 6 quotes these)
     for name, nk, L in (("M shard 1/8: linear,linear 131072 leaves on 25M u64", 25_000_000, 1 << 17),
                         ("C4 shard 1/8: linear,linear 262144 leaves on 100M u64 (381 keys a leaf)", 100_000_000, 1 << 18)):
@@ -247,7 +260,7 @@ def side_configs(T, tr_m, device, with_oracle):
                 acc += np.array(ts.train_leaves(root, 0, L).kernel_ns, dtype=float)
             e["kernel_groups_us"] = [float(x) / 4e3 for x in acc[:5]]
             e["note"] = "root from the parallel sums (its coefficients do not matter to the leaf path's time); single GPU, exact mode, no exchange"
-            res[name] = {"exact": e}
+            res[name] = {"exact": with_traffic(e, "ms" if nk == 25_000_000 else "c4s")}
             ts.close()
         except Exception as ex:
             res[name] = {"error": str(ex)}
@@ -257,7 +270,7 @@ def side_configs(T, tr_m, device, with_oracle):
         n, L = tr_m.n, 1 << 20
         root = tr_m.fit_root("cubic", L)
         e, r = run(tr_m, root, 0, L, 0, 20, n, 8)
-        res["C3 cubic,linear 2^20 on 200M u64"] = {"exact": e}
+        res["C3 cubic,linear 2^20 on 200M u64"] = {"exact": with_traffic(e, "c3")}
         tr_m.set_fit_mode(0)
     except Exception as ex:                                   # a side figure must not take the headline down
         res["C3"] = {"error": str(ex)}
@@ -268,7 +281,7 @@ def side_configs(T, tr_m, device, with_oracle):
             t5.generate_keys(ds, np.uint32, 400_000_000)
             root = t5.fit_root("radix", 1 << 22)
             e, r = run(t5, root, 1, 1 << 22, 0, 20, 400_000_000, 4)
-            res[f"C5 radix,linear_spline 2^22 on 400M u32 ({ds})"] = {"exact": e}
+            res[f"C5 radix,linear_spline 2^22 on 400M u32 ({ds})"] = {"exact": with_traffic(e, "c5" if ds == "uniform" else "c5_dups")}
             t5.close()
         except Exception as ex:
             res[f"C5 {ds}"] = {"error": str(ex)}
@@ -282,7 +295,7 @@ def side_configs(T, tr_m, device, with_oracle):
         root = t2.fit_root("linear", L)
         ent = {}
         e, r_exact = run(t2, root, 0, L, 0, 3, 200_000_000, 8)
-        ent["exact"] = e
+        ent["exact"] = with_traffic(e, "c2")
         g_exact = r_exact.materialize()
         # what bounds the exact mode here: the recurrence of a leaf is ONE sequential chain by the definition of bit-identical
         # coefficients; the longest container sets the floor -- on a host core (~3.2 ns a point, containers of more than
