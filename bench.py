@@ -130,6 +130,15 @@ def sources_sha256():
     return h.hexdigest()
 
 
+def traffic_file(tag):
+    """The counter file of configuration `tag` under profiles/, the newest round's first."""
+    for rnd in ("r06", "r05"):
+        p = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (rnd, tag))
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "traffic_r06_%s.json" % tag)
+
+
 def env_info(torch):
     """Versions and clocks of the box the line was measured on (best effort: never fails the bench)."""
     import subprocess
@@ -237,11 +246,12 @@ def side_configs(T, tr_m, device, with_oracle):
         """HBM bytes of the step from profiles/traffic_r05_<tag>.json (rocprofv3 counters of the same workload), quoted only if that
         file was taken on a build of these kernel sources."""
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r05_%s.json" % tag)))
+            tpath = traffic_file(tag)
+            tj = json.load(open(tpath))
             if tj.get("sources_sha256") == sources_sha256():
                 e["traffic"] = tj.get("step_hbm_bytes")
                 e["traffic_ratio"] = tj.get("traffic_ratio")
-                e["traffic_note"] = "not measured in this run: profiles/traffic_r05_%s.json (tools/profile_r05.sh), same kernel sources" % tag
+                e["traffic_note"] = "not measured in this run: %s (tools/profile_cfg.sh), same kernel sources" % os.path.relpath(tpath, ROOT)
         except Exception:
             pass
         return e
@@ -270,6 +280,14 @@ def side_configs(T, tr_m, device, with_oracle):
         n, L = tr_m.n, 1 << 20
         root = tr_m.fit_root("cubic", L)
         e, r = run(tr_m, root, 0, L, 0, 20, n, 8)
+        if with_oracle:
+            from oracle import binding as oracle
+            t0 = time.perf_counter()
+            o = oracle.train_two_layer("cubic", "linear", tr_m.download_keys(), L, threads=2)
+            e["parity_check"] = parity_against(o, r.materialize(), "C3 at full size, exact mode (root included: the oracle fits its own cubic)")
+            e["parity_check"]["root_equal"] = bool(tuple(root.p) == tuple(o.root.p))
+            e["parity_check"]["oracle_seconds"] = time.perf_counter() - t0
+            del o
         res["C3 cubic,linear 2^20 on 200M u64"] = {"exact": with_traffic(e, "c3")}
         tr_m.set_fit_mode(0)
     except Exception as ex:                                   # a side figure must not take the headline down
@@ -281,6 +299,14 @@ def side_configs(T, tr_m, device, with_oracle):
             t5.generate_keys(ds, np.uint32, 400_000_000)
             root = t5.fit_root("radix", 1 << 22)
             e, r = run(t5, root, 1, 1 << 22, 0, 20, 400_000_000, 4)
+            if with_oracle:
+                from oracle import binding as oracle
+                t0 = time.perf_counter()
+                o = oracle.train_two_layer("radix", "linear_spline", t5.download_keys(), 1 << 22, threads=2)
+                e["parity_check"] = parity_against(o, r.materialize(), f"C5 ({ds}) at full size: every leaf of the 2^22")
+                e["parity_check"]["root_equal"] = bool(tuple(root.p) == tuple(o.root.p) and tuple(root.ip) == tuple(o.root.ip))
+                e["parity_check"]["oracle_seconds"] = time.perf_counter() - t0
+                del o
             res[f"C5 radix,linear_spline 2^22 on 400M u32 ({ds})"] = {"exact": with_traffic(e, "c5" if ds == "uniform" else "c5_dups")}
             t5.close()
         except Exception as ex:
@@ -329,8 +355,25 @@ def side_configs(T, tr_m, device, with_oracle):
     return res
 
 
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment (the way the driver starts N = 1): start the N ranks
+    ourselves -- the same command under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 at a free port.  Launched by
+    torchrun already (WORLD_SIZE set), nothing happens here."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse_args()
+    respawn_under_torchrun(args)
     import numpy as np
     import torch
 
@@ -544,7 +587,7 @@ def main():
             if getattr(sh, "auto_report", None):
                 out["exchange_ab"] = sh.auto_report
         tag = args.config.lower() + ("_dups" if args.dataset == "dups" and args.config == "C5" else "")
-        tpath = os.path.join(ROOT, "profiles", "traffic_r05_%s.json" % tag)
+        tpath = traffic_file(tag)
         if os.path.exists(tpath) and world == 1 and not used:
             try:
                 tj = json.load(open(tpath))
@@ -554,11 +597,11 @@ def main():
                     out["roofline"]["traffic_ratio"] = tj.get("traffic_ratio")
                     out["roofline"]["traffic_kernels"] = {k: v.get("hbm_bytes_per_launch") for k, v in tj.get("kernels", {}).items()}
                     out["roofline"]["traffic_note"] = "the STEP's sum over its kernels; NOT measured in this run: rocprofv3 FETCH_SIZE / WRITE_SIZE of the same " \
-                                                      "workload (tools/profile_r05.sh) on a build of the same kernel sources (sha256 " + sources_sha256()[:12] + \
+                                                      "workload (tools/profile_cfg.sh) on a build of the same kernel sources (sha256 " + sources_sha256()[:12] + \
                                                       "), from " + os.path.relpath(tpath, ROOT) + " (" + str(tj.get("note", ""))[:160] + " ...)"
                 else:
                     out["roofline"]["traffic_note"] = "profiles/ holds counters of OTHER kernel sources (" + str(tj.get("sources_sha256"))[:12] + \
-                                                      " against " + sources_sha256()[:12] + "): not quoted; tools/profile_r05.sh takes them again"
+                                                      " against " + sources_sha256()[:12] + "): not quoted; tools/profile_cfg.sh takes them again"
             except Exception:
                 pass
 

@@ -543,7 +543,7 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
   }
   std::atomic<uint64_t> next{0};
   std::vector<int> lrc(count, RMI_OK);
-  std::vector<std::string> werr((size_t)in_flight);                    // a worker's first message; merged behind the join
+  std::vector<std::string> cerr((size_t)count);                        // a failing configuration's message; merged behind the join
   auto work = [&](rmi_hip_ctx* w, int slot) {
     (void)hipSetDevice(w->device);
     for (;;) {
@@ -552,9 +552,9 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
       std::memset(&results[i], 0, sizeof results[i]);
       lrc[i] = cfgs[i].root_table ? rmi_hip_set_root_table(w, cfgs[i].root_table, cfgs[i].root_table_entries) : RMI_OK;
       if (lrc[i] == RMI_OK) lrc[i] = rmi_hip_train_two_layer(w, &cfgs[i].root, cfgs[i].leaf_kind, cfgs[i].num_leaves, &results[i]);
-      if (lrc[i] != RMI_OK && werr[(size_t)slot].empty()) {
+      if (lrc[i] != RMI_OK) {
         char head[64]; snprintf(head, sizeof head, "configuration %llu: ", (unsigned long long)i);
-        werr[(size_t)slot] = std::string(head) + w->err;
+        cerr[(size_t)i] = std::string(head) + w->err;
       }
     }
   };
@@ -568,9 +568,9 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
     if (rcs) rcs[i] = lrc[i];
     if (first == RMI_OK && lrc[i] != RMI_OK) first = lrc[i];
   }
-  if (first != RMI_OK) {                                               // (every failing worker's first message, in worker order)
+  if (first != RMI_OK) {                                               // (every failing configuration's message, "configuration <i>: ..." joined by "; ")
     std::string all;
-    for (const auto& e : werr) if (!e.empty()) { if (!all.empty()) all += "; "; all += e; }
+    for (const auto& e : cerr) if (!e.empty()) { if (!all.empty()) all += "; "; all += e; }
     c->err = all;
   }
   return first;
@@ -1457,11 +1457,11 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           if (cubic_margin)
             hipLaunchKernelGGL((k_regs_finalize<K, K_CUBIC>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, (const unsigned int*)(c->d_tickets + 1), params,
                                (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
-                               err, count, rows, part, peers, rp, c->cubic_margin_scale);
+                               err, count, rows, part, peers, rp, c->cubic_margin_scale, listed_late);
           else
             hipLaunchKernelGGL((k_regs_finalize<K>), dim3((unsigned)((wb * 64 + 255) / 256)), dim3(256), 0, s, keys, sp, L, leaf_start, c->d_state, (const unsigned int*)(c->d_tickets + 1), params,
                                (const unsigned long long*)maxerr, (const K*)c->d_bnext, (const K*)c->d_bnext + wb * 64, (const unsigned char*)c->d_tile_slow, (unsigned int)wb,
-                               err, count, rows, part, peers, rp, 1.0);
+                               err, count, rows, part, peers, rp, 1.0, listed_late);
           HIPCHK(c, hipGetLastError());
         }
       }
@@ -1469,7 +1469,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       if (scan5) {
         ScanLaunch sl; std::memset(&sl, 0, sizeof sl);
         sl.keys = keys; sl.sp = sp; sl.rp = rp; sl.st = c->d_state; sl.fl = fl; sl.long_min = lmin;
-        const bool lean5 = c->lean && !c->stream_mode && !c->defer_sync;  // (a streamed / sharded training fills the arrays shard by shard: kept whole there)
+        // (a streamed / sharded training fills the arrays shard by shard: kept whole there; rows in a caller's buffer -- rmi_hip_set_rows_output --
+        //  may be gone or overwritten when the arrays are asked for: lean_fill derives them from the rows, so no lean outputs then)
+        const bool lean5 = c->lean && !c->stream_mode && !c->defer_sync && c->d_rows_ext == nullptr;
         sl.out.leaf_start = leaf_start; sl.out.rows = rows; sl.out.partials = part;
         sl.out.params = lean5 ? nullptr : params; sl.out.leaf_err = lean5 ? nullptr : err; sl.out.leaf_count = lean5 ? nullptr : count;
         c->last_lean = lean5;

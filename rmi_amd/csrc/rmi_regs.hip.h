@@ -662,8 +662,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // here in O(L) instead of per key: the host has checked that the exact cubic is increasing over the resident keys' range (its
 // derivative's minimum there, rmi_hip.hip), the computed value c(x) differs from the exact one by at most E(x) = 2^-53 (|v3| + |x| |v2| +
 // x^2 |v1|) (one rounding per fma of the Horner form, cubic_spline.rs:146-148), so if the first key of leaf j computes to >= j + 2 E and
-// its last key to < j + 1 - 2 E, every key between them has an exact value in [j + E, j + 1 - E] and therefore the target j.  The margin
-// used is 4 E.  A leaf that does not clear it (an end key within ~1e-9 of a leaf border: about one leaf in a training of 2^20) is verified
+// its last key to < j + 1 - 2 E -- E an upper bound of E(x) over the WHOLE leaf, taken from the coefficients' magnitudes at the larger |x| of
+// the two ends --, every key between them has an exact value in [j + E, j + 1 - E] and therefore the target j.  The margin used is 4 E.  A leaf that does not clear it (an end key within ~1e-9 of a leaf border: about one leaf in a training of 2^20) is verified
 // key by key on the spot, by the 64 lanes of its wave together: the check k_leaf_lanes<.., K_CUBIC> makes for every key.
 __device__ __forceinline__ uint64_t rg_readlane_u64(uint64_t v, int src) {
   const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src), hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), src);
@@ -677,7 +677,8 @@ __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ key
                                                        const unsigned char* __restrict__ tile_slow, unsigned int ntiles,
                                                        unsigned long long* __restrict__ leaf_err, unsigned long long* __restrict__ leaf_count,
                                                        unsigned char* __restrict__ rows, StatsPartial* __restrict__ partials, PeerRows peers, RootP vr,
-                                                       double margin_scale) {   // (1; a test widens the margin until every leaf falls back)
+                                                       double margin_scale,     // (1; a test widens the margin until every leaf falls back)
+                                                       bool listed_behind) {    // the listed groups' kernel runs BEHIND this one (and behind the first k_lane_reduce)
   const uint64_t jl = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const unsigned int tile = (unsigned int)(jl >> 6);
   if (jl == 0) st->regs_listed = *slow_count;                          // (into the record the host reads: rmi_hip.hip, regs_off)
@@ -690,10 +691,9 @@ __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ key
       const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
       vs = s; ve = e;
       if (s < e) {
-        auto val = [&](K k, double& E4) -> double {
+        auto val = [&](K k) -> double {
           const double x = KeyTraits<K>::as_float(k);
           const double v1 = __builtin_fma(vr.p0, x, vr.p1), v2 = __builtin_fma(v1, x, vr.p2), v3 = __builtin_fma(v2, x, vr.p3);
-          E4 = margin_scale * 0x1p-51 * (fabs(v3) + fabs(x) * fabs(v2) + (x * x) * fabs(v1));
           return v3;
         };
         // the leaf's first key is the key behind leaf j - 1 (bnext[j - 1]), its last key the key in front of leaf j + 1 (bprev[j + 1]): k_leaf_regs
@@ -701,12 +701,19 @@ __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ key
         const uint64_t nl = sp.leaf_hi - sp.leaf_lo;
         const K ka = (jl > 0 && tile_slow[(jl - 1) >> 6] == 0) ? bnext[jl - 1] : keys[s];
         const K kb = (jl + 1 < nl && tile_slow[(jl + 1) >> 6] == 0) ? bprev[jl + 1] : keys[e - 1];
-        double Ea, Eb;
-        const double ca = val(ka, Ea), cb = val(kb, Eb);
+        // The margin must hold for EVERY key of the leaf, not only for its two end keys: E(x) taken at the ends can be smaller than at an
+        // interior key when the cubic's terms cancel there.  So E is bounded over the whole leaf from the magnitudes alone -- with
+        // xm = max(|x|) over the leaf, |v1| <= |p0| xm + |p1| = V1, |v2| <= V1 xm + |p2| = V2, |v3| <= V2 xm + |p3| = V3: monotone in |x|, so
+        // the bound at xm covers every key between the ends.  (Weaker than the pointwise E where the terms cancel; a leaf that fails it is
+        // verified key by key below, which costs a wave one pass over that leaf.)
+        const double ca = val(ka), cb = val(kb);
+        const double xm = fmax(fabs(KeyTraits<K>::as_float(ka)), fabs(KeyTraits<K>::as_float(kb)));
+        const double V1 = fabs(vr.p0) * xm + fabs(vr.p1), V2 = V1 * xm + fabs(vr.p2), V3 = V2 * xm + fabs(vr.p3);
+        const double E4 = margin_scale * 0x1p-51 * (V3 + xm * V2 + (xm * xm) * V1);
         const double Lf = (double)vr.L;
-        if (j > 0) ok = ok && (ca >= (double)j + Ea);
-        if (j + 1 < L) ok = ok && (cb < (double)(j + 1) - Eb);
-        else ok = ok && (cb < Lf - Eb);                                 // (the largest prediction of all: below L, two_layer.rs:45-48)
+        if (j > 0) ok = ok && (ca >= (double)j + E4);
+        if (j + 1 < L) ok = ok && (cb < (double)(j + 1) - E4);
+        else ok = ok && (cb < Lf - E4);                                 // (the largest prediction of all: below L, two_layer.rs:45-48)
       }                                                                 // (NaN and infinities: undecided as well)
     }
     unsigned long long um = __ballot(!ok);
@@ -725,7 +732,12 @@ __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ key
     }
     if (vflags) atomicOr(&st->err_flags, vflags);
   }
-  if (tile_slow[tile] != 0) return;                                    // (wave-uniform)
+  if (tile_slow[tile] != 0) {                                          // (wave-uniform)
+    // a listed group's aggregate record is written by k_leaf_lanes_listed; where that runs only behind the host's first synchronisation
+    // the first k_lane_reduce reads the record before: a neutral one, so that what it publishes meanwhile is well defined
+    if (listed_behind && (threadIdx.x & 63) == 0) partials[tile] = StatsPartial{0ull, 0ull, 0ull, 0.0, 0.0};
+    return;
+  }
   unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;
   double st_l2 = 0.0, st_lg = 0.0;
   if (j < sp.leaf_hi) {

@@ -828,7 +828,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
     const unsigned int t_tile_last = sc_lane63(t_lane_last);
     const bool virt_here = edge && rel_hi >= relA && rel_hi - relA < (unsigned int)TILE;   // the position it_hi lies in this tile: its last "start" is the end of the data
     // the last key's leaf (Q7's owner), for the record
-    if (lane == 63 && edge && n_it > 0u && rel_hi > relA && rel_hi - relA <= (unsigned int)TILE) st->last_target = (unsigned long long)t_tile_last;
+    // (only the launch that holds the data's last key, as in k_leaf_search: a shard whose it_hi < n falls exactly on this tile's end has
+    //  rel_hi - relA == TILE too, and t_tile_last is then the target of ITS last key -- a leaf it owns, which would get the extra count)
+    if (lane == 63 && edge && n_it > 0u && sp.it_hi == sp.n && rel_hi > relA && rel_hi - relA <= (unsigned int)TILE) st->last_target = (unsigned long long)t_tile_last;
     if (nb == 0u) continue;                                                      // the tile lies inside one leaf that started earlier
     if (RMI_SC_STOP == 1) continue;
     // duplicates: a valid key that equals the key before it

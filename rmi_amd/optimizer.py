@@ -174,7 +174,8 @@ def measure_rmis(tr: train.Trainer, configs: list[tuple[str, int]], threads: int
         for i, d in zip(batch, res):
             done[i] = d
             if d[0] != 0:
-                errors[i] = getattr(tr, "last_many_error", "")
+                # this configuration's own message (its position inside the batch is its number in the library's message)
+                errors[i] = getattr(tr, "last_many_errors", {}).get(batch.index(i), getattr(tr, "last_many_error", ""))
         pending[:] = [i for i in pending if i not in batch]
 
     with ThreadPoolExecutor(max_workers=max(1, threads)) as root_pool:

@@ -7,6 +7,7 @@ models/mod.rs:233-317.  The arithmetic runs in the HIP kernels behind include/rm
 from __future__ import annotations
 
 import ctypes as C
+import re
 import threading
 import time
 from dataclasses import dataclass, field
@@ -387,7 +388,10 @@ class Trainer:
             self._table_in_ctx = None                             # (the context's table is whatever its last configuration set)
         if rc not in (0,) and all(int(r) == 0 for r in rcs[:n]):
             _check(rc, self._h)                                   # (the call itself failed, not a configuration)
-        self.last_many_error = (self._lib.rmi_hip_last_error(self._h) or b"").decode() if rc else ""   # every failing worker's first message
+        self.last_many_error = (self._lib.rmi_hip_last_error(self._h) or b"").decode() if rc else ""   # every failing configuration's message
+        # ... and by configuration ("configuration <i>: <message>", joined by "; ")
+        self.last_many_errors = {int(m.group(1)): m.group(2).strip() for m in
+                                 re.finditer(r"configuration (\d+): (.*?)(?=; configuration \d+: |$)", self.last_many_error, re.S)}
         out = []
         for i, (root, _leaf, L) in enumerate(configs):
             if int(rcs[i]) != 0:

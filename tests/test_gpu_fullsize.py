@@ -99,6 +99,109 @@ def test_config3_cubic_root_full_size_vs_oracle(oracle):
     assert g1.fit_mode_used == 1
 
 
+@pytest.mark.parametrize("gen", ["uniform", "dups"])
+def test_config5_full_size_vs_oracle(oracle, gen):
+    """BASELINE config 5's workload at its stated size on one GPU: 400M uint32 keys (uniform and duplicate-heavy), radix root,
+    2^22 linear_spline leaves -- k_spline_scan (pipeline 5) against the oracle, every array bit for bit."""
+    from rmi_amd import train
+    n, L = 400_000_000, 1 << 22
+    tr = train.Trainer()
+    tr.generate_keys(gen, np.uint32, n)
+    keys = tr.download_keys()
+    root = tr.fit_root("radix", L)
+    g = tr.train_leaves(root, "linear_spline", L).materialize()
+    assert g.pipeline == 5
+    tr.close()
+    o = oracle.train_two_layer("radix", "linear_spline", keys, L, threads=2)
+    assert root.p == o.root.p and tuple(root.ip) == tuple(o.root.ip)
+    assert np.array_equal(g.leaf_starts, o.leaf_start), "bucket assignment differs at full size"
+    assert np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64)), "leaf coefficients differ at full size"
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err), f"{np.count_nonzero(g.last_layer_max_l1s != o.leaf_err)} max-error integers differ"
+    assert np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx and g.model_avg_error == o.model_avg_error
+    rows = g.rows.view(np.uint64).reshape(L, 3)
+    assert np.array_equal(rows[:, :2], o.leaf_params.view(np.uint64)) and np.array_equal(rows[:, 2], o.leaf_err)
+
+
+def test_config4_workload_one_gpu_vs_oracle(oracle):
+    """BASELINE config 4's workload (800M uniform uint64, linear,linear, 2^21 leaves: 381 keys a leaf) at its stated size on ONE GPU
+    against the oracle, bit for bit.  (As configured -- 8 devices, RCCL -- it needs a node; the shards' kernels are these.)"""
+    from rmi_amd import train
+    n, L = 800_000_000, 1 << 21
+    tr = train.Trainer()
+    tr.generate_keys("uniform", np.uint64, n)
+    keys = tr.download_keys()
+    root = tr.fit_root("linear", L)
+    g = tr.train_leaves(root, "linear", L).materialize()
+    pl = g.pipeline
+    tr.close()
+    o = oracle.train_two_layer("linear", "linear", keys, L, threads=2)
+    assert root.p == o.root.p
+    assert np.array_equal(g.leaf_starts, o.leaf_start)
+    assert np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64)), f"coefficients differ (pipeline {pl})"
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err), f"{np.count_nonzero(g.last_layer_max_l1s != o.leaf_err)} max-error integers differ (pipeline {pl})"
+    assert np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx and g.model_avg_error == o.model_avg_error
+
+
+def test_pipeline5_at_its_index_limit(oracle):
+    """k_spline_scan keeps indices in 32 bits and takes key sets below 2^32 - 2^16 keys: the largest one it takes (17 GB of uint32 keys,
+    duplicate runs of 2 and 8) through the size-independent properties, and -- on sampled leaves, the last ones among them, whose
+    offsets lie just below 2^32 -- against the oracle's line through the container's end points and the reference's soundness property,
+    with the keys regenerated on the host from their closed form."""
+    from rmi_amd import train, datagen as dg
+    n, L = (1 << 32) - (1 << 16) - 1, 1 << 22
+    tr = train.Trainer()
+    tr.generate_keys("dups", np.uint32, n)
+    root = tr.fit_root("radix", L)
+    g = tr.train_leaves(root, "linear_spline", L)
+    assert g.pipeline == 5
+    starts = g.leaf_starts.astype(np.int64)
+    assert starts[0] == 0 and starts[-1] == n and (np.diff(starts) >= 0).all()
+    counts = g.leaf_counts.astype(np.int64)
+    assert int(counts.sum()) == n + 1
+    sizes = np.diff(starts)
+    last_leaf = int(np.nonzero(sizes > 0)[0][-1])
+    expect = sizes.copy(); expect[last_leaf] += 1
+    assert np.array_equal(counts, expect)
+    params, errs = g.leaf_params, g.last_layer_max_l1s
+    assert errs.max() == g.model_max_error
+    rows = g.rows.view(np.uint64).reshape(L, 3)
+    assert np.array_equal(rows[:, 2], errs) and np.array_equal(rows[:, :2], params.view(np.uint64))
+
+    stride = ((1 << 32) - 3) // n
+
+    def window(a, b):
+        """keys[a:b] of dups_u32(n) and their FixDups offsets (first occurrence: a duplicate run lies inside its aligned group of 8)"""
+        i = np.arange(a, b, dtype=np.uint64)
+        choice = (dg._h(i >> np.uint64(3), 47) % np.uint64(5)).astype(np.int64)
+        r = np.array([1, 1, 1, 2, 8], dtype=np.uint64)[choice]
+        src = i - (i % r)
+        k = np.uint64(1) + src * np.uint64(stride) + (dg._h(src, 46) % np.uint64(stride))
+        return k.astype(np.uint32), src
+    rng = np.random.default_rng(2)
+    picked = 0
+    nonempty = np.nonzero(sizes > 0)[0]
+    tail = [int(v) for v in nonempty[-6:-1]]
+    for j in [1, 2, L // 4, L // 2 - 5, L // 2 + 5] + tail + [int(v) for v in rng.integers(3, last_leaf - 3, size=40)]:
+        s, e = int(starts[j]), int(starts[j + 1])
+        if abs(j - int(g.split_target)) <= 2 or e <= s or s == 0 or e >= n or sizes[j - 1] == 0 or sizes[j + 1] == 0:
+            continue                                                        # (Q2/Q3 neighbourhoods and empty neighbours: covered at small sizes)
+        a = (s - 1) & ~7
+        kw, yw = window(a, min(n, ((e + 1 + 7) & ~7)))
+        keys, ys = kw[s - 1 - a:e + 1 - a], yw[s - 1 - a:e + 1 - a]       # prev-last, own keys, next-first
+        m = oracle.fit_pairs("linear_spline", keys, ys)
+        assert (m.p[0], m.p[1]) == (float(params[j, 0]), float(params[j, 1])), (j, s, e)
+        x = keys[1:-1].astype(np.float64)
+        pred = np.floor(np.clip([float(np.float64(params[j, 1]) * xi + params[j, 0]) for xi in x], 0, n - 1))
+        assert np.all(np.abs(pred - ys[1:-1].astype(np.float64)) <= float(errs[j]) + 1), j   # (+1: fma vs mul+add in this check)
+        picked += 1
+    assert picked >= 25
+    g2 = tr.train_leaves(root, "linear_spline", L)
+    assert np.array_equal(g2.rows.view(np.uint64).reshape(L, 3), rows)
+    tr.close()
+
+
 @pytest.mark.parametrize("n,dtype,spec,L,gen", [
     (800_000_000, np.uint64, "linear,linear", 1 << 21, "uniform"),          # config 4's size on one GPU
     (400_000_000, np.uint32, "radix,linear_spline", 1 << 22, "dups"),       # config 5's shape (u32, duplicate runs)

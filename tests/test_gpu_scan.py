@@ -147,6 +147,40 @@ def test_scan_shards_of_a_streamed_training(oracle, gen, root, n, L, chunks):
     tr.close()
 
 
+@pytest.mark.parametrize("gen,leaf", [("uniform_u64", "linear_spline"), ("uniform_u32", "linear_spline"), ("dups_u32", "linear_spline"), ("uniform_u64", "linear")])
+def test_shard_cut_on_a_tile_end(oracle, gen, leaf):
+    """A shard whose last key is the last position of a tile of k_spline_scan (1 024 8-byte / 2 048 4-byte keys from the line the shard's
+    first key lies in): the tile's last target is then the target of a key the shard OWNS, and only the launch that holds the data's last
+    key may record it as the owner of the extra count (Q7, two_layer.rs:226-232) -- ADVICE round 5.  The cut is put there by dropping keys
+    from the first shard under a caller-provided root (the targets of the other keys do not move)."""
+    from rmi_amd import train, sharded
+    keys0 = dg.GENERATORS[gen](300_000)
+    L = 2048
+    tile = 1024 if keys0.dtype.itemsize == 8 else 2048
+    tr = train.Trainer(keys0)
+    root = tr.fit_root("linear", L)
+    tr.close()
+    cut = sharded.Planner(lambda i: keys0[i], len(keys0), keys0.dtype, root, L).plan(2)[0].key_hi
+    drop = cut % tile
+    keys = np.ascontiguousarray(np.concatenate([keys0[:100], keys0[100 + drop:]]))
+    plans = sharded.Planner(lambda i: keys[i], len(keys), keys.dtype, root, L).plan(2)
+    assert plans[0].key_hi % tile == 0 and plans[0].read_lo == 0 and plans[0].key_hi < len(keys)
+    o = oracle.train_two_layer("linear", leaf, keys, L, root=oracle.Model(root.kind, root.p, root.ip))
+    starts, params, errs, counts = [], [], [], []
+    for pl in plans:
+        t = train.Trainer(np.ascontiguousarray(keys[pl.read_lo:pl.read_hi]))
+        res = sharded.run_shard(t, pl, root, leaf)
+        starts.append(res.leaf_starts[:-1].copy()); params.append(res.leaf_params.copy())
+        errs.append(res.last_layer_max_l1s.copy()); counts.append(res.leaf_counts.copy())
+        if leaf == "linear_spline":
+            assert res.pipeline == 5
+        t.close()
+    assert np.array_equal(np.concatenate(starts), o.leaf_start[:-1])
+    assert np.array_equal(np.concatenate(counts), o.leaf_count), "a shard that does not hold the last key claimed the extra count"
+    assert np.array_equal(np.concatenate(params).view(np.uint64), o.leaf_params.view(np.uint64))
+    assert np.array_equal(np.concatenate(errs), o.leaf_err)
+
+
 def test_scan_equals_the_leaf_lane_kernel(monkeypatch):
     """k_spline_scan against k_leaf_lanes<.., K_LINEAR_SPLINE> (RMI_HIP_SCAN=0) on 20 M keys: every output array the same bytes."""
     from rmi_amd import train
