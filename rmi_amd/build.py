@@ -15,7 +15,7 @@ SO = os.path.join(HERE, "librmi_hip.so")
 COMMON = ["rmi_kernels.hip.h", "rmi_stream.hip.h", "rmi_sigma.hip.h", "rmi_lanes.hip.h", "rmi_device.hip.h", "rmi_scan_launch.h"]
 # source -> the headers it includes (besides COMMON)
 UNITS = {
-    "rmi_hip.hip": ["rmi_regs.hip.h", "rmi_regs_block.inc.h", "rmi_multi.inc.h", "rmi_root_host.h", "../../include/rmi_hip.h"],
+    "rmi_hip.hip": ["rmi_regs.hip.h", "rmi_regs_block.inc.h", "rmi_regs_replay.inc.h", "rmi_multi.inc.h", "rmi_root_host.h", "../../include/rmi_hip.h"],
     "rmi_scan.hip": ["rmi_scan.hip.h"],
 }
 SOURCES = list(UNITS)

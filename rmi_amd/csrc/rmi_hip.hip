@@ -93,9 +93,9 @@ struct rmi_hip_ctx {
   // pipeline 4 (rmi_regs.hip.h): k_leaf_regs -- one read of the keys, a leaf's keys stay in registers between its fit and its error pass --
   // in place of k_leaf_lanes where the leaves are short enough on average; the groups it does not take go through k_leaf_lanes_listed
   bool regs = true;                             // RMI_HIP_REGS=0: k_leaf_lanes for everything
-  bool regs_nt = true;                          // non-temporal LDS-DMA loads (the keys are read once)
   unsigned int regs_grid = 0;                   // persistent waves of k_leaf_regs (0: 4 per CU)
   unsigned int regs_max_avg = 208;              // average keys per leaf above which most groups would not fit (RG_MAXPTS = 240 per container)
+  unsigned int regs_long_max_avg = 640;         // ... and up to which k_leaf_regs<K, LONG> takes them (the steps behind the stash through the ring twice); above: k_leaf_lanes
   unsigned int regs_slow = 0;                   // debugging: every group on the list
   bool regs_backoff = true;                     // RMI_HIP_REGS_BACKOFF=0: k_leaf_regs also for key sets on which it listed most groups last time
   uint64_t regs_off_epoch = 0; uint64_t regs_off_L[8] = {}; int regs_off_n = 0;   // ... the (key set, leaves) pairs remembered
@@ -348,7 +348,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* ln = std::getenv("RMI_HIP_LEAN"); if (ln && *ln) c->lean = std::atoi(ln) != 0; }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN_SCALE"); if (cm && *cm) c->cubic_margin_scale = std::atof(cm); }
   { const char* sc = std::getenv("RMI_HIP_SCAN_WAVES"); if (sc && *sc) c->scan_waves = (unsigned int)std::atoi(sc); }
-  { const char* rg = std::getenv("RMI_HIP_REGS_NT"); if (rg && *rg) c->regs_nt = std::atoi(rg) != 0; }
+  { const char* rg = std::getenv("RMI_HIP_REGS_LONG_MAX_AVG"); if (rg && *rg) c->regs_long_max_avg = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_GRID"); if (rg && *rg) c->regs_grid = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_MAX_AVG"); if (rg && *rg) c->regs_max_avg = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_QUEUE"); if (rg && *rg) c->regs_queue = std::atoi(rg) != 0; }
@@ -416,7 +416,7 @@ void rmi_hip_destroy(rmi_hip_ctx* c) {
   if (c->d_regprof) {
     unsigned long long h[16] = {};
     if (hipMemcpy(h, c->d_regprof, 128, hipMemcpyDeviceToHost) == hipSuccess)
-      std::fprintf(stderr, "k_leaf_regs cycles (sum over waves and trainings): fit %llu, epilogue+tail %llu, hand-over %llu, error pass %llu, finalize %llu; (unused %llu) hand-over requests %llu, (unused %llu), finalize stores %llu, finalize up to the shuffles' end %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+      std::fprintf(stderr, "k_leaf_regs cycles (sum over waves and trainings): fit %llu, epilogue+tail %llu, hand-over %llu, error pass %llu, finalize %llu; (unused %llu) hand-over requests %llu, (unused %llu), finalize stores %llu, finalize up to the shuffles' end %llu; RG_PROF 2, inside the fit: panel requests %llu, stash %llu, arithmetic %llu, constants + landed %llu, wait for the panel %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[5], h[7], h[8], h[9], h[11]);
     (void)hipFree(c->d_regprof);
   }
   if (c->d_slow_list) (void)hipFree(c->d_slow_list);
@@ -1373,12 +1373,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       }
       // pipeline 4's conditions besides the root's: 8-byte keys, linear leaves, leaves short enough on average that most groups of 64 qualify,
       // not a key set on which k_leaf_regs listed most groups last time
-      bool regs_plan = false;
+      bool regs_plan = false, regs_long = false;
       if constexpr (LEAF == K_LINEAR && sizeof(K) == 8) {
         bool regs_off = false;
         if (c->regs_off_epoch == c->keys_epoch)
           for (int h = 0; h < c->regs_off_n && h < 8; h++) regs_off = regs_off || c->regs_off_L[h] == L_own;
-        regs_plan = lanes_fused_plan && c->regs && !regs_off && c->pipeline >= 3 && n_it <= (uint64_t)c->regs_max_avg * L_own;
+        regs_long = n_it > (uint64_t)c->regs_max_avg * L_own;            // long leaves on average: the LONG variant of the kernel
+        const unsigned int cap = c->regs_long_max_avg > c->regs_max_avg ? c->regs_long_max_avg : c->regs_max_avg;
+        regs_plan = lanes_fused_plan && c->regs && !regs_off && c->pipeline >= 3 && n_it <= (uint64_t)cap * L_own;
       }
       // a cubic root on pipeline 4: increasing over the resident keys' range as an exact polynomial (here), every leaf's end keys clear
       // their leaf's interval by the rounding bound (k_regs_finalize<K, K_CUBIC>) -- else the per-key verification of k_leaf_lanes
@@ -1422,11 +1424,11 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           HIPCHK(c, hipGetLastError());
           unsigned int grid = c->regs_grid ? c->regs_grid : 4u * (unsigned int)c->n_cu;
           if ((uint64_t)grid > wb) grid = (unsigned int)wb;
-          if (c->regs_nt)
-            hipLaunchKernelGGL((k_leaf_regs<K, true>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
+          if (regs_long)
+            hipLaunchKernelGGL((k_leaf_regs<K, 1>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
                                L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
           else
-            hipLaunchKernelGGL((k_leaf_regs<K, false>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
+            hipLaunchKernelGGL((k_leaf_regs<K, 0>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
                                L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
           mark();                                                       // (slot 0: k_leaf_regs alone; slot 1: the listed groups + k_regs_finalize)
           // The groups k_leaf_regs listed.  As a rule there are none: with the result published early (k_lane_reduce) and the host

@@ -68,6 +68,15 @@ __device__ __forceinline__ void rg_static_for(F&& f) {
 #ifndef RG_UBLK
 #define RG_UBLK 9                // blocks of the walk whose code is written out per block (STATIC in k_leaf_regs); 0: none
 #endif
+#ifndef RG_LONG_F32
+#define RG_LONG_F32 0            // 1: the LONG variant stashes (float)(x - x0) for integer keys -- 384 steps in registers, the error pass over them certified per
+                                 // leaf, flagged leaves redone by k_regs_finalize.  Measured SLOWER (C4's shard shape: kernel 278 against 254 us with the doubles and
+                                 // the second trip through the ring): the kernel is bound by its instructions, not by its reads, and the float path costs a conversion
+                                 // and three operations of the certificate per step more.  Kept as a build switch (tests: tools/build_var.sh).
+#endif
+#ifndef RG_WALK_PIPE
+#define RG_WALK_PIPE 1           // LONG: the walk through the ring asks for the next half block's keys before this half's steps run
+#endif
 #ifndef RG_DIAG
 #define RG_DIAG 0                // & 1 the constants of the first half block for all, & 2 no duplicate test, & 8 no lane ever tests, & 16 only bank 0 stashed, & 64 all panels from one place (cache hits: results wrong)
 #endif
@@ -158,10 +167,18 @@ template <typename K> __device__ __forceinline__ double rg_as_float(uint2 v) {
   else return __builtin_fma((double)v.y, 4294967296.0, (double)v.x);
 }
 
+__device__ __forceinline__ double rg_fract(double v) { return __builtin_amdgcn_fract(v); }   // v_fract_f64: v - floor(v), in [0, 1)
+
 // ---------------------------------------------------------------------------------------------
 // k_leaf_regs
 // ---------------------------------------------------------------------------------------------
-template <typename K, bool NT>
+// LONG: the variant for groups of LONG leaves (averages above 208 keys a leaf: C4's shard shape, 381).  The walk goes on through the
+// ring behind the stash -- up to RG_FARPTS points per container, the ring refilled all the way -- and the error steps behind the stash
+// come through the ring ONCE MORE after the fit (panels 12 ...: 2 - 192 / n reads of a key instead of k_leaf_lanes' 2; at 381 keys a
+// leaf 1.5).  Why not everything on chip: 65 536 chains must be in flight to fill the device's 1 024 SIMDs with lockstep waves, and
+// their keys between fit and error pass are 65 536 x n x 8 B -- 200 MB at n = 381, more than every register and LDS byte of the chip
+// (172 MB); above ~330 keys a leaf NO exact one-read design exists at full lane efficiency.
+template <typename K, int LONG>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_leaf_regs(const K* __restrict__ keys, Span sp,
                                                    const unsigned long long* __restrict__ leaf_start,
                                                    DevState* __restrict__ st, double* __restrict__ params,
@@ -177,8 +194,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                                                    K* __restrict__ bnext, K* __restrict__ bprev, unsigned char* __restrict__ tile_slow,
                                                    unsigned int* __restrict__ tile_queue) {
   static_assert(sizeof(K) == 8, "8-byte keys");
-  using B = unsigned long long;
+  constexpr bool NT = true;                                          // non-temporal LDS-DMA loads (plain ones measured equal: the switch is gone)
+  constexpr unsigned int WALK = LONG ? (unsigned int)RG_FARPTS : (unsigned int)RG_MAXPTS;   // steps of a container that come through the ring
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
+  // LONG, integer keys: the stash holds (float)(x - x0), x0 = the double of the container's first key -- ONE register a step, 384 steps.
+  // The error pass over the stash then works on x~ with |x~ - x| <= 2^-23.9 (x - x0) and is CERTIFIED per leaf (rg_stash_err below): a
+  // leaf one of whose predictions lies within the bound of an integer is flagged and its error pass redone from the key array by
+  // k_regs_finalize (about 2 % of the leaves at 381 keys a leaf); every other leaf's maximum is the exact one.
+  constexpr bool F32 = LONG && !DIVK && (RG_LONG_F32 != 0);
+  using XT = typename std::conditional<F32, float, double>::type;
+  constexpr int STASH = F32 ? 2 * RG_STASH : RG_STASH;                // steps whose keys stay in registers
+  constexpr int SBLK = STASH / RG_ROW;
+  static_assert(SBLK % 4 == 0, "groups of four banks");
   __shared__ __attribute__((aligned(1024))) unsigned char ringc[RG_RING * RG_PANEL_B];   // 32 KB: 4 waves per CU
   __shared__ unsigned int park[10][64];                              // k_hi, k_lom1, k_next, k_prev (two words each), next group's s, e
   static_assert(RG_RING * RG_PANEL_B >= 64 * LnGeom<K>::STRIDE * 8, "the ring holds the LDS image of k_leaf_lanes");
@@ -265,9 +292,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     t.a0 = rel & (unsigned int)(RG_ROW - 1);
     // the walk through the ring covers RG_MAXPTS = 240 steps (panels 0 .. 15: the ring then still holds the panels behind the
     // stash); the few lanes with more points go on from there by themselves (far_fit below)
-    const unsigned int wl = t.npts < (unsigned int)RG_MAXPTS ? t.npts : (unsigned int)RG_MAXPTS;
+    const unsigned int wl = t.npts < WALK ? t.npts : WALK;
     t.maxfar = rg_wave_max(t.npts);
-    t.maxlen = t.maxfar < (unsigned int)RG_MAXPTS ? t.maxfar : (unsigned int)RG_MAXPTS;
+    t.maxlen = t.maxfar < WALK ? t.maxfar : WALK;
     t.lastp = rg_wave_max(t.act ? (t.a0 + wl - 1u) >> 4 : 0u);
     t.ulong = __all(!t.act || t.npts > (unsigned int)(RG_UBLK * RG_ROW));
     if (t.fast) {
@@ -379,6 +406,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const unsigned int d1 = sg_absdiff(min(c1, n32), cur.lo + k1), d2 = sg_absdiff(min(c2, n32), cur.lo + k2);
       emax = max(emax, max(d1, d2));
     };
+    // F32 stash: the same steps on x~ = x0 + d (d the stashed float of x - x0), as fma(beta, d, A) with A = fma(beta, x0, alpha), and
+    // the certificate beside them: the largest distance of a prediction's fraction from 1/2 (three more operations a step)
+    double sA = 0.0, tmax = 0.0;
+    auto err_pair_f = [&](float d1, unsigned int k1, float d2, unsigned int k2) {
+      // (opaque: the stash does not change inside the loop over its banks, and the compiler would compute all 384 predictions and
+      //  fractions in front of it -- one block of 2 500 instructions with its results in scratch memory)
+      asm volatile("" : "+v"(d1), "+v"(d2));
+      const double f1 = __builtin_fma(pb, (double)d1, sA), f2 = __builtin_fma(pb, (double)d2, sA);
+      const unsigned int c1 = sg_cvt_u32(f1), c2 = sg_cvt_u32(f2);
+      const unsigned int e1 = sg_absdiff(min(c1, n32), cur.lo + k1), e2 = sg_absdiff(min(c2, n32), cur.lo + k2);
+      emax = max(emax, max(e1, e2));
+      const double g1 = __builtin_fabs(rg_fract(f1) - 0.5), g2 = __builtin_fabs(rg_fract(f2) - 0.5);
+      tmax = __builtin_fmax(tmax, __builtin_fmax(g1, g2));
+      // (pair by pair: left alone, the chain of maxima is rebalanced into a tree over the whole bank, every pair's result parked in scratch)
+      asm volatile("" : "+v"(tmax));
+    };
+    auto err_step_f = [&](float d, unsigned int k) {
+      asm volatile("" : "+v"(d));
+      const double f = __builtin_fma(pb, (double)d, sA);
+      emax = max(emax, sg_absdiff(min(sg_cvt_u32(f), n32), cur.lo + k));
+      tmax = __builtin_fmax(tmax, __builtin_fabs(rg_fract(f) - 0.5));
+      asm volatile("" : "+v"(tmax));
+    };
     // ---- hand-over: the ring is free -- the next group's descriptor and its first panels, under the rest of this group's work
     Tile nxt = cur;
     auto hand_over = [&]() {
@@ -393,7 +443,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     };
     bool done = false;
     if (fast) {
-      double xs[RG_STASH];                                             // the stash: the doubles of this lane's first 192 points
+      XT xs[STASH];                                                    // the stash: the doubles of this lane's first 192 points (F32: 384 floats, x - x0)
+      double x0 = 0.0;                                                 // (F32) the double of the container's first key
       // =========================== the fit ===========================
       // Rolled over the blocks of 16 steps (the code of a block is ~3 KB; unrolled over the whole walk it would be 60 KB, and two
       // CUs share 64 KB of instruction cache): a block leaves its 16 doubles in T[], and a switch on the block index copies
@@ -449,7 +500,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         constexpr bool STATIC = false;
 #include "rmi_regs_block.inc.h"
       }
-      if (cur.maxfar > (unsigned int)RG_MAXPTS) {
+      if (!LONG && cur.maxfar > (unsigned int)RG_MAXPTS) {
         // ---- the lanes with more than 240 points (3 in 10 000 leaves of the metric configuration) go on from the key array: the same
         //      steps, 8 keys a trip, every step tested; the other lanes' sums were put aside where their walks ended
         for (unsigned int k0 = (unsigned int)RG_MAXPTS; k0 < cur.maxfar; k0 += 8u) {
@@ -478,13 +529,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         }
         if (npts > (unsigned int)RG_MAXPTS) { fmx = mx; fcc = cc; fm2 = m2; fdmin = dmin; }
       }
+      // LONG: the fit's panels have all landed (its last wait was vmcnt(0)) and been read: the ring is free, and the panels of the
+      // error steps behind the stash are requested once more -- under the arithmetic that ends the fit
+      // (a walk of at most 3 panels behind the stash: they are the ring's last panels, still there -- nothing is read again)
+      const unsigned int err_lastb = cur.maxlen > 0u ? (cur.maxlen - 1u) >> 4 : 0u;     // last block of the walk
+      const bool reread = LONG && cur.lastp > (unsigned int)(SBLK + RG_RING - 1);
+      if (LONG && !(RG_KO & 4) && reread) {
+#pragma unroll
+        for (unsigned int p = (unsigned int)SBLK; p < (unsigned int)(SBLK + RG_RING); p++)
+          if (p <= cur.lastp) issue_panel(cur.kb, p, cur.off, cur.lim);
+      }
       mark(0);
       if (!(RG_KO & 4)) { k_hi = parked_key(0); k_lom1 = parked_key(2); k_next = parked_key(4); k_prev = parked_key(6); }
       if (!cur.valid || !((uint64_t)cur.e < sp.n)) k_next = KeyTraits<K>::max_value();
       if (!cur.valid || !(cur.s > 0u)) k_prev = KeyTraits<K>::zero_value();
       // a duplicate key somewhere in the group, or in front of a container's first point (compared as doubles: a superset
       // of key equality): the closed form of the y half does not hold -- the whole group goes through the general walk
-      const bool dup0 = cur.act && (uint64_t)cur.lo > sp.rd_lo && KeyTraits<K>::as_float(k_lom1) == xs[0];
+      const bool dup0 = cur.act && (uint64_t)cur.lo > sp.rd_lo && KeyTraits<K>::as_float(k_lom1) == (F32 ? x0 : (double)xs[0]);
       if (!__any(dup0 || (cur.act && fdmin == 0u))) {
         // ---- the container's last item once more (Q1, models/mod.rs:180), then linear.rs:36-58
         if (cur.act) {
@@ -504,7 +565,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           if (var == 0.0) { pa = my; pb = 0.0; }                           // linear.rs:50-53
           else { pb = cov / var; pa = my - pb * mx; }                      // no fma: linear.rs:56
         } else if (cur.ck == 1) { pa = (double)cur.lo; pb = 0.0; }         // Q4: one borrowed point (two identical items)
-      if (!(RG_KO & 2) && cur.maxfar > (unsigned int)RG_MAXPTS) {
+      if (!LONG && !(RG_KO & 2) && cur.maxfar > (unsigned int)RG_MAXPTS) {
         // (the steps of the long containers behind the ring's reach: from the key array once more, 16 keys a lane and trip)
         for (unsigned int k0 = (unsigned int)RG_MAXPTS; __any(k0 < eend); k0 += 16u) {
           K kk[16];
@@ -520,7 +581,76 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           }
         }
       }
-      if (!(RG_KO & 2)) {
+      // ---- LONG: the error steps behind the stash, through the ring once more (or, for a walk of at most 3 panels behind the stash, from
+      //      the ring as the fit left it).  Half blocks of 8 steps, the next half's keys requested from LDS before this half's steps run
+      //      (a lone wave has nobody to fill an LDS round trip); half (b, 1)'s reads landed, panel b + 4 takes the slot of panel b;
+      //      panel b + 2 has landed once at most the panels requested behind it are outstanding -- the waits of the fit.
+      auto ring_walk = [&]() {
+        if (!(LONG && !(RG_KO & 2) && cur.maxlen > (unsigned int)STASH)) return;
+        const unsigned int hlast = (cur.maxlen - 1u) >> 3;               // last half block of the walk
+        uint2 rkA[8], rkB[8];
+        auto read_half = [&](unsigned int h, uint2 (&rk)[8]) {
+          unsigned int in_b, dlt;
+          block_base(h >> 1, in_b, dlt);
+          if (h & 1u) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) rk[q] = slot_key(in_b, dlt, 8 + q);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) rk[q] = slot_key(in_b, dlt, q);
+          }
+        };
+        auto steps = [&](unsigned int h, const uint2 (&rk)[8]) {
+          const unsigned int k0 = h * 8u;
+          if (__all(eend >= k0 + 8u || eend <= k0)) {                      // no leaf ends inside the half: one test for its steps
+            if (eend > k0) {
+#pragma unroll
+              for (int q = 0; q < 8; q += 2) err_pair(rg_as_float<K>(rk[q]), k0 + (unsigned int)q, rg_as_float<K>(rk[q + 1]), k0 + (unsigned int)(q + 1));
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) { if (k0 + (unsigned int)q < eend) err_step(rg_as_float<K>(rk[q]), k0 + (unsigned int)q); }
+          }
+        };
+        auto landed = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };   // lgkmcnt(0)
+        auto wait_panel = [&](unsigned int b) {                            // panel b + 2 (for block b + 1)
+          if (RG_KO & 4) return;
+          if (cur.lastp >= b + 4u) rg_wait_vm<16>();
+          else if (cur.lastp == b + 3u) rg_wait_vm<8>();
+          else rg_wait_vm<0>();
+        };
+        if (reread) wait_panel((unsigned int)SBLK - 1u);
+        if (!RG_WALK_PIPE) {                                               // (the plain form: a half block's reads, the wait, its steps)
+#pragma nounroll
+          for (unsigned int h = 2u * (unsigned int)SBLK; h <= hlast; h++) {
+            const unsigned int b = h >> 1;
+            read_half(h, rkA);
+            landed();
+            if ((h & 1u) && reread && !(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING, cur.off, cur.lim);
+            steps(h, rkA);
+            if ((h & 1u) && h < hlast && reread) wait_panel(b);
+          }
+          return;
+        }
+        read_half(2u * (unsigned int)SBLK, rkA);
+#pragma nounroll
+        for (unsigned int h = 2u * (unsigned int)SBLK; h <= hlast; h += 2u) {
+          const unsigned int b = h >> 1;
+          landed();
+          if (h + 1u <= hlast) read_half(h + 1u, rkB);                     // (the same two panels)
+          steps(h, rkA);
+          if (h + 1u <= hlast) {
+            landed();                                                      // (every key of block b is in registers: panel b's slot is free)
+            if (reread && !(RG_KO & 4) && b + (unsigned int)RG_RING <= cur.lastp) issue_panel(cur.kb, b + (unsigned int)RG_RING, cur.off, cur.lim);
+            if (h + 2u <= hlast) {
+              if (reread) wait_panel(b);
+              read_half(h + 2u, rkA);
+            }
+            steps(h + 1u, rkB);
+          }
+        }
+      };
+      if (!LONG && !(RG_KO & 2)) {
         // the steps behind the stash: still in the ring (masked the plain way: a few blocks)
 #pragma nounroll
         for (unsigned int b = (unsigned int)RG_SBLK; b * (unsigned int)RG_ROW < cur.maxlen; b++) {
@@ -554,78 +684,49 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
       mark(1);
       asm volatile("" : "+v"(k_next), "+v"(k_prev));                   // (read from their parking rows before the next group's keys are sent there)
-      // Every load of the compiler's own is waited for HERE, by the builtin its score keeping understands: behind the hand-over the
-      // next group's panels are in flight, which it does not count -- a wait it places there for a load of the far lanes' (a
-      // register about to be overwritten) comes out as vmcnt(0) and stands until the panels have landed, at the head of the
-      // error pass that was to run under them.
-      // (stores count as well: the coefficients are stored behind this wait, not in front of it)
+      const unsigned int sl = cur.maxlen < (unsigned int)STASH ? cur.maxlen : (unsigned int)STASH;
+      // Every load of the compiler's own is waited for in front of the hand-over, by the builtin its score keeping understands: behind the
+      // hand-over the next group's panels are in flight, which it does not count -- a wait it places there for a load of the far lanes' (a
+      // register about to be overwritten) comes out as vmcnt(0) and stands until the panels have landed, at the head of the error pass that
+      // was to run under them.  (stores count as well: the coefficients are stored behind this wait, not in front of it)
+      auto step0 = [&]() {
+        if ((int)es <= 0 && eend > 0u) err_step(F32 ? x0 : (double)xs[0], 0u);   // (step 0 belongs to the leaf only where the container starts with it or behind it)
+        if (es == 0xFFFFFFFFu && cur.act) err_step(KeyTraits<K>::as_float(k_lom1), 0xFFFFFFFFu);
+      };
+      // (LONG, tried: the replay in two phases -- four banks while the error panels requested behind the fit are on their way, then the walk and
+      //  the hand-over, then the other banks: the loop around the banks' code makes the compiler keep copies of the stash values it reads, 0.298
+      //  against 0.279 ms for C4's shard shape)
+      if constexpr (LONG != 0) ring_walk();
+      if constexpr (F32) sA = __builtin_fma(pb, x0, pa);
       __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
       if (cur.valid) { params[2 * j] = pa; params[2 * j + 1] = pb; }
       hand_over();
       mark(2);
       if (!(RG_KO & 2)) {
-        if ((int)es <= 0 && eend > 0u) err_step(xs[0], 0u);              // (step 0 belongs to the leaf only where the container starts with it or behind it)
-        if (es == 0xFFFFFFFFu && cur.act) err_step(KeyTraits<K>::as_float(k_lom1), 0xFFFFFFFFu);
-        const unsigned int sl = cur.maxlen < (unsigned int)RG_STASH ? cur.maxlen : (unsigned int)RG_STASH;
-        // (tried: bank by bank statically, the banks with a leaf's end noted for a second loop: no search for the bank's code, but the
-        //  register allocator moves parts of the stash around between the banks' codes -- error pass 13 % slower)
-#pragma nounroll
-        for (unsigned int b = 0; b * (unsigned int)RG_ROW < sl; b++) {
-          const unsigned int kb0 = b * (unsigned int)RG_ROW;
-          // a block in which no leaf ends, and not the one with step 0: straight from the bank's registers under ONE test (one
-          // copy of the 16 steps per bank: 5.5 instructions a step); else through T[] with a test per step
-          if (b != 0u && __all(eend >= kb0 + 16u || eend <= kb0)) {
-            if (eend > kb0) {
-              auto group = [&](auto g_tag) {
-                constexpr int g = decltype(g_tag)::value;
-                rg_static_for<(g == 0 ? 1 : 4 * g), 4 * g + 4>([&](auto i_tag) {
-                  constexpr int i = decltype(i_tag)::value;
-                  if (b == (unsigned int)i) {
-#pragma unroll
-                    for (int qq = 0; qq < RG_ROW; qq += 2)
-                      err_pair(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
-                    asm volatile("; stash bank %0" ::"n"(i));
-                  }
-                });
-              };
-              if (b < 4u) group(std::integral_constant<int, 0>{});
-              if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
-              if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
-            }
-            continue;
-          }
-          double T[RG_ROW];
-          {
-            auto group = [&](auto g_tag) {
-              constexpr int g = decltype(g_tag)::value;
-              rg_static_for<4 * g, 4 * g + 4>([&](auto i_tag) {
-                constexpr int i = decltype(i_tag)::value;
-                if (b == (unsigned int)i) {
-#pragma unroll
-                  for (int qq = 0; qq < RG_ROW; qq++) T[qq] = xs[i * RG_ROW + qq];
-                  asm volatile("; stash bank %0" ::"n"(i));
-                }
-              });
-            };
-            if (b < 4u) group(std::integral_constant<int, 0>{});
-            if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
-            if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
-          }
-#pragma unroll
-          for (int qq = 0; qq < RG_ROW; qq++) {
-            const unsigned int k = kb0 + (unsigned int)qq;
-            if (k < eend && k != 0u) err_step(T[qq], k);                    // (step 0: above)
-          }
-        }
+        step0();
+        const unsigned int b_from = 0u, b_to = (sl + (unsigned int)RG_ROW - 1u) >> 4;
+#include "rmi_regs_replay.inc.h"
       }
       mark(3);
       // ---- what k_regs_finalize needs to finish the leaf: the raw maximum and the keys on either side of the leaf (they lie in this
       //      wave's LDS; there they would be two scattered loads per leaf).  The rest of the leaf's end -- widening, row, counts, the
       //      group's aggregate record: ~400 instructions a lane, a logarithm and a division among them -- costs a lone wave 6 us per
       //      group here and a fully occupied launch ~15 us for ALL groups.
+      unsigned long long flagged = 0ull;
+      if constexpr (F32) {
+        // The certificate.  x~ - x0 = d with |d - (x - x0)| <= 2^-23.9 (x - x0) (the subtraction's rounding, then the float's), so
+        // |fma(beta, d, A) - RN(beta x + alpha)| <= E = 2^-23.5 |beta| D + 2^-51 (|A| + |beta| D), D = x_hi - x0 >= x - x0 for every key of
+        // the leaf (the container's last key; the second term: A's rounding and the two results').  sg_cvt_u32 and the clamp are monotone:
+        // if every prediction's fraction lies in [E, 1 - E] -- tmax <= 1/2 - E -- the integers are the reference's.  Anything not finite
+        // fails the comparison and flags the leaf.
+        const double D = KeyTraits<K>::as_float(k_hi) - x0;
+        const double bD = __builtin_fabs(pb) * D;
+        const double E = 0x1p-23 * 0.7072 * bD + 0x1p-51 * (__builtin_fabs(sA) + bD);
+        if (cur.act && eend > 0u && !(tmax <= 0.5 - E)) flagged = 1ull << 63;
+      }
       if (cur.valid) {
         const uint64_t jl = (uint64_t)done_tile * 64 + (uint64_t)lane_j;
-        leaf_maxerr[j] = (unsigned long long)emax;
+        leaf_maxerr[j] = (unsigned long long)emax | flagged;
         bnext[jl] = k_next; bprev[jl] = k_prev;
       }
       if (lane == 0) tile_slow[done_tile] = 0;
@@ -740,13 +841,39 @@ __global__ void __launch_bounds__(256) k_regs_finalize(const K* __restrict__ key
   }
   unsigned long long st_mx = 0, st_mi = 0, st_sum = 0;
   double st_l2 = 0.0, st_lg = 0.0;
+  // A leaf k_leaf_regs<K, LONG> could not certify (bit 63 of its maximum: a prediction from the float stash within the rounding bound of an
+  // integer): its error pass once more, from the key array, on the keys themselves -- the 64 lanes of the wave together, 64 keys a trip
+  // (two_layer.rs:207-217; no duplicate among them: the group would have been listed).
+  unsigned long long me = 0ull;
+  uint64_t fs = 0, fe = 0;
+  double fa = 0.0, fb = 0.0;
+  if (j < sp.leaf_hi) { me = leaf_maxerr[j]; fs = leaf_start[j]; fe = leaf_start[j + 1]; fa = params[2 * j]; fb = params[2 * j + 1]; }
+  {
+    unsigned long long um = __ballot((me >> 63) != 0ull);
+    const unsigned int n32 = (unsigned int)sp.n;
+    const int ln = (int)(threadIdx.x & 63);
+    while (um) {
+      const int src = __builtin_ctzll(um);
+      um &= um - 1ull;
+      const uint64_t us = rg_readlane_u64(fs, src), ue = rg_readlane_u64(fe, src);
+      const double ua = __longlong_as_double((long long)rg_readlane_u64((uint64_t)__double_as_longlong(fa), src));
+      const double ub = __longlong_as_double((long long)rg_readlane_u64((uint64_t)__double_as_longlong(fb), src));
+      unsigned int em = 0u;
+      for (uint64_t i = us + (uint64_t)ln; i < ue; i += 64) {
+        const double f = __builtin_fma(ub, KeyTraits<K>::as_float(keys[i]), ua);      // linear.rs:87-90
+        em = max(em, sg_absdiff(min(sg_cvt_u32(f), n32), (unsigned int)i));            // models/mod.rs:735-737, two_layer.rs:14-18
+      }
+      em = rg_wave_max(em);
+      if (ln == src) me = (unsigned long long)em;
+    }
+  }
   if (j < sp.leaf_hi) {
-    const uint64_t s = leaf_start[j], e = leaf_start[j + 1];
-    double pp[2] = {params[2 * j], params[2 * j + 1]};
+    const uint64_t s = fs, e = fe;
+    double pp[2] = {fa, fb};
     const K k_next = e < sp.n ? bnext[jl] : KeyTraits<K>::max_value();
     const K k_prev = s > 0 ? bprev[jl] : KeyTraits<K>::zero_value();
     uint64_t final_err, cnt_j;
-    finalize_one_pre<K_LINEAR, K>(j, s, e, sp, L, keys, pp, leaf_maxerr[j], 0ull, st->last_target, k_next, k_prev, final_err, cnt_j);
+    finalize_one_pre<K_LINEAR, K>(j, s, e, sp, L, keys, pp, me, 0ull, st->last_target, k_next, k_prev, final_err, cnt_j);
     if (!(s < e)) { params[2 * j] = pp[0]; params[2 * j + 1] = pp[1]; }
     leaf_err[j] = final_err;
     leaf_count[j] = cnt_j;

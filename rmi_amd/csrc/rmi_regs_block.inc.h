@@ -5,7 +5,7 @@
 // sums and their copies, rawA / rawB, cA / cB and the lambdas of the kernel.
         unsigned int in_b, dlt;
         block_base(b, in_b, dlt);
-        double T[8];
+        XT T[8];                                                         // (F32: already x - x0 as a float)
         // Masking: a lane is finished behind its container's last point, and stays finished.  Its sums are put aside at the end
         // of the half block (8 steps) in which it finishes; from then on it may compute what it likes.  So a half block in
         // which every lane is either alive for all 8 steps or finished before the first -- the rule while the walk is younger
@@ -31,7 +31,10 @@
             const int q = qr * 4 + u;
             const unsigned int k = k0 + (unsigned int)u;
             const double x = rg_as_float<K>(raw[q]);
-            T[q] = x;
+            if constexpr (F32) {
+              if (rg_block_index(b) == 0u && hb == 0 && q == 0) x0 = x;   // (the container's first key)
+              T[q] = (float)(x - x0);
+            } else T[q] = x;
             if (FULL || k < npts) {
               if (!(RG_DIAG & 2)) {
                 if constexpr (DIVK) { if (x == xp) dmin = 0u; }
@@ -65,10 +68,10 @@
               }
             });
           };
-          static_assert(RG_SBLK == 12, "three groups of four banks");
-          if (b < 4u) group(std::integral_constant<int, 0>{});
-          if (b >= 4u && b < 8u) group(std::integral_constant<int, 1>{});
-          if (b >= 8u && b < 12u) group(std::integral_constant<int, 2>{});
+          rg_static_for<0, SBLK / 4>([&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            if (b >= (unsigned int)(4 * g) && b < (unsigned int)(4 * g + 4)) group(g_tag);
+          });
         };
         auto run_half = [&](int hb, const uint2 (&raw)[8], auto&& prefetch) {
           const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
@@ -90,7 +93,7 @@
             sub(8);
           } else {
 #pragma unroll
-            for (int q = 4; q < 8; q++) T[q] = 0.0;                      // (stashed with the others; no leaf has these steps)
+            for (int q = 4; q < 8; q++) T[q] = (XT)0;                    // (stashed with the others; no leaf has these steps)
           }
           if constexpr (!STATIC) {
             const bool ends = npts > k0 && npts <= k0 + 8u;

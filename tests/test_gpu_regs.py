@@ -1,6 +1,6 @@
 """The register-resident leaf kernel (rmi_amd/csrc/rmi_regs.hip.h: k_leaf_regs, k_regs_finalize, k_leaf_lanes_listed) against the
 oracle through the C ABI, and against the leaf-lane pipeline it replaces: every variant of the path (non-temporal / plain
-loads, a handful of persistent waves, every group on the list, groups dealt from the counter), on the seeded generators and on
+loads (gone: measured equal), the LONG variant forced on every shape, a handful of persistent waves, every group on the list, groups dealt from the counter), on the seeded generators and on
 key sets that exercise its special cases -- containers of more than 240 points (the lanes that go on from the key array),
 of more than 1 008 (the group is listed), duplicate keys found while walking (listed), the leaf behind the split, empty
 leaves, f64 keys (IEEE division), shards.  Bar: bucket table, error integers, counts AND coefficients bit-identical."""
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = {
     "default": {"RMI_HIP_REGS": "1"},
-    "plain_loads": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_NT": "0"},
+    "long": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_MAX_AVG": "0", "RMI_HIP_REGS_LONG_MAX_AVG": "100000"},   # k_leaf_regs<K, LONG> for every shape
     "seven_waves": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_GRID": "7"},          # every wave takes many groups, the last ones uneven
     "all_listed": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_SLOW": "1"},           # k_leaf_lanes_listed does all the work
     "counter": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_QUEUE": "1", "RMI_HIP_REGS_GRID": "16"},
@@ -32,6 +32,10 @@ CASES = [
     ("uniform_f64", 300_000, 4096, "linear"), ("uniform_f64", 1_000_000, 6000, "linear"),
     ("uniform_u64", 300_000, 4096, "radix"), ("uniform_u64", 70_000, 1000, "linear"), ("uniform_u64", 5_000, 64, "linear"),
     ("uniform_u64", 300_000, 100_000, "linear"), ("uniform_u64", 300_001, 1000, "linear"),
+    # long leaves (k_leaf_regs<K, LONG> by default between 208 and 640 keys a leaf): C4's shard shape (381), walks of two dozen blocks
+    # whose error steps behind the stash come through the ring a second time; 600; skewed; f64 keys; C1's shape (977: most groups listed)
+    ("uniform_u64", 1_500_000, 3937, "linear"), ("uniform_u64", 2_000_000, 3333, "linear"), ("books_u64", 2_000_000, 5000, "linear"),
+    ("uniform_f64", 1_200_000, 3000, "linear"), ("uniform_u64", 1_000_000, 1024, "linear"), ("uniform_u64", 1_500_000, 4096, "radix"),
 ]
 
 
@@ -39,7 +43,8 @@ CASES = [
 @pytest.mark.parametrize("gen,n,L,root", CASES)
 def test_regs_variants(monkeypatch, oracle, variant, gen, n, L, root):
     g = _check(monkeypatch, oracle, VARIANTS[variant], dg.GENERATORS[gen](n), root, L)
-    if g is not None and n >= 1024 and n <= (100000 if variant == "any_average" else 208) * L:
+    # (skewed long leaves -- books, 400 keys a leaf -- : most groups hold a container of more than 1 008 points and are listed: reported as 3)
+    if g is not None and n >= 1024 and n <= (100000 if variant in ("any_average", "long") else 640) * L and not (gen == "books_u64" and n > 208 * L):
         # (every group listed -- by the switch, because the boundary search met duplicates, or because every group met keys whose f64 images
         #  collapse: k_leaf_lanes_listed did the work, reported as 3)
         assert g.pipeline in ((3, 4) if (variant == "all_listed" or gen.startswith("dups") or gen == "clustered_u64") else (4,))

@@ -39,6 +39,9 @@ CFG = {
 
 def setup(cfg, dataset=None):
     _gpu()
+    if cfg.startswith("X"):                                  # X<keys>x<leaves>: uniform u64, linear,linear (sweeps over the keys per leaf)
+        a, b = cfg[1:].split("x")
+        CFG[cfg] = (int(a), int(b), "linear", "linear", "uniform", np.uint64)
     n, L, root_kind, leaf, ds, dt = CFG[cfg]
     ds = dataset or ds
     tr = train.Trainer()

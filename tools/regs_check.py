@@ -15,7 +15,7 @@ from lanes_check import mk  # noqa: E402
 
 VARIANTS = {
     "p4 regs": {"RMI_HIP_REGS": "1"},
-    "p4 regs, plain loads": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_NT": "0"},
+    "p4 regs, LONG everywhere": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_MAX_AVG": "0", "RMI_HIP_REGS_LONG_MAX_AVG": "100000"},
     "p4 all listed": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_SLOW": "1"},
     "p4 small grid": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_GRID": "7"},
 }
@@ -118,6 +118,6 @@ if __name__ == "__main__":
         n = int(rest[0]) if len(rest) > 0 else 200_000_000
         L = int(rest[1]) if len(rest) > 1 else 1 << 20
         steps = int(rest[2]) if len(rest) > 2 else 30
-        tv = {"p3 lanes": {"RMI_HIP_REGS": "0"}, "p4 regs": {"RMI_HIP_REGS": "1"}, "p4 regs, plain loads": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_NT": "0"},
+        tv = {"p3 lanes": {"RMI_HIP_REGS": "0"}, "p4 regs": {"RMI_HIP_REGS": "1"}, "p4 regs, LONG everywhere": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_MAX_AVG": "0", "RMI_HIP_REGS_LONG_MAX_AVG": "100000"},
               "p4 regs grid 512": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_GRID": "512"}, "p4 regs grid 2048": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_GRID": "2048"}}
         timing(n, L, steps, tv)
