@@ -74,6 +74,9 @@ __device__ __forceinline__ void rg_static_for(F&& f) {
                                  // the second trip through the ring): the kernel is bound by its instructions, not by its reads, and the float path costs a conversion
                                  // and three operations of the certificate per step more.  Kept as a build switch (tests: tools/build_var.sh).
 #endif
+#ifndef RG_PRE
+#define RG_PRE 3                 // LONG: banks of the stash replayed in front of the walk through the ring (while its first panels land); 0: none
+#endif
 #ifndef RG_WALK_PIPE
 #define RG_WALK_PIPE 1           // LONG: the walk through the ring asks for the next half block's keys before this half's steps run
 #endif
@@ -696,8 +699,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // (LONG, tried: the replay in two phases -- four banks while the error panels requested behind the fit are on their way, then the walk and
       //  the hand-over, then the other banks: the loop around the banks' code makes the compiler keep copies of the stash values it reads, 0.298
       //  against 0.279 ms for C4's shard shape)
-      if constexpr (LONG != 0) ring_walk();
+      // LONG: the banks 1 .. RG_PRE of the stash are replayed HERE, in front of the walk through the ring, while its first panels (requested behind
+      // the fit) are on their way -- written out once, for groups in which every leaf covers them whole or not at all; the loop behind the
+      // hand-over then goes on behind them.
       if constexpr (F32) sA = __builtin_fma(pb, x0, pa);
+      unsigned int b_after0 = 1u;
+      if constexpr (LONG != 0 && RG_PRE > 0) {
+        constexpr unsigned int PE = (unsigned int)((RG_PRE + 1) * RG_ROW);
+        if (!(RG_KO & 2) && reread && sl >= PE && __all(eend >= PE || eend <= (unsigned int)RG_ROW)) {
+          if (eend >= PE) {
+            rg_static_for<1, RG_PRE + 1>([&](auto i_tag) {
+              constexpr int i = decltype(i_tag)::value;
+#pragma unroll
+              for (int qq = 0; qq < RG_ROW; qq += 2) {
+                if constexpr (F32) err_pair_f(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
+                else err_pair(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
+              }
+              asm volatile("; stash bank %0 (ahead)" ::"n"(i));
+            });
+          }
+          b_after0 = (unsigned int)RG_PRE + 1u;
+        }
+      }
+      if constexpr (LONG != 0) ring_walk();
       __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
       if (cur.valid) { params[2 * j] = pa; params[2 * j + 1] = pb; }
       hand_over();

@@ -1,9 +1,9 @@
 // The replay of the stash's banks [b_from, b_to) in k_leaf_regs' error pass (rmi_regs.hip.h includes this text once per instantiation: behind the
-// hand-over in the plain kernel, inside the loop over the two phases in the LONG one).  Context: b_from, b_to, eend, xs, the err_* lambdas.
+// hand-over in the plain kernel, inside the loop over the two phases in the LONG one).  Context: b_from, b_to, b_after0 (the bank behind bank 0: 1, or more where the first banks were replayed ahead), eend, xs, the err_* lambdas.
       // (tried: bank by bank statically, the banks with a leaf's end noted for a second loop: no search for the bank's code, but the
       //  register allocator moves parts of the stash around between the banks' codes -- error pass 13 % slower)
 #pragma nounroll
-        for (unsigned int b = b_from; b < b_to; b++) {
+        for (unsigned int b = b_from; b < b_to; b = (b == 0u ? b_after0 : b + 1u)) {
           const unsigned int kb0 = b * (unsigned int)RG_ROW;
           // a block in which no leaf ends, and not the one with step 0: straight from the bank's registers under ONE test (one
           // copy of the 16 steps per bank: 5.5 instructions a step); else through T[] with a test per step
