@@ -73,6 +73,9 @@
 #ifndef RMI_SC_FAST_DUPS
 #define RMI_SC_FAST_DUPS 1            // 0: tiles with duplicate keys through the general form
 #endif
+#ifndef RMI_SC_CLAMPFREE
+#define RMI_SC_CLAMPFREE 0            // the short form's error pass without the clamp to n where no prediction of the tile can reach it
+#endif
 #ifndef RMI_SC_WPE
 #define RMI_SC_WPE 2                  // waves per SIMD the kernel is compiled for (register budget 512 / that)
 #endif
@@ -139,6 +142,28 @@ __device__ __forceinline__ unsigned int sc_wave_max(unsigned int v) {
   return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
 }
 __device__ __forceinline__ unsigned int sc_mask_below(unsigned int x) { return x >= 32u ? ~0u : ((1u << x) - 1u); }
+
+// log2 of an integer 2 <= v <= 2^34 given as a double (the term log2(2 err + 2) of two_layer.rs:279-283), to the last bit or two: the
+// library's log2 is 85 instructions of double-double arithmetic per leaf in a phase where a third of the lanes work -- 11 % of the short form's
+// time.  Here: v = m 2^e with m in [sqrt(1/2), sqrt(2)), log(m) by fdlibm's e_log.c (s = f / (2 + f), a polynomial of degree 7 in s^2), the
+// reciprocal by v_rcp_f64 and two Newton steps: 30 instructions, relative error <= 2.3e-16 against the library over every even v below
+// 2 10^5 and 2 10^5 random ones below 2^33 (tools/log2_check.py).  The aggregates are compared to 1e-9 (the sums run in another order
+// than the reference's anyway).
+__device__ __forceinline__ double sc_log2_int(double v) {
+  double m = __builtin_amdgcn_frexp_mant(v) * 2.0;                                // [1, 2)
+  int e = __builtin_amdgcn_frexp_exp(v) - 1;
+  const bool big = m > 1.4142135623730951;
+  m = big ? m * 0.5 : m; e = big ? e + 1 : e;
+  const double f = m - 1.0, d = 2.0 + f;
+  double r = __builtin_amdgcn_rcp(d);
+  r = r * __builtin_fma(-d, r, 2.0); r = r * __builtin_fma(-d, r, 2.0);
+  const double s = f * r, z = s * s, w = z * z;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double hfsq = 0.5 * f * f;
+  const double lnm = f - (hfsq - s * (hfsq + (t1 + t2)));
+  return __builtin_fma(lnm, 1.4426950408889634, (double)e);
+}
 
 // per-lane accumulators of the aggregates (two_layer.rs:267-287)
 struct ScAgg {
@@ -243,6 +268,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
   const double Lm1f = (double)(r.L - 1);
   const unsigned int mid = (unsigned int)(r.L / 2);                              // two_layer.rs:131
   const double nf = (double)sp.n;
+  const double inv_nf = 1.0 / nf;
   unsigned int flags = 0;
 
   auto wave_sync = [&]() {
@@ -364,11 +390,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
     wave_sync();
     if (!take) {
     } else if (PHASE == 0 || plain_t) {
+      // (dword offset of chunk c 64 + ln from the big tile's first key: d0 = 256 c + 4 ln, and d0 + 4 (d0 >> 5) = (4 ln + 4 (ln >> 3)) + 288 c
+      //  for ln < 64 -- one address and immediate offsets; from the general rule the compiler forms every chunk's address by itself: 6
+      //  instructions each)
+      unsigned int* const srow = trow0 + 4 * ln + 4 * (ln >> 3);
 #pragma unroll
-      for (int c = 0; c < NCHB; c++) {
-        const int d0 = (c * 64 + ln) * 4;                                        // dword offset of the chunk from the big tile's first key
-        *reinterpret_cast<uint4*>(trow0 + d0 + 4 * (d0 >> 5)) = pf[c];
-      }
+      for (int c = 0; c < NCHB; c++) *reinterpret_cast<uint4*>(srow + 288 * c) = pf[c];
       if (ln < FHC + G::EXTC) {
         const int d0 = ln < FHC ? (ln - FHC) * 4 : NSUB * 64 * G::ROWD + (ln - FHC) * 4;
         *reinterpret_cast<uint4*>(trow0 + d0 + 4 * (d0 >> 5)) = pfx;
@@ -549,6 +576,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
           // ---- F3: the models.  Lane l: slot l.  Container [s - 1, e]: both end points exist (no split, no end of the data nearby) and their keys differ
           // (nothing of a slot stays in registers across the error pass: F5 reads records, model and end keys from LDS again -- registers held
           //  there were spilled, and a spilled register's reload waits for the key loads in flight)
+          // (... and whether the clamp of a prediction to n, two_layer.rs:14-18, can bind at all: a leaf's keys lie between its container's end
+          //  keys, fma and the saturating conversion are monotone, so both ends predicting below n + 1 means every key does -- the error pass
+          //  of a tile whose leaves all pass drops the min, one instruction of seven per key)
+          bool cfree = true;
           if ((unsigned int)lane < nb) {
             const unsigned int q_s = r_s[lane], q_e = r_s[lane + 1];
             const K k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))), k_hi = bits_to_key<K>(lds_bits0((int)(q_e - A2)));
@@ -558,7 +589,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
             const double ma = y0f - mb * x0;                                     // :28, plain multiply-subtract
             m_ab[2 * (lane + 1)] = ma; m_ab[2 * (lane + 1) + 1] = mb;
             m_err[lane + 1] = 0u; m_run[lane + 1] = 0u;
+            const double np1 = (double)n32 + 1.0;
+            cfree = (__builtin_fma(mb, x0, ma) < np1) && (__builtin_fma(mb, x1, ma) < np1);
           }
+          const bool clampfree = RMI_SC_CLAMPFREE && __all(cfree);
           // which positions hold some lane's start (a scalar mask: the error pass tests it, not the lanes)
           unsigned long long am;
           {
@@ -583,6 +617,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
             unsigned int m = 0u, m0 = 0u, rn = 0u, rn0 = 0u, y_last = 0u;
             unsigned int amlo = (unsigned int)am, amhi = (unsigned int)(am >> 32);
             if (!dups) {
+              auto pass = [&](auto cf_tag) {
+              constexpr bool CF = decltype(cf_tag)::value;
 #pragma unroll
               for (int rr = 0; rr < NSUB; rr++) {
                 read_row(rr);
@@ -608,10 +644,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
                   amr >>= 1;
 #endif
                   const double x = KeyTraits<K>::as_float(bits_to_key<K>(kk[v]));
-                  const unsigned int pr = min(sg_cvt_u32(__builtin_fma(pb, x, pa)), n32);   // linear_spline.rs:52, models/mod.rs:735-737, two_layer.rs:14-18
+                  const unsigned int pc = sg_cvt_u32(__builtin_fma(pb, x, pa));             // linear_spline.rs:52, models/mod.rs:735-737
+                  const unsigned int pr = CF ? pc : min(pc, n32);                           // two_layer.rs:14-18
                   m = max(m, sg_absdiff(pr, f + (unsigned int)gv));
                 }
               }
+              };
+              if (clampfree) pass(std::true_type{}); else pass(std::false_type{});
             } else {
               unsigned int y = y_in;
               bool ne = false;
@@ -735,8 +774,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
               asum += ts;
               if (cnt_j) {
                 const double v = (double)ts;
-                aggp[0] += (v * v) / nf;
-                aggp[1] += (double)cnt_j * log2((double)(2ull * (unsigned long long)final_err + 2ull));
+                aggp[0] += (v * v) * inv_nf;                                       // (the reference divides by n: one rounding apart, the sums are compared to 1e-9)
+                aggp[1] += (double)cnt_j * sc_log2_int((double)(2ull * (unsigned long long)final_err + 2ull));
               }
             }
             // the empty leaves [g0, t) in front of this start (s == e): the constant model next_index = s (two_layer.rs:185-197), widened by 1
@@ -1171,8 +1210,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
     }  // h
   }
 #if RMI_SC_PROF
-  if (lane == 0 && (blockIdx.x == 777 || blockIdx.x == 1500 || blockIdx.x == 2222))
-    printf("wave %u: tiles %u fast %u total %llu | stage %llu prefetch %llu F1 %llu F2-3 %llu F4 %llu F5 %llu looptop %llu\n", blockIdx.x, ntile, nfast,
+  if (lane == 0 && blockIdx.x % 61u == 0u)
+    printf("wave %u xcd %u: tiles %u fast %u total %llu | stage %llu prefetch %llu F1 %llu F2-3 %llu F4 %llu F5 %llu looptop %llu\n", blockIdx.x, blockIdx.x & 7u, ntile, nfast,
            (unsigned long long)__builtin_readcyclecounter() - tstart, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[7]);
 #endif
   if (flags) atomicOr(&st->err_flags, flags);
