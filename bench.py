@@ -515,7 +515,7 @@ def main():
 
     if rank == 0:
         used = int(getattr(res, "fit_mode_used", 0))
-        lanes_path = used == 0 and leaf_kind in (0, 1) and os.environ.get("RMI_HIP_PIPELINE", "3") not in ("1", "2") and n_local >= 1024
+        lanes_path = used == 0 and leaf_kind in (0, 1) and os.environ.get("RMI_HIP_PIPELINE", "3") not in ("2",) and n_local >= 1024
         last_pl = int(tr._lib.rmi_hip_last_pipeline(tr._h))
         regs_path = lanes_path and last_pl == 4
         scan_path = lanes_path and last_pl == 5

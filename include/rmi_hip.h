@@ -158,8 +158,7 @@ const char* rmi_hip_last_error(const rmi_hip_ctx* ctx);
 const char* rmi_hip_strerror(int code);
 /* Timing detail of rmi_hip_result: -1 = none (no event is recorded; device_ns = 0), 0 = device_ns only (default),
  * 1 = also kernel_ns[0], the first and dominant kernel of the call, 2 = every kernel group (RMI_K_*).  An event
- * between two kernels costs ~5 us of idle device time, so the detail is not free.  RMI_HIP_PROFILE_KERNELS=1
- * selects 2 at creation. */
+ * between two kernels costs ~5 us of idle device time, so the detail is not free. */
 int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
 /* How linear leaves (linear.rs:12-59) are fitted:
  *   RMI_FIT_EXACT (default, and the fastest mode): the reference's recurrence in the reference's order; coefficients,

@@ -96,10 +96,10 @@ struct rmi_hip_ctx {
   unsigned int regs_grid = 0;                   // persistent waves of k_leaf_regs (0: 4 per CU)
   unsigned int regs_max_avg = 208;              // average keys per leaf above which most groups would not fit (RG_MAXPTS = 240 per container)
   unsigned int regs_long_max_avg = 640;         // ... and up to which k_leaf_regs<K, LONG> takes them (the steps behind the stash through the ring twice); above: k_leaf_lanes
-  unsigned int regs_slow = 0;                   // debugging: every group on the list
+  static constexpr unsigned int regs_slow = 0;  // (debugging aid of round 4: every group on the list)
   bool regs_backoff = true;                     // RMI_HIP_REGS_BACKOFF=0: k_leaf_regs also for key sets on which it listed most groups last time
   uint64_t regs_off_epoch = 0; uint64_t regs_off_L[8] = {}; int regs_off_n = 0;   // ... the (key set, leaves) pairs remembered
-  bool regs_queue = false;                      // RMI_HIP_REGS_QUEUE=1: groups dealt to the waves from a counter instead of by wave number (measured: 473 against 460 us)
+  static constexpr bool regs_queue = false;     // (groups dealt to the waves from a counter instead of by wave number: measured 473 against 460 us; the switch is gone)
   double* d_regtab = nullptr;                   // the interleaved step table of k_leaf_regs
   unsigned long long* d_regprof = nullptr;      // RG_PROF builds: cycles per phase, summed over the waves
   std::vector<rmi_hip_ctx*> many_views;         // rmi_hip_train_many: contexts that borrow this one's keys (kept for the next call)
@@ -118,11 +118,9 @@ struct rmi_hip_ctx {
   bool lean = true;                             // RMI_HIP_LEAN=0: the kernel writes all five arrays
   bool last_lean = false, lean_derived = false;
   unsigned long long lean_last_target = ~0ull, lean_leaf_lo = 0;   // (of the training the arrays belong to: the shard may be gone when they are asked for)
-  bool scan = true;                             // pipeline 5 (rmi_scan.hip.h): linear_spline leaves by the key-parallel one-read kernel (RMI_HIP_SCAN=0: k_leaf_lanes)
   bool last_scan = false;
   unsigned int scan_waves = 0;                  // its persistent waves per kernel at most (0: as many as the device holds, rmi_scan_waves_per_cu)
   bool lanes_search = true;                     // leaf boundaries by k_leaf_search where the root allows it (else the bucketing scan)
-  bool spline_lanes = true;                     // linear_spline leaves through k_leaf_lanes where k_spline_scan is switched off (RMI_HIP_SPLINE_LANES=0: the per-pass kernels)
   uint64_t edge_epoch = 0;                      // first / last resident key of the key set `keys_epoch` (radix roots: is the prefix common?)
   uint64_t edge_first = 0, edge_last = 0;
   uint64_t edgef_epoch = 0;                     // ... as doubles (cubic roots: is the polynomial increasing between them?)
@@ -227,7 +225,7 @@ static void set_err(rmi_hip_ctx* c, const char* fmt, ...) {
 extern "C" {
 
 int rmi_hip_abi_version(void) { return RMI_HIP_ABI_VERSION; }
-int rmi_hip_last_pipeline(rmi_hip_ctx* c) { return !c ? RMI_ERR_BAD_ARG : (c->last_scan ? 5 : c->last_regs ? 4 : (c->last_lanes ? 3 : (c->pipeline == 1 ? 1 : 2))); }
+int rmi_hip_last_pipeline(rmi_hip_ctx* c) { return !c ? RMI_ERR_BAD_ARG : (c->last_scan ? 5 : c->last_regs ? 4 : (c->last_lanes ? 3 : 2)); }
 
 int rmi_hip_device_count(void) {
   int n = 0;
@@ -333,17 +331,13 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
       hipHostGetDevicePointer((void**)&c->h_state_dev, c->h_state, 0) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   if (hipHostMalloc((void**)&c->h_sentinel, 64, hipHostMallocDefault) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
-  const char* pk = std::getenv("RMI_HIP_PROFILE_KERNELS");
-  c->profile_level = (pk && *pk && *pk != '0') ? 2 : 0;
+  c->profile_level = 0;                                 // (rmi_hip_set_profile_level)
   const char* pl = std::getenv("RMI_HIP_PIPELINE");
-  if (pl && *pl) c->pipeline = std::atoi(pl);
-  { const char* lf = std::getenv("RMI_HIP_LANES_FUSE"); if (lf && *lf) c->lanes_fuse = std::atoi(lf) != 0; }
+  if (pl && *pl) c->pipeline = std::atoi(pl) >= 3 ? 3 : 2;       // 2: the streaming passes of round 2 (what tiny and huge key sets and cubic / robust leaves take anyway); default 3: everything newer
   { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
   { const char* otl = std::getenv("RMI_HIP_OPT_TAIL"); if (otl && *otl) c->opt_tail = std::atoi(otl) != 0; }
   { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
-  { const char* sl = std::getenv("RMI_HIP_SPLINE_LANES"); if (sl && *sl) c->spline_lanes = std::atoi(sl) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) c->regs = std::atoi(rg) != 0; }
-  { const char* sc = std::getenv("RMI_HIP_SCAN"); if (sc && *sc) c->scan = std::atoi(sc) != 0; }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN"); if (cm && *cm) c->cubic_margin = std::atoi(cm) != 0; }
   { const char* ln = std::getenv("RMI_HIP_LEAN"); if (ln && *ln) c->lean = std::atoi(ln) != 0; }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN_SCALE"); if (cm && *cm) c->cubic_margin_scale = std::atof(cm); }
@@ -351,9 +345,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* rg = std::getenv("RMI_HIP_REGS_LONG_MAX_AVG"); if (rg && *rg) c->regs_long_max_avg = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_GRID"); if (rg && *rg) c->regs_grid = (unsigned int)std::atoi(rg); }
   { const char* rg = std::getenv("RMI_HIP_REGS_MAX_AVG"); if (rg && *rg) c->regs_max_avg = (unsigned int)std::atoi(rg); }
-  { const char* rg = std::getenv("RMI_HIP_REGS_QUEUE"); if (rg && *rg) c->regs_queue = std::atoi(rg) != 0; }
   { const char* rg = std::getenv("RMI_HIP_REGS_BACKOFF"); if (rg && *rg) c->regs_backoff = std::atoi(rg) != 0; }
-  { const char* rg = std::getenv("RMI_HIP_REGS_SLOW"); if (rg && *rg) c->regs_slow = (unsigned int)std::atoi(rg); }
   { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) c->n_cu = cu; }
   if (hipMalloc(&c->d_lntab, sizeof(double) * (3 * LN_TMAX + 2 * (LS_SAMPLES + 1))) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
   hipLaunchKernelGGL(k_lane_table, dim3((LN_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_lntab, LN_TMAX);
@@ -361,20 +353,13 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (RG_PROF) { if (hipMalloc(&c->d_regprof, 128) != hipSuccess || hipMemset(c->d_regprof, 0, 128) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; } }
   hipLaunchKernelGGL(k_regs_table, dim3((RG_TMAX + 255) / 256), dim3(256), 0, c->stream, c->d_regtab, RG_TMAX);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rmi_hip_destroy(c); return RMI_ERR_HIP; }
+  // (the chunk geometry of pass A, pipeline 2: its tests vary it)
   const char* ft = std::getenv("RMI_HIP_FIT_THREADS");
   if (ft && *ft) c->fit_threads = std::strtoull(ft, nullptr, 10);
-  const char* et = std::getenv("RMI_HIP_ERR_THREADS");
-  if (et && *et) c->err_threads = std::strtoull(et, nullptr, 10);
-  const char* lm = std::getenv("RMI_HIP_LONG_MIN");
-  if (lm && *lm) { long v = std::atol(lm); if (v >= 64) c->long_min = (unsigned int)v; }
   const char* fc = std::getenv("RMI_HIP_FIT_MIN_CHUNK");
   if (fc && *fc) c->fit_min_chunk = std::atoi(fc);
-  const char* fm = std::getenv("RMI_HIP_FIT_MODE");
-  if (fm && *fm) { const int v = std::atoi(fm); if (v >= 0 && v <= 2) c->fit_mode = v; }
-  const char* gk = std::getenv("RMI_HIP_GUARD_K");
-  if (gk && *gk) { const double v = std::atof(gk); if (v > 0.0) c->guard_k = v; }
-  const char* sw = std::getenv("RMI_HIP_SIGMA_WAVES");
-  if (sw && *sw) { const long v = std::atol(sw); if (v > 0) c->sigma_waves = (uint64_t)v; }
+  const char* lm = std::getenv("RMI_HIP_LONG_MIN");
+  if (lm && *lm) { long v = std::atol(lm); if (v >= 64) c->long_min = (unsigned int)v; }
   *out = c;
   return RMI_OK;
 }
@@ -539,7 +524,7 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
     if (arc != RMI_OK) return arc;
     // what the caller has set on the context holds for every training of the batch
     v->fit_mode = c->fit_mode; v->guard_k = c->guard_k; v->profile_level = c->profile_level; v->host_min = c->host_min;
-    v->long_min = c->long_min; v->pipeline = c->pipeline; v->regs = c->regs; v->scan = c->scan; v->opt_tail = c->opt_tail;
+    v->long_min = c->long_min; v->pipeline = c->pipeline; v->regs = c->regs; v->opt_tail = c->opt_tail;
   }
   std::atomic<uint64_t> next{0};
   std::vector<int> lrc(count, RMI_OK);
@@ -1218,8 +1203,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   c->giant_armed = false;
   if (!c->d_flist_cnt) HIPCHK(c, hipMalloc(&c->d_flist_cnt, (2 * SG_REGIONS + 8) * 8));  // (the one-pass mode's list + merge counters: zeroed by k_init)
   // pipeline 1 launches one thread per key: a grid dimension holds fewer than 2^32 threads
-  const int pipeline = (c->pipeline == 1 && n_it < (1ull << 32) - 1024) ? 1 : 2;
-  const bool stream_fit = (pipeline != 1) && (LEAF == K_LINEAR) && !c->robust_leaf;
+  const bool stream_fit = (LEAF == K_LINEAR) && !c->robust_leaf;
   // one pass from sufficient statistics: leaves of at least a few dozen keys on average (the rows of a tile hold
   // 16 keys; shorter leaves are cheap chains for the exact kernels anyway), indices below 2^32
   bool hinted = false;
@@ -1230,10 +1214,9 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   // ... and, in front of it, the leaf-lane kernel (two end points per leaf, then its error pass with duplicates handled natively)
   // pipeline 5 (rmi_scan.hip.h): linear_spline leaves in ONE key-parallel pass, the bucketing scan included -- every root, every key type,
   // any number of keys (an empty shard as well); 32-bit indices
-  const bool scan5 = c->pipeline >= 3 && (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->scan && c->lanes_fuse && sp.n < (1ull << 32) - (1ull << 16);
+  const bool scan5 = c->pipeline >= 3 && (LEAF == K_LINEAR_SPLINE) && sp.n < (1ull << 32) - (1ull << 16);
   c->last_scan = scan5;
-  const bool spline_l = scan5 || (c->pipeline >= 3 && (pipeline != 1) && (LEAF == K_LINEAR_SPLINE) && c->spline_lanes && n_it >= 1024 &&
-                        sp.n < (1ull << 32) - (1ull << 16));
+  const bool spline_l = scan5;                             // (round 6: k_leaf_lanes<.., K_LINEAR_SPLINE>, the second route for these leaves, is gone)
   // (round 5: the one-pass kernel's linear_spline variant is gone -- k_spline_scan serves them, and where it does not (RMI_HIP_SCAN=0 with
   //  RMI_HIP_SPLINE_LANES=0, 2^32 keys and more, RMI_HIP_PIPELINE <= 2) the per-pass kernels do; the variant missed the borrowed point of
   //  a leaf behind an emptied split leaf, Q4)
@@ -1501,12 +1484,14 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         (void)rmi_scan_gaps_launch(c->dtype, sl, s);
         nrec = sl.waves;
       } else if (verify || regs) {
-      } else if (lanes_fused)
-        hipLaunchKernelGGL((k_leaf_lanes<K, true, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                           L, err, count, rows, part, rp, peers);
-      else
-        hipLaunchKernelGGL((k_leaf_lanes<K, false, LEAF>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
-                           L, err, count, rows, part, rp, peers);
+      } else if constexpr (LEAF == K_LINEAR) {                            // (linear_spline leaves reach this point only with scan5)
+        if (lanes_fused)
+          hipLaunchKernelGGL((k_leaf_lanes<K, true, K_LINEAR>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
+                             L, err, count, rows, part, rp, peers);
+        else
+          hipLaunchKernelGGL((k_leaf_lanes<K, false, K_LINEAR>), dim3((unsigned)wb), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, fl, lmin, maxerr, run,
+                             L, err, count, rows, part, rp, peers);
+      }
       mark();
       // --- the leaves handed over (containers too long for the lockstep walk): one wave each, fit + error pass; the
       //     listed leaves' share of the finalize, the aggregates, the result record ---
@@ -1569,7 +1554,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       }
       SgParams sgp; sgp.guard_k = c->guard_k; sgp.mode = c->fit_mode;
       sgp.flist.ids = c->d_flist; sgp.flist.cnt = c->d_flist_cnt; sgp.flist.cap = c->flist_cap;
-      { const char* dbg = std::getenv("RMI_HIP_SIGMA_DBG"); sgp.dbg = dbg ? std::atoi(dbg) : 0; }
+      sgp.dbg = 0;
       {
         auto launch2 = [&](auto ring_tag, auto batch_tag) -> int {
           constexpr int RING = decltype(ring_tag)::value, BATCH = decltype(batch_tag)::value;
@@ -1612,10 +1597,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
     mark();                                              // a shard without keys: every leaf is empty
   } else if (!stream_fit) {
     // --- bucketing scan ---
-    if (pipeline == 1) {
-      const uint64_t blocks = (n_it + 255) / 256;
-      hipLaunchKernelGGL((k_boundaries<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
-    } else {
+    {
       constexpr uint64_t V = 16 / sizeof(K);
       const uint64_t blocks = ((n_it + V - 1) / V + 256 * BV_UNROLL - 1) / (256 * BV_UNROLL);
       hipLaunchKernelGGL((k_bounds_vec<ROOT, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, leaf_start, c->d_state);
@@ -1702,9 +1684,6 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
   if (!sigma && !lanes) mark();
   // --- error pass ---
   if (n_it == 0 || sigma || lanes_fused) {
-  } else if (pipeline == 1) {
-    const uint64_t blocks = (n_it + 255) / 256;
-    hipLaunchKernelGGL((k_err<ROOT, LEAF, K>), dim3((unsigned)blocks), dim3(256), 0, s, keys, sp, rp, params, maxerr, run);
   } else {
     uint64_t C = (n_it + c->err_threads - 1) / c->err_threads;
     C = ((C + FS_ROW - 1) / FS_ROW) * FS_ROW;

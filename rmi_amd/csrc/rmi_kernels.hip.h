@@ -1,14 +1,14 @@
 // rmi_kernels.hip.h -- gfx950 kernels of the two-layer leaf path (pipeline "v1": one kernel per
 // reference pass; see DESIGN.md for the roofline of each and for the fused successors).
 //
-//   k_boundaries   bucketing scan: target(key) for every key, leaf boundary table, split point,
+//   k_bounds_vec   bucketing scan: target(key) for every key, leaf boundary table, split point,
 //                  monotonicity / bounds checks            (two_layer.rs:43-50, 130-156)
 //   k_fill_*       suffix-min fill of leaf_start for empty leaves
 //   k_fit_leaf     per-leaf fit on the reference's container C_j (two_layer.rs:52-90) in
 //                  reference order: Welford SLR (linear.rs:12-59) / endpoints
 //                  (linear_spline.rs:13-35)
-//   k_err          last-level error pass + run lengths    (two_layer.rs:207-217,
-//                  lower_bound_correction.rs:104-125)
+//   (round 6: k_boundaries and k_err, the one-thread-per-key kernels of round 1 -- RMI_HIP_PIPELINE=1 -- are gone; k_bounds_vec and
+//    k_err_range, rmi_stream.hip.h, do their work)
 //   k_finalize     empty-leaf fix, lower-bound widening, row packing
 //                  (two_layer.rs:185-197, 226-259; codegen.rs:288-315)
 //   k_stats_reduce aggregates from k_finalize's block records (two_layer.rs:267-287)
@@ -19,44 +19,6 @@ namespace rmi {
 
 constexpr int WAVE = 64;
 constexpr unsigned long long NO_START = ~0ull;
-
-// ---------------------------------------------------------------------------------------------
-// k_boundaries: one thread per key.  Targets are monotone non-decreasing (else the reference
-// panics), so leaf_start[j] = first i with target(key[i]) >= j is a boundary detect.
-// ---------------------------------------------------------------------------------------------
-template <int ROOT, typename K>
-__global__ void __launch_bounds__(256) k_boundaries(const K* __restrict__ keys, Span sp, RootP r,
-                                                    unsigned long long* __restrict__ leaf_start,
-                                                    DevState* __restrict__ st) {
-  const uint64_t i = sp.it_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= sp.it_hi) return;
-  const uint64_t n = sp.n;
-  const uint64_t Lm1 = root_cap<ROOT>(r);
-  const uint64_t mid = r.L / 2;                                   // two_layer.rs:131
-  const uint64_t p = root_predict<ROOT, K>(r, keys[i]);
-  if constexpr (!root_needs_bounds_check<ROOT>()) {
-    if (p > root_oob_above<ROOT>(r)) atomicOr(&st->err_flags, EF_ROOT_OOB);           // two_layer.rs:45-48
-  }
-  const uint64_t t = p < Lm1 ? p : Lm1;                           // two_layer.rs:49
-  const bool mine = t >= sp.leaf_lo && t < sp.leaf_hi;
-  if (i == 0) {
-    if (mine) leaf_start[t] = 0;
-    if (t >= mid) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);  // split_idx == 0 -> :27
-  } else if (i > sp.rd_lo) {
-    const uint64_t pp = root_predict<ROOT, K>(r, keys[i - 1]);
-    const uint64_t tp = pp < Lm1 ? pp : Lm1;
-    if (t < tp) atomicOr(&st->err_flags, EF_NON_MONOTONE);        // two_layer.rs:50 / :144
-    else if (t > tp) {
-      if (mine) leaf_start[t] = i;
-      if (tp < mid && t >= mid) {                                 // two_layer.rs:132-136,152-156
-        st->split_idx = i;
-        st->split_target = t;
-        if (i + 1 >= n) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);  // second half empty -> :27
-      }
-    }
-  }
-  if (i == n - 1) st->last_target = t;
-}
 
 // ---------------------------------------------------------------------------------------------
 // FAST (not bit-identical) root fit of `linear` / `robust_linear`: the same least-squares line over
@@ -666,42 +628,6 @@ __device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v
   return ((unsigned long long)hi << 32) | lo;
 }
 
-template <int ROOT, int LEAF, typename K>
-__global__ void __launch_bounds__(256) k_err(const K* __restrict__ keys, Span sp, RootP r,
-                                             const double* __restrict__ params,
-                                             unsigned long long* __restrict__ leaf_maxerr,
-                                             unsigned long long* __restrict__ leaf_run) {
-  constexpr int PPL = (LEAF == K_CUBIC) ? 4 : 2;
-  const uint64_t i = sp.it_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const uint64_t n = sp.n;
-  const bool active = i < sp.it_hi;
-  const uint64_t Lm1 = root_cap<ROOT>(r);
-  unsigned long long t = ~0ull, err = 0, run = 0;
-  if (active) {
-    const K k = keys[i];
-    const uint64_t p = root_predict<ROOT, K>(r, k);
-    t = p < Lm1 ? p : Lm1;
-    const uint64_t y = first_occurrence(keys, i, sp.rd_lo);
-    const uint64_t pred = leaf_predict<LEAF, K>(params + t * PPL, k);
-    err = error_between(pred, y, n);
-    if (i + 1 < n && !(keys[i + 1] == k)) run = i - y + 1;   // a run is recorded when the next different item arrives
-  }
-  // segmented inclusive max-scan over lanes with equal t (segments are contiguous)
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    unsigned long long ot = shfl_up_u64(t, d);
-    unsigned long long oe = shfl_up_u64(err, d);
-    unsigned long long orn = shfl_up_u64(run, d);
-    if (lane >= d && ot == t) { err = oe > err ? oe : err; run = orn > run ? orn : run; }
-  }
-  unsigned long long nt = shfl_down_u64(t, 1);
-  const bool tail = active && (lane == WAVE - 1 || nt != t);
-  if (tail) {
-    if (err) atomicMax(&leaf_maxerr[t], err);
-    if (run) atomicMax(&leaf_run[t], run);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Aggregates of two_layer.rs:267-287.  Every block of k_finalize reduces its leaves to one partial

@@ -25,8 +25,7 @@ def run_case(rng, c=0):
     streamed = bool(rng.integers(0, 2))
     leaf = "linear_spline" if rng.integers(0, 4) == 0 else "linear"      # (linear_spline: one-pass in every mode, bit for bit)
     waves = [None, "64", "1000", "100000"][rng.integers(4)]
-    if waves: os.environ["RMI_HIP_SIGMA_WAVES"] = waves
-    else: os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
+    # (RMI_HIP_SIGMA_WAVES, the one-pass kernel's wave count, was an environment switch until round 6)
     # the leaf-lane pipeline's own switches (exact mode): leaves handed to the list kernels / to the host, the tail in-stream
     knobs = {"RMI_HIP_LONG_MIN": [None, "64", "512"][rng.integers(3)], "RMI_HIP_HOST_MIN": [None, "2000"][rng.integers(2)],
              "RMI_HIP_OPT_TAIL": [None, "0"][rng.integers(2)], "RMI_HIP_LANES_SEARCH": [None, "0"][rng.integers(2)]}
@@ -76,7 +75,6 @@ def run_case(rng, c=0):
         mx = np.zeros(L, np.int64); np.maximum.at(mx, leaf_of, np.abs(pred - first))
         over = mx - ge
         ok = ok and int(np.count_nonzero(over > 0)) <= 2 and (over.max() <= 1)
-    os.environ.pop("RMI_HIP_SIGMA_WAVES", None)
     for k in knobs: os.environ.pop(k, None)
     kn = ",".join(f"{k[8:].lower()}={v}" for k, v in knobs.items() if v is not None)
     return ok, (f"[{kn}] " + f"{c:3d} {gen:14s} {root:13s} n={n:8d} L={L:7d} leaf={leaf} mode={mode} streamed={chunks if streamed else 0} waves={waves} used={g.fit_mode_used} exact={g.exact_leaves} "

@@ -1,5 +1,5 @@
 """The leaf-lane pipeline (rmi_amd/csrc/rmi_lanes.hip.h: k_leaf_search, k_leaf_lanes, the giant-leaf epilogue) against
-the oracle through the C ABI: every variant of the path (fused / separate error pass, boundaries by search / by the
+the oracle through the C ABI: every variant of the path (boundaries by search / by the
 bucketing scan, leaves handed to the list kernels and to the host), on the seeded generators and on adversarial key
 sets with exact linear structure.  Bar: bucket table, error integers, counts AND coefficients bit-identical."""
 import numpy as np
@@ -10,9 +10,8 @@ from rmi_amd import datagen as dg
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {
-    "fused_search": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_FUSE": "1", "RMI_HIP_LANES_SEARCH": "1"},
-    "unfused_search": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_FUSE": "0", "RMI_HIP_LANES_SEARCH": "1"},
-    "fused_scan": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_FUSE": "1", "RMI_HIP_LANES_SEARCH": "0"},
+    "fused_search": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_SEARCH": "1"},
+    "fused_scan": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_LANES_SEARCH": "0"},
     # leaves of more than 512 points go to the list kernels, of more than 2000 to the host
     "lists_and_host": {"RMI_HIP_PIPELINE": "3", "RMI_HIP_HOST_MIN": "2000", "RMI_HIP_LONG_MIN": "512"},
     # the list kernels and k_finalize_listed inside the stream of every training (default: k_lane_reduce publishes, the list

@@ -23,8 +23,8 @@ def trainer_mod():
 
 
 # The whole matrix runs on the default pipelines (3 = leaf-lane kernels, with the register-resident kernel of pipeline 4 taking the
-# configurations it applies to); the round-1/2 pipelines (RMI_HIP_PIPELINE=2: streaming passes, =1: one kernel per reference
-# pass) serve as fall-backs for tiny key sets and special leaves and keep a smoke set of their own.
+# configurations it applies to); the round-2 pipeline (RMI_HIP_PIPELINE=2: streaming passes; round 1's one-kernel-per-pass
+# pipeline is gone) serves as the fall-back for tiny key sets and special leaves and keep a smoke set of their own.
 LEGACY_SMOKE = {"test_parity_config1", "test_parity_tiny", "test_parity_degenerate_inputs", "test_parity_long_leaves",
                 "test_parity_many_empty_leaves", "test_parity_f64_keys", "test_parity_chunk_geometry", "test_error_codes",
                 # (the leaf kinds and roots only these pipelines serve on their own kernels: cubic and robust_linear leaves, a radix table)
@@ -33,7 +33,7 @@ LEGACY_SMOKE = {"test_parity_config1", "test_parity_tiny", "test_parity_degenera
 
 def pytest_generate_tests(metafunc):
     if "pipeline" in metafunc.fixturenames:
-        params = ["3", "2", "1"] if metafunc.function.__name__ in LEGACY_SMOKE else ["3"]
+        params = ["3", "2"] if metafunc.function.__name__ in LEGACY_SMOKE else ["3"]
         metafunc.parametrize("pipeline", params, ids=[f"pipeline{p}" for p in params], indirect=True)
 
 

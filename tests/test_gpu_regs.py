@@ -1,6 +1,6 @@
 """The register-resident leaf kernel (rmi_amd/csrc/rmi_regs.hip.h: k_leaf_regs, k_regs_finalize, k_leaf_lanes_listed) against the
 oracle through the C ABI, and against the leaf-lane pipeline it replaces: every variant of the path (non-temporal / plain
-loads (gone: measured equal), the LONG variant forced on every shape, a handful of persistent waves, every group on the list, groups dealt from the counter), on the seeded generators and on
+loads (gone: measured equal), the LONG variant forced on every shape, a handful of persistent waves, ), on the seeded generators and on
 key sets that exercise its special cases -- containers of more than 240 points (the lanes that go on from the key array),
 of more than 1 008 (the group is listed), duplicate keys found while walking (listed), the leaf behind the split, empty
 leaves, f64 keys (IEEE division), shards.  Bar: bucket table, error integers, counts AND coefficients bit-identical."""
@@ -17,8 +17,7 @@ VARIANTS = {
     "default": {"RMI_HIP_REGS": "1"},
     "long": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_MAX_AVG": "0", "RMI_HIP_REGS_LONG_MAX_AVG": "100000"},   # k_leaf_regs<K, LONG> for every shape
     "seven_waves": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_GRID": "7"},          # every wave takes many groups, the last ones uneven
-    "all_listed": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_SLOW": "1"},           # k_leaf_lanes_listed does all the work
-    "counter": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_QUEUE": "1", "RMI_HIP_REGS_GRID": "16"},
+    "sixteen_waves": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_GRID": "16"},
     "any_average": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_MAX_AVG": "100000"},  # also where most groups hold long containers
 }
 CASES = [
@@ -47,7 +46,7 @@ def test_regs_variants(monkeypatch, oracle, variant, gen, n, L, root):
     if g is not None and n >= 1024 and n <= (100000 if variant in ("any_average", "long") else 640) * L and not (gen == "books_u64" and n > 208 * L):
         # (every group listed -- by the switch, because the boundary search met duplicates, or because every group met keys whose f64 images
         #  collapse: k_leaf_lanes_listed did the work, reported as 3)
-        assert g.pipeline in ((3, 4) if (variant == "all_listed" or gen.startswith("dups") or gen == "clustered_u64") else (4,))
+        assert g.pipeline in ((3, 4) if (gen.startswith("dups") or gen == "clustered_u64") else (4,))
 
 
 @pytest.mark.parametrize("name", sorted(dg.ADVERSARIAL))

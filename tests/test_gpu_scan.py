@@ -181,23 +181,6 @@ def test_shard_cut_on_a_tile_end(oracle, gen, leaf):
     assert np.array_equal(np.concatenate(errs), o.leaf_err)
 
 
-def test_scan_equals_the_leaf_lane_kernel(monkeypatch):
-    """k_spline_scan against k_leaf_lanes<.., K_LINEAR_SPLINE> (RMI_HIP_SCAN=0) on 20 M keys: every output array the same bytes."""
-    from rmi_amd import train
-    res = {}
-    for scan in ("1", "0"):
-        monkeypatch.setenv("RMI_HIP_SCAN", scan)
-        tr = train.Trainer()
-        tr.generate_keys("dups", np.uint32, 20_000_000)
-        root = tr.fit_root("radix", 1 << 18)
-        g = tr.train_leaves(root, "linear_spline", 1 << 18).materialize()
-        res[scan] = (g.pipeline, g.leaf_starts.copy(), g.rows.copy(), g.leaf_counts.copy(), g.model_max_error, g.model_max_error_idx, g.model_avg_error)
-        tr.close()
-    assert res["1"][0] == 5 and res["0"][0] == 3
-    for a, b in zip(res["1"][1:], res["0"][1:]):
-        assert np.array_equal(a, b)
-
-
 def test_scan_repeated_trainings_lean_and_full(monkeypatch, oracle):
     """The same configuration three times on one context (the second and third launch size the general form's kernel by the first one's list),
     then with RMI_HIP_LEAN=0 (the kernel writes the coefficient / error / count arrays itself instead of leaving them to be filled from the

@@ -191,18 +191,6 @@ def test_onepass_giant_leaf_at_the_special_positions(T, oracle, where, mode, roo
         assert np.array_equal(g.leaf_params[big], o.leaf_params[big])
 
 
-def test_onepass_results_do_not_depend_on_the_wave_count(T, oracle, monkeypatch):
-    """The cut of the key array into per-wave chunks must not show in any integer output."""
-    keys = dg.books_u64(1_500_000)
-    outs = []
-    for waves in ("64", "4096", "100000"):
-        monkeypatch.setenv("RMI_HIP_SIGMA_WAVES", waves)
-        g, o = _run(T, oracle, keys, "linear", 4096, 1)
-        _check(g, o, keys, 1)
-        outs.append(g.last_layer_max_l1s.copy())
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
-
-
 def test_onepass_shards_match_the_oracle(T, oracle):
     """2 and 4 leaf-aligned shards in guarded one-pass mode, run one after the other on one GPU:
     every shard's error integers and counts are the oracle's."""

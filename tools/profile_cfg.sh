@@ -1,12 +1,12 @@
 #!/bin/bash
-# rocprofv3 of ONE configuration (round 5): kernel-trace stats, the PMC passes (each on its own, under `timeout -k`, nothing reads
+# rocprofv3 of ONE configuration (round tag RND, default r06): kernel-trace stats, the PMC passes (each on its own, under `timeout -k`, nothing reads
 # stdin), then FETCH_SIZE / WRITE_SIZE per kernel, calibrated on k_read_bw of the same run and tied to the kernel sources' sha256.
-# usage (GPU box): tools/profile_r05.sh <M|C2|C3|C5|Ms|C4s|D> [dataset] [--no-pmc]
-#   -> gpurun_out/prof_r05/<tag>/{r05_<tag>_kernel_stats.csv, r05_<tag>_summary.txt, traffic_r05_<tag>.json}
+# usage (GPU box): [RND=r06] tools/profile_cfg.sh <M|C2|C3|C5|Ms|C4s|D> [dataset] [--no-pmc]
+#   -> gpurun_out/prof_$RND/<tag>/{$RND_<tag>_kernel_stats.csv, $RND_<tag>_summary.txt, traffic_$RND_<tag>.json}
 set -u
-CFG=$1; DS=${2:--}; NOPMC=${3:-}
+CFG=$1; DS=${2:--}; NOPMC=${3:-}; RND=${RND:-r06}
 TAG=$(echo "$CFG" | tr 'A-Z' 'a-z'); [ "$DS" != "-" ] && TAG=${TAG}_$DS
-R=$PWD; OUT=$R/gpurun_out/prof_r05/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+R=$PWD; OUT=$R/gpurun_out/prof_$RND/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 cd /tmp
 W="python $R/tools/cfg_run.py $CFG $DS"
 RMI_CFG_TRACE=1 RMI_CFG_BW=0 timeout -k 5 200 rocprofv3 --kernel-trace --stats -T -d $OUT/kt -o kt -f csv -- $W 50 < /dev/null > $OUT/kt.log 2>&1
@@ -21,13 +21,13 @@ K="k_read_bw|$INC"
 RMI_CFG_TRACE=1 timeout -k 5 150 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$K" -d $OUT/tf -o p -f csv -- $W 3 < /dev/null > $OUT/tf.log 2>&1
 RMI_CFG_TRACE=1 timeout -k 5 150 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$K" -d $OUT/tw -o p -f csv -- $W 3 < /dev/null > $OUT/tw.log 2>&1
 cd $R
-python tools/summarize_prof.py $OUT > $OUT/r05_${TAG}_summary.txt 2>&1 < /dev/null
-F=$(find $OUT/kt -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" $OUT/r05_${TAG}_kernel_stats.csv
-python tools/traffic_r05_json.py $OUT $CFG $DS > $OUT/traffic_r05_${TAG}.json 2> $OUT/traffic_json.err < /dev/null
-head -24 $OUT/r05_${TAG}_summary.txt
+python tools/summarize_prof.py $OUT > $OUT/${RND}_${TAG}_summary.txt 2>&1 < /dev/null
+F=$(find $OUT/kt -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$F" ] && cp "$F" $OUT/${RND}_${TAG}_kernel_stats.csv
+python tools/traffic_json.py $OUT $CFG $DS > $OUT/traffic_${RND}_${TAG}.json 2> $OUT/traffic_json.err < /dev/null
+head -24 $OUT/${RND}_${TAG}_summary.txt
 python - <<PY
 import json
-j = json.load(open("$OUT/traffic_r05_${TAG}.json"))
+j = json.load(open("$OUT/traffic_${RND}_${TAG}.json"))
 print({k: j[k] for k in ("algorithmic_bytes", "step_hbm_bytes", "traffic_ratio", "read_correction")})
 print({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in j["kernels"].items()})
 PY

@@ -16,7 +16,6 @@ from lanes_check import mk  # noqa: E402
 VARIANTS = {
     "p4 regs": {"RMI_HIP_REGS": "1"},
     "p4 regs, LONG everywhere": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_MAX_AVG": "0", "RMI_HIP_REGS_LONG_MAX_AVG": "100000"},
-    "p4 all listed": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_SLOW": "1"},
     "p4 small grid": {"RMI_HIP_REGS": "1", "RMI_HIP_REGS_GRID": "7"},
 }
 

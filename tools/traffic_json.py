@@ -1,5 +1,5 @@
-"""FETCH_SIZE / WRITE_SIZE CSVs of tools/profile_r05.sh -> one JSON per configuration: bytes per launch and kernel, the step's sum, its
-ratio to the algorithmic bytes.  usage: traffic_r05_json.py <outdir> <cfg> [dataset]"""
+"""FETCH_SIZE / WRITE_SIZE CSVs of tools/profile_cfg.sh -> one JSON per configuration: bytes per launch and kernel, the step's sum, its
+ratio to the algorithmic bytes.  usage: traffic_json.py <outdir> <cfg> [dataset]"""
 import csv
 import glob
 import json
@@ -33,7 +33,7 @@ key_bytes = n * np.dtype(dt).itemsize
 corr = key_bytes / (avg["k_read_bw"]["FETCH_SIZE"] * 1024) if "k_read_bw" in avg and avg["k_read_bw"].get("FETCH_SIZE") else 2.0
 b_alg = key_bytes + 24 * L
 res = {"config": cfg, "dataset": ds or ds0, "keys": n, "leaves": L, "spec": f"{root},{leaf}",
-       "note": "rocprofv3 FETCH_SIZE / WRITE_SIZE (KB) per launch, separate PMC passes (tools/profile_r05.sh); reads scaled by %.3f = the key array's bytes / "
+       "note": "rocprofv3 FETCH_SIZE / WRITE_SIZE (KB) per launch, separate PMC passes (tools/profile_cfg.sh); reads scaled by %.3f = the key array's bytes / "
                "FETCH_SIZE(k_read_bw), the streaming kernel of the same run that reads every key byte exactly once with 16-byte loads per lane (the guide's "
                "gfx950 factor for that width is 2); Infinity-Cache hits are counted like HBM reads; writes as counted" % corr,
        "raw_kb": avg, "read_correction": corr, "sources_sha256": bench.sources_sha256(), "algorithmic_bytes": b_alg, "kernels": {}}
