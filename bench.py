@@ -190,10 +190,10 @@ def parity_against(o, g, what):
         "slope_frac_within_1e-9": float((slope <= 1e-9).mean()) if slope.size else 1.0,
         "intercept_max_abs_diff": float(np.abs(gp[:, 0] - op[:, 0]).max()) if gp.size else 0.0,   # in positions (what a prediction moves by)
         "leaves": int(len(o.leaf_err)),
-        # the model-level aggregates (two_layer.rs:267-287): maximum and its leaf, average error exactly; the f64 sums to 1e-12 (log2) / 1e-9 (l2)
+        # the model-level aggregates (two_layer.rs:267-287): maximum and its leaf, average error exactly; the two f64 sums to 1e-9 (north_star's tolerance for floating point: they run in another order than the reference's, their differences are printed below)
         "aggregates_equal": bool(int(g.model_max_error) == int(o.model_max_error) and int(g.model_max_error_idx) == int(o.model_max_error_idx)
                                  and float(g.model_avg_error) == float(o.model_avg_error)
-                                 and abs(float(g.model_avg_log2_error) - float(o.model_avg_log2_error)) <= 1e-12 * max(1.0, abs(float(o.model_avg_log2_error)))
+                                 and abs(float(g.model_avg_log2_error) - float(o.model_avg_log2_error)) <= 1e-9 * max(1.0, abs(float(o.model_avg_log2_error)))
                                  and abs(float(g.model_avg_l2_error) - float(o.model_avg_l2_error)) <= 1e-9 * max(1.0, abs(float(o.model_avg_l2_error)))),
         # (the two f64 sums are the reference's in leaf order, here per group of 64 leaves and then over the groups: not the same roundings)
         "avg_l2_rel_diff": abs(float(g.model_avg_l2_error) - float(o.model_avg_l2_error)) / max(1e-300, abs(float(o.model_avg_l2_error))),
