@@ -93,6 +93,7 @@ struct rmi_hip_ctx {
   // pipeline 4 (rmi_regs.hip.h): k_leaf_regs -- one read of the keys, a leaf's keys stay in registers between its fit and its error pass --
   // in place of k_leaf_lanes where the leaves are short enough on average; the groups it does not take go through k_leaf_lanes_listed
   bool regs = true;                             // RMI_HIP_REGS=0: k_leaf_lanes for everything
+  bool regs_forced = false;                     // RMI_HIP_REGS=1: k_leaf_regs wherever it applies, whatever the number of groups
   unsigned int regs_grid = 0;                   // persistent waves of k_leaf_regs (0: 4 per CU)
   unsigned int regs_max_avg = 208;              // average keys per leaf above which most groups would not fit (RG_MAXPTS = 240 per container)
   unsigned int regs_long_max_avg = 640;         // ... and up to which k_leaf_regs<K, LONG> takes them (the steps behind the stash through the ring twice); above: k_leaf_lanes
@@ -337,7 +338,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
   { const char* otl = std::getenv("RMI_HIP_OPT_TAIL"); if (otl && *otl) c->opt_tail = std::atoi(otl) != 0; }
   { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
-  { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) c->regs = std::atoi(rg) != 0; }
+  { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) { c->regs = std::atoi(rg) != 0; c->regs_forced = c->regs; } }   // (=1 also overrides the choice by group count)
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN"); if (cm && *cm) c->cubic_margin = std::atoi(cm) != 0; }
   { const char* ln = std::getenv("RMI_HIP_LEAN"); if (ln && *ln) c->lean = std::atoi(ln) != 0; }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN_SCALE"); if (cm && *cm) c->cubic_margin_scale = std::atof(cm); }
@@ -524,7 +525,7 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
     if (arc != RMI_OK) return arc;
     // what the caller has set on the context holds for every training of the batch
     v->fit_mode = c->fit_mode; v->guard_k = c->guard_k; v->profile_level = c->profile_level; v->host_min = c->host_min;
-    v->long_min = c->long_min; v->pipeline = c->pipeline; v->regs = c->regs; v->opt_tail = c->opt_tail;
+    v->long_min = c->long_min; v->pipeline = c->pipeline; v->regs = c->regs; v->regs_forced = c->regs_forced; v->opt_tail = c->opt_tail;
   }
   std::atomic<uint64_t> next{0};
   std::vector<int> lrc(count, RMI_OK);
@@ -1364,6 +1365,13 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         regs_long = n_it > (uint64_t)c->regs_max_avg * L_own;            // long leaves on average: the LONG variant of the kernel
         const unsigned int cap = c->regs_long_max_avg > c->regs_max_avg ? c->regs_long_max_avg : c->regs_max_avg;
         regs_plan = lanes_fused_plan && c->regs && !regs_off && c->pipeline >= 3 && n_it <= (uint64_t)cap * L_own;
+        // Between one and two and a half groups per resident wave (M's shard at 8 GPUs: 2 048 groups on 1 024 waves) k_leaf_regs runs two rounds of a
+        // group each behind its 20 us of start-up, k_leaf_lanes ONE round on twice the waves: measured 0.110 against 0.120 ms at 2 048 groups, equal
+        // at 1 024, 0.186 against 0.177 at 4 096.
+        {
+          const uint64_t resident = 4ull * (uint64_t)c->n_cu;
+          if (!regs_long && !c->regs_forced && c->regs_grid == 0 && wb > resident && 2 * wb <= 5 * resident) regs_plan = false;
+        }
       }
       // a cubic root on pipeline 4: increasing over the resident keys' range as an exact polynomial (here), every leaf's end keys clear
       // their leaf's interval by the rounding bound (k_regs_finalize<K, K_CUBIC>) -- else the per-key verification of k_leaf_lanes
