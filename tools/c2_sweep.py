@@ -6,7 +6,7 @@ import time
 sys.path.insert(0, ".")
 sys.path.insert(0, "tools")
 import numpy as np
-from lanes_check import mk
+from cfg_run import mk
 from rmi_amd import datagen as dg
 
 n, L = 200_000_000, 262_144

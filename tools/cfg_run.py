@@ -37,6 +37,20 @@ CFG = {
 }
 
 
+def mk(env):
+    """a Trainer created under the environment switches `env` (they are read when the context is created)"""
+    _gpu()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    tr = train.Trainer()
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    return tr
+
+
 def setup(cfg, dataset=None):
     _gpu()
     if cfg.startswith("X"):                                  # X<keys>x<leaves>: uniform u64, linear,linear (sweeps over the keys per leaf)

@@ -11,7 +11,7 @@ sys.path.insert(0, ".")
 from rmi_amd import datagen as dg, train  # noqa: E402
 
 sys.path.insert(0, "tools")
-from lanes_check import mk  # noqa: E402
+from cfg_run import mk  # noqa: E402
 
 VARIANTS = {
     "p4 regs": {"RMI_HIP_REGS": "1"},

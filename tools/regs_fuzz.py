@@ -1,7 +1,9 @@
 """Development aid for the GPU box: random configurations through pipeline 4 against the oracle, bit for bit (leaf boundaries,
 coefficients, error integers, counts, the integer aggregates) -- key sets of every generator, 2 000 .. 3 000 000 keys, 6 .. 300 keys
-per leaf on average (the written-out blocks, the rolled loop, the far lanes, the listed groups), a few seconds each.
-usage: python tools/regs_fuzz.py [seconds [seed]]"""
+per leaf on average (the written-out blocks, the rolled loop, the far lanes, the listed groups), a few seconds each.  With `long` as third
+argument: 150 .. 1 000 keys per leaf (k_leaf_regs<K, LONG>: the walk behind the stash, the second trip through the ring, the tail that is
+still in the ring, containers beyond 1 008 points listed), half of the configurations with LONG forced on every shape.
+usage: python tools/regs_fuzz.py [seconds [seed [long]]]"""
 import sys
 import time
 
@@ -11,7 +13,7 @@ sys.path.insert(0, ".")
 from rmi_amd import datagen as dg, train  # noqa: E402
 
 sys.path.insert(0, "tools")
-from lanes_check import mk  # noqa: E402
+from cfg_run import mk  # noqa: E402
 
 
 def main():
@@ -20,17 +22,21 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260927)
     gens = [g for g in dg.GENERATORS if g.endswith("u64") or g.endswith("f64")]
+    long_mode = len(sys.argv) > 3 and sys.argv[3] == "long"
     t0, done, bad, p4 = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
         gen = gens[int(rng.integers(len(gens)))]
         n = int(10 ** rng.uniform(3.3, 6.48))
-        per = float(10 ** rng.uniform(0.8, 2.48))
+        per = float(10 ** (rng.uniform(2.18, 3.0) if long_mode else rng.uniform(0.8, 2.48)))
         L = max(2, int(n / per))
         env = {"RMI_HIP_REGS": "1"}
         if rng.random() < 0.3:
             env["RMI_HIP_REGS_GRID"] = str(int(rng.integers(1, 40)))
-        if rng.random() < 0.3:
+        if rng.random() < 0.3 and not long_mode:
             env["RMI_HIP_REGS_MAX_AVG"] = "100000"
+        if long_mode and rng.random() < 0.5:
+            env["RMI_HIP_REGS_MAX_AVG"] = "0"
+            env["RMI_HIP_REGS_LONG_MAX_AVG"] = "100000"
         keys = dg.GENERATORS[gen](n)
         tr = mk(env)
         tr.set_keys(keys)
