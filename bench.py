@@ -311,6 +311,25 @@ def side_configs(T, tr_m, device, with_oracle):
             t5.close()
         except Exception as ex:
             res[f"C5 {ds}"] = {"error": str(ex)}
+    # 4-byte keys with `linear` leaves (src/load.rs:47-69 `*_uint32` files): the register kernel at TWO waves per SIMD (k_leaf_regs<K, 2>: raw keys stashed)
+    try:
+        t4 = T.Trainer(device=device)
+        t4.generate_keys("uniform", np.uint32, 400_000_000)
+        L = 1 << 21
+        root = t4.fit_root("linear", L)
+        e, r = run(t4, root, 0, L, 0, 20, 400_000_000, 4)
+        if with_oracle:
+            from oracle import binding as oracle
+            t0 = time.perf_counter()
+            o = oracle.train_two_layer("linear", "linear", t4.download_keys(), L, threads=2)
+            e["parity_check"] = parity_against(o, r.materialize(), "400M u32 linear,linear 2^21 at full size: every leaf")
+            e["parity_check"]["root_equal"] = bool(tuple(root.p) == tuple(o.root.p))
+            e["parity_check"]["oracle_seconds"] = time.perf_counter() - t0
+            del o
+        res["U32 linear,linear 2^21 on 400M u32 (uniform)"] = {"exact": with_traffic(e, "u32")}
+        t4.close()
+    except Exception as ex:
+        res["U32"] = {"error": str(ex)}
     # C2: books-shaped 200M (heavy-tailed: one leaf of ~2.5 M keys), 262144 leaves, every mode
     try:
         t2 = T.Trainer(device=device)

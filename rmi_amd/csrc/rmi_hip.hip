@@ -93,6 +93,8 @@ struct rmi_hip_ctx {
   // pipeline 4 (rmi_regs.hip.h): k_leaf_regs -- one read of the keys, a leaf's keys stay in registers between its fit and its error pass --
   // in place of k_leaf_lanes where the leaves are short enough on average; the groups it does not take go through k_leaf_lanes_listed
   bool regs = true;                             // RMI_HIP_REGS=0: k_leaf_lanes for everything
+  int regs_u32 = 2;                             // 4-byte keys through k_leaf_regs: 2 = two waves per SIMD with the raw keys stashed (k_leaf_regs<K, 2>), 1 = the
+                                                // one-wave kernel in half-line panels, 0 = k_leaf_lanes (RMI_HIP_REGS_U32)
   bool regs_forced = false;                     // RMI_HIP_REGS=1: k_leaf_regs wherever it applies, whatever the number of groups
   unsigned int regs_grid = 0;                   // persistent waves of k_leaf_regs (0: 4 per CU)
   unsigned int regs_max_avg = 208;              // average keys per leaf above which most groups would not fit (RG_MAXPTS = 240 per container)
@@ -339,6 +341,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   { const char* otl = std::getenv("RMI_HIP_OPT_TAIL"); if (otl && *otl) c->opt_tail = std::atoi(otl) != 0; }
   { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
   { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) { c->regs = std::atoi(rg) != 0; c->regs_forced = c->regs; } }   // (=1 also overrides the choice by group count)
+  { const char* ru = std::getenv("RMI_HIP_REGS_U32"); if (ru && *ru) c->regs_u32 = std::atoi(ru); }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN"); if (cm && *cm) c->cubic_margin = std::atoi(cm) != 0; }
   { const char* ln = std::getenv("RMI_HIP_LEAN"); if (ln && *ln) c->lean = std::atoi(ln) != 0; }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN_SCALE"); if (cm && *cm) c->cubic_margin_scale = std::atof(cm); }
@@ -525,7 +528,7 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
     if (arc != RMI_OK) return arc;
     // what the caller has set on the context holds for every training of the batch
     v->fit_mode = c->fit_mode; v->guard_k = c->guard_k; v->profile_level = c->profile_level; v->host_min = c->host_min;
-    v->long_min = c->long_min; v->pipeline = c->pipeline; v->regs = c->regs; v->regs_forced = c->regs_forced; v->opt_tail = c->opt_tail;
+    v->long_min = c->long_min; v->pipeline = c->pipeline; v->regs = c->regs; v->regs_forced = c->regs_forced; v->regs_u32 = c->regs_u32; v->opt_tail = c->opt_tail;
   }
   std::atomic<uint64_t> next{0};
   std::vector<int> lrc(count, RMI_OK);
@@ -1312,7 +1315,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       const bool optimistic = lanes_fused_plan && c->opt_tail && !c->stream_mode;
       if constexpr (ROOT == K_LINEAR || ROOT == K_RADIX || ROOT == K_CUBIC) {
         if (lanes_search_plan) {
-          const uint64_t sb = (L_own + LS_BLOCK - 1) / LS_BLOCK;
+          const uint64_t sb = (L_own + (uint64_t)LS_BLOCK * LS_ILP - 1) / ((uint64_t)LS_BLOCK * LS_ILP);
           double* smp = c->d_lntab + 3 * LN_TMAX;                       // 2 (LS_SAMPLES + 1) doubles behind the step tables
           LaneInit li; std::memset(&li, 0, sizeof li);
           if (init_folded) {
@@ -1320,7 +1323,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
             li.list_cnt = c->d_flist_cnt; li.n_list_cnt = 2 * SG_REGIONS + 8; li.tickets = c->d_tickets; li.n_tickets = 3;
           }
           hipLaunchKernelGGL((k_leaf_samples<ROOT, K>), dim3((LS_SAMPLES + 256) / 256), dim3(256), 0, s, keys, sp, rp, smp, li);
-          hipLaunchKernelGGL((k_leaf_search<ROOT, K>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state, (const double*)smp);
+          hipLaunchKernelGGL((k_leaf_search<ROOT, K, LS_ILP>), dim3((unsigned)sb), dim3(LS_BLOCK), 0, s, keys, sp, rp, leaf_start, c->d_state, (const double*)smp);
           searched = true;
         }
       }
@@ -1358,13 +1361,13 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // pipeline 4's conditions besides the root's: 8-byte keys, linear leaves, leaves short enough on average that most groups of 64 qualify,
       // not a key set on which k_leaf_regs listed most groups last time
       bool regs_plan = false, regs_long = false;
-      if constexpr (LEAF == K_LINEAR && sizeof(K) == 8) {
+      if constexpr (LEAF == K_LINEAR) {
         bool regs_off = false;
         if (c->regs_off_epoch == c->keys_epoch)
           for (int h = 0; h < c->regs_off_n && h < 8; h++) regs_off = regs_off || c->regs_off_L[h] == L_own;
         regs_long = n_it > (uint64_t)c->regs_max_avg * L_own;            // long leaves on average: the LONG variant of the kernel
         const unsigned int cap = c->regs_long_max_avg > c->regs_max_avg ? c->regs_long_max_avg : c->regs_max_avg;
-        regs_plan = lanes_fused_plan && c->regs && !regs_off && c->pipeline >= 3 && n_it <= (uint64_t)cap * L_own;
+        regs_plan = lanes_fused_plan && c->regs && !regs_off && c->pipeline >= 3 && n_it <= (uint64_t)cap * L_own && (sizeof(K) == 8 || c->regs_u32);
         // Between one and two and a half groups per resident wave (M's shard at 8 GPUs: 2 048 groups on 1 024 waves) k_leaf_regs runs two rounds of a
         // group each behind its 20 us of start-up, k_leaf_lanes ONE round on twice the waves: measured 0.110 against 0.120 ms at 2 048 groups, equal
         // at 1 024, 0.186 against 0.177 at 4 096.
@@ -1376,7 +1379,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // a cubic root on pipeline 4: increasing over the resident keys' range as an exact polynomial (here), every leaf's end keys clear
       // their leaf's interval by the rounding bound (k_regs_finalize<K, K_CUBIC>) -- else the per-key verification of k_leaf_lanes
       bool cubic_margin = false;
-      if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR && sizeof(K) == 8) {
+      if constexpr (ROOT == K_CUBIC && LEAF == K_LINEAR) {
         if (searched && regs_plan && c->cubic_margin) {
           if (c->edgef_epoch != c->keys_epoch) {
             K k0{}, k1{};
@@ -1397,7 +1400,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       }
       // pipeline 4: one read of the keys (8-byte keys, linear leaves, leaves short enough on average that most groups of 64 qualify)
       bool regs = false;
-      if constexpr (LEAF == K_LINEAR && sizeof(K) == 8) {
+      if constexpr (LEAF == K_LINEAR) {
         // (a key set on which k_leaf_regs listed most groups -- duplicate-heavy keys: every group meets a duplicate -- is remembered, like
         //  the one-pass modes' hint: the next trainings of it with that many leaves go straight to k_leaf_lanes, 0.80 against 2.25 ms)
         regs = !verify && lanes_fused && regs_plan;
@@ -1413,9 +1416,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
             c->slow_cap = wb;
           }
           HIPCHK(c, hipGetLastError());
-          unsigned int grid = c->regs_grid ? c->regs_grid : 4u * (unsigned int)c->n_cu;
+          const bool w2 = sizeof(K) == 4 && c->regs_u32 >= 2;           // two waves per SIMD
+          unsigned int grid = c->regs_grid ? c->regs_grid : (w2 ? 8u : 4u) * (unsigned int)c->n_cu;
           if ((uint64_t)grid > wb) grid = (unsigned int)wb;
-          if (regs_long)
+          if constexpr (sizeof(K) == 4) {
+            if (w2)
+              hipLaunchKernelGGL((k_leaf_regs<K, 2>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
+                                 L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
+          }
+          if (w2) {}
+          else if (regs_long)
             hipLaunchKernelGGL((k_leaf_regs<K, 1>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
                                L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
           else

@@ -75,7 +75,11 @@ constexpr int LN_TMAX = LN_LONG_MAX + 64;   // entries of the reciprocal table
 #ifndef RMI_LS_BLOCK
 #define RMI_LS_BLOCK 512          // (128: 59.8 us, 256: 50.3, 512: 48.0, 1024: 48.1 for 2^20 leaves: the table copy per block)
 #endif
-constexpr int LS_BLOCK = RMI_LS_BLOCK;   // leaves per block of k_leaf_search
+constexpr int LS_BLOCK = RMI_LS_BLOCK;   // threads per block of k_leaf_search
+#ifndef RMI_LS_ILP
+#define RMI_LS_ILP 1           // (2^20 leaves, block 512: 39.7 / 44.9 / 51.4 us with 1 / 2 / 4 -- the probes are bound by scattered line requests, not by their latency)
+#endif
+constexpr int LS_ILP = RMI_LS_ILP;       // leaves per thread of k_leaf_search: probe chains in flight per lane
 
 // RN(1 / k) for the running count k of the lockstep walk: rtab[i] = 1 / (i + 1).  Wave-uniform, read through the
 // scalar cache in two 64-byte loads per panel (SGPR operands of the quotient: no vector instruction, no VGPR).
@@ -141,12 +145,16 @@ __global__ void __launch_bounds__(256) k_leaf_samples(const K* __restrict__ keys
   smp[LS_SAMPLES + 1 + t] = ls_root_value<ROOT, K>(r, k);
 }
 
-template <int ROOT, typename K>
+// ILP leaves per thread (leaves j, j + LS_BLOCK, ... of the block's stretch), their probe chains interleaved: the kernel is bound by the
+// latency of a chain of ~5 dependent scattered loads, so a thread keeps ILP of them in flight -- a search is a little state machine
+// (`ph`: what the probe in flight is, `q`: where), all leaves of a thread issue their next probe back to back and then consume them.
+template <int ROOT, typename K, int ILP>
 __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ keys, Span sp, RootP r,
                                                           unsigned long long* __restrict__ leaf_start,
                                                           DevState* __restrict__ st, const double* __restrict__ smp) {
+  typedef typename LnBits<K>::type BT;
+  typedef BT vec_t __attribute__((ext_vector_type(2), aligned(sizeof(K))));
   const double Lm1f = (double)(r.L - 1);
-  const uint64_t j = sp.leaf_lo + (uint64_t)blockIdx.x * LS_BLOCK + threadIdx.x;
   const uint64_t A = sp.it_lo, Bn = sp.it_hi;
   auto tgt = [&](uint64_t i) -> double { bool oob; return root_target_f<ROOT, K>(r, Lm1f, keys[i], oob); };
   // the sample table into LDS (16 KB: the occupancy stays at 8 waves per SIMD): the bracket search is 11 dependent reads,
@@ -154,97 +162,108 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
   __shared__ double t_tgt[LS_SAMPLES + 1], t_val[LS_SAMPLES + 1];
   for (int t = threadIdx.x; t <= LS_SAMPLES; t += LS_BLOCK) { t_tgt[t] = smp[t]; t_val[t] = smp[LS_SAMPLES + 1 + t]; }
   __syncthreads();
-  bool dup_seen = false;                                             // a probe of this leaf held two equal keys
-  if (j < sp.leaf_hi) {
-    const double jf = (double)j;
-    uint64_t lo = A, hi = Bn;                                        // the answer lies in [lo, hi]
-    double pv = 0.0;                                                 // unfloored root value of the first key of the last probe
-    // pair probe at i (lo <= i < hi): narrows [lo, hi] by the keys i and i + 1
-    auto probe = [&](uint64_t i) {
-      typedef typename LnBits<K>::type BT;
-      K k0, k1;
-      if (i + 1 < sp.rd_hi) {
-        typedef BT vec_t __attribute__((ext_vector_type(2), aligned(sizeof(K))));
-        const vec_t v = *reinterpret_cast<const vec_t*>(keys + i);
-        k0 = bits_to_key<K>(v.x); k1 = bits_to_key<K>(v.y);
-        dup_seen = dup_seen || (k0 == k1);
-      } else { k0 = keys[i]; k1 = k0; }
+  enum { DONE = 0, P1, P2, FIRST, UP, DOWN, BISECT };
+  // one search: the answer lies in [lo, hi]; `q` = index of the pair probe in flight; `slope` = keys per unit of root value;
+  // (v1, q1) = unfloored root value and place of the first probe; `d` = gallop step; `mark` = the bound the gallop moves, before the probe
+  struct Search { uint64_t lo, hi, q, q1, mark; double jf, slope, v1; unsigned int d; int ph; };
+  Search s[ILP];
+  bool dup_seen[ILP];                                                // a probe of this leaf held two equal keys
+  // the pair (g - 1, g) around a guess g of the answer, kept inside the bracket
+  auto pair_at = [&](const Search& z, double gf) -> uint64_t {
+    uint64_t g = gf >= 1.0 ? (gf < 1.8e19 ? (uint64_t)gf - 1 : ~0ull - 1) : 0;
+    if (g < z.lo) g = z.lo;
+    if (g >= z.hi) g = z.hi - 1;
+    return g;
+  };
+  // the next probe of a gallop or of the bisection behind it (lo < hi)
+  auto plan = [&](Search& z) {
+    if (z.ph == UP) {
+      const uint64_t q = z.lo + z.d - 1;
+      if (q >= z.hi) z.ph = BISECT; else { z.q = q; z.mark = z.lo; }
+    } else if (z.ph == DOWN) {
+      if (z.hi - z.lo <= z.d) z.ph = BISECT; else { z.q = z.hi - z.d; z.mark = z.hi; }
+    }
+    if (z.ph == BISECT) z.q = z.lo + ((z.hi - z.lo) >> 1);
+  };
+#pragma unroll
+  for (int u = 0; u < ILP; u++) {
+    Search& z = s[u];
+    const uint64_t j = sp.leaf_lo + ((uint64_t)blockIdx.x * ILP + (uint64_t)u) * LS_BLOCK + threadIdx.x;
+    dup_seen[u] = false;
+    z.jf = (double)j; z.lo = A; z.hi = Bn; z.ph = DONE; z.q = A; z.q1 = 0; z.mark = 0; z.slope = 0.0; z.v1 = 0.0; z.d = 2u;
+    if (!(j < sp.leaf_hi)) { z.hi = z.lo; continue; }
+    if (!(Bn > A)) { z.hi = z.lo; continue; }
+    // first sample whose target is >= j
+    int a = 0, b = LS_SAMPLES + 1;
+    while (a < b) { const int m = (a + b) >> 1; if (t_tgt[m] < z.jf) a = m + 1; else b = m; }
+    if (a == 0) z.hi = z.lo;                                         // the launch's first key is already in leaf j or behind it
+    else if (a > LS_SAMPLES) z.lo = z.hi;                            // even the last key is below: no key reaches leaf j
+    else {
+      const uint64_t i1 = ls_sample_index(A, Bn, a - 1), i2 = ls_sample_index(A, Bn, a);
+      z.lo = i1 + 1; z.hi = i2;                                      // key i1 is below, key i2 is not
+      // Interpolation on the unfloored values: from the table (off by ~sqrt(bracket) / 2 keys where the keys are locally
+      // uniform), then two secant steps from the values the probes see themselves (a few keys, then ~1), then gallop and
+      // bisect from there.  Only the comparisons of exact targets narrow [lo, hi]: the guesses place the probes.
+      const double f1 = t_val[a - 1], f2 = t_val[a];
+      z.slope = (f2 > f1) ? (double)(i2 - i1) / (f2 - f1) : 0.0;
+      const double g1 = (f2 > f1) ? (double)i1 + (z.jf - f1) * z.slope : (double)i1 + 0.5 * (double)(i2 - i1);
+      if (z.lo < z.hi) { z.q = pair_at(z, g1); z.ph = P1; }
+    }
+  }
+  for (;;) {
+    bool any = false;
+    K k0[ILP], k1[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+      k0[u] = KeyTraits<K>::zero_value(); k1[u] = k0[u];
+      if (s[u].ph != DONE) {
+        const uint64_t i = s[u].q;
+        if (i + 1 < sp.rd_hi) {
+          const vec_t v = *reinterpret_cast<const vec_t*>(keys + i);
+          k0[u] = bits_to_key<K>(v.x); k1[u] = bits_to_key<K>(v.y);
+        } else { k0[u] = keys[i]; k1[u] = k0[u]; }
+        any = true;
+      }
+    }
+    if (!any) break;
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+      Search& z = s[u];
+      if (z.ph == DONE) continue;
+      // the pair probe at i (lo <= i < hi) narrows [lo, hi] by the keys i and i + 1
+      const uint64_t i = z.q;
+      if (i + 1 < sp.rd_hi) dup_seen[u] = dup_seen[u] || (k0[u] == k1[u]);
       bool oob;
-      const bool b0 = root_target_f<ROOT, K>(r, Lm1f, k0, oob) < jf;
-      const bool b1 = root_target_f<ROOT, K>(r, Lm1f, k1, oob) < jf;
-      pv = ls_root_value<ROOT, K>(r, k0);
-      if (!b0) hi = i;
-      else if (!b1 || i + 1 >= hi) { lo = i + 1; if (!b1) hi = i + 1; }
-      else lo = i + 2 < hi ? i + 2 : hi;
-    };
-    // the pair (g - 1, g) around a guess g of the answer, kept inside the bracket
-    auto pair_at = [&](double gf) -> uint64_t {
-      uint64_t g = gf >= 1.0 ? (gf < 1.8e19 ? (uint64_t)gf - 1 : ~0ull - 1) : 0;
-      if (g < lo) g = lo;
-      if (g >= hi) g = hi - 1;
-      return g;
-    };
-    auto search_from = [&](uint64_t g, uint64_t d) {                 // first probe at g, first gallop step d
-      if (!(lo < hi)) return;
-      if (g < lo) g = lo;
-      if (g >= hi) g = hi - 1;
-      probe(g);
-      if (lo < hi) {
-        if (lo > g) {                                                // the keys at the guess are below: gallop upwards
-          while (lo < hi) {
-            const uint64_t q = lo + d - 1;
-            if (q >= hi) break;
-            const uint64_t before = lo;
-            probe(q);
-            if (!(lo > q && lo > before)) break;                     // not "both below": bracketed
-            d <<= 1;
-          }
-        } else {                                                     // downwards
-          while (lo < hi) {
-            if (hi - lo <= d) break;
-            const uint64_t q = hi - d;
-            const uint64_t before = hi;
-            probe(q);
-            if (!(hi == q && hi < before)) break;                    // not "none below"
-            d <<= 1;
-          }
-        }
-        while (lo < hi) probe(lo + ((hi - lo) >> 1));
+      const bool b0 = root_target_f<ROOT, K>(r, Lm1f, k0[u], oob) < z.jf;
+      const bool b1 = root_target_f<ROOT, K>(r, Lm1f, k1[u], oob) < z.jf;
+      if (!b0) z.hi = i;
+      else if (!b1 || i + 1 >= z.hi) { z.lo = i + 1; if (!b1) z.hi = i + 1; }
+      else z.lo = i + 2 < z.hi ? i + 2 : z.hi;
+      if (!(z.lo < z.hi)) { z.ph = DONE; continue; }
+      if (z.ph == P1) {
+        if (z.slope > 0.0) {
+          z.v1 = ls_root_value<ROOT, K>(r, k0[u]); z.q1 = i;
+          z.q = pair_at(z, (double)i + (z.jf - z.v1) * z.slope + 1.0);
+          z.ph = P2;
+        } else { z.q = z.lo + ((z.hi - z.lo) >> 1); z.ph = FIRST; }
+      } else if (z.ph == P2) {
+        const double v2 = ls_root_value<ROOT, K>(r, k0[u]);
+        const double s2 = (i != z.q1 && v2 != z.v1) ? ((double)i - (double)z.q1) / (v2 - z.v1) : z.slope;
+        z.q = pair_at(z, (double)i + (z.jf - v2) * ((s2 > 0.0 && s2 < 64.0 * z.slope) ? s2 : z.slope) + 1.0);
+        z.ph = FIRST;
+      } else {
+        if (z.ph == FIRST) z.ph = z.lo > i ? UP : DOWN;              // the keys at the guess are below: gallop upwards, else downwards
+        else if (z.ph == UP) { if (z.lo > i && z.lo > z.mark) z.d <<= 1; else z.ph = BISECT; }       // "both below": on; else bracketed
+        else if (z.ph == DOWN) { if (z.hi == i && z.hi < z.mark) z.d <<= 1; else z.ph = BISECT; }    // "none below": on
+        plan(z);
       }
-    };
-    if (Bn > A) {
-      // first sample whose target is >= j
-      int a = 0, b = LS_SAMPLES + 1;
-      while (a < b) { const int m = (a + b) >> 1; if (t_tgt[m] < jf) a = m + 1; else b = m; }
-      if (a == 0) hi = lo;                                           // the launch's first key is already in leaf j or behind it
-      else if (a > LS_SAMPLES) lo = hi;                              // even the last key is below: no key reaches leaf j
-      else {
-        const uint64_t i1 = ls_sample_index(A, Bn, a - 1), i2 = ls_sample_index(A, Bn, a);
-        lo = i1 + 1; hi = i2;                                        // key i1 is below, key i2 is not
-        // Interpolation on the unfloored values: from the table (off by ~sqrt(bracket) / 2 keys where the keys are locally
-        // uniform), then two secant steps from the values the probes see themselves (a few keys, then ~1), then gallop and
-        // bisect from there.  Only the comparisons of exact targets narrow [lo, hi]: the guesses place the probes.
-        const double f1 = t_val[a - 1], f2 = t_val[a];
-        const double slope = (f2 > f1) ? (double)(i2 - i1) / (f2 - f1) : 0.0;      // keys per unit of root value
-        double g1 = (f2 > f1) ? (double)i1 + (jf - f1) * slope : (double)i1 + 0.5 * (double)(i2 - i1);
-        if (lo < hi) {
-          const uint64_t q1 = pair_at(g1);
-          probe(q1);
-          if (lo < hi && slope > 0.0) {
-            const double v1 = pv;
-            const double g2 = (double)q1 + (jf - v1) * slope;
-            const uint64_t q2 = pair_at(g2 + 1.0);
-            probe(q2);
-            if (lo < hi) {
-              const double v2 = pv;
-              const double s2 = (q2 != q1 && v2 != v1) ? ((double)q2 - (double)q1) / (v2 - v1) : slope;
-              const double g3 = (double)q2 + (jf - v2) * ((s2 > 0.0 && s2 < 64.0 * slope) ? s2 : slope);
-              search_from(pair_at(g3 + 1.0), 2);
-            }
-          } else search_from(lo + ((hi - lo) >> 1), 2);
-        }
-      }
-    } else hi = lo;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < ILP; u++) {
+    const uint64_t j = sp.leaf_lo + ((uint64_t)blockIdx.x * ILP + (uint64_t)u) * LS_BLOCK + threadIdx.x;
+    if (!(j < sp.leaf_hi)) continue;
+    const uint64_t lo = s[u].lo;
     leaf_start[j] = (unsigned long long)lo;
     if (j == r.L / 2 && lo < sp.it_hi) {                              // two_layer.rs:131-136, 152-156
       if (lo == 0) atomicOr(&st->err_flags, EF_DEGENERATE_SPLIT);     // split_idx == 0 -> :27
@@ -256,9 +275,11 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_search(const K* __restrict__ 
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && sp.n - 1 >= sp.it_lo && sp.n - 1 < sp.it_hi) st->last_target = (unsigned long long)tgt(sp.n - 1);
-  // DevState::regs_dups from every 16th block (a sample: thousands of additions to one counter serialise at ~26 ns each)
-  if ((blockIdx.x & 15u) == 0u) {
-    const int nd = __syncthreads_count(dup_seen ? 1 : 0);
+  // DevState::regs_dups from every 16th stretch of LS_BLOCK leaves (a sample: thousands of additions to one counter serialise at ~26 ns each)
+#pragma unroll
+  for (int u = 0; u < ILP; u++) {
+    if (((blockIdx.x * (unsigned int)ILP + (unsigned int)u) & 15u) != 0u) continue;
+    const int nd = __syncthreads_count(dup_seen[u] ? 1 : 0);
     if (threadIdx.x == 0 && nd > 0) atomicAdd(&st->regs_dups, (unsigned long long)nd);
   }
 }

@@ -46,6 +46,10 @@ constexpr int RG_ROW = 16;                          // steps (keys) per row and 
 constexpr int RG_RING = 4;                          // panels in the LDS ring
 constexpr int RG_PANEL_B = 64 * RG_ROW * 8;         // bytes of a panel: 64 rows x 128 B
 constexpr int RG_STASH = RG_STASH_N;                       // steps whose keys stay in registers
+#ifndef RG_STASH2_N
+#define RG_STASH2_N 160          // (U32, 400 M keys in 2^21 leaves: 128: 535 us, 160: 510 us, 176: 548 us with 21 spilled registers; one wave per SIMD: 655 us)
+#endif
+constexpr int RG_STASH2 = RG_STASH2_N;                     // ... of k_leaf_regs<K, 2> (two waves per SIMD: half the registers)
 constexpr int RG_MAXPTS = RG_STASH_N + 48;                      // longest container whose steps behind the stash are still in the ring at the end
 constexpr int RG_FARPTS = 1008;                                 // longest container of a group that takes the register path at all
 constexpr int RG_NBLK = RG_MAXPTS / RG_ROW;         // 15 blocks of 16 steps
@@ -121,6 +125,20 @@ __device__ __forceinline__ void rg_dma_panel(const void* kb, unsigned int lds, c
   unsigned int keep;
   if constexpr (NT) RG_DMA8(" nt"); else RG_DMA8("");
 }
+// 4-byte keys: a panel is 64 rows of 64 bytes (16 keys: HALF a line; the other half comes with the next panel and hits the L2 -- plain loads,
+// the non-temporal hint would have evicted it): 4 instructions, instruction i = rows 4 g + i of the 16 groups g of 4 loader lanes
+__device__ __forceinline__ void rg_dma_panel4(const void* kb, unsigned int lds, const unsigned int (&off)[4]) {
+  unsigned int keep;
+  asm volatile("s_mov_b32 %[keep], m0\n\t"
+               "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[kb]\n\t"
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[kb]\n\t"
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o2], %[kb]\n\t"
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o3], %[kb]\n\t"
+               "s_mov_b32 m0, %[keep]"
+               : [keep] "=&s"(keep)
+               : [lds] "s"(lds), [kb] "s"(kb), [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3])
+               : "memory", "scc");
+}
 // one dword per lane to LDS (M0 + 4 lane): the single keys and the leaf boundaries a group needs late are parked in LDS this way --
 // no register holds them meanwhile and, more important, no wait of the compiler's stands behind a panel request for them
 __device__ __forceinline__ void rg_dma_dword(const void* base, unsigned int lds, unsigned int voff) {
@@ -165,6 +183,9 @@ template <int B> __device__ __forceinline__ unsigned int rg_block_index(std::int
 template <typename K> __device__ __forceinline__ unsigned long long key_to_bits_rg(K k) {
   if constexpr (std::is_same<K, double>::value) return (unsigned long long)__double_as_longlong(k); else return (unsigned long long)k;
 }
+template <typename K> __device__ __forceinline__ double rg_as_float(unsigned int v) { return (double)v; }   // 4-byte keys: one exact conversion
+__device__ __forceinline__ unsigned int rg_raw_lo(uint2 v) { return v.x; }
+__device__ __forceinline__ unsigned int rg_raw_lo(unsigned int v) { return v; }
 template <typename K> __device__ __forceinline__ double rg_as_float(uint2 v) {
   if constexpr (std::is_same<K, double>::value) return __hiloint2double((int)v.y, (int)v.x);
   else return __builtin_fma((double)v.y, 4294967296.0, (double)v.x);
@@ -181,8 +202,11 @@ __device__ __forceinline__ double rg_fract(double v) { return __builtin_amdgcn_f
 // leaf 1.5).  Why not everything on chip: 65 536 chains must be in flight to fill the device's 1 024 SIMDs with lockstep waves, and
 // their keys between fit and error pass are 65 536 x n x 8 B -- 200 MB at n = 381, more than every register and LDS byte of the chip
 // (172 MB); above ~330 keys a leaf NO exact one-read design exists at full lane efficiency.
+// LONG == 2 (4-byte keys only): TWO waves per SIMD, 256 registers each -- the stash holds the RAW keys (one register a step; the conversion
+// to the double is exact and is made again in the error pass), RG_STASH2 = 128 steps of them, and everything behind goes the LONG way.  The
+// experiment behind it: a lone wave issues ~57 % of the cycles (the recurrence's dependent chain); a second wave on the SIMD fills the gaps.
 template <typename K, int LONG>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_leaf_regs(const K* __restrict__ keys, Span sp,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG == 2 ? 2 : 1, LONG == 2 ? 2 : 1))) k_leaf_regs(const K* __restrict__ keys, Span sp,
                                                    const unsigned long long* __restrict__ leaf_start,
                                                    DevState* __restrict__ st, double* __restrict__ params,
                                                    const double* __restrict__ rtab, const double* __restrict__ rtab4, SgList fl, unsigned int long_min,
@@ -196,7 +220,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                                                    unsigned long long* __restrict__ prof,
                                                    K* __restrict__ bnext, K* __restrict__ bprev, unsigned char* __restrict__ tile_slow,
                                                    unsigned int* __restrict__ tile_queue) {
-  static_assert(sizeof(K) == 8, "8-byte keys");
+  static_assert(sizeof(K) == 8 || sizeof(K) == 4, "8-byte keys, or 4-byte keys in half-line panels");
+  constexpr unsigned int KB = (unsigned int)sizeof(K);                 // bytes of a key
+  constexpr unsigned int ROWB = (unsigned int)RG_ROW * KB;             // bytes of a row's share of a panel: a 128-byte line, or half of one
+  constexpr unsigned int PANEL_B = 64u * ROWB;                         // bytes of a panel: 8 KB / 4 KB
+  using RAW = typename std::conditional<sizeof(K) == 8, uint2, unsigned int>::type;   // a key as it lies in the ring
+  constexpr int NI = KB == 8u ? 8 : 4;                                 // LDS-DMA instructions of a panel (the hand-written waits count them)
   constexpr bool NT = true;                                          // non-temporal LDS-DMA loads (plain ones measured equal: the switch is gone)
   constexpr unsigned int WALK = LONG ? (unsigned int)RG_FARPTS : (unsigned int)RG_MAXPTS;   // steps of a container that come through the ring
   constexpr bool DIVK = !UseRecipTable<K>::value;                     // f64 keys: plain IEEE division
@@ -204,14 +233,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // The error pass over the stash then works on x~ with |x~ - x| <= 2^-23.9 (x - x0) and is CERTIFIED per leaf (rg_stash_err below): a
   // leaf one of whose predictions lies within the bound of an integer is flagged and its error pass redone from the key array by
   // k_regs_finalize (about 2 % of the leaves at 381 keys a leaf); every other leaf's maximum is the exact one.
-  constexpr bool F32 = LONG && !DIVK && (RG_LONG_F32 != 0);
-  using XT = typename std::conditional<F32, float, double>::type;
-  constexpr int STASH = F32 ? 2 * RG_STASH : RG_STASH;                // steps whose keys stay in registers
+  constexpr bool W2 = LONG == 2;                                      // two waves per SIMD: raw 4-byte keys in the stash
+  static_assert(!W2 || sizeof(K) == 4, "the two-wave variant stashes raw 4-byte keys");
+  constexpr bool F32 = LONG && !W2 && !DIVK && (RG_LONG_F32 != 0);
+  using XT = typename std::conditional<W2, unsigned int, typename std::conditional<F32, float, double>::type>::type;
+  constexpr int STASH = W2 ? RG_STASH2 : (F32 ? 2 * RG_STASH : RG_STASH);   // steps whose keys stay in registers
   constexpr int SBLK = STASH / RG_ROW;
-  static_assert(SBLK % 4 == 0, "groups of four banks");
-  __shared__ __attribute__((aligned(1024))) unsigned char ringc[RG_RING * RG_PANEL_B];   // 32 KB: 4 waves per CU
+  static_assert(STASH % RG_ROW == 0 && SBLK > RG_PRE, "whole banks");
+  __shared__ __attribute__((aligned(1024))) unsigned char ringc[RG_RING * 64 * RG_ROW * sizeof(K)];   // 32 KB (16 KB for 4-byte keys): 4 waves per CU
   __shared__ unsigned int park[10][64];                              // k_hi, k_lom1, k_next, k_prev (two words each), next group's s, e
-  static_assert(RG_RING * RG_PANEL_B >= 64 * LnGeom<K>::STRIDE * 8, "the ring holds the LDS image of k_leaf_lanes");
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   const unsigned int ring_lds = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(lds_byte*)ringc);
   const unsigned int park_lds = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(lds_byte*)&park[0][0]);
@@ -219,8 +249,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const int lane = threadIdx.x;
   // A panel in LDS: instruction i of a request carries row 8 g + i for each group g of 8 loader lanes (LDS: i * 1 KB + g * 128 B),
   // so that a loader lane's 8 rows are the 8 lanes of its own group -- their offsets reach it by DPP, not through LDS.
-  const unsigned int rowpart = (unsigned int)(lane & 7) * 1024u + (unsigned int)(lane >> 3) * 128u;   // this lane's row inside a panel
-  const unsigned int piece = (unsigned int)(lane & 7) * 16u;         // its 16-byte piece of a line as a loader
+  const unsigned int rowpart = KB == 8u ? (unsigned int)(lane & 7) * 1024u + (unsigned int)(lane >> 3) * 128u    // this lane's row inside a panel
+                                        : (unsigned int)(lane & 3) * 1024u + (unsigned int)(lane >> 2) * 64u;   // (4-byte keys: 4 loader lanes a row)
+  const unsigned int piece = (unsigned int)(lane & (KB == 8u ? 7 : 3)) * 16u;   // its 16-byte piece of a row as a loader
   const unsigned int n32 = (unsigned int)sp.n;
   const uint64_t split_idx = st->split_idx, split_target = st->split_target;
   // duplicate-heavy keys (DevState::regs_dups): every group would meet a duplicate and go on the list after its panels were requested
@@ -255,8 +286,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // (a finished row keeps re-reading its last line); lane 8 g + i's value reaches the 8 lanes of group g in two DPP moves: lane
   // i mod 4 of every quad to its quad, then the right quad of the pair to both.  (Through LDS it was four round trips per panel.)
   auto issue_panel = [&](const K* kb, unsigned int p, unsigned int off_own, unsigned int lim_own) {
-    const unsigned int o = off_own + p * 128u;
+    const unsigned int o = off_own + p * ROWB;
     const int mine = (int)(o < lim_own ? o : lim_own);
+    if constexpr (KB == 4u) {
+      // (a loader lane's 4 rows are the lanes of its own quad: one DPP move each)
+      unsigned int off4[4];
+      rg_static_for<0, 4>([&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        off4[i] = (unsigned int)__builtin_amdgcn_update_dpp(mine, mine, i * 0x55, 0xF, 0xF, false) + piece;
+      });
+      rg_dma_panel4(kb, ring_lds + (p & (unsigned int)(RG_RING - 1)) * PANEL_B, off4);
+      return;
+    }
     unsigned int off[8];
     rg_static_for<0, 8>([&](auto i_tag) {
       constexpr int i = decltype(i_tag)::value;
@@ -266,7 +307,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                             : __builtin_amdgcn_update_dpp(t, t, 0x104, 0xF, 0x5, false);     // row_shl:4 into the lower quads
       off[i] = (unsigned int)g + piece;
     });
-    rg_dma_panel<NT>((RG_DIAG & 64) ? (const K*)keys + 4096 : kb, ring_lds + (p & (unsigned int)(RG_RING - 1)) * (unsigned int)RG_PANEL_B, off);   // (& 64: every group's panels from the same 100 KB)
+    rg_dma_panel<NT>((RG_DIAG & 64) ? (const K*)keys + 4096 : kb, ring_lds + (p & (unsigned int)(RG_RING - 1)) * PANEL_B, off);   // (& 64: every group's panels from the same 100 KB)
   };
   unsigned int nxt_off = 0u, nxt_lim = 0u;                             // row descriptors of the group requested last (this lane's row)
   // descriptor of tile `tl` from its leaves' boundaries; a fast tile's first panels are requested at once
@@ -301,8 +342,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     t.lastp = rg_wave_max(t.act ? (t.a0 + wl - 1u) >> 4 : 0u);
     t.ulong = __all(!t.act || t.npts > (unsigned int)(RG_UBLK * RG_ROW));
     if (t.fast) {
-      nxt_off = (rel & ~(unsigned int)(RG_ROW - 1)) * 8u;
-      nxt_lim = t.act ? ((rel + wl - 1u) & ~(unsigned int)(RG_ROW - 1)) * 8u : 0u;
+      nxt_off = (rel & ~(unsigned int)(RG_ROW - 1)) * KB;
+      nxt_lim = t.act ? ((rel + wl - 1u) & ~(unsigned int)(RG_ROW - 1)) * KB : 0u;
       t.off = nxt_off; t.lim = nxt_lim;
       unsigned long long m0t = 0;
       if (RG_PROF) m0t = rg_now();
@@ -310,14 +351,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         // the single keys of this group's end -- the container's last key (Q1), the key in front of the container (FixDups offset
         // of its first point), the keys on either side of the leaf (finalize_one) -- in FRONT of the panels: landed before them
         const K* const kbm = t.kb - RG_ROW;                              // (offsets from one line in front of the wave base: never negative)
-        const unsigned int o_hi = t.act ? (rel + t.npts - 1u + (unsigned int)RG_ROW) * 8u : (unsigned int)RG_ROW * 8u;
-        const unsigned int o_lom1 = (t.act && lo > sp.rd_lo) ? (rel - 1u + (unsigned int)RG_ROW) * 8u : (unsigned int)RG_ROW * 8u;
-        const unsigned int o_next = (t.valid && e < sp.n) ? ((unsigned int)(e - wb) + (unsigned int)RG_ROW) * 8u : (unsigned int)RG_ROW * 8u;
-        const unsigned int o_prev = (t.valid && s > 0) ? ((unsigned int)(s - wb) - 1u + (unsigned int)RG_ROW) * 8u : (unsigned int)RG_ROW * 8u;
-        rg_dma_dword(kbm, park_lds + 0u * 256u, o_hi); rg_dma_dword(kbm, park_lds + 1u * 256u, o_hi + 4u);
-        rg_dma_dword(kbm, park_lds + 2u * 256u, o_lom1); rg_dma_dword(kbm, park_lds + 3u * 256u, o_lom1 + 4u);
-        rg_dma_dword(kbm, park_lds + 4u * 256u, o_next); rg_dma_dword(kbm, park_lds + 5u * 256u, o_next + 4u);
-        rg_dma_dword(kbm, park_lds + 6u * 256u, o_prev); rg_dma_dword(kbm, park_lds + 7u * 256u, o_prev + 4u);
+        const unsigned int o_hi = t.act ? (rel + t.npts - 1u + (unsigned int)RG_ROW) * KB : (unsigned int)RG_ROW * KB;
+        const unsigned int o_lom1 = (t.act && lo > sp.rd_lo) ? (rel - 1u + (unsigned int)RG_ROW) * KB : (unsigned int)RG_ROW * KB;
+        const unsigned int o_next = (t.valid && e < sp.n) ? ((unsigned int)(e - wb) + (unsigned int)RG_ROW) * KB : (unsigned int)RG_ROW * KB;
+        const unsigned int o_prev = (t.valid && s > 0) ? ((unsigned int)(s - wb) - 1u + (unsigned int)RG_ROW) * KB : (unsigned int)RG_ROW * KB;
+        constexpr unsigned int HW = KB == 8u ? 4u : 0u;                  // (the key's second word; 4-byte keys: the same word again, nothing behind it is read)
+        rg_dma_dword(kbm, park_lds + 0u * 256u, o_hi); rg_dma_dword(kbm, park_lds + 1u * 256u, o_hi + HW);
+        rg_dma_dword(kbm, park_lds + 2u * 256u, o_lom1); rg_dma_dword(kbm, park_lds + 3u * 256u, o_lom1 + HW);
+        rg_dma_dword(kbm, park_lds + 4u * 256u, o_next); rg_dma_dword(kbm, park_lds + 5u * 256u, o_next + HW);
+        rg_dma_dword(kbm, park_lds + 6u * 256u, o_prev); rg_dma_dword(kbm, park_lds + 7u * 256u, o_prev + HW);
 #pragma unroll
         for (unsigned int p = 0; p < (unsigned int)RG_RING; p++)
           if (p <= t.lastp) issue_panel(t.kb, p, nxt_off, nxt_lim);
@@ -335,8 +377,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if (!(RG_KO & 4)) { rg_dma_dword(base, park_lds + 8u * 256u, jl * 8u); rg_dma_dword(base, park_lds + 9u * 256u, jl * 8u + 8u); }
   };
   auto parked_key = [&](int row) -> K {
-    const unsigned long long v = ((unsigned long long)park[row + 1][lane] << 32) | (unsigned long long)park[row][lane];
-    return bits_to_key<K>(v);
+    if constexpr (KB == 4u) return (K)park[row][lane];
+    else {
+      const unsigned long long v = ((unsigned long long)park[row + 1][lane] << 32) | (unsigned long long)park[row][lane];
+      return bits_to_key<K>(v);
+    }
   };
   auto load_bounds = [&](unsigned int tl, uint64_t& s, uint64_t& e) {
     const uint64_t j = sp.leaf_lo + (uint64_t)tl * 64 + (uint64_t)lane;
@@ -370,23 +415,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     unsigned int lane_j = (unsigned int)lane;
     asm volatile("" : "+v"(lane_j));                                   // (the addresses of this group's results are formed when they are stored: not kept, not spilled)
     const uint64_t j = sp.leaf_lo + (uint64_t)done_tile * 64 + (uint64_t)lane_j;
-    const unsigned int a8 = cur.a0 * 8u;
+    const unsigned int a8 = cur.a0 * KB;
     // LDS address of step 16 b + qq of this lane's row: slot a0 + qq of the two-panel window that starts at panel b -- in panel
     // b (ring slot b mod 4) for the lanes that have not crossed their line's end yet, in panel b + 1 for the others
     // (the select: bit qq of `cm` says "crossed"; times the distance between the two places: two VOP3 operations, no VCC)
     const unsigned int cm = 0xFFFFu << ((unsigned int)RG_ROW - cur.a0);  // crossed at qq >= 16 - a0 (a0 = 0: never)
     auto block_base = [&](unsigned int b, unsigned int& in_b, unsigned int& delta) {
       const unsigned int sb = b & (unsigned int)(RG_RING - 1), sb1 = (b + 1u) & (unsigned int)(RG_RING - 1);
-      in_b = rowpart + a8 + sb * (unsigned int)RG_PANEL_B;
-      delta = (sb1 - sb) * (unsigned int)RG_PANEL_B - 128u;              // (wrapping: the ring's last slot is followed by its first)
+      in_b = rowpart + a8 + sb * PANEL_B;
+      delta = (sb1 - sb) * PANEL_B - ROWB;                               // (wrapping: the ring's last slot is followed by its first)
     };
-    auto slot_key = [&](unsigned int in_b, unsigned int delta, int qq) -> uint2 {
+    auto slot_key = [&](unsigned int in_b, unsigned int delta, int qq) -> RAW {
       // (written out: from C the compiler makes 16 comparisons of it, kept in 32 SGPRs across the whole walk)
       unsigned int crossed, addr0;
       asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(crossed) : "v"(cm), "n"(qq));
       asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(addr0) : "v"(crossed), "s"(delta), "v"(in_b));   // (signed: the ring wraps backwards)
-      const unsigned int addr = addr0 + (unsigned int)(qq * 8);
-      return *reinterpret_cast<const uint2*>(ringc + addr);
+      const unsigned int addr = addr0 + (unsigned int)qq * KB;
+      return *reinterpret_cast<const RAW*>(ringc + addr);
     };
     K k_hi = KeyTraits<K>::zero_value(), k_lom1 = KeyTraits<K>::zero_value();
     K k_next = KeyTraits<K>::max_value(), k_prev = KeyTraits<K>::zero_value();    // the two boundary keys of finalize_one
@@ -408,6 +453,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const unsigned int c1 = sg_cvt_u32(f1), c2 = sg_cvt_u32(f2);
       const unsigned int d1 = sg_absdiff(min(c1, n32), cur.lo + k1), d2 = sg_absdiff(min(c2, n32), cur.lo + k2);
       emax = max(emax, max(d1, d2));
+    };
+    // W2 (raw 4-byte keys in the stash): the conversion is made HERE, on an opaque copy -- the stash does not change inside the loop over its
+    // banks, and the compiler would otherwise convert all of it in front of the loop (twice the stash in registers: spills)
+    auto err_pair_w = [&](unsigned int r1, unsigned int k1, unsigned int r2, unsigned int k2) {
+      asm volatile("" : "+v"(r1), "+v"(r2));
+      err_pair((double)r1, k1, (double)r2, k2);
+    };
+    auto err_step_w = [&](unsigned int r, unsigned int k) {
+      asm volatile("" : "+v"(r));
+      err_step((double)r, k);
     };
     // F32 stash: the same steps on x~ = x0 + d (d the stashed float of x - x0), as fma(beta, d, A) with A = fma(beta, x0, alpha), and
     // the certificate beside them: the largest distance of a prediction's fraction from 1/2 (three more operations a step)
@@ -461,7 +516,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       unsigned int plo = 0u;
       double xp = __builtin_nan("");
       const unsigned int npts = cur.npts;
-      uint2 rawA[8], rawB[8];                                            // the keys of the half block in work / of the next one
+      RAW rawA[8], rawB[8];                                              // the keys of the half block in work / of the next one
       double cA[12], cB[12];                                             // the constants of the quarter block in work / of the next one
       auto request = [&](double (&c)[12], unsigned int quarter_index) {
         const double* const tq = rtab4 + ((RG_DIAG & 1) ? 0u : quarter_index * 16u);
@@ -472,15 +527,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // panel 1 has landed once at most the panels behind it are outstanding (requested at the hand-over: up to panel 3)
       if (cur.maxlen > 0u) {
         if (!(RG_KO & 4)) {
-          if (cur.lastp >= 3u) rg_wait_vm<16>();
-          else if (cur.lastp == 2u) rg_wait_vm<8>();
+          if (cur.lastp >= 3u) rg_wait_vm<2 * NI>();
+          else if (cur.lastp == 2u) rg_wait_vm<NI>();
           else rg_wait_vm<0>();
         }
         unsigned int in_b, dlt;
         block_base(0u, in_b, dlt);
 #pragma unroll
         for (int q = 0; q < 8; q++) rawA[q] = slot_key(in_b, dlt, q);
-        plo = ~rawA[0].x;                                                  // (the walk's first step has nothing in front of it)
+        plo = ~rg_raw_lo(rawA[0]);                                         // (the walk's first step has nothing in front of it)
       }
       // One block of 16 steps.  STATIC: `b` is a constant of the call (the first RG_UBLK blocks of a group whose containers are
       // all longer than that: no lane ends there, so no test, no sums put aside, and every double goes straight to its register
@@ -548,7 +603,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       if (!cur.valid || !(cur.s > 0u)) k_prev = KeyTraits<K>::zero_value();
       // a duplicate key somewhere in the group, or in front of a container's first point (compared as doubles: a superset
       // of key equality): the closed form of the y half does not hold -- the whole group goes through the general walk
-      const bool dup0 = cur.act && (uint64_t)cur.lo > sp.rd_lo && KeyTraits<K>::as_float(k_lom1) == (F32 ? x0 : (double)xs[0]);
+      const bool dup0 = cur.act && (uint64_t)cur.lo > sp.rd_lo && KeyTraits<K>::as_float(k_lom1) == (F32 ? x0 : (double)xs[0]);   // (W2: the raw key's exact double)
       if (!__any(dup0 || (cur.act && fdmin == 0u))) {
         // ---- the container's last item once more (Q1, models/mod.rs:180), then linear.rs:36-58
         if (cur.act) {
@@ -591,8 +646,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       auto ring_walk = [&]() {
         if (!(LONG && !(RG_KO & 2) && cur.maxlen > (unsigned int)STASH)) return;
         const unsigned int hlast = (cur.maxlen - 1u) >> 3;               // last half block of the walk
-        uint2 rkA[8], rkB[8];
-        auto read_half = [&](unsigned int h, uint2 (&rk)[8]) {
+        RAW rkA[8], rkB[8];
+        auto read_half = [&](unsigned int h, RAW (&rk)[8]) {
           unsigned int in_b, dlt;
           block_base(h >> 1, in_b, dlt);
           if (h & 1u) {
@@ -603,7 +658,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             for (int q = 0; q < 8; q++) rk[q] = slot_key(in_b, dlt, q);
           }
         };
-        auto steps = [&](unsigned int h, const uint2 (&rk)[8]) {
+        auto steps = [&](unsigned int h, const RAW (&rk)[8]) {
           const unsigned int k0 = h * 8u;
           if (__all(eend >= k0 + 8u || eend <= k0)) {                      // no leaf ends inside the half: one test for its steps
             if (eend > k0) {
@@ -618,8 +673,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         auto landed = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };   // lgkmcnt(0)
         auto wait_panel = [&](unsigned int b) {                            // panel b + 2 (for block b + 1)
           if (RG_KO & 4) return;
-          if (cur.lastp >= b + 4u) rg_wait_vm<16>();
-          else if (cur.lastp == b + 3u) rg_wait_vm<8>();
+          if (cur.lastp >= b + 4u) rg_wait_vm<2 * NI>();
+          else if (cur.lastp == b + 3u) rg_wait_vm<NI>();
           else rg_wait_vm<0>();
         };
         if (reread) wait_panel((unsigned int)SBLK - 1u);
@@ -665,7 +720,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
           for (int hb = 0; hb < 2; hb++) {
             if (hb == 1 && !(b * (unsigned int)RG_ROW + 8u < cur.maxlen)) break;
-            uint2 rk[8];
+            RAW rk[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) rk[q] = slot_key(in_b, dlt, hb * 8 + q);
             __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0)
@@ -713,6 +768,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
               for (int qq = 0; qq < RG_ROW; qq += 2) {
                 if constexpr (F32) err_pair_f(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
+                else if constexpr (W2) err_pair_w(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
                 else err_pair(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
               }
               asm volatile("; stash bank %0 (ahead)" ::"n"(i));

@@ -23,7 +23,7 @@
         // (the builtin, not an asm statement: the compiler keeps its own score of the LDS reads and scalar loads in flight, and
         //  what it cannot see waited for it waits for again -- with lgkmcnt(0) at every step while a scalar load is out)
         auto landed = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); };   // vmcnt 63, expcnt 7, lgkmcnt 0
-        auto quarter = [&](int hb, int qr, const uint2 (&raw)[8], const double (&c)[12], auto full_tag) {
+        auto quarter = [&](int hb, int qr, const RAW (&raw)[8], const double (&c)[12], auto full_tag) {
           constexpr bool FULL = decltype(full_tag)::value;
           const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8 + qr * 4);
 #pragma unroll
@@ -34,11 +34,12 @@
             if constexpr (F32) {
               if (rg_block_index(b) == 0u && hb == 0 && q == 0) x0 = x;   // (the container's first key)
               T[q] = (float)(x - x0);
-            } else T[q] = x;
+            } else if constexpr (W2) T[q] = rg_raw_lo(raw[q]);
+            else T[q] = x;
             if (FULL || k < npts) {
               if (!(RG_DIAG & 2)) {
                 if constexpr (DIVK) { if (x == xp) dmin = 0u; }
-                else { const unsigned int d = raw[q].x ^ plo; dmin = dmin < d ? dmin : d; }
+                else { const unsigned int d = rg_raw_lo(raw[q]) ^ plo; dmin = dmin < d ? dmin : d; }
               }
               if (!(RG_KO & 1)) {
                 const double dx = x - mx;                                 // linear.rs:26
@@ -47,7 +48,7 @@
                 m2 += dx * (x - mx);                                      // :30-31
               }
             }
-            xp = x; plo = raw[q].x;
+            xp = x; plo = rg_raw_lo(raw[q]);
           }
           // (written out, the blocks are separated only by the branches around the panel requests, and the compiler sinks the
           //  whole arithmetic behind the last of them -- with every quarter's 24 constants parked in VGPR lanes meanwhile)
@@ -59,7 +60,7 @@
           //  allocator then shuffles the whole stash around in every case)
           auto group = [&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
-            rg_static_for<4 * g, 4 * g + 4>([&](auto i_tag) {
+            rg_static_for<4 * g, (4 * g + 4 < SBLK ? 4 * g + 4 : SBLK)>([&](auto i_tag) {
               constexpr int i = decltype(i_tag)::value;
               if (b == (unsigned int)i && !((RG_DIAG & 16) && i > 0)) {
 #pragma unroll
@@ -68,12 +69,12 @@
               }
             });
           };
-          rg_static_for<0, SBLK / 4>([&](auto g_tag) {
+          rg_static_for<0, (SBLK + 3) / 4>([&](auto g_tag) {
             constexpr int g = decltype(g_tag)::value;
             if (b >= (unsigned int)(4 * g) && b < (unsigned int)(4 * g + 4)) group(g_tag);
           });
         };
-        auto run_half = [&](int hb, const uint2 (&raw)[8], auto&& prefetch) {
+        auto run_half = [&](int hb, const RAW (&raw)[8], auto&& prefetch) {
           const unsigned int k0 = b * (unsigned int)RG_ROW + (unsigned int)(hb * 8);
           const bool full = STATIC || (RG_DIAG & 8) || __all(npts >= k0 + 8u || npts <= k0);
           sub0();
@@ -117,8 +118,8 @@
           sub(5);
           if ((b + 1u) * (unsigned int)RG_ROW < cur.maxlen) {
             if (!(RG_KO & 4)) {
-              if (cur.lastp >= b + 4u) rg_wait_vm<16>();
-              else if (cur.lastp == b + 3u) rg_wait_vm<8>();
+              if (cur.lastp >= b + 4u) rg_wait_vm<2 * NI>();
+              else if (cur.lastp == b + 3u) rg_wait_vm<NI>();
               else rg_wait_vm<0>();
             }
             sub(3 + 8);

@@ -11,19 +11,20 @@
             if (eend > kb0) {
               auto group = [&](auto g_tag) {
                 constexpr int g = decltype(g_tag)::value;
-                rg_static_for<(g == 0 ? 1 : 4 * g), 4 * g + 4>([&](auto i_tag) {
+                rg_static_for<(g == 0 ? 1 : 4 * g), (4 * g + 4 < SBLK ? 4 * g + 4 : SBLK)>([&](auto i_tag) {
                   constexpr int i = decltype(i_tag)::value;
                   if (b == (unsigned int)i) {
 #pragma unroll
                     for (int qq = 0; qq < RG_ROW; qq += 2) {
                       if constexpr (F32) err_pair_f(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
+                      else if constexpr (W2) err_pair_w(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
                       else err_pair(xs[i * RG_ROW + qq], (unsigned int)(i * RG_ROW + qq), xs[i * RG_ROW + qq + 1], (unsigned int)(i * RG_ROW + qq + 1));
                     }
                     asm volatile("; stash bank %0" ::"n"(i));
                   }
                 });
               };
-              rg_static_for<0, SBLK / 4>([&](auto g_tag) {
+              rg_static_for<0, (SBLK + 3) / 4>([&](auto g_tag) {
                 constexpr int g = decltype(g_tag)::value;
                 if (b >= (unsigned int)(4 * g) && b < (unsigned int)(4 * g + 4)) group(g_tag);
               });
@@ -34,7 +35,7 @@
           {
             auto group = [&](auto g_tag) {
               constexpr int g = decltype(g_tag)::value;
-              rg_static_for<4 * g, 4 * g + 4>([&](auto i_tag) {
+              rg_static_for<4 * g, (4 * g + 4 < SBLK ? 4 * g + 4 : SBLK)>([&](auto i_tag) {
                 constexpr int i = decltype(i_tag)::value;
                 if (b == (unsigned int)i) {
 #pragma unroll
@@ -43,7 +44,7 @@
                 }
               });
             };
-            rg_static_for<0, SBLK / 4>([&](auto g_tag) {
+            rg_static_for<0, (SBLK + 3) / 4>([&](auto g_tag) {
               constexpr int g = decltype(g_tag)::value;
               if (b >= (unsigned int)(4 * g) && b < (unsigned int)(4 * g + 4)) group(g_tag);
             });
@@ -52,7 +53,7 @@
           for (int qq = 0; qq < RG_ROW; qq++) {
             const unsigned int k = kb0 + (unsigned int)qq;
             if (k < eend && k != 0u) {                                      // (step 0: above)
-              if constexpr (F32) err_step_f(T[qq], k); else err_step(T[qq], k);
+              if constexpr (F32) err_step_f(T[qq], k); else if constexpr (W2) err_step_w(T[qq], k); else err_step(T[qq], k);
             }
           }
         }

@@ -35,6 +35,10 @@ CASES = [
     # whose error steps behind the stash come through the ring a second time; 600; skewed; f64 keys; C1's shape (977: most groups listed)
     ("uniform_u64", 1_500_000, 3937, "linear"), ("uniform_u64", 2_000_000, 3333, "linear"), ("books_u64", 2_000_000, 5000, "linear"),
     ("uniform_f64", 1_200_000, 3000, "linear"), ("uniform_u64", 1_000_000, 1024, "linear"), ("uniform_u64", 1_500_000, 4096, "radix"),
+    # 4-byte keys (src/load.rs:47-69): one stash register a key, half-line panels; the C5-like shape (95 keys a leaf), ~200 keys a leaf,
+    # duplicates (the groups that meet one are listed), long leaves, a radix root
+    ("uniform_u32", 400_000, 4096, "linear"), ("uniform_u32", 1_000_000, 5300, "linear"), ("uniform_u32", 300_000, 4096, "radix"),
+    ("dups_u32", 300_000, 4096, "linear"), ("uniform_u32", 1_500_000, 3937, "linear"), ("uniform_u32", 70_000, 1000, "linear"),
 ]
 
 
