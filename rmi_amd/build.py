@@ -16,7 +16,7 @@ COMMON = ["rmi_kernels.hip.h", "rmi_stream.hip.h", "rmi_sigma.hip.h", "rmi_lanes
 # source -> the headers it includes (besides COMMON)
 UNITS = {
     "rmi_hip.hip": ["rmi_regs.hip.h", "rmi_regs_block.inc.h", "rmi_regs_replay.inc.h", "rmi_multi.inc.h", "rmi_root_host.h", "../../include/rmi_hip.h"],
-    "rmi_scan.hip": ["rmi_scan.hip.h"],
+    "rmi_scan.hip": ["rmi_scan.hip.h", "rmi_scan_ends.inc.h"],
 }
 SOURCES = list(UNITS)
 HEADERS = sorted(set(COMMON + [h for hs in UNITS.values() for h in hs]))

@@ -48,6 +48,12 @@
 #ifndef RMI_SC_STOP
 #define RMI_SC_STOP 0                 // debugging: leave a tile after phase n (results wrong)
 #endif
+#ifndef RMI_SC_F5BATCH
+#define RMI_SC_F5BATCH 1              // the short form's leaf ends for several tiles at once (4-byte keys): see `FB` in k_spline_scan
+#endif
+#ifndef RMI_SC_DIAG
+#define RMI_SC_DIAG 0                 // timing experiments on the short form's leaf ends (results wrong): & 1 no aggregate terms, & 2 no stores
+#endif
 #ifndef RMI_SC_PROF
 #define RMI_SC_PROF 0                 // development: cycles per phase of the short form, printed by a few waves (perturbs the kernel)
 #endif
@@ -251,9 +257,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
   constexpr int DW = G::DW, KPC = G::KPC, TILE = G::TILE, S = G::S, NCH = G::NCH, EXTN = G::EXTN, FHC = G::FHC, FHN = G::FHN, T0 = G::T0;
   constexpr int NSUB = G::NSUB, BTILE = G::BTILE, NCHB = G::NCHB, VF = G::VF;
   __shared__ __attribute__((aligned(16))) unsigned int lds[G::LDS_DW];
-  __shared__ unsigned int r_s[SC_SLOTS + 1], r_t[SC_SLOTS + 1], r_g0[SC_SLOTS + 1], r_yp[SC_SLOTS + 1];   // boundary records of a batch
-  __shared__ __attribute__((aligned(16))) double m_ab[2 * (SC_SLOTS + 2)];                                   // (alpha, beta) per slot, one entry of padding either side
-  __shared__ unsigned int m_err[SC_SLOTS + 2], m_run[SC_SLOTS + 2];
+  // (FB, below: the gfx950 LDS is dealt out in granules of 1 280 bytes and 12 waves a CU get 10 of them -- 12 800 B; the kernel used 12 552.  So the batched
+  //  form counts bytes: no r_g0 -- the number of empty leaves in front of a start, at most 4 in an ordinary tile, rides in the top bits of r_t --, no spare entries)
+  constexpr bool FB = PHASE == 0 && RMI_SC_F5BATCH != 0 && sizeof(K) == 4 && ScMono<ROOT>::value;
+  constexpr int NS1 = FB ? SC_SLOTS : SC_SLOTS + 1, NS2 = FB ? SC_SLOTS + 1 : SC_SLOTS + 2;
+  __shared__ unsigned int r_s[NS1], r_t[NS1], r_g0[FB ? 1 : SC_SLOTS + 1], r_yp[NS1];                      // boundary records of a batch
+  __shared__ __attribute__((aligned(16))) double m_ab[2 * NS2];                                              // (alpha, beta) per slot, one entry of padding in front (and behind)
+  __shared__ unsigned int m_err[NS2], m_run[NS2];
+  // FB: the short form's leaf ends (F5) are run for the slots of SEVERAL tiles at once.  An ordinary tile of C5 starts ~21 leaves: F3 and F5 -- lane =
+  // slot, ~64 us of 400 by a knock-out build, a chain of LDS reads, conversions, a logarithm and four scattered stores -- ran with a third of the
+  // lanes.  The slots of a tile are appended to the tables behind those still pending (`cnt`), with their ends and their containers' end keys
+  // (the tile image is gone when the ends are computed); the ends run when the next tile's starts might not fit.  4-byte keys only (an 8-byte key's
+  // end keys would take another 512 B); the containers' first keys take the place of r_yp, which a slot needs only until its model is computed (F3).
+  // With 13 072 B a wave -- 11 waves a CU, the twelfth of the launch a second round -- the batched form ran 0.51 against 0.45 ms.
+  __shared__ unsigned int r_e[FB ? SC_SLOTS : 1], r_khi[FB ? SC_SLOTS : 1];
+  unsigned int* const r_end = FB ? r_e : r_s + 1;                       // end of slot i (not batched: the start of slot i + 1)
+  unsigned int* const r_klo = r_yp;                                     // (FB) written by the lane that has just read r_yp of the same slot
 
   unsigned int* const trow0 = lds + T0;               // row r of the big tile at trow0[r S ...]; the front chunks and the look-ahead by the same rule (ScGeom)
 
@@ -343,6 +362,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
   // per CU leave 168; an array of their own took the LDS over what 12 waves can have)
   double* const aggp = reinterpret_cast<double*>(trow0 + lane * G::S + G::ROWD);
   if constexpr (PHASE == 0) { aggp[0] = 0.0; aggp[1] = 0.0; }
+  unsigned int pend = 0u;                                                       // (FB) slots whose ends are pending
+  unsigned int nbmax = 0u;                                                      // (FB) the most leaf starts a tile of this wave has had
   // the sequence of this wave's tiles: position k0, k0 + kstep, ... below kend; the tile at a position is the position itself, or the list's entry
   const unsigned int* const tlist = PHASE == 1 ? SC_ARG(kp, unsigned int*, tile_list) : (const unsigned int*)nullptr;
   unsigned int kpos = t_lo + wix, kstep = wpx, kend = t_hi;
@@ -367,6 +388,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
     ntile++;
 #endif
     SC_TICK(7);
+    // (FB) the pending leaf ends, HERE -- nothing of a tile is live, only the loads of this one in flight -- when another tile's starts might not fit
+    // behind them: as many as the fullest tile so far, and 4 more (evenly filled leaves: the count varies by one or two from tile to tile)
+    if constexpr (FB) {
+      if (pend && pend + nbmax + 4u > (unsigned int)SC_SLOTS) {
+        const unsigned int ends_count = pend, ends_A2 = 0u;
+#include "rmi_scan_ends.inc.h"
+        pend = 0u;
+      }
+    }
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const unsigned int relA2 = tile * (unsigned int)BTILE;                      // relative index of the big tile's first key
@@ -385,7 +415,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
       }
     };
     // (ONE place that issues the next tile's loads, below: a second one makes the compiler carry the tile in two register sets)
-    const bool take = PHASE == 1 || (mono && plain_t && relA2 >= rel_lo + (unsigned int)FHN + 1u);
+    const bool take = PHASE == 1 || (mono && plain_t && relA2 >= rel_lo + (unsigned int)FHN + 1u && (!FB || r.L <= (1ull << 29)));
     // ---- stage the big tile (padded rows) and the aux chunks
     wave_sync();
     if (!take) {
@@ -481,6 +511,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
           const bool has = tl != tp;                                            // a leaf starts in this lane (targets are monotone)
           const unsigned long long hm = __ballot(has);
           if (hm == 0ull) { done = true; break; }                               // the big tile lies inside one leaf that started earlier
+          // (FB: this tile's starts go behind the pending slots.  The loop's head has made room for as many as any tile of this wave has had so far,
+          //  and a few more; a tile with still more than that -- and slots pending -- goes to the general form)
+          if constexpr (FB) { if (pend + (unsigned int)__builtin_popcountll(hm) > (unsigned int)SC_SLOTS) break; }
           // ---- the look-ahead's targets and the duplicate tests first: independent of the bisection below, their LDS round trips overlap
           unsigned int t_ext[EXTN / 64];
           bool dq = false;
@@ -568,10 +601,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
             const unsigned long long hb = hd & ((1ull << (p & 63u)) - 1ull);      // (p < VF <= 64 in the lanes that use it)
             yp = hb ? f + (63u - (unsigned int)__builtin_clzll(hb)) : y_in;
           }
-          // ---- F2: the records of the starts; the open leaf's end closes them
+          // ---- F2: the records of the starts; the open leaf's end closes them.  (FB: behind the pending slots)
+          const unsigned int pq = pend + q;                                     // this lane's slot (entry pq + 1 of the model tables; entry pq: the leaf in front)
           wave_sync();
-          if (has) { r_s[q] = f + p; r_t[q] = t_hi; r_g0[q] = tp + 1u; r_yp[q] = yp; }
-          if (lane == 0) r_s[nb] = A2 + term_rel;
+          if (has) {
+            r_s[pq] = f + p; r_yp[pq] = yp;
+            if constexpr (FB) r_t[pq] = t_hi | ((t_hi - tp - 1u) << 29);         // (leaf ids below 2^29: `take`; at most 4 empty leaves in front: above)
+            else { r_t[pq] = t_hi; r_g0[pq] = tp + 1u; }
+            if (q >= 1u) r_end[pq - 1u] = f + p;
+          }
+          if (lane == 0) r_end[pend + nb - 1u] = A2 + term_rel;
           wave_sync();
           // ---- F3: the models.  Lane l: slot l.  Container [s - 1, e]: both end points exist (no split, no end of the data nearby) and their keys differ
           // (nothing of a slot stays in registers across the error pass: F5 reads records, model and end keys from LDS again -- registers held
@@ -581,14 +620,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
           //  of a tile whose leaves all pass drops the min, one instruction of seven per key)
           bool cfree = true;
           if ((unsigned int)lane < nb) {
-            const unsigned int q_s = r_s[lane], q_e = r_s[lane + 1];
+            const unsigned int sl = pend + (unsigned int)lane;
+            const unsigned int q_s = r_s[sl], q_e = r_end[sl];
             const K k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))), k_hi = bits_to_key<K>(lds_bits0((int)(q_e - A2)));
             const double x0 = KeyTraits<K>::as_float(k_lo), x1 = KeyTraits<K>::as_float(k_hi);
-            const double y0f = (double)r_yp[lane], y1f = (double)q_e;
+            const double y0f = (double)r_yp[sl], y1f = (double)q_e;
+            if constexpr (FB) { r_klo[sl] = (unsigned int)key_to_bits<K>(k_lo); r_khi[sl] = (unsigned int)key_to_bits<K>(k_hi); }   // (behind the read of r_yp[sl]: the same words)
             const double mb = (y0f - y1f) / (x0 - x1);                           // linear_spline.rs:27
             const double ma = y0f - mb * x0;                                     // :28, plain multiply-subtract
-            m_ab[2 * (lane + 1)] = ma; m_ab[2 * (lane + 1) + 1] = mb;
-            m_err[lane + 1] = 0u; m_run[lane + 1] = 0u;
+            m_ab[2 * (sl + 1u)] = ma; m_ab[2 * (sl + 1u) + 1] = mb;
+            m_err[sl + 1u] = 0u; m_run[sl + 1u] = 0u;
             const double np1 = (double)n32 + 1.0;
             cfree = (__builtin_fma(mb, x0, ma) < np1) && (__builtin_fma(mb, x1, ma) < np1);
           }
@@ -611,9 +652,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
           // ---- F4: the error pass.  The lane's keys in front of its start belong to the leaf of slot q - 1 (table entry q; entry 0: a leaf
           //      of an earlier tile, nothing is kept), those from the start on to slot q (entry q + 1)
           {
-            double pa = m_ab[2 * q], pb = m_ab[2 * q + 1];
+            double pa = m_ab[2 * pq], pb = m_ab[2 * pq + 1];
             double pa1 = 0.0, pb1 = 0.0;
-            if (has) { pa1 = m_ab[2 * (q + 1)]; pb1 = m_ab[2 * (q + 1) + 1]; }
+            if (has) { pa1 = m_ab[2 * (pq + 1u)]; pb1 = m_ab[2 * (pq + 1u) + 1]; }
             unsigned int m = 0u, m0 = 0u, rn = 0u, rn0 = 0u, y_last = 0u;
             unsigned int amlo = (unsigned int)am, amhi = (unsigned int)(am >> 32);
             if (!dups) {
@@ -697,11 +738,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
               y_last = y;
             }
             const unsigned int mA = has ? m0 : m, rA = has ? rn0 : rn;
-            if (q >= 1u) { if (mA) atomicMax(&m_err[q], mA); if (rA > 1u) atomicMax(&m_run[q], rA); }
-            if (has) { if (m) atomicMax(&m_err[q + 1u], m); if (rn > 1u) atomicMax(&m_run[q + 1u], rn); }
+            if (q >= 1u) { if (mA) atomicMax(&m_err[pq], mA); if (rA > 1u) atomicMax(&m_run[pq], rA); }
+            if (has) { if (m) atomicMax(&m_err[pq + 1u], m); if (rn > 1u) atomicMax(&m_run[pq + 1u], rn); }
             // ---- the keys of the open leaf behind the big tile: [A2 + BTILE, A2 + term_rel)
             {
-              const double ta = m_ab[2 * nb], tb = m_ab[2 * nb + 1];
+              const double ta = m_ab[2 * (pend + nb)], tb = m_ab[2 * (pend + nb) + 1];
               unsigned int em = 0u, rm = 0u;
               unsigned int y_carry = (unsigned int)__builtin_amdgcn_readlane((int)y_last, 63);
               for (unsigned int o = (unsigned int)BTILE; o < term_rel; o += 64u) {
@@ -726,64 +767,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
                 }
               }
               if (term_rel > (unsigned int)BTILE) {
-                if (em) atomicMax(&m_err[nb], em);
-                if (rm > 1u) atomicMax(&m_run[nb], rm);
+                if (em) atomicMax(&m_err[pend + nb], em);
+                if (rm > 1u) atomicMax(&m_run[pend + nb], rm);
               }
             }
           }
           wave_sync();
           if (RMI_SC_STOP == 4) { done = true; break; }
           SC_TICK(4);
-          // ---- F5: the leaf ends (two_layer.rs:185-197, 226-259) in 32 bits -- every index and every clamped prediction is below 2^32 --,
-          //      rows, aggregates; then the empty leaves in front of the starts
-          const sc_kargp cp = cold();
-          const ScanOut out = cold_out(cp);
-          const int npeers = SC_ARG(cp, int, peers.n);
-          auto store_leaf = [&](unsigned int j, unsigned int s_, double a, double b2, unsigned int final_err, unsigned int cnt_j) {
-            out.leaf_start[j] = (unsigned long long)s_;
-            if (out.params) { out.params[2 * (size_t)j] = a; out.params[2 * (size_t)j + 1] = b2; }
-            if (out.leaf_err) out.leaf_err[j] = (unsigned long long)final_err;
-            if (out.leaf_count) out.leaf_count[j] = (unsigned long long)cnt_j;
-            double* rp = reinterpret_cast<double*>(out.rows + (size_t)j * 24);
-            rp[0] = a; rp[1] = b2;
-            *reinterpret_cast<unsigned long long*>(out.rows + (size_t)j * 24 + 16) = (unsigned long long)final_err;
-            for (int pi = 0; pi < npeers; pi++) {                                // (wave-uniform trip count)
-              unsigned char* const pt = cold_peer(cp, pi);
-              double* pr = reinterpret_cast<double*>(pt + (size_t)j * 24);
-              pr[0] = a; pr[1] = b2;
-              *reinterpret_cast<unsigned long long*>(pt + (size_t)j * 24 + 16) = (unsigned long long)final_err;
-            }
-          };
-          if ((unsigned int)lane < nb) {
-            const unsigned int q_s = r_s[lane], q_e = r_s[lane + 1], q_t = r_t[lane];
-            const K k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))), k_hi = bits_to_key<K>(lds_bits0((int)(q_e - A2)));
-            const double ma = m_ab[2 * (lane + 1)], mb = m_ab[2 * (lane + 1) + 1];
-            const unsigned int curr = m_err[lane + 1], ru = m_run[lane + 1];
-            const unsigned int up = min(sg_cvt_u32(__builtin_fma(mb, KeyTraits<K>::as_float(KeyTraits<K>::minus_eps(k_hi)), ma)), n32);   // lower_bound_correction.rs:47-49
-            const unsigned int upper = sg_absdiff(up, min(q_e + 1u, n32));                                                              // two_layer.rs:229-235
-            const unsigned int lw = min(sg_cvt_u32(__builtin_fma(mb, KeyTraits<K>::as_float(KeyTraits<K>::plus_eps(k_lo)), ma)), n32);    // lower_bound_correction.rs:62-63
-            const unsigned int lower = sg_absdiff(lw, q_t == 0u ? q_e : q_s);                                                          // two_layer.rs:237-247
-            const unsigned int final_err = max(max(curr, upper), lower) + (ru > 1u ? ru : 1u);                                       // :250-251 (a leaf with keys owns a recorded run)
-            const unsigned int cnt_j = q_e - q_s;
-            store_leaf(q_t, q_s, ma, mb, final_err, cnt_j);
-            // the terms of the aggregates (two_layer.rs:267-287), as ScAgg::add forms them
-            auto agg_max = [&](unsigned int j, unsigned int e) { if (e > amx || (e == amx && j > ami)) { amx = e; ami = j; } };   // max_by_key: the LAST maximum
-            agg_max(q_t, final_err);
-            {
-              const unsigned long long ts = (unsigned long long)cnt_j * (unsigned long long)final_err;
-              asum += ts;
-              if (cnt_j) {
-                const double v = (double)ts;
-                aggp[0] += (v * v) * inv_nf;                                       // (the reference divides by n: one rounding apart, the sums are compared to 1e-9)
-                aggp[1] += (double)cnt_j * sc_log2_int((double)(2ull * (unsigned long long)final_err + 2ull));
-              }
-            }
-            // the empty leaves [g0, t) in front of this start (s == e): the constant model next_index = s (two_layer.rs:185-197), widened by 1
-            const unsigned int g0 = r_g0[lane];
-            for (unsigned int j = g0; j < q_t; j++) {
-              store_leaf(j, q_s, (double)q_s, 0.0, 1u, 0u);
-              agg_max(j, 1u);
-            }
+          // ---- F5: the leaf ends (rmi_scan_ends.inc.h) -- at once, or (FB) at the head of the loop when the next tile's starts might not fit behind the pending ones
+          if constexpr (FB) { pend += nb; nbmax = nb > nbmax ? nb : nbmax; }
+          else {
+            const unsigned int ends_count = nb, ends_A2 = A2;
+#include "rmi_scan_ends.inc.h"
           }
           done = true;
           SC_TICK(5);
@@ -1214,6 +1210,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
     printf("wave %u xcd %u: tiles %u fast %u total %llu | stage %llu prefetch %llu F1 %llu F2-3 %llu F4 %llu F5 %llu looptop %llu\n", blockIdx.x, blockIdx.x & 7u, ntile, nfast,
            (unsigned long long)__builtin_readcyclecounter() - tstart, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5], prof[7]);
 #endif
+  if constexpr (FB) {
+    if (pend) {
+      const unsigned int ends_count = pend, ends_A2 = 0u;
+#include "rmi_scan_ends.inc.h"
+    }
+  }
   if (flags) atomicOr(&st->err_flags, flags);
   if constexpr (PHASE == 1) { if (blockIdx.x == 0 && lane == 0) st->scan_listed = tlist != nullptr ? *SC_ARG(kp, unsigned long long*, tile_cnt) : 0ull; }
   // ---- this wave's aggregate record
