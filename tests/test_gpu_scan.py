@@ -80,6 +80,26 @@ def test_scan_lists_and_grids(monkeypatch, oracle, gen, env):
     _check(monkeypatch, oracle, dg.GENERATORS[gen](400_000), "radix" if gen != "uniform_f64" else "linear", 4096, env=env)
 
 
+@pytest.mark.parametrize("dups", [False, True])
+@pytest.mark.parametrize("waves", ["8", "3"])
+def test_scan_batched_leaf_ends_uneven_density(monkeypatch, oracle, dups, waves):
+    """4-byte keys: the short form keeps the leaf ends of several tiles pending and runs them together (rmi_scan.hip.h, `FB`).  Few persistent waves, so
+    that a wave takes many tiles; keys whose density changes fivefold and back, so that tiles with ~10 leaf starts are followed by tiles with ~50: the
+    pending slots are run early, and a tile whose starts do not fit behind them after all goes to the general form.  Same bits as the oracle."""
+    rng = np.random.default_rng(5)
+    parts = []
+    for lo, hi, cnt in ((0, 1 << 30, 1_500_000), (1 << 30, 1 << 32, 900_000)):
+        parts.append(rng.choice(np.arange(lo, hi, 64, dtype=np.uint64), size=cnt, replace=False) + rng.integers(0, 64, cnt).astype(np.uint64))
+    keys = np.sort(np.concatenate(parts)).astype(np.uint32)
+    # (dense, sparse, dense, sparse: interleave the two regions in four stripes by folding the key space)
+    keys = np.sort(np.where((keys >> 29) & 1, keys ^ np.uint32(1 << 31), keys)).astype(np.uint32)
+    if dups:
+        keys[100_000:1_000_000:7] = keys[99_999:999_999:7]
+        keys = np.sort(keys)
+    g = _check(monkeypatch, oracle, keys, "linear", 30_000, env={"RMI_HIP_SCAN_WAVES": waves})
+    assert g is not None
+
+
 @pytest.mark.parametrize("root,params", [("cubic", (0.0, 0.0, -1e-15, 3000.0)), ("cubic", (0.0, 0.0, 1e-13, 0.0)), ("cubic", (1e-50, -3e-32, 2e-14, 5.0)),
                                          ("linear", (5000.0, -2e-16, 0.0, 0.0)), ("linear", (0.0, 1e-12, 0.0, 0.0)), ("linear", (-3.0, 2.3e-16, 0.0, 0.0))])
 def test_scan_reports_the_reference_panics(monkeypatch, oracle, root, params):
