@@ -140,16 +140,17 @@ typedef struct {
   uint64_t generation;            /* number of this train call on the context, for rmi_hip_download_checked */
 } rmi_hip_result;
 
-/* kernel_ns slots of the round-1/2 pipelines (RMI_HIP_PIPELINE=1|2).  The default leaf-lane pipeline fills slot 0 with
+/* kernel_ns slots of the streaming passes (pipeline 2).  The default leaf-lane pipeline fills slot 0 with
  * k_leaf_lanes (bracketed behind the search), slot 1 with k_lane_reduce (or k_list when RMI_HIP_OPT_TAIL=0, then k_list_tail
  * and k_finalize_listed in 2 and 3); kernel_ns[7] is the exchange of rmi_hip_train_sharded. */
 enum { RMI_K_BOUNDARIES = 0, RMI_K_FILL = 1, RMI_K_FIT = 2, RMI_K_ERR = 3, RMI_K_FINALIZE = 4 };
 
 /* ---- lifetime ---- */
 int rmi_hip_abi_version(void);
-/* Which leaf kernels the context's last training ran: 4 = k_leaf_regs + k_regs_finalize (one read of the keys: 8-byte keys, linear
- * leaves, <= 208 keys per leaf on average; kernel_ns[0] = k_leaf_regs, [1] = the groups it listed for k_leaf_lanes + k_regs_finalize,
- * [2] = k_lane_reduce), 3 = k_leaf_lanes, 2 / 1 = the round-1/2 pipelines.  (v5) */
+/* Which leaf kernels the context's last training ran: 5 = k_spline_scan (linear_spline leaves: one key-parallel read, v6), 4 = k_leaf_regs +
+ * k_regs_finalize (linear leaves, one read of the keys: up to 640 keys per leaf on average, 4-byte keys at two waves per SIMD;
+ * kernel_ns[0] = k_leaf_regs, [1] = the groups it listed for k_leaf_lanes + k_regs_finalize, [2] = k_lane_reduce), 3 = k_leaf_lanes,
+ * 2 = the streaming passes (tiny key sets, 2^32 keys and more, cubic leaves, the one-pass modes).  (v5) */
 int rmi_hip_last_pipeline(rmi_hip_ctx* ctx);
 int rmi_hip_device_count(void);
 int rmi_hip_create(int device_id, rmi_hip_ctx** out);
@@ -163,10 +164,11 @@ int rmi_hip_set_profile_level(rmi_hip_ctx* ctx, int level);
 /* How linear leaves (linear.rs:12-59) are fitted:
  *   RMI_FIT_EXACT (default, and the fastest mode): the reference's recurrence in the reference's order; coefficients,
  *     error integers and counts bit-identical to the reference.  Leaf boundaries by search, 64 leaves per wave in lockstep.
- *     8-byte keys with at most 208 keys a leaf on average: k_leaf_regs (rmi_regs.hip.h) -- the keys are read ONCE and stay
- *     in the lanes' registers between a leaf's fit and its error pass, the leaf ends in k_regs_finalize.  Otherwise
- *     k_leaf_lanes (rmi_lanes.hip.h): error pass and finalize fused behind the fit, the keys are read twice (the second
- *     read largely from the Infinity Cache).  Containers of more than 4 096 points one wave each, of more than 262 144
+ *     Up to 640 keys a leaf on average: k_leaf_regs (rmi_regs.hip.h) -- the keys are read ONCE and stay in the lanes' registers
+ *     between a leaf's fit and its error pass (the steps behind the 192nd of a long leaf come through the LDS ring a second time;
+ *     4-byte keys: two waves per SIMD with the raw keys stashed), the leaf ends in k_regs_finalize.  Otherwise k_leaf_lanes
+ *     (rmi_lanes.hip.h): error pass and finalize fused behind the fit, the keys are read twice (the second read largely from
+ *     the Infinity Cache while the leaves are short).  Containers of more than 4 096 points one wave each, of more than 262 144
  *     points on a host core (RMI_HIP_HOST_MIN).  This is the mode every figure of merit is quoted in; DESIGN.md holds the
  *     table configuration -> kernels.
  *   RMI_FIT_ONEPASS_GUARDED (an opt-in FAST mode: its coefficients do NOT meet a 1e-9 relative tolerance on every
