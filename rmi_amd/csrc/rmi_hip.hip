@@ -1419,18 +1419,16 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
           const bool w2 = sizeof(K) == 4 && c->regs_u32 >= 2;           // two waves per SIMD
           unsigned int grid = c->regs_grid ? c->regs_grid : (w2 ? 8u : 4u) * (unsigned int)c->n_cu;
           if ((uint64_t)grid > wb) grid = (unsigned int)wb;
-          if constexpr (sizeof(K) == 4) {
-            if (w2)
-              hipLaunchKernelGGL((k_leaf_regs<K, 2>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
-                                 L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
-          }
-          if (w2) {}
-          else if (regs_long)
-            hipLaunchKernelGGL((k_leaf_regs<K, 1>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
-                               L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
-          else
-            hipLaunchKernelGGL((k_leaf_regs<K, 0>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
-                               L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof, (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
+          // (the variant: 0 = leaves that fit the stash and the ring, 1 = LONG, 2 = 4-byte keys at two waves per SIMD)
+          auto launch_regs = [&](auto variant_tag) {
+            constexpr int VARIANT = decltype(variant_tag)::value;
+            hipLaunchKernelGGL((k_leaf_regs<K, VARIANT>), dim3(grid), dim3(64), 0, s, keys, sp, leaf_start, c->d_state, params, c->d_lntab, c->d_regtab, fl, lmin, maxerr, run,
+                               L, err, count, rows, part, rp, peers, (unsigned int)wb, (c->regs_slow & 1u) | (c->regs_backoff ? 2u : 0u), c->d_slow_list, c->d_tickets + 1, c->d_regprof,
+                               (K*)c->d_bnext, (K*)c->d_bnext + wb * 64, c->d_tile_slow, c->regs_queue ? c->d_tickets + 2 : (unsigned int*)nullptr);
+          };
+          bool launched = false;
+          if constexpr (sizeof(K) == 4) { if (w2) { launch_regs(std::integral_constant<int, 2>{}); launched = true; } }
+          if (!launched) { if (regs_long) launch_regs(std::integral_constant<int, 1>{}); else launch_regs(std::integral_constant<int, 0>{}); }
           mark();                                                       // (slot 0: k_leaf_regs alone; slot 1: the listed groups + k_regs_finalize)
           // The groups k_leaf_regs listed.  As a rule there are none: with the result published early (k_lane_reduce) and the host
           // synchronising itself, the kernel is launched only when the record says a group was listed (DevState::regs_listed) --

@@ -257,11 +257,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ==
   // duplicate-heavy keys (DevState::regs_dups): every group would meet a duplicate and go on the list after its panels were requested
   // and its walk begun; listed at once instead, k_leaf_lanes_listed takes them all
   slow = (slow & 1u) | (((slow & 2u) && st->regs_dups * (64ull * 16ull) > (unsigned long long)(sp.leaf_hi - sp.leaf_lo)) ? 1u : 0u);   // (bit 1 of the argument: the routing is on)
-  auto wave_sync = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
 
   unsigned long long pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                   // (RG_PROF)
   unsigned long long pt = 0;
@@ -590,7 +585,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ==
       // LONG: the fit's panels have all landed (its last wait was vmcnt(0)) and been read: the ring is free, and the panels of the
       // error steps behind the stash are requested once more -- under the arithmetic that ends the fit
       // (a walk of at most 3 panels behind the stash: they are the ring's last panels, still there -- nothing is read again)
-      const unsigned int err_lastb = cur.maxlen > 0u ? (cur.maxlen - 1u) >> 4 : 0u;     // last block of the walk
       const bool reread = LONG && cur.lastp > (unsigned int)(SBLK + RG_RING - 1);
       if (LONG && !(RG_KO & 4) && reread) {
 #pragma unroll
