@@ -438,26 +438,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
       //  that ends with the shard's last key IS recorded, lower_bound_correction.rs:108-119; behind the last key of all nothing follows, Q5)
       if (n_it > 0u) { k_first = (B)key_to_bits<K>(kb[rel_lo]); k_last = (B)key_to_bits<K>(sp.it_hi < sp.n ? keys[sp.it_hi] : kb[rel_hi - 1u]); }
       constexpr int NCHT = FHC + NCHB * 64 + G::EXTC;                            // chunks of the LDS image
-      // (three chunks a lane and trip, their loads together: one after the other the nine trips were nine round trips to HBM -- the tile is
-      //  nobody's prefetch --, 15 us for the general form's kernel on the two ends of a launch)
-      constexpr int SLOWU = 3;
 #pragma unroll 1
-      for (int ch0 = lane; ch0 < NCHT; ch0 += 64 * SLOWU) {
-        uint4 qq[SLOWU];
-#pragma unroll
-        for (int u = 0; u < SLOWU; u++) {
-          const int ch = ch0 + 64 * u;
-          const long long rel_first = a + (long long)(ch - FHC) * KPC;
-          qq[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (ch < NCHT && rel_first + KPC > rd_lo_rel && rel_first < rd_hi_rel) qq[u] = *reinterpret_cast<const uint4*>(kb + rel_first);
-        }
-#pragma unroll
-        for (int u = 0; u < SLOWU; u++) {
-        const int ch = ch0 + 64 * u;
-        if (ch >= NCHT) break;
+      for (int ch = lane; ch < NCHT; ch += 64) {
         const int d0 = (ch - FHC) * 4;
         const long long rel_first = a + (long long)(ch - FHC) * KPC;
-        unsigned int w[4] = {qq[u].x, qq[u].y, qq[u].z, qq[u].w};
+        unsigned int w[4] = {0u, 0u, 0u, 0u};
+        if (rel_first + KPC > rd_lo_rel && rel_first < rd_hi_rel) {
+          const uint4 q = *reinterpret_cast<const uint4*>(kb + rel_first);
+          w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        }
         if (edge2 && n_it > 0u) {
 #pragma unroll
           for (int k = 0; k < KPC; k++) {
@@ -470,7 +459,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
           }
         }
         *reinterpret_cast<uint4*>(trow0 + d0 + 4 * (d0 >> 5)) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
       }
     }
     wave_sync();
