@@ -87,7 +87,7 @@ struct rmi_hip_multi {
   unsigned char** d_peer_rows = nullptr;    // the two tables above for the kernels
   unsigned char** d_peer_mail = nullptr;
   unsigned long long epoch = 0;
-  bool fuse_peer_stores = true;             // direct exchange: rows to the peers from k_leaf_lanes itself (RMI_HIP_PEER_FUSE=0: k_peer_push behind the kernels)
+  bool fuse_peer_stores = true;             // direct exchange: rows to the peers from k_leaf_lanes itself (false: k_peer_push behind the kernels -- more than 8 ranks)
 };
 // A rank's record in the exchange of the aggregates: the 6 words of DevState from max_err on (max_err, max_err_idx, sum_n_err,
 // sum_l2, sum_log2, pending): the last one tells every rank whether SOME rank still has listed leaves to finish.
@@ -413,7 +413,7 @@ int rmi_hip_train_sharded(rmi_hip_ctx* c, const rmi_hip_model_params* root, int 
     auto exchange = [&]() -> int {
       // rows: in place (this rank's piece already sits in its slot); aggregates: the record of RMI_STATS_WORDS words.
       // One group: RCCL launches the two gathers as one kernel (one launch latency instead of two on a ~0.1 ms step)
-      const bool grouped = a.GroupStart && a.GroupEnd && !std::getenv("RMI_HIP_NO_NCCL_GROUP");
+      const bool grouped = a.GroupStart && a.GroupEnd;
       int n0 = grouped ? a.GroupStart() : 0;
       int n1 = a.AllGather(c->d_rows_ext, m->d_rows_full, (size_t)(L_own * rowb), 1 /* ncclUint8 */, m->comm, c->stream);
       int n2 = a.AllGather(&c->d_state->max_err, m->d_stats_all, RMI_STATS_BYTES, 1, m->comm, c->stream);
@@ -611,7 +611,6 @@ int rmi_hip_peer_import(rmi_hip_ctx* c, int peer_rank, const void* handle) {
 int rmi_hip_set_exchange(rmi_hip_ctx* c, int mode) {
   if (!c || (mode != RMI_EXCHANGE_RCCL && mode != RMI_EXCHANGE_DIRECT)) return RMI_ERR_BAD_ARG;
   multi_of(c)->exchange = mode;
-  { const char* pf = std::getenv("RMI_HIP_PEER_FUSE"); if (pf && *pf) multi_of(c)->fuse_peer_stores = std::atoi(pf) != 0; }
   return RMI_OK;
 }
 

@@ -53,6 +53,18 @@ def test_regs_variants(monkeypatch, oracle, variant, gen, n, L, root):
         assert g.pipeline in ((3, 4) if (gen.startswith("dups") or gen == "clustered_u64") else (4,))
 
 
+@pytest.mark.parametrize("u32", ["0", "1", "2"])
+@pytest.mark.parametrize("gen,n,L,root", [c for c in CASES if c[0].endswith("u32")] + [("uniform_u32", 2_000_000, 8192, "cubic"), ("dups_u32", 1_000_000, 4000, "radix")])
+def test_regs_four_byte_keys_every_route(monkeypatch, oracle, u32, gen, n, L, root):
+    """4-byte keys with linear leaves on their three routes (RMI_HIP_REGS_U32): 2 = k_leaf_regs<u32, 2>, two waves per SIMD with the raw keys stashed (the
+    default), 1 = the one-wave kernel in half-line panels (short and LONG variants by the average), 0 = k_leaf_lanes.  Same bits as the oracle every way."""
+    g = _check(monkeypatch, oracle, {"RMI_HIP_REGS": "1" if u32 != "0" else "", "RMI_HIP_REGS_U32": u32}, dg.GENERATORS[gen](n), root, L)
+    if g is not None and u32 == "0":
+        assert g.pipeline == 3
+    if g is not None and u32 != "0" and gen == "uniform_u32" and root != "cubic":
+        assert g.pipeline == 4
+
+
 @pytest.mark.parametrize("name", sorted(dg.ADVERSARIAL))
 def test_regs_adversarial(monkeypatch, oracle, name):
     """Key sets with exact linear structure (progressions, keys around 2^53 and 2^63, an outlier): the closed form of the y
