@@ -123,6 +123,28 @@ def test_config5_full_size_vs_oracle(oracle, gen):
     assert np.array_equal(rows[:, :2], o.leaf_params.view(np.uint64)) and np.array_equal(rows[:, 2], o.leaf_err)
 
 
+@pytest.mark.parametrize("spec_root", ["linear", "radix"])
+def test_four_byte_keys_linear_leaves_full_size_vs_oracle(oracle, spec_root):
+    """`*_uint32` key files (src/load.rs:47-69) with linear leaves at C5's key count: 400M uniform uint32, 2^21 leaves (190 keys a leaf) -- the register kernel at
+    two waves per SIMD (k_leaf_regs<u32, 2>, pipeline 4) against the oracle, every array bit for bit."""
+    from rmi_amd import train
+    n, L = 400_000_000, 1 << 21
+    tr = train.Trainer()
+    tr.generate_keys("uniform", np.uint32, n)
+    keys = tr.download_keys()
+    root = tr.fit_root(spec_root, L)
+    g = tr.train_leaves(root, "linear", L).materialize()
+    assert g.pipeline == 4
+    tr.close()
+    o = oracle.train_two_layer(spec_root, "linear", keys, L, threads=2)
+    assert root.p == o.root.p and tuple(root.ip) == tuple(o.root.ip)
+    assert np.array_equal(g.leaf_starts, o.leaf_start), "bucket assignment differs at full size"
+    assert np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64)), "leaf coefficients differ at full size"
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err), f"{np.count_nonzero(g.last_layer_max_l1s != o.leaf_err)} max-error integers differ"
+    assert np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx and g.model_avg_error == o.model_avg_error
+
+
 def test_config4_workload_one_gpu_vs_oracle(oracle):
     """BASELINE config 4's workload (800M uniform uint64, linear,linear, 2^21 leaves: 381 keys a leaf) at its stated size on ONE GPU
     against the oracle, bit for bit.  (As configured -- 8 devices, RCCL -- it needs a node; the shards' kernels are these.)"""
