@@ -292,6 +292,24 @@ def side_configs(T, tr_m, device, with_oracle):
         tr_m.set_fit_mode(0)
     except Exception as ex:                                   # a side figure must not take the headline down
         res["C3"] = {"error": str(ex)}
+    # S64: linear_spline leaves over the metric configuration's keys (191 keys a leaf against 64 keys of look-ahead: k_spline_scan's short form
+    # looks for the open leaf's end in the key array)
+    try:
+        n, L = tr_m.n, 1 << 20
+        root = tr_m.fit_root("linear", L)
+        e, r = run(tr_m, root, 1, L, 0, 20, n, 8)
+        if with_oracle:
+            from oracle import binding as oracle
+            t0 = time.perf_counter()
+            o = oracle.train_two_layer("linear", "linear_spline", tr_m.download_keys(), L, threads=2)
+            e["parity_check"] = parity_against(o, r.materialize(), "200M u64 linear,linear_spline 2^20 at full size: every leaf")
+            e["parity_check"]["root_equal"] = bool(tuple(root.p) == tuple(o.root.p))
+            e["parity_check"]["oracle_seconds"] = time.perf_counter() - t0
+            del o
+        res["S64 linear,linear_spline 2^20 on 200M u64"] = {"exact": with_traffic(e, "s64")}
+        tr_m.set_fit_mode(0)
+    except Exception as ex:
+        res["S64"] = {"error": str(ex)}
     # C5: 400M u32, radix root, linear_spline leaves (one pass, bit-identical in every mode), uniform and duplicate-heavy
     for ds in ("uniform", "dups"):
         try:

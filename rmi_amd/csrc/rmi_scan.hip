@@ -35,7 +35,10 @@ static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
     if (a.mono && a.tile_list != nullptr) {
       // the short form's kernel over all tiles; what it leaves goes on the list
       const unsigned int g0 = grid_for(0);
-      hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 0>), dim3(g0), dim3(64), 0, s, ka);
+      // leaves longer than the look-ahead on average (8-byte keys: 64 keys, 4-byte keys: 128): the variant that looks for an open leaf's end behind it
+      const uint64_t n_keys = a.sp.it_hi - a.sp.it_lo, n_leaves = a.sp.leaf_hi > a.sp.leaf_lo ? a.sp.leaf_hi - a.sp.leaf_lo : 1;
+      if (n_keys > (uint64_t)G::EXTN * n_leaves) hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 0, 1>), dim3(g0), dim3(64), 0, s, ka);
+      else hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 0, 0>), dim3(g0), dim3(64), 0, s, ka);
       a.waves += g0;
       ka.out.partials = a.out.partials + g0;
       listed = true;
@@ -65,7 +68,7 @@ static int scan_launch_k(int dtype, ScanLaunch& a, hipStream_t s) {
 // (what the registers and the LDS of a CU hold: 4 SIMDs x the waves per SIMD the phase is compiled for, 160 KB over the kernel's static LDS;
 //  the same for every instance.  A launch of more waves than are resident would run its surplus as a second round behind the first.)
 unsigned int rmi_scan_waves_per_cu(int phase) {
-  const unsigned int lds_bytes = (((unsigned int)ScGeom<uint32_t, 32>::LDS_DW * 4u + 2720u) + 511u) & ~511u;   // (the tile image + the slot tables, in the allocation's granules)
+  const unsigned int lds_bytes = (((unsigned int)ScGeom<uint32_t, 32>::LDS_DW * 4u + 2864u) + 1279u) / 1280u * 1280u;   // (the tile image + the slot tables, in the allocation's granules of 1 280 B)
   const unsigned int by_lds = 163840u / lds_bytes;
   const unsigned int by_regs = 4u * (phase == 0 ? RMI_SC_WPE0 : RMI_SC_WPE);
   return by_lds < by_regs ? by_lds : by_regs;

@@ -229,7 +229,9 @@ struct ScanArgs {
 // PHASE 0: the short form alone, at RMI_SC_WPE0 waves per SIMD -- the general form's registers are what kept the whole kernel at 2 --; a tile
 //          it cannot take (an end of the launch, a lane with two leaf starts, a long gap or leaf, the split nearby) goes on a list.
 // PHASE 1: the general form over the tiles of that list, or -- a root that is not monotone by arithmetic: no PHASE 0 -- over all tiles.
-template <int ROOT, typename K, int V, int PHASE>
+// FAR (PHASE 0): the end of the leaf that is open at a tile's end is looked for BEHIND the look-ahead too (in the key array); the launcher takes this variant
+//          where the leaves are longer than the look-ahead on average -- the other keeps C5's code as it was (the far search costs it 2-3 %: registers).
+template <int ROOT, typename K, int V, int PHASE, int FAR = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE == 0 ? RMI_SC_WPE0 : RMI_SC_WPE, PHASE == 0 ? RMI_SC_WPE0 : RMI_SC_WPE))) k_spline_scan(ScanArgs) {
   const sc_kargp kp = sc_kernarg_ptr();
   const ScanArgs* const ka = reinterpret_cast<const ScanArgs*>((const unsigned char*)kp);
@@ -259,7 +261,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
   __shared__ __attribute__((aligned(16))) unsigned int lds[G::LDS_DW];
   // (FB, below: the gfx950 LDS is dealt out in granules of 1 280 bytes and 12 waves a CU get 10 of them -- 12 800 B; the kernel used 12 552.  So the batched
   //  form counts bytes: no r_g0 -- the number of empty leaves in front of a start, at most 4 in an ordinary tile, rides in the top bits of r_t --, no spare entries)
-  constexpr bool FB = PHASE == 0 && RMI_SC_F5BATCH != 0 && sizeof(K) == 4 && ScMono<ROOT>::value;
+  constexpr bool FB = PHASE == 0 && RMI_SC_F5BATCH != 0 && ScMono<ROOT>::value;
+  constexpr bool FBK = FB && sizeof(K) == 4;            // the pending slots' end keys in LDS (8-byte keys: read from the key array again when the ends are run)
   constexpr int NS1 = FB ? SC_SLOTS : SC_SLOTS + 1, NS2 = FB ? SC_SLOTS + 1 : SC_SLOTS + 2;
   __shared__ unsigned int r_s[NS1], r_t[NS1], r_g0[FB ? 1 : SC_SLOTS + 1], r_yp[NS1];                      // boundary records of a batch
   __shared__ __attribute__((aligned(16))) double m_ab[2 * NS2];                                              // (alpha, beta) per slot, one entry of padding in front (and behind)
@@ -267,10 +270,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
   // FB: the short form's leaf ends (F5) are run for the slots of SEVERAL tiles at once.  An ordinary tile of C5 starts ~21 leaves: F3 and F5 -- lane =
   // slot, ~64 us of 400 by a knock-out build, a chain of LDS reads, conversions, a logarithm and four scattered stores -- ran with a third of the
   // lanes.  The slots of a tile are appended to the tables behind those still pending (`cnt`), with their ends and their containers' end keys
-  // (the tile image is gone when the ends are computed); the ends run when the next tile's starts might not fit.  4-byte keys only (an 8-byte key's
-  // end keys would take another 512 B); the containers' first keys take the place of r_yp, which a slot needs only until its model is computed (F3).
+  // (the tile image is gone when the ends are computed); the ends run when the next tile's starts might not fit.  4-byte keys: the containers' first
+  // keys take the place of r_yp, which a slot needs only until its model is computed (F3); 8-byte keys (their end keys would take another 768 B): the two
+  // keys of a slot are read from the key array again when the ends are run -- two scattered loads a lane, once per batch of up to 64 leaves.
   // With 13 072 B a wave -- 11 waves a CU, the twelfth of the launch a second round -- the batched form ran 0.51 against 0.45 ms.
-  __shared__ unsigned int r_e[FB ? SC_SLOTS : 1], r_khi[FB ? SC_SLOTS : 1];
+  __shared__ unsigned int r_e[FB ? SC_SLOTS : 1], r_khi[FBK ? SC_SLOTS : 1];
   unsigned int* const r_end = FB ? r_e : r_s + 1;                       // end of slot i (not batched: the start of slot i + 1)
   unsigned int* const r_klo = r_yp;                                     // (FB) written by the lane that has just read r_yp of the same slot
 
@@ -551,9 +555,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
             if (has) p = hi;
           }
           if (__any(has && (t_hi != tl || t_hi - tp > 5u))) break;              // a lane with more than one start, or more than 4 empty leaves in front of it
-          const bool dups = __any(dq) != 0;                                     // duplicates among the keys [A2 - 2, A2 + BTILE + EXTN)
+          bool dups = __any(dq) != 0;                                           // duplicates among the keys [A2 - 2, A2 + BTILE + EXTN) (... and of the open leaf behind them: below)
           if (dups && !RMI_SC_FAST_DUPS) break;
-          // ---- the end of the leaf that is open at the big tile's end: in the look-ahead, or the general form takes the tiles
+          // ---- the end of the leaf that is open at the big tile's end: in the look-ahead; else looked for in the key array, 64 keys a step, up to long_min
+          //      keys (8-byte keys have 64 keys of look-ahead, and a leaf of M's 191 keys that is open at a tile's end runs on for 95 on average: two tiles in
+          //      three went to the general form -- and their listing, one counter for all, cost more than their work: 2.26 ms for 200 M u64 keys)
           const unsigned int t_tile_last = sc_lane63(tl);
           unsigned int term_rel = 0u, tt = 0u;
           {
@@ -570,11 +576,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
                 }
               }
             }
-            if (!found) break;
+            if (!found) {
+              if constexpr (FAR == 0) break;
+              bool dq_far = false;
+              const unsigned int lim = long_min > (unsigned int)EXTN ? long_min : (unsigned int)EXTN;
+              for (unsigned int o = (unsigned int)EXTN; o < lim && !found; o += 64u) {
+                const unsigned int relx = relA2 + (unsigned int)BTILE + o;        // launch-relative index of this step's first key
+                if (relx + 64u + 1u > rel_hi) break;                              // the launch's end: the general form
+                const K kx = kb[(long long)relx + lane], kxp = kb[(long long)relx + lane - 1];
+                bool o2;
+                const unsigned int t = target_of(kx, o2);
+                dq_far = dq_far || (kx == kxp);
+                const unsigned long long dm = __ballot(t != t_tile_last);
+                if (dm) {
+                  const int src = __builtin_ctzll(dm);
+                  term_rel = (unsigned int)BTILE + o + (unsigned int)src;
+                  tt = (unsigned int)__builtin_amdgcn_readlane((int)t, src);
+                  found = true;
+                }
+              }
+              if (!found) break;                                                  // (a leaf that runs on for more than long_min keys: the list kernels, through the general form)
+              if (__any(dq_far)) { dups = true; if (!RMI_SC_FAST_DUPS) break; }
+            }
           }
+          // key with the tile-relative index rr: in the image up to the look-ahead's end, behind it from the key array (the open leaf's far keys)
+          auto key_rel = [&](int rr) -> K {
+            if constexpr (FAR != 0) { if (rr >= BTILE + EXTN) return kb[(long long)relA2 + rr]; }
+            return bits_to_key<K>(lds_bits0(rr));
+          };
           // ---- the split of the 2-way join (two_layer.rs:130-175) anywhere near: the general form knows Q2-Q4
           if (host_split) {
-            if ((unsigned int)(h_split - (A2 - 2u)) <= (unsigned int)(BTILE + EXTN + 2)) break;
+            if ((unsigned int)(h_split - (A2 - 2u)) <= (term_rel > (unsigned int)(BTILE + EXTN) ? term_rel : (unsigned int)(BTILE + EXTN)) + 2u) break;
           } else {
             if (t2 < mid && tt >= mid) break;                                   // the targets of [A2 - 2, end of the open leaf] cross L / 2
           }
@@ -622,10 +654,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
           if ((unsigned int)lane < nb) {
             const unsigned int sl = pend + (unsigned int)lane;
             const unsigned int q_s = r_s[sl], q_e = r_end[sl];
-            const K k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))), k_hi = bits_to_key<K>(lds_bits0((int)(q_e - A2)));
+            const K k_lo = bits_to_key<K>(lds_bits0((int)(q_s - 1u - A2))), k_hi = key_rel((int)(q_e - A2));
             const double x0 = KeyTraits<K>::as_float(k_lo), x1 = KeyTraits<K>::as_float(k_hi);
             const double y0f = (double)r_yp[sl], y1f = (double)q_e;
-            if constexpr (FB) { r_klo[sl] = (unsigned int)key_to_bits<K>(k_lo); r_khi[sl] = (unsigned int)key_to_bits<K>(k_hi); }   // (behind the read of r_yp[sl]: the same words)
+            if constexpr (FBK) { r_klo[sl] = (unsigned int)key_to_bits<K>(k_lo); r_khi[sl] = (unsigned int)key_to_bits<K>(k_hi); }   // (behind the read of r_yp[sl]: the same words)
             const double mb = (y0f - y1f) / (x0 - x1);                           // linear_spline.rs:27
             const double ma = y0f - mb * x0;                                     // :28, plain multiply-subtract
             m_ab[2 * (sl + 1u)] = ma; m_ab[2 * (sl + 1u) + 1] = mb;
@@ -749,11 +781,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
                 const unsigned int rel = o + (unsigned int)lane;
                 const bool in = rel < term_rel;
                 const int rr = (int)(in ? rel : o);
-                const K kv = bits_to_key<K>(lds_bits0(rr));
+                const K kv = key_rel(rr);
                 const unsigned int i = A2 + rel;
                 unsigned int y = i;
                 if (dups) {
-                  const K kpv = bits_to_key<K>(lds_bits0(rr - 1)), knx = bits_to_key<K>(lds_bits0(rr + 1));
+                  const K kpv = key_rel(rr - 1), knx = key_rel(rr + 1);
                   const unsigned int hidx = (in && !(kv == kpv)) ? i : 0u;
                   const unsigned int pm = sc_scan_max(hidx);
                   y = max(pm, y_carry);

@@ -27,10 +27,13 @@
       const unsigned int q_s = r_s[lane], q_e = r_end[lane], q_tw = r_t[lane];
       const unsigned int q_t = FB ? (q_tw & 0x1FFFFFFFu) : q_tw;
       K k_lo, k_hi;
-      if constexpr (FB) { k_lo = bits_to_key<K>((B)r_klo[lane]); k_hi = bits_to_key<K>((B)r_khi[lane]); }
+      if constexpr (FBK) { k_lo = bits_to_key<K>((B)r_klo[lane]); k_hi = bits_to_key<K>((B)r_khi[lane]); }
+      else if constexpr (FB) { k_lo = keys[q_s - 1u]; k_hi = keys[q_e]; }   // (n < 2^32: the indices ARE the global ones; an ordinary tile's containers lie inside the launch)
       else {
         const int d_lo = (int)(q_s - 1u - ends_A2) * DW, d_hi = (int)(q_e - ends_A2) * DW;
-        k_lo = bits_to_key<K>(bits_at(trow0 + d_lo + 4 * (d_lo >> 5))); k_hi = bits_to_key<K>(bits_at(trow0 + d_hi + 4 * (d_hi >> 5)));
+        k_lo = bits_to_key<K>(bits_at(trow0 + d_lo + 4 * (d_lo >> 5)));
+        if (FAR == 0 || (int)(q_e - ends_A2) < BTILE + EXTN) k_hi = bits_to_key<K>(bits_at(trow0 + d_hi + 4 * (d_hi >> 5)));
+        else k_hi = keys[q_e];                                              // (FAR: the open leaf's end behind the look-ahead)
       }
       const double ma = m_ab[2 * (lane + 1)], mb = m_ab[2 * (lane + 1) + 1];
       const unsigned int curr = m_err[lane + 1], ru = m_run[lane + 1];

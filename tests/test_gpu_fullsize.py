@@ -123,6 +123,30 @@ def test_config5_full_size_vs_oracle(oracle, gen):
     assert np.array_equal(rows[:, :2], o.leaf_params.view(np.uint64)) and np.array_equal(rows[:, 2], o.leaf_err)
 
 
+@pytest.mark.parametrize("gen,dtype,n,L", [("uniform", np.uint64, 200_000_000, 1 << 20), ("dups", np.uint64, 200_000_000, 1 << 20),
+                                           ("uniform", np.uint32, 400_000_000, 1 << 20)])
+def test_spline_leaves_longer_than_the_look_ahead_full_size_vs_oracle(oracle, gen, dtype, n, L):
+    """linear_spline leaves on the metric configuration's keys (200M uint64, 2^20 leaves: 191 keys a leaf against 64 keys of look-ahead) and on C5's keys
+    in a quarter of its leaves (381 against 128): k_spline_scan's short form looks for the open leaf's end in the key array (FAR) -- against the
+    oracle, every array bit for bit."""
+    from rmi_amd import train
+    tr = train.Trainer()
+    tr.generate_keys(gen, dtype, n)
+    keys = tr.download_keys()
+    spec_root = "linear" if dtype == np.uint64 else "radix"
+    root = tr.fit_root(spec_root, L)
+    g = tr.train_leaves(root, "linear_spline", L).materialize()
+    assert g.pipeline == 5
+    tr.close()
+    o = oracle.train_two_layer(spec_root, "linear_spline", keys, L, threads=2)
+    assert root.p == o.root.p and tuple(root.ip) == tuple(o.root.ip)
+    assert np.array_equal(g.leaf_starts, o.leaf_start), "bucket assignment differs at full size"
+    assert np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64)), "leaf coefficients differ at full size"
+    assert np.array_equal(g.last_layer_max_l1s, o.leaf_err), f"{np.count_nonzero(g.last_layer_max_l1s != o.leaf_err)} max-error integers differ"
+    assert np.array_equal(g.leaf_counts, o.leaf_count)
+    assert g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx and g.model_avg_error == o.model_avg_error
+
+
 @pytest.mark.parametrize("spec_root", ["linear", "radix"])
 def test_four_byte_keys_linear_leaves_full_size_vs_oracle(oracle, spec_root):
     """`*_uint32` key files (src/load.rs:47-69) with linear leaves at C5's key count: 400M uniform uint32, 2^21 leaves (190 keys a leaf) -- the register kernel at

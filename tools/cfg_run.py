@@ -4,6 +4,7 @@ usage: [TAG=name] [RMI_HIP_...=..] python tools/cfg_run.py <M|C2|C3|C4s|C5|Ms|D>
    C3  200 M uniform u64, cubic,linear 2^20           C5  400 M u32 (uniform | dups), radix,linear_spline 2^22
    Ms  M's 1/8 shard shape: 25 M u64, 131072 leaves   C4s C4's 1/8 shard shape: 100 M u64, 262144 leaves (381 keys a leaf)
    D   200 M dups u64, linear,linear 2^20             U32 / U32r  400 M uniform u32, linear,linear / radix,linear 2^21
+   S64 200 M uniform u64, linear,linear_spline 2^20
 With RMI_CFG_TRACE=1 only the trainings run (no read-bandwidth kernel, few steps): the workload of a counter pass."""
 import os
 import sys
@@ -36,6 +37,8 @@ CFG = {
     "D": (200_000_000, 1 << 20, "linear", "linear", "dups", np.uint64),
     "U32": (400_000_000, 1 << 21, "linear", "linear", "uniform", np.uint32),      # 4-byte keys, linear leaves (190 keys a leaf)
     "U32r": (400_000_000, 1 << 21, "radix", "linear", "uniform", np.uint32),
+    "S32": (400_000_000, 1 << 20, "radix", "linear_spline", "uniform", np.uint32),    # C5's keys in a quarter of its leaves (381 keys a leaf)
+    "S64": (200_000_000, 1 << 20, "linear", "linear_spline", "uniform", np.uint64),   # linear_spline leaves on M's keys (k_spline_scan, 8-byte keys)
 }
 
 

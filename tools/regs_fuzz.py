@@ -5,7 +5,8 @@ argument: 150 .. 1 000 keys per leaf (k_leaf_regs<K, LONG>: the walk behind the 
 still in the ring, containers beyond 1 008 points listed), half of the configurations with LONG forced on every shape.  With `u32`: 4-byte keys,
 6 .. 800 keys per leaf, linear and radix roots, the one-wave and the two-wave kernel (RMI_HIP_REGS_U32 = 1 / 2).  With `spline`: linear_spline leaves of
 4-byte keys through k_spline_scan with few persistent waves (a wave takes many tiles: the batched leaf ends), 8 .. 3 000 keys per leaf.
-usage: python tools/regs_fuzz.py [seconds [seed [long|u32|spline]]]"""
+`spline64`: the same on 8-byte keys.
+usage: python tools/regs_fuzz.py [seconds [seed [long|u32|spline|spline64]]]"""
 import sys
 import time
 
@@ -28,6 +29,8 @@ def main():
     long_mode = mode == "long"
     if mode in ("u32", "spline"):
         gens = [g for g in dg.GENERATORS if g.endswith("u32")]
+    if mode == "spline64":
+        mode = "spline"                                      # (8-byte keys: the pending slots' end keys are read from the key array again)
     t0, done, bad, p4 = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
         gen = gens[int(rng.integers(len(gens)))]
@@ -38,7 +41,7 @@ def main():
         if mode == "spline":
             per = float(10 ** rng.uniform(0.9, 3.48))
         L = max(2, int(n / per))
-        root_kind = "linear" if mode not in ("u32", "spline") or rng.random() < 0.5 else "radix"
+        root_kind = "linear" if mode not in ("u32", "spline") or gen.endswith("f64") or rng.random() < 0.5 else "radix"
         leaf_kind = "linear_spline" if mode == "spline" else "linear"
         want = 5 if mode == "spline" else 4
         env = {"RMI_HIP_REGS": "1"}
