@@ -137,6 +137,7 @@ struct rmi_hip_ctx {
   uint64_t giant_cap = 0;
   uint64_t host_min = 262144;                   // RMI_HIP_HOST_MIN; 0: never.  (A wave walks 262 144 points in ~7 ms, a host core in ~1: below that the
                                                 //  leaves of a skewed key set are many and run side by side on the device)
+  bool host_min_set = false;                    // RMI_HIP_HOST_MIN given: the threshold alone decides (else giant leaves only where the AVERAGE leaf is far below it)
   bool giant_armed = false;                     // the last launch recorded giant leaves for the host
   // the giant list early (k_giant_scan in front of k_list, read through pinned memory): the host walks the chains while
   // the device fits the other listed leaves
@@ -339,7 +340,7 @@ int rmi_hip_create(int device_id, rmi_hip_ctx** out) {
   if (pl && *pl) c->pipeline = std::atoi(pl) >= 3 ? 3 : 2;       // 2: the streaming passes of round 2 (what tiny and huge key sets and cubic / robust leaves take anyway); default 3: everything newer
   { const char* lsr = std::getenv("RMI_HIP_LANES_SEARCH"); if (lsr && *lsr) c->lanes_search = std::atoi(lsr) != 0; }
   { const char* otl = std::getenv("RMI_HIP_OPT_TAIL"); if (otl && *otl) c->opt_tail = std::atoi(otl) != 0; }
-  { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) c->host_min = std::strtoull(hm, nullptr, 10); }
+  { const char* hm = std::getenv("RMI_HIP_HOST_MIN"); if (hm && *hm) { c->host_min = std::strtoull(hm, nullptr, 10); c->host_min_set = true; } }
   { const char* rg = std::getenv("RMI_HIP_REGS"); if (rg && *rg) { c->regs = std::atoi(rg) != 0; c->regs_forced = c->regs; } }   // (=1 also overrides the choice by group count)
   { const char* ru = std::getenv("RMI_HIP_REGS_U32"); if (ru && *ru) c->regs_u32 = std::atoi(ru); }
   { const char* cm = std::getenv("RMI_HIP_CUBIC_MARGIN"); if (cm && *cm) c->cubic_margin = std::atoi(cm) != 0; }
@@ -527,7 +528,7 @@ int rmi_hip_train_many(rmi_hip_ctx* c, const rmi_hip_train_config* cfgs, uint64_
     const int arc = rmi_hip_attach_device_keys(v, c->d_keys, c->n, c->dtype);
     if (arc != RMI_OK) return arc;
     // what the caller has set on the context holds for every training of the batch
-    v->fit_mode = c->fit_mode; v->guard_k = c->guard_k; v->profile_level = c->profile_level; v->host_min = c->host_min;
+    v->fit_mode = c->fit_mode; v->guard_k = c->guard_k; v->profile_level = c->profile_level; v->host_min = c->host_min; v->host_min_set = c->host_min_set;
     v->long_min = c->long_min; v->pipeline = c->pipeline; v->regs = c->regs; v->regs_forced = c->regs_forced; v->regs_u32 = c->regs_u32; v->opt_tail = c->opt_tail;
   }
   std::atomic<uint64_t> next{0};
@@ -1342,7 +1343,10 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       // --- exact fit of 64 leaves per wave in lockstep, and their error pass behind it ---
       lanes_fused = lanes_fused_plan;
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
-      const bool giants = LEAF == K_LINEAR && lanes_fused_plan && c->host_min > 0 && !c->stream_mode && !c->defer_sync;
+      // (giant leaves are for the OUTLIERS of a skewed key set: where the average leaf is within a factor of four of the threshold nearly every leaf would go
+      //  to the host -- 400 M u32 keys in 1 024 leaves: 680 ms, the keys over PCIe and 1 024 chains on a few cores, against 14 ms of 1 024 waves side by side)
+      const bool giants_pay = c->host_min > 0 && (c->host_min_set || n_it / (L_own ? L_own : 1) <= c->host_min / 4);
+      const bool giants = LEAF == K_LINEAR && lanes_fused_plan && giants_pay && !c->stream_mode && !c->defer_sync;
       if (giants) { const int grc = arm_giants(); if (grc != RMI_OK) return grc; }
       const unsigned int lmin = c->long_min < (unsigned int)LN_LONG_MAX ? c->long_min : (unsigned int)LN_LONG_MAX;
       StatsPartial* const part = c->d_partials;
@@ -1647,7 +1651,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
       SgList fl; fl.ids = c->d_flist; fl.cnt = c->d_flist_cnt; fl.cap = c->flist_cap;
       // (the guarded mode re-fits its long leaves exactly: a giant one is a chain for a host core, as on the exact path;
       //  RMI_FIT_ONEPASS merges their partial sums instead -- tagged entries, never handed to the host)
-      sigma_giants = LEAF == K_LINEAR && c->host_min > 0 && !c->stream_mode && !c->defer_sync;
+      sigma_giants = LEAF == K_LINEAR && c->host_min > 0 && (c->host_min_set || n_it / (L_own ? L_own : 1) <= c->host_min / 4) && !c->stream_mode && !c->defer_sync;
       if (sigma_giants) {
         const int grc = arm_giants(); if (grc != RMI_OK) return grc;
         // (their list first, through pinned memory: the host walks those chains while k_list fits the other listed leaves)

@@ -1,6 +1,8 @@
 // rmi_scan.hip -- translation unit of pipeline 5 (k_spline_scan, rmi_scan.hip.h) and its launcher.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "rmi_scan.hip.h"
 
 namespace rmi {
@@ -32,16 +34,42 @@ static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
   a.waves = 0;
   bool listed = false;
   if constexpr (ScMono<ROOT>::value && RMI_SC_FAST) {
-    if (a.mono && a.tile_list != nullptr) {
+    // leaves shorter than a lane's row on average (8-byte keys: 16 keys, 4-byte keys: 32; the limit: 1.25 rows): nearly every tile has a lane with two leaf
+    // starts, the short form would list them all -- one counter -- and the general form take them from the list: 3.7 ms for 200 M u64 keys in 2^24 leaves,
+    // 4.1 for 400 M u32 keys, against 1.3 with the general form over all tiles at once (what roots that are not monotone by arithmetic get)
+    const uint64_t n_keys = a.sp.it_hi - a.sp.it_lo, n_leaves = a.sp.leaf_hi > a.sp.leaf_lo ? a.sp.leaf_hi - a.sp.leaf_lo : 1;
+    const bool short_leaves = 4ull * n_keys < 5ull * (uint64_t)G::VF * n_leaves;
+    if (a.mono && a.tile_list != nullptr && !short_leaves) {
       // the short form's kernel over all tiles; what it leaves goes on the list
       const unsigned int g0 = grid_for(0);
       // leaves longer than the look-ahead on average (8-byte keys: 64 keys, 4-byte keys: 128): the variant that looks for an open leaf's end behind it
-      const uint64_t n_keys = a.sp.it_hi - a.sp.it_lo, n_leaves = a.sp.leaf_hi > a.sp.leaf_lo ? a.sp.leaf_hi - a.sp.leaf_lo : 1;
+      // (... and where they are several hundred keys long, the variant that finds that end with one gather and reads the open leaf's far keys four blocks a trip)
+      if (n_keys > 384ull * n_leaves) {
+        // Leaves of several tiles: a leaf start every P tiles, and the wave that meets one reads the whole leaf.  A wave of an XCD takes every wpx-th tile
+        // (wpx = the waves of the XCD): if wpx / P is a fraction of a small denominator q, every start meets the same wpx q / P waves -- 400 M u32 keys
+        // (a jittered grid of stride 10) under a radix root of 2^14 leaves: P = 2^18 / 10 / 2 048 = 12.8 tiles, wpx = 384 = 30 P, 30 waves of 384 did all
+        // the work (6.7 ms against 0.77).  The shapes that do this are made of powers of two, like 384 = 3 * 2^7: wpx is the largest PRIME the device
+        // holds (383).  P itself is not known here -- the leaves a radix root leaves empty are not.  (Measured instead: a wave's place rotating from
+        // round to round 0.81 ms, but 0.74 -> 0.97 for the shapes without such a fraction; tiles drawn from a counter per XCD, four a ticket, 0.96, and
+        // 0.55 -> 0.77: a fixed stride deals evenly filled leaves out perfectly, any other rule like a Poisson process, and the tickets cost.)
+        unsigned int gf = g0;
+        if (g0 >= 8u * 32u) {
+          unsigned int w = g0 / 8u;
+          auto prime = [](unsigned int v) { for (unsigned int d = 2; d * d <= v; d++) if (v % d == 0) return false; return true; };
+          while (!prime(w)) w--;
+          gf = 8u * w;
+        }
+        hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 0, 2>), dim3(gf), dim3(64), 0, s, ka);
+        a.waves += gf;
+        ka.out.partials = a.out.partials + gf;
+        listed = true;
+      } else {
       if (n_keys > (uint64_t)G::EXTN * n_leaves) hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 0, 1>), dim3(g0), dim3(64), 0, s, ka);
       else hipLaunchKernelGGL((k_spline_scan<ROOT, K, V, 0, 0>), dim3(g0), dim3(64), 0, s, ka);
       a.waves += g0;
       ka.out.partials = a.out.partials + g0;
       listed = true;
+      }
     }
   }
   if (!listed) ka.tile_list = nullptr;                                            // the general form's kernel takes every tile

@@ -70,6 +70,12 @@
 #ifndef RMI_SC_NSUB
 #define RMI_SC_NSUB 1                 // tiles per big tile: 1 (2: the short form's lanes hold two rows -- fewer instructions a key, but 21.7 KB of LDS and spills: 0.59 against 0.52 ms)
 #endif
+#ifndef RMI_SC_FARB
+#define RMI_SC_FARB 8                 // FAR = 2: blocks of 64 keys of an open leaf's far part read per trip
+#endif
+#ifndef RMI_SC_FAR_MAX
+#define RMI_SC_FAR_MAX 32768          // FAR = 2: an open leaf's end is looked for this many keys behind the tile (beyond: the general form lists the leaf)
+#endif
 #ifndef RMI_SC_WPE0
 #define RMI_SC_WPE0 3                 // waves per SIMD of the short form's kernel (PHASE 0: 168 registers)
 #endif
@@ -231,6 +237,10 @@ struct ScanArgs {
 // PHASE 1: the general form over the tiles of that list, or -- a root that is not monotone by arithmetic: no PHASE 0 -- over all tiles.
 // FAR (PHASE 0): the end of the leaf that is open at a tile's end is looked for BEHIND the look-ahead too (in the key array); the launcher takes this variant
 //          where the leaves are longer than the look-ahead on average -- the other keeps C5's code as it was (the far search costs it 2-3 %: registers).
+//          FAR = 1: 64 keys a step, in the search and in the error pass (each step a memory round trip: fine while a leaf ends a block or two behind the
+//          look-ahead).  FAR = 2, for leaves of several hundred keys and more: ONE gather finds the block that holds the end (lane l probes the last key of
+//          the l-th block), the error pass reads four blocks a trip -- 200 M u64 keys in 2^16 leaves 1.19 -> 0.64 ms.  An instance of its own because its
+//          code left 5 spilled registers around the tile's error pass (FAR = 1 has none; M's keys in 2^20 spline leaves 0.43 -> 0.49 ms with them).
 template <int ROOT, typename K, int V, int PHASE, int FAR = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE == 0 ? RMI_SC_WPE0 : RMI_SC_WPE, PHASE == 0 ? RMI_SC_WPE0 : RMI_SC_WPE))) k_spline_scan(ScanArgs) {
   const sc_kargp kp = sc_kernarg_ptr();
@@ -577,26 +587,54 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
               }
             }
             if (!found) {
-              if constexpr (FAR == 0) break;
-              bool dq_far = false;
-              const unsigned int lim = long_min > (unsigned int)EXTN ? long_min : (unsigned int)EXTN;
-              for (unsigned int o = (unsigned int)EXTN; o < lim && !found; o += 64u) {
-                const unsigned int relx = relA2 + (unsigned int)BTILE + o;        // launch-relative index of this step's first key
-                if (relx + 64u + 1u > rel_hi) break;                              // the launch's end: the general form
-                const K kx = kb[(long long)relx + lane], kxp = kb[(long long)relx + lane - 1];
-                bool o2;
-                const unsigned int t = target_of(kx, o2);
-                dq_far = dq_far || (kx == kxp);
-                const unsigned long long dm = __ballot(t != t_tile_last);
-                if (dm) {
-                  const int src = __builtin_ctzll(dm);
-                  term_rel = (unsigned int)BTILE + o + (unsigned int)src;
-                  tt = (unsigned int)__builtin_amdgcn_readlane((int)t, src);
-                  found = true;
+              if constexpr (FAR == 0 || (FAR == 2 && !RMI_SC_FAST_DUPS)) break;
+              if constexpr (FAR == 1) {
+                bool dq_far = false;
+                const unsigned int lim = long_min > (unsigned int)EXTN ? long_min : (unsigned int)EXTN;
+                for (unsigned int o = (unsigned int)EXTN; o < lim && !found; o += 64u) {
+                  const unsigned int relx = relA2 + (unsigned int)BTILE + o;        // launch-relative index of this step's first key
+                  if (relx + 64u + 1u > rel_hi) break;                              // the launch's end: the general form
+                  const K kx = kb[(long long)relx + lane], kxp = kb[(long long)relx + lane - 1];
+                  bool o2;
+                  const unsigned int t = target_of(kx, o2);
+                  dq_far = dq_far || (kx == kxp);
+                  const unsigned long long dm = __ballot(t != t_tile_last);
+                  if (dm) {
+                    const int src = __builtin_ctzll(dm);
+                    term_rel = (unsigned int)BTILE + o + (unsigned int)src;
+                    tt = (unsigned int)__builtin_amdgcn_readlane((int)t, src);
+                    found = true;
+                  }
                 }
+                if (!found) break;                                                  // (a leaf that runs on for more than long_min keys: the list kernels, through the general form)
+                if (__any(dq_far)) { dups = true; if (!RMI_SC_FAST_DUPS) break; }
               }
-              if (!found) break;                                                  // (a leaf that runs on for more than long_min keys: the list kernels, through the general form)
-              if (__any(dq_far)) { dups = true; if (!RMI_SC_FAST_DUPS) break; }
+              if constexpr (FAR == 2) {
+                // lane l probes the LAST key of the l-th block of 64 keys behind the look-ahead: the targets are monotone, so the first block whose last key
+                // has left the open leaf holds its end -- one gather instead of a trip per block (a leaf of 3 000 keys: 48 dependent trips), then that block's keys.
+                // (Whether the keys behind the look-ahead repeat is not looked at here: the error pass treats them as if they might.)  Leaves of up to
+                // SC_FAR_MAX keys stay with this wave -- the way over the general form and the list kernels costs a training ~2 ms whatever it lists.
+                const unsigned int lim = long_min > (unsigned int)RMI_SC_FAR_MAX ? long_min : (unsigned int)RMI_SC_FAR_MAX;
+                for (unsigned int o0 = (unsigned int)EXTN; o0 < lim && !found; o0 += 64u * 64u) {
+                  const unsigned int ob = o0 + 64u * (unsigned int)lane;              // this lane's block: the keys [ob, ob + 64) behind the tile
+                  const unsigned int relb = relA2 + (unsigned int)BTILE + ob;
+                  const bool vb = ob < lim && relb + 64u + 1u <= rel_hi;              // (beyond the limit, or the launch's end: the general form)
+                  bool o2;
+                  const unsigned int tb_ = vb ? target_of(kb[(long long)relb + 63], o2) : t_tile_last;
+                  const unsigned long long nem = __ballot(vb && tb_ != t_tile_last), ivm = __ballot(!vb);
+                  const int fne = nem ? __builtin_ctzll(nem) : 64, fiv = ivm ? __builtin_ctzll(ivm) : 64;
+                  if (fne < fiv) {
+                    const unsigned int o = o0 + 64u * (unsigned int)fne;
+                    const unsigned int t = target_of(kb[(long long)(relA2 + (unsigned int)BTILE + o) + lane], o2);
+                    const unsigned long long dm = __ballot(t != t_tile_last);       // (not empty: the block's last key has another target)
+                    const int src = __builtin_ctzll(dm);
+                    term_rel = (unsigned int)BTILE + o + (unsigned int)src;
+                    tt = (unsigned int)__builtin_amdgcn_readlane((int)t, src);
+                    found = true;
+                  } else if (fiv < 64) break;
+                }
+                if (!found) break;                                                  // (a leaf that runs on for more than long_min keys: the list kernels, through the general form)
+              }
             }
           }
           // key with the tile-relative index rr: in the image up to the look-ahead's end, behind it from the key array (the open leaf's far keys)
@@ -777,25 +815,96 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE =
               const double ta = m_ab[2 * (pend + nb)], tb = m_ab[2 * (pend + nb) + 1];
               unsigned int em = 0u, rm = 0u;
               unsigned int y_carry = (unsigned int)__builtin_amdgcn_readlane((int)y_last, 63);
-              for (unsigned int o = (unsigned int)BTILE; o < term_rel; o += 64u) {
-                const unsigned int rel = o + (unsigned int)lane;
-                const bool in = rel < term_rel;
-                const int rr = (int)(in ? rel : o);
-                const K kv = key_rel(rr);
-                const unsigned int i = A2 + rel;
-                unsigned int y = i;
-                if (dups) {
-                  const K kpv = key_rel(rr - 1), knx = key_rel(rr + 1);
-                  const unsigned int hidx = (in && !(kv == kpv)) ? i : 0u;
-                  const unsigned int pm = sc_scan_max(hidx);
-                  y = max(pm, y_carry);
-                  if (in && !(knx == kv)) rm = max(rm, i + 1u - y);
-                  y_carry = sc_lane63(y);
+              if constexpr (FAR != 2) {
+                for (unsigned int o = (unsigned int)BTILE; o < term_rel; o += 64u) {
+                  const unsigned int rel = o + (unsigned int)lane;
+                  const bool in = rel < term_rel;
+                  const int rr = (int)(in ? rel : o);
+                  const K kv = key_rel(rr);
+                  const unsigned int i = A2 + rel;
+                  unsigned int y = i;
+                  if (dups) {
+                    const K kpv = key_rel(rr - 1), knx = key_rel(rr + 1);
+                    const unsigned int hidx = (in && !(kv == kpv)) ? i : 0u;
+                    const unsigned int pm = sc_scan_max(hidx);
+                    y = max(pm, y_carry);
+                    if (in && !(knx == kv)) rm = max(rm, i + 1u - y);
+                    y_carry = sc_lane63(y);
+                  }
+                  if (in) {
+                    const double x = KeyTraits<K>::as_float(kv);
+                    const unsigned int pr = min(sg_cvt_u32(__builtin_fma(tb, x, ta)), n32);
+                    em = max(em, sg_absdiff(pr, y));
+                  }
                 }
-                if (in) {
-                  const double x = KeyTraits<K>::as_float(kv);
-                  const unsigned int pr = min(sg_cvt_u32(__builtin_fma(tb, x, ta)), n32);
-                  em = max(em, sg_absdiff(pr, y));
+              } else {
+                // one block of 64 keys of the open leaf: the lane's key kv at the relative index rel, the keys on either side of it
+                auto open_block = [&](unsigned int rel, bool in, bool dq_, K kv, K kpv, K knx) {
+                  const unsigned int i = A2 + rel;
+                  unsigned int y = i;
+                  if (dq_) {
+                    const unsigned int hidx = (in && !(kv == kpv)) ? i : 0u;
+                    const unsigned int pm = sc_scan_max(hidx);
+                    y = max(pm, y_carry);
+                    if (in && !(knx == kv)) rm = max(rm, i + 1u - y);
+                    y_carry = sc_lane63(y);
+                  }
+                  if (in) {
+                    const double x = KeyTraits<K>::as_float(kv);
+                    const unsigned int pr = min(sg_cvt_u32(__builtin_fma(tb, x, ta)), n32);
+                    em = max(em, sg_absdiff(pr, y));
+                  }
+                };
+                unsigned int o = (unsigned int)BTILE;
+                {
+                  // the look-ahead's part (from the tile image)
+                  const unsigned int t_la = term_rel < (unsigned int)(BTILE + EXTN) ? term_rel : (unsigned int)(BTILE + EXTN);
+                  for (; o < t_la; o += 64u) {
+                    const unsigned int rel = o + (unsigned int)lane;
+                    const bool in = rel < term_rel;
+                    const int rr = (int)(in ? rel : o);
+                    const K kv = key_rel(rr);
+                    K kpv = kv, knx = kv;
+                    if (dups) { kpv = key_rel(rr - 1); knx = key_rel(rr + 1); }
+                    open_block(rel, in, dups, kv, kpv, knx);
+                  }
+                }
+                if constexpr (FAR == 2) {
+                  // ... and what lies behind it, from the key array: FARB blocks a trip, their loads issued together (a trip is a memory round trip; whether these
+                  // keys repeat has not been looked at: the duplicate form of the block, which is the plain form's values where they do not)
+                  constexpr unsigned int FARB = RMI_SC_FARB;
+                  if (!dups) y_carry = A2 + (unsigned int)(BTILE + EXTN) - 1u;   // (no key of the tile and its look-ahead repeats: the last of them is its own first occurrence)
+                  // (a lane's neighbours' keys come from the neighbouring lanes -- three loads a block held 24 registers for 8-byte keys and spilled --, the key in
+                  //  front of a block from the block before it, the key behind a trip's last block by one load of a uniform address)
+                  auto lane_of = [&](B v, int src) -> B {
+                    if constexpr (sizeof(B) == 8) {
+                      const unsigned int lo_ = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src), hi_ = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), src);
+                      return (B)(((unsigned long long)hi_ << 32) | lo_);
+                    } else return (B)__builtin_amdgcn_readlane((int)v, src);
+                  };
+                  unsigned int relA2f = relA2;
+                  asm volatile("" : "+s"(relA2f));                              // (the addresses below formed HERE, not in registers held across the tile's error pass: they were spilled)
+                  const K* const pt = kb + (long long)relA2f;
+                  B kfront = (B)key_to_bits<K>(pt[o - 1u]);
+                  for (; o < term_rel; o += 64u * FARB) {
+                    B kv[FARB];
+  #pragma unroll
+                    for (unsigned int u = 0; u < FARB; u++) {
+                      const unsigned int rel = o + 64u * u + (unsigned int)lane;
+                      kv[u] = (B)key_to_bits<K>(pt[rel < term_rel ? rel : term_rel]);   // (behind the leaf's end: the key that ends it)
+                    }
+                    const B kback = (B)key_to_bits<K>(pt[o + 64u * FARB < term_rel ? o + 64u * FARB : term_rel]);
+  #pragma unroll
+                    for (unsigned int u = 0; u < FARB; u++) {
+                      if (o + 64u * u < term_rel) {
+                        const unsigned int rel = o + 64u * u + (unsigned int)lane;
+                        const B up = __shfl_up(kv[u], 1, 64), dn = __shfl_down(kv[u], 1, 64);
+                        const B nxt0 = u + 1u < FARB ? lane_of(kv[u + 1u < FARB ? u + 1u : u], 0) : kback;
+                        open_block(rel, rel < term_rel, true, bits_to_key<K>(kv[u]), bits_to_key<K>(lane == 0 ? kfront : up), bits_to_key<K>(lane == 63 ? nxt0 : dn));
+                        kfront = lane_of(kv[u], 63);
+                      }
+                    }
+                  }
                 }
               }
               if (term_rel > (unsigned int)BTILE) {

@@ -124,11 +124,13 @@ def test_config5_full_size_vs_oracle(oracle, gen):
 
 
 @pytest.mark.parametrize("gen,dtype,n,L", [("uniform", np.uint64, 200_000_000, 1 << 20), ("dups", np.uint64, 200_000_000, 1 << 20),
-                                           ("uniform", np.uint32, 400_000_000, 1 << 20)])
+                                           ("uniform", np.uint32, 400_000_000, 1 << 20), ("dups", np.uint64, 200_000_000, 1 << 14),
+                                           ("uniform", np.uint64, 200_000_000, 1 << 24)])
 def test_spline_leaves_longer_than_the_look_ahead_full_size_vs_oracle(oracle, gen, dtype, n, L):
     """linear_spline leaves on the metric configuration's keys (200M uint64, 2^20 leaves: 191 keys a leaf against 64 keys of look-ahead) and on C5's keys
-    in a quarter of its leaves (381 against 128): k_spline_scan's short form looks for the open leaf's end in the key array (FAR) -- against the
-    oracle, every array bit for bit."""
+    in a quarter of its leaves (381 against 128): k_spline_scan's short form looks for the open leaf's end in the key array (FAR = 1); leaves of 12 207
+    keys (FAR = 2: the end by one gather, the far keys eight blocks a trip); leaves of 12 keys (shorter than a lane's row: the general form over all
+    tiles) -- against the oracle, every array bit for bit."""
     from rmi_amd import train
     tr = train.Trainer()
     tr.generate_keys(gen, dtype, n)

@@ -61,6 +61,9 @@ def setup(cfg, dataset=None):
     if cfg.startswith("X"):                                  # X<keys>x<leaves>: uniform u64, linear,linear (sweeps over the keys per leaf)
         a, b = cfg[1:].split("x")
         CFG[cfg] = (int(a), int(b), "linear", "linear", "uniform", np.uint64)
+    if cfg.startswith("Y:"):                                 # Y:<keys>:<leaves>:<root>:<leaf kind>:<u64|u32|f64>: any shape of the sweep (tools/sweep_shapes.py)
+        _, a, b, rk, lk, dtn = cfg.split(":")
+        CFG[cfg] = (int(a), int(b), rk, lk, "uniform", {"u64": np.uint64, "u32": np.uint32, "f64": np.float64}[dtn])
     n, L, root_kind, leaf, ds, dt = CFG[cfg]
     ds = dataset or ds
     tr = train.Trainer()
@@ -68,6 +71,14 @@ def setup(cfg, dataset=None):
         import torch
         from rmi_amd import datagen
         kt = datagen.books_u64_torch(n, device="cuda:0")
+        torch.cuda.synchronize()
+        tr.set_keys(kt)
+    elif ds == "iid":                                        # independent uniform draws, sorted: Poisson-filled leaves (`uniform` is a jittered grid)
+        import torch
+        if np.dtype(dt).itemsize == 8:
+            kt = torch.sort(torch.randint(0, (1 << 63) - 1, (n,), dtype=torch.int64, device="cuda:0")).values
+        else:
+            kt = torch.sort(torch.randint(0, (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda:0")).values
         torch.cuda.synchronize()
         tr.set_keys(kt)
     else:

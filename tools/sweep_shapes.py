@@ -1,7 +1,7 @@
 """Where does the leaf path fall off its roofline?  One GPU, resident keys, every (root, leaf kind) the dispatch table has a fast pipeline for,
 over the numbers of leaves the reference's optimizer walks (optimizer.rs:43-58: 2^6 .. 2^25): ms per training (wall, synchronisation included),
 the pipeline that ran, B_leaf over the wall time as a fraction of 8 TB/s.
-usage: python tools/sweep_shapes.py [u64|u32|f64|dups64|dups32|books]... [steps]"""
+usage: python tools/sweep_shapes.py [u64|u32|f64|dups64|dups32|books|iid64|iid32]... [L<lo>-<hi>] [steps]"""
 import sys
 import time
 
@@ -32,6 +32,9 @@ SETS = {
     "dups64": ("dups", np.uint64, 200_000_000, ("linear",)),
     "dups32": ("dups", np.uint32, 400_000_000, ("radix",)),
     "books": ("books", np.uint64, 200_000_000, ("linear",)),
+    # independent uniform draws, sorted: Poisson-filled leaves (the `uniform` generator is a jittered grid: evenly filled ones)
+    "iid64": ("iid", np.uint64, 200_000_000, ("linear",)),
+    "iid32": ("iid", np.uint32, 400_000_000, ("radix",)),
 }
 
 
@@ -39,12 +42,23 @@ def main():
     args = [a for a in sys.argv[1:] if not a.isdigit()] or ["u64", "u32"]
     steps = next((int(a) for a in sys.argv[1:] if a.isdigit()), 10)
     lo, hi = 10, 25
+    for a in sys.argv[1:]:
+        if a.startswith("L"):                                 # L<lo>-<hi>: the range of log2(leaves)
+            lo, hi = (int(x) for x in a[1:].split("-"))
+    args = [a for a in args if not a.startswith("L")] or ["u64", "u32"]
     for name in args:
         ds, dt, n, roots = SETS[name]
         tr = train.Trainer()
         if ds == "books":
             from rmi_amd import datagen
             kt = datagen.books_u64_torch(n, device="cuda:0")
+            torch.cuda.synchronize()
+            tr.set_keys(kt)
+        elif ds == "iid":
+            if dt == np.uint64:
+                kt = torch.sort(torch.randint(0, (1 << 63) - 1, (n,), dtype=torch.int64, device="cuda:0")).values
+            else:
+                kt = torch.sort(torch.randint(0, (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda:0")).values
             torch.cuda.synchronize()
             tr.set_keys(kt)
         elif ds == "f64":
