@@ -74,7 +74,7 @@
 #define RMI_SC_FARB 8                 // FAR = 2: blocks of 64 keys of an open leaf's far part read per trip
 #endif
 #ifndef RMI_SC_FAR_MAX
-#define RMI_SC_FAR_MAX 32768          // FAR = 2: an open leaf's end is looked for this many keys behind the tile (beyond: the general form lists the leaf)
+#define RMI_SC_FAR_MAX 262144         // FAR = 2: an open leaf's end is looked for this many keys behind the tile (beyond: the general form lists the leaf; a leaf of that many keys is ~1.2 ms on its wave, the list kernels cost a training ~2.3 ms)
 #endif
 #ifndef RMI_SC_WPE0
 #define RMI_SC_WPE0 3                 // waves per SIMD of the short form's kernel (PHASE 0: 168 registers)

@@ -6,7 +6,7 @@ still in the ring, containers beyond 1 008 points listed), half of the configura
 6 .. 800 keys per leaf, linear and radix roots, the one-wave and the two-wave kernel (RMI_HIP_REGS_U32 = 1 / 2).  With `spline`: linear_spline leaves of
 4-byte keys through k_spline_scan with few persistent waves (a wave takes many tiles: the batched leaf ends), 8 .. 3 000 keys per leaf.
 `spline64`: the same on 8-byte keys.
-`splinelong` / `splinelong64`: 300 .. 50 000 keys per spline leaf (k_spline_scan<.., FAR = 2>).
+`splinelong` / `splinelong64`: 300 .. 280 000 keys per spline leaf (k_spline_scan<.., FAR = 2>).
 usage: python tools/regs_fuzz.py [seconds [seed [long|u32|spline|spline64|splinelong|splinelong64]]]"""
 import sys
 import time
@@ -30,7 +30,7 @@ def main():
     long_mode = mode == "long"
     if mode in ("u32", "spline"):
         gens = [g for g in dg.GENERATORS if g.endswith("u32")]
-    spline_long = mode in ("splinelong", "splinelong64")     # leaves of 300 .. 50 000 keys: the FAR = 2 instance (one gather for the open leaf's end, eight blocks a trip)
+    spline_long = mode in ("splinelong", "splinelong64")     # leaves of 300 .. 280 000 keys: the FAR = 2 instance (one gather for the open leaf's end, eight blocks a trip)
     if mode == "splinelong":
         gens = [g for g in dg.GENERATORS if g.endswith("u32")]
     if mode in ("spline64", "splinelong", "splinelong64"):
@@ -46,7 +46,7 @@ def main():
             per = float(10 ** rng.uniform(0.9, 3.48))
         if spline_long:
             n = int(10 ** rng.uniform(4.5, 6.6))
-            per = float(10 ** rng.uniform(2.5, 4.7))
+            per = float(10 ** rng.uniform(2.5, 5.45))
         L = max(2, int(n / per))
         root_kind = "linear" if mode not in ("u32", "spline") or gen.endswith("f64") or rng.random() < 0.5 else "radix"
         leaf_kind = "linear_spline" if mode == "spline" else "linear"

@@ -10,7 +10,11 @@ from collections import defaultdict
 def short(name: str) -> str:
     n = name.split("(")[0]
     if "k_spline_scan" in n:                              # two kernels of one template
-        return "k_spline_scan<short>" if n.rstrip().endswith(", 0>") else ("k_spline_scan<general>" if n.rstrip().endswith(", 1>") else "k_spline_scan")
+        # k_spline_scan<ROOT, K, V, PHASE, FAR>: PHASE 0 = the short form's kernel, 1 = the general form's (the stats file truncates long names: then unnamed)
+        a = n.rstrip().rstrip(">").split("<", 1)[-1].split(",") if n.rstrip().endswith(">") else []
+        if len(a) == 5:
+            return "k_spline_scan<short>" if a[3].strip() == "0" else "k_spline_scan<general>"
+        return "k_spline_scan"
     for key in ("k_spline_scan", "k_scan_gaps", "k_long_regs", "k_verify_listed", "k_giant_scan", "k_finalize_listed", "k_leaf_regs", "k_regs_finalize", "k_regs_table", "k_leaf_lanes_listed", "k_leaf_lanes", "k_leaf_search", "k_leaf_samples", "k_lane_reduce", "k_lane_table", "k_sigma2", "k_list_tail", "k_list", "k_err_long", "k_fit_list", "k_err_list", "k_read_bw", "k_init", "k_fit_stream", "k_err_range", "k_fit_long", "k_fill_tilemin", "k_fill_scan_tiles", "k_fill_apply", "k_finalize",
                 "k_stats_reduce", "k_generate", "k_boundaries", "k_fit_leaf", "k_err"):
         if key in n:

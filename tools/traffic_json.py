@@ -25,7 +25,8 @@ for d in (f"{out_dir}/tf", f"{out_dir}/tw"):
             kn = r["Kernel_Name"]
             k = next((x for x in names if x in kn), None)
             if k == "k_spline_scan":                      # two kernels of one template: the short form's (PHASE 0) and the general form's (PHASE 1)
-                k = "k_spline_scan<short form>" if kn.split("(")[0].rstrip().endswith(", 0>") else "k_spline_scan<general form>"
+                targs = kn.split("(")[0].rstrip().rstrip(">").split("<", 1)[-1].split(",")     # <ROOT, K, V, PHASE, FAR>
+                k = "k_spline_scan<short form>" if len(targs) == 5 and targs[3].strip() == "0" else "k_spline_scan<general form>"
             if k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
