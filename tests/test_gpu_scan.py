@@ -80,6 +80,29 @@ def test_scan_lists_and_grids(monkeypatch, oracle, gen, env):
     _check(monkeypatch, oracle, dg.GENERATORS[gen](400_000), "radix" if gen != "uniform_f64" else "linear", 4096, env=env)
 
 
+@pytest.mark.parametrize("gen,root", [("uniform_u64", "linear"), ("dups_u64", "linear"), ("books_u64", "linear"), ("uniform_f64", "linear"),
+                                      ("uniform_u32", "radix"), ("dups_u32", "radix"), ("dups_u32", "linear")])
+@pytest.mark.parametrize("n,L,waves", [
+    (1_500_000, 3000, None), (1_500_000, 3000, "8"),     # 500 keys a leaf: FAR = 2, an open leaf ends a block or two behind the look-ahead
+    (2_000_000, 301, "24"),                              # 6 600 keys a leaf: the end found by the gather's first round, eight blocks a trip with a ragged last trip
+    (3_000_000, 37, None), (3_000_000, 37, "8"),         # 81 000 keys a leaf: twenty rounds of the gather; few waves: a wave meets several such leaves
+    (3_000_000, 9, "16"),                                # 333 000 keys a leaf: beyond the far limit (262 144) -- the general form lists them
+])
+def test_scan_long_leaves(monkeypatch, oracle, gen, root, n, L, waves):
+    """Leaves of hundreds to hundreds of thousands of keys (k_spline_scan<.., FAR = 2>, rmi_scan.hip.h): the open leaf's end by one gather of the
+    blocks' last keys, its far keys eight blocks a trip from the key array, their duplicates found on the way (the search does not look), a prime
+    number of waves per XCD in the launch -- same bits as the oracle."""
+    _check(monkeypatch, oracle, dg.GENERATORS[gen](n), root, L, env={"RMI_HIP_SCAN_WAVES": waves} if waves else None)
+
+
+@pytest.mark.parametrize("gen,root", [("uniform_u64", "linear"), ("dups_u64", "linear"), ("uniform_u32", "radix"), ("dups_u32", "radix"), ("uniform_f64", "linear")])
+@pytest.mark.parametrize("n,L", [(400_000, 40_000), (400_000, 25_000), (300_000, 60_000)])
+def test_scan_leaves_shorter_than_a_row(monkeypatch, oracle, gen, root, n, L):
+    """Fewer than 1.25 rows of a lane per leaf (8-byte keys: 20 keys, 4-byte keys: 40): the launcher skips the short form -- nearly every tile has a
+    lane with two leaf starts -- and runs the general form over all tiles; around that limit (10 / 16 / 5 keys a leaf) both routes give the oracle's bits."""
+    _check(monkeypatch, oracle, dg.GENERATORS[gen](n), root, L)
+
+
 @pytest.mark.parametrize("dups", [False, True])
 @pytest.mark.parametrize("waves", ["8", "3"])
 def test_scan_batched_leaf_ends_uneven_density(monkeypatch, oracle, dups, waves):
