@@ -1,7 +1,6 @@
 // rmi_scan.hip -- translation unit of pipeline 5 (k_spline_scan, rmi_scan.hip.h) and its launcher.
 #include <hip/hip_runtime.h>
 
-#include <cmath>
 
 #include "rmi_scan.hip.h"
 
@@ -43,7 +42,7 @@ static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
       // the short form's kernel over all tiles; what it leaves goes on the list
       const unsigned int g0 = grid_for(0);
       // leaves longer than the look-ahead on average (8-byte keys: 64 keys, 4-byte keys: 128): the variant that looks for an open leaf's end behind it
-      // (... and where they are several hundred keys long, the variant that finds that end with one gather and reads the open leaf's far keys four blocks a trip)
+      // (... and where they are several hundred keys long, the variant that finds that end with one gather and reads the open leaf's far keys eight blocks a trip)
       if (n_keys > 384ull * n_leaves) {
         // Leaves of several tiles: a leaf start every P tiles, and the wave that meets one reads the whole leaf.  A wave of an XCD takes every wpx-th tile
         // (wpx = the waves of the XCD): if wpx / P is a fraction of a small denominator q, every start meets the same wpx q / P waves -- 400 M u32 keys

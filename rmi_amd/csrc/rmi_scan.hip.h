@@ -239,7 +239,7 @@ struct ScanArgs {
 //          where the leaves are longer than the look-ahead on average -- the other keeps C5's code as it was (the far search costs it 2-3 %: registers).
 //          FAR = 1: 64 keys a step, in the search and in the error pass (each step a memory round trip: fine while a leaf ends a block or two behind the
 //          look-ahead).  FAR = 2, for leaves of several hundred keys and more: ONE gather finds the block that holds the end (lane l probes the last key of
-//          the l-th block), the error pass reads four blocks a trip -- 200 M u64 keys in 2^16 leaves 1.19 -> 0.64 ms.  An instance of its own because its
+//          the l-th block), the error pass reads eight blocks a trip -- 200 M u64 keys in 2^16 leaves 1.19 -> 0.64 ms.  An instance of its own because its
 //          code left 5 spilled registers around the tile's error pass (FAR = 1 has none; M's keys in 2^20 spline leaves 0.43 -> 0.49 ms with them).
 template <int ROOT, typename K, int V, int PHASE, int FAR = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE == 0 ? RMI_SC_WPE0 : RMI_SC_WPE, PHASE == 0 ? RMI_SC_WPE0 : RMI_SC_WPE))) k_spline_scan(ScanArgs) {
