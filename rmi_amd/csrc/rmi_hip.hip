@@ -114,6 +114,7 @@ struct rmi_hip_ctx {
   bool last_regs = false;
   void* d_gaps = nullptr;                       // pipeline 5: the listed stretches of empty leaves (GapRec)
   uint64_t scan_hint_epoch = 0, scan_hint_L = 0; unsigned int scan_hint_n = ~0u;   // ... and how many it left the last time (key set, leaves per launch)
+  uint64_t scan_skew_epoch = ~0ull, scan_skew_L = 0;   // (key set, leaves) whose short form listed hundreds of tiles: a skewed key set -- its next trainings take the long-leaf instance
   unsigned int* d_tile_list = nullptr;          // ... the tiles the short form's kernel leaves to the general form's
   uint64_t tile_list_cap = 0;
   // pipeline 5 writes the rows (codegen.rs:288-315: alpha, beta, error -- the 24 L bytes of SURVEY 8d) and the bucket table only; the separate
@@ -1488,6 +1489,7 @@ static int launch_pipeline(rmi_hip_ctx* c, const RootP& rp, uint64_t L) {
         // the general form's kernel gets as many waves as tiles were left to it by the last training of this (key set, leaf count) -- twice
         // that and 64 more; a first training, or one in which the list outgrows them, launches what the device holds
         sl.listed_hint = (c->scan_hint_epoch == c->keys_epoch && c->scan_hint_L == L_own) ? c->scan_hint_n : ~0u;
+        sl.long_leaves = (c->scan_skew_epoch == c->keys_epoch && c->scan_skew_L == L_own) ? 1 : 0;
         {
           const uint64_t need = rmi_scan_tiles(c->dtype, n_it);
           if (c->tile_list_cap < need) {
@@ -1986,7 +1988,10 @@ static int finish_train(rmi_hip_ctx* c, int leaf_kind, uint64_t num_leaves, rmi_
   }
   c->last_L = L_own; c->last_ppl = ppl;
   c->lean_last_target = st.last_target;
-  if (c->last_scan && !c->stream_mode) { c->scan_hint_epoch = c->keys_epoch; c->scan_hint_L = L_own; c->scan_hint_n = (unsigned int)(st.scan_listed < 0xFFFFFFFFull ? st.scan_listed : 0xFFFFFFFFull); }
+  if (c->last_scan && !c->stream_mode) {
+    c->scan_hint_epoch = c->keys_epoch; c->scan_hint_L = L_own; c->scan_hint_n = (unsigned int)(st.scan_listed < 0xFFFFFFFFull ? st.scan_listed : 0xFFFFFFFFull);
+    if (st.scan_listed > 512ull) { c->scan_skew_epoch = c->keys_epoch; c->scan_skew_L = L_own; }
+  }
   c->lean_leaf_lo = c->have_shard ? c->shard.leaf_lo : 0;
   std::memset(out, 0, sizeof *out);
   out->generation = c->generation;

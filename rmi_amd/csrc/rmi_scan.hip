@@ -43,7 +43,9 @@ static int scan_launch_t(ScanLaunch& a, hipStream_t s) {
       const unsigned int g0 = grid_for(0);
       // leaves longer than the look-ahead on average (8-byte keys: 64 keys, 4-byte keys: 128): the variant that looks for an open leaf's end behind it
       // (... and where they are several hundred keys long, the variant that finds that end with one gather and reads the open leaf's far keys eight blocks a trip)
-      if (n_keys > 384ull * n_leaves) {
+      // (... or where an earlier training of the configuration listed hundreds of tiles -- books-shaped keys in 2^20 leaves: 4 700 leaves run on for more than
+      //  long_min keys, each a search of 64 round trips before its tile is listed, 1.9 ms: the long-leaf instance keeps them)
+      if (n_keys > 384ull * n_leaves || a.long_leaves) {
         // Leaves of several tiles: a leaf start every P tiles, and the wave that meets one reads the whole leaf.  A wave of an XCD takes every wpx-th tile
         // (wpx = the waves of the XCD): if wpx / P is a fraction of a small denominator q, every start meets the same wpx q / P waves -- 400 M u32 keys
         // (a jittered grid of stride 10) under a radix root of 2^14 leaves: P = 2^18 / 10 / 2 048 = 12.8 tiles, wpx = 384 = 30 P, 30 waves of 384 did all

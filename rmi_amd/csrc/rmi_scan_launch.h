@@ -35,6 +35,7 @@ struct ScanLaunch {
   unsigned long long* tile_cnt;   // their counter (zero before the launch)
   unsigned int n_cu;              // compute units of the device
   unsigned int listed_hint;       // tiles the short form left to the general form in the last training of this configuration (~0: unknown)
+  int long_leaves;                // an earlier training of this configuration left hundreds of tiles: long leaves among short ones (a skewed key set) -- the long-leaf instance
   int host_split;                 // the split of the 2-way join is in *st already (a shard)
   int mono;                       // the root's targets are monotone in the key by arithmetic: a linear root with finite coefficients and a slope >= 0, a radix
                                   // root whose prefix is common to all resident keys (then equal targets at two keys prove that no leaf starts between them)

@@ -103,6 +103,30 @@ def test_scan_leaves_shorter_than_a_row(monkeypatch, oracle, gen, root, n, L):
     _check(monkeypatch, oracle, dg.GENERATORS[gen](n), root, L)
 
 
+@pytest.mark.parametrize("gen,root,n,L,env", [("uniform_u64", "linear", 2_000_000, 20_000, {"RMI_HIP_LONG_MIN": "32"}), ("dups_u64", "linear", 2_000_000, 20_000, {"RMI_HIP_LONG_MIN": "32"}),
+                                              ("dups_u32", "radix", 4_000_000, 1 << 15, {"RMI_HIP_LONG_MIN": "40"}), ("books_u64", "linear", 3_000_000, 30_000, {})])
+def test_scan_second_training_of_a_key_set_that_listed_many_tiles(monkeypatch, oracle, gen, root, n, L, env):
+    """A training whose short form leaves hundreds of tiles to the general form (here: a tiny long_min; in the field: a skewed key set, long leaves among
+    short ones) marks the configuration: its next trainings on the same context take the long-leaf instance of the short form (rmi_scan.hip, `long_leaves`),
+    which keeps such leaves.  Both trainings give the oracle's bits."""
+    from rmi_amd import train
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    keys = dg.GENERATORS[gen](n)
+    tr = train.Trainer(keys)
+    g_root = tr.fit_root(root, L)
+    o = oracle.train_two_layer(root, "linear_spline", keys, L)
+    for rep in range(3):
+        g = tr.train_leaves(g_root, "linear_spline", L).materialize()
+        assert g.pipeline == 5
+        assert np.array_equal(g.leaf_starts, o.leaf_start), f"bucket assignment differs (training {rep})"
+        assert np.array_equal(g.leaf_params.view(np.uint64), o.leaf_params.view(np.uint64)), f"coefficients differ (training {rep})"
+        assert np.array_equal(g.last_layer_max_l1s, o.leaf_err), f"error integers differ (training {rep})"
+        assert np.array_equal(g.leaf_counts, o.leaf_count)
+        assert g.model_max_error == o.model_max_error and g.model_max_error_idx == o.model_max_error_idx and g.model_avg_error == o.model_avg_error
+    tr.close()
+
+
 @pytest.mark.parametrize("dups", [False, True])
 @pytest.mark.parametrize("waves", ["8", "3"])
 def test_scan_batched_leaf_ends_uneven_density(monkeypatch, oracle, dups, waves):
